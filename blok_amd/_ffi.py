@@ -1,0 +1,157 @@
+"""ctypes bindings for the two product libraries.
+
+* ``libblok_host.so`` — host data model (include/blok_world.h), g++ only.
+* ``libblok_hip.so``  — gfx950 trace backend (include/blok_hip.h), hipcc.
+
+The bindings are the same stub a maintainer would write for any C consumer; see INTEGRATION.md
+for the C++ one.  There is no fallback: a missing library raises ``BlokLibraryError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+PKG_DIR = Path(__file__).resolve().parent
+HOST_LIB = PKG_DIR / "libblok_host.so"
+HIP_LIB = PKG_DIR / "libblok_hip.so"
+
+
+class BlokLibraryError(RuntimeError):
+    pass
+
+
+class BlokError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"blok status {status}: {message}")
+        self.status = status
+
+
+# ---------------------------------------------------------------- records (include/blok_hip.h)
+SVO_NODE = np.dtype([("child_mask", "<u4"), ("first_child", "<u4"), ("material_id", "<u4"),
+                     ("occupancy", "<f4")])
+SUB_CHUNK = np.dtype([("node_offset", "<u4"), ("root_node_index", "<u4"), ("node_count", "<u4"),
+                      ("start_depth", "<u4"), ("world_min", "<f4", 3), ("sub_chunk_size", "<f4"),
+                      ("world_max", "<f4", 3), ("pad0", "<f4")])
+MATERIAL = np.dtype([("albedo", "<f4", 3), ("flags", "<u4"), ("emission", "<f4", 3), ("ior", "<f4")])
+CAMERA = np.dtype([("pos", "<f4", 3), ("fwd", "<f4", 3), ("right", "<f4", 3), ("up", "<f4", 3),
+                   ("tan_half_fov", "<f4"), ("aspect", "<f4")])
+HIT = np.dtype([("t", "<f4"), ("material_id", "<u4"), ("voxel", "<i2", 3), ("face", "u1"), ("hit", "u1")])
+RAY = np.dtype([("org", "<f4", 3), ("tmin", "<f4"), ("dir", "<f4", 3), ("tmax", "<f4")])
+assert SVO_NODE.itemsize == 16 and SUB_CHUNK.itemsize == 48 and MATERIAL.itemsize == 32
+assert CAMERA.itemsize == 56 and HIT.itemsize == 16 and RAY.itemsize == 32
+
+
+class WorldStats(C.Structure):
+    _fields_ = [("n_voxels", C.c_uint64), ("n_ref_nodes", C.c_uint64), ("n_sub_chunks", C.c_uint64),
+                ("n_tree_nodes", C.c_uint64), ("tree_bytes", C.c_uint64), ("levels", C.c_uint32),
+                ("origin", C.c_int32 * 3)]
+
+
+HOST_SYMBOLS = {
+    "blok_morton_encode": (C.c_uint64, [C.c_int32, C.c_int32, C.c_int32]),
+    "blok_morton_decode": (None, [C.c_uint64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "blok_morton_octant": (C.c_uint32, [C.c_uint64, C.c_uint32, C.c_uint32]),
+    "blok_world_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint32, C.c_float]),
+    "blok_world_destroy": (None, [C.c_void_p]),
+    "blok_world_last_error": (C.c_char_p, [C.c_void_p]),
+    "blok_world_set_voxel": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.c_float]),
+    "blok_world_set_voxels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "blok_world_get_voxel_material": (C.c_uint32, [C.c_void_p, C.POINTER(C.c_float)]),
+    "blok_world_rebuild_dirty": (C.c_int, [C.c_void_p, C.c_int]),
+    "blok_world_pack": (C.c_int, [C.c_void_p]),
+    "blok_world_node_count": (C.c_size_t, [C.c_void_p]),
+    "blok_world_sub_chunk_count": (C.c_size_t, [C.c_void_p]),
+    "blok_world_nodes": (C.c_void_p, [C.c_void_p]),
+    "blok_world_sub_chunks": (C.c_void_p, [C.c_void_p]),
+    "blok_world_chunk_count": (C.c_size_t, [C.c_void_p]),
+    "blok_world_chunk_info": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]),
+    "blok_world_chunk_nodes": (C.c_void_p, [C.c_void_p, C.c_size_t]),
+    "blok_world_find_leaf": (C.c_int64, [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "blok_camera_from_yaw_pitch": (C.c_int, [C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float,
+                                             C.c_uint32, C.c_uint32, C.c_void_p]),
+    "blok_camera_look_at": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float,
+                                      C.c_uint32, C.c_uint32, C.c_void_p]),
+    "blok_scene_generate": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
+    "blok_scene_generate_dense": (C.c_int, [C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64)]),
+    "blok_scene_materials": (C.c_int, [C.c_uint32, C.c_void_p]),
+    "blok_scene_camera": (C.c_int, [C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p]),
+}
+
+HIP_SYMBOLS = {
+    "blok_hip_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_uint32, C.c_uint32]),
+    "blok_hip_resize": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
+    "blok_hip_destroy": (None, [C.c_void_p]),
+    "blok_hip_last_error": (C.c_char_p, [C.c_void_p]),
+    "blok_hip_upload_world": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                        C.c_void_p, C.c_size_t]),
+    "blok_hip_upload_dense": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                        C.POINTER(C.c_int32), C.c_void_p, C.c_size_t]),
+    "blok_hip_world_stats": (C.c_int, [C.c_void_p, C.POINTER(WorldStats)]),
+    "blok_hip_trace_primary": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                         C.c_uint32, C.c_void_p]),
+    "blok_hip_trace_primary_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                                C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "blok_hip_tiles_for_rank": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "blok_hip_trace_tiles_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                              C.c_void_p, C.c_void_p]),
+    "blok_hip_untile_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                         C.c_void_p, C.c_void_p]),
+    "blok_hip_trace_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "blok_hip_shade_rgba8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                       C.c_uint32, C.c_void_p]),
+    "blok_hip_reset_accum": (C.c_int, [C.c_void_p]),
+    "blok_hip_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "blok_hip_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "blok_hip_abi_version": (C.c_uint32, []),
+}
+
+
+def _load(path: Path, symbols: dict) -> C.CDLL:
+    if not path.exists():
+        raise BlokLibraryError(
+            f"{path.name} is not built (expected at {path}); run `python -c 'import __graft_entry__ as g; g.build()'`")
+    try:
+        lib = C.CDLL(os.fspath(path))
+    except OSError as e:  # e.g. libamdhip64 missing
+        raise BlokLibraryError(f"cannot load {path}: {e}") from e
+    for name, (res, args) in symbols.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise BlokLibraryError(f"{path.name} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+_host = None
+_hip = None
+
+
+def host_lib() -> C.CDLL:
+    global _host
+    if _host is None:
+        _host = _load(HOST_LIB, HOST_SYMBOLS)
+    return _host
+
+
+def hip_lib() -> C.CDLL:
+    global _hip
+    if _hip is None:
+        _hip = _load(HIP_LIB, HIP_SYMBOLS)
+    return _hip
+
+
+def ptr(a: np.ndarray) -> C.c_void_p:
+    return C.c_void_p(a.ctypes.data)
+
+
+def as_array(address: int, count: int, dtype: np.dtype) -> np.ndarray:
+    """Copy `count` records of `dtype` from a C pointer into a fresh numpy array."""
+    if count == 0 or not address:
+        return np.zeros(0, dtype=dtype)
+    buf = (C.c_char * (count * dtype.itemsize)).from_address(address)
+    return np.frombuffer(buf, dtype=dtype, count=count).copy()

@@ -1,0 +1,227 @@
+/*
+ * blok_hip.h — C ABI of the MI355X (gfx950) voxel ray-march backend for blok.
+ *
+ * This is the drop-in boundary.  blok has no plugin ABI; a backend is whatever
+ * `App` calls on it (reference blok/src/app.cpp:73-128,130-192) and whatever
+ * `Renderer::addWorld` consumes (reference blok/include/renderer.hpp:40-72).
+ * Each entry point below names the reference interface it stands in for.
+ *
+ * Conventions
+ *   - every function returns BLOK_OK (0) or a negative blok_status; the text of the
+ *     last failure is available from blok_hip_last_error(ctx) (ctx may be NULL for
+ *     create-time failures).  The reference throws std::runtime_error instead
+ *     (reference blok/src/main.cpp:19-22); the C++ HipTracer wrapper rethrows.
+ *   - plain pointers and sizes only; caller owns every host array, the context owns
+ *     every device copy (same ownership split as reference renderer.hpp:195 +
+ *     renderer_init.cpp:123-169).
+ *   - a context is bound to one device and is not thread-safe (the reference is
+ *     single-threaded: one context, one frame in flight on the compute path,
+ *     reference blok/src/cuda_tracer.cu:539).
+ *   - there is NO CPU fallback: without a gfx950 device / code object every entry
+ *     point that would compute fails with BLOK_ERR_NO_DEVICE.
+ */
+#ifndef BLOK_HIP_H
+#define BLOK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ records */
+
+/* = blok::SvoNode, reference blok/include/svo.hpp:23-28.  16 B.
+ * childMask bit i set <=> child i non-empty (reference blok/src/svo.cpp:99);
+ * leaf <=> childMask == 0 (reference assets/shaders/intersect.rint:136). */
+typedef struct blok_svo_node {
+    uint32_t child_mask;
+    uint32_t first_child; /* chunk-relative index of child 0, 8 siblings contiguous; 0xFFFFFFFF none */
+    uint32_t material_id;
+    float    occupancy;   /* >0 filled */
+} blok_svo_node;
+
+/* = blok::SubChunkGpu, reference blok/include/resources.hpp:170-184.  48 B. */
+typedef struct blok_sub_chunk {
+    uint32_t node_offset;     /* start of the parent chunk's nodes in the global array */
+    uint32_t root_node_index; /* relative to node_offset */
+    uint32_t node_count;      /* nodes in the parent chunk */
+    uint32_t start_depth;
+    float    world_min[3];
+    float    sub_chunk_size;
+    float    world_max[3];
+    float    pad0;
+} blok_sub_chunk;
+
+/* = blok::MaterialGpu, reference blok/include/material.hpp:88-114.  32 B.
+ * flags = metal<<24 | rough<<16 | type<<12 | alpha4<<8 | spec. */
+typedef struct blok_material {
+    float    albedo[3];
+    uint32_t flags;
+    float    emission[3];
+    float    ior;
+} blok_material;
+
+/* = CameraCUDA, the reference's own compute-backend camera contract
+ * (reference blok/src/cuda_tracer.cu:51-58, filled at :404-415 from blok::Camera,
+ * reference blok/include/camera.hpp:25-42). */
+typedef struct blok_camera {
+    float pos[3];
+    float fwd[3];
+    float right[3];
+    float up[3];
+    float tan_half_fov; /* tanf(0.5*fov) */
+    float aspect;       /* width / height of the FULL frame */
+} blok_camera;
+
+/* First-hit record, 16 B per ray.  What closest-hit sees of a procedural hit in the
+ * reference: gl_HitTEXT, hitAttribs.materialId, gl_HitKindEXT
+ * (reference assets/shaders/intersect.rint:138-141, hit.rchit:58-74), plus the voxel
+ * that produced it.  Miss: t = -1 (reference miss.rmiss:25-27), hit = 0, face = 0xFF. */
+typedef struct blok_hit {
+    float    t;
+    uint32_t material_id;
+    int16_t  voxel[3];    /* world voxel coordinates of the leaf */
+    uint8_t  face;        /* 0:+X 1:-X 2:+Y 3:-Y 4:+Z 5:-Z  (reference hit.rchit:46-53) */
+    uint8_t  hit;         /* 1 hit, 0 miss */
+} blok_hit;
+
+/* Explicit ray, for secondary rays and edge-case tests (same interval semantics as
+ * traceRayEXT: reference assets/shaders/raygen.rgen:217-229). */
+typedef struct blok_ray {
+    float org[3];
+    float tmin;
+    float dir[3];
+    float tmax;
+} blok_ray;
+
+typedef enum blok_status {
+    BLOK_OK              =  0,
+    BLOK_ERR_INVALID_ARG = -1,
+    BLOK_ERR_NO_DEVICE   = -2, /* no gfx950 device, or the HIP runtime failed */
+    BLOK_ERR_HIP         = -3, /* a HIP call failed; message has the call and code */
+    BLOK_ERR_NO_WORLD    = -4, /* trace before upload */
+    BLOK_ERR_UNSUPPORTED = -5, /* world not on the unit-voxel integer lattice, leaf above voxel level, ... */
+    BLOK_ERR_OOM         = -6
+} blok_status;
+
+/* Reference constants of the primary trace (reference assets/shaders/raygen.rgen:225,227). */
+#define BLOK_RAY_TMIN 0.001f
+#define BLOK_RAY_TMAX 10000.0f
+
+typedef struct blok_hip_ctx blok_hip_ctx;
+
+/* ---------------------------------------------------------------- lifecycle */
+
+/* = CudaTracer::CudaTracer(w,h) + init()   (reference blok/include/cuda_tracer.hpp:25-28,
+ *   blok/src/cuda_tracer.cu:425-448).  Binds the context to `device_ordinal`. */
+int blok_hip_create(blok_hip_ctx** out_ctx, int device_ordinal, uint32_t width, uint32_t height);
+
+/* = CudaTracer::resize (reference blok/src/cuda_tracer.cu:557-575). */
+int blok_hip_resize(blok_hip_ctx* ctx, uint32_t width, uint32_t height);
+
+/* = CudaTracer::shutdown / Renderer::cleanupWorld (reference blok/src/cuda_tracer.cu:577-602,
+ *   blok/src/renderer_init.cpp:123-169). */
+void blok_hip_destroy(blok_hip_ctx* ctx);
+
+const char* blok_hip_last_error(const blok_hip_ctx* ctx);
+
+/* ------------------------------------------------------------------- world */
+
+/* = Renderer::addWorld / updateWorld  (reference blok/include/renderer.hpp:40-72,
+ *   uploadSvoBuffers + uploadMaterialBuffer, blok/src/renderer_upload.cpp:237-312).
+ * Takes the three host arrays of WorldSvoGpu (reference blok/include/resources.hpp:195-203)
+ * exactly as packChunksToGpuSvo emits them (reference blok/src/chunk_manager.cpp:234-314),
+ * copies them to HBM and builds the traversal structure there (this also replaces
+ * buildChunkBlas/buildChunkTlas, reference blok/src/renderer_raytracing.cpp:15-254).
+ * Replaces any previous world. */
+int blok_hip_upload_world(blok_hip_ctx* ctx,
+                          const blok_svo_node* nodes, size_t n_nodes,
+                          const blok_sub_chunk* sub_chunks, size_t n_sub_chunks,
+                          const blok_material* materials, size_t n_materials);
+
+/* Dense form (BASELINE.json configs[0..1]): material_ids[x + y*nx + z*nx*ny], 0 = empty,
+ * i.e. the reference's dense store with density>0 <=> id != 0
+ * (reference blok/include/chunk.hpp:35-36, blok/src/chunk_manager.cpp:57-59,330-348).
+ * origin = world coordinate of voxel (0,0,0). */
+int blok_hip_upload_dense(blok_hip_ctx* ctx, const uint32_t* material_ids,
+                          uint32_t nx, uint32_t ny, uint32_t nz, const int32_t origin[3],
+                          const blok_material* materials, size_t n_materials);
+
+/* Sizes of the device-resident world, for accounting (bytes). */
+typedef struct blok_world_stats {
+    uint64_t n_voxels;          /* filled leaves */
+    uint64_t n_ref_nodes;       /* reference SvoNode records uploaded */
+    uint64_t n_sub_chunks;
+    uint64_t n_tree_nodes;      /* 16-B 4x4x4 nodes of the derived structure */
+    uint64_t tree_bytes;        /* nodes + material side array */
+    uint32_t levels;            /* 4^levels voxels per axis */
+    int32_t  origin[3];         /* world coordinate of the structure's corner */
+} blok_world_stats;
+int blok_hip_world_stats(const blok_hip_ctx* ctx, blok_world_stats* out);
+
+/* -------------------------------------------------------------------- trace */
+
+/* = CudaTracer::drawFrame(cam, ...) restricted to the primary hit
+ *   (reference blok/src/cuda_tracer.cu:484-555) == raygen.rgen bounce 0 / sample 0
+ *   -> traceRayEXT -> intersect.rint -> hit.rchit
+ *   (reference assets/shaders/raygen.rgen:194-229).
+ * Traces the pixel rectangle [x0,x0+w) x [y0,y0+h) of the ctx-sized frame (tile-able for
+ * the multi-GPU partition) and copies the w*h records row-major to `out_hits_host`.
+ * Blocking, like the reference's cudaDeviceSynchronize (cuda_tracer.cu:539). */
+int blok_hip_trace_primary(blok_hip_ctx* ctx, const blok_camera* cam,
+                           uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
+                           blok_hit* out_hits_host);
+
+/* Same work, device-resident output, asynchronous on `hip_stream` (a hipStream_t, or NULL
+ * for the default stream).  `out_hits_dev` is a device pointer to w*h records.
+ * This is the entry the benchmark times and the one a graph capture may record
+ * (no allocation, no host sync inside). */
+int blok_hip_trace_primary_device(blok_hip_ctx* ctx, const blok_camera* cam,
+                                  uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
+                                  void* out_hits_dev, void* hip_stream);
+
+/* Interleaved-tile form of the multi-GPU partition: rank r of n traces the tiles
+ * (tile x tile pixels, row-major tile index i) with i % n == r and writes them densely,
+ * tile after tile, each tile row-major; out_hits_dev holds
+ * blok_hip_tiles_for_rank(...) * tile*tile records (edge tiles are padded with misses). */
+uint32_t blok_hip_tiles_for_rank(uint32_t width, uint32_t height, uint32_t tile,
+                                 uint32_t rank, uint32_t n_ranks);
+int blok_hip_trace_tiles_device(blok_hip_ctx* ctx, const blok_camera* cam,
+                                uint32_t tile, uint32_t rank, uint32_t n_ranks,
+                                void* out_hits_dev, void* hip_stream);
+/* Root side: scatter n_ranks gathered tile buffers (rank-major, each padded to
+ * `tiles_per_rank_max` tiles) back into a row-major width*height frame. */
+int blok_hip_untile_device(blok_hip_ctx* ctx, const void* gathered_dev, uint32_t tile,
+                           uint32_t n_ranks, uint32_t tiles_per_rank_max,
+                           void* out_frame_dev, void* hip_stream);
+
+/* Explicit rays (secondary rays; edge-case tests). n rays in, n records out, host arrays. */
+int blok_hip_trace_rays(blok_hip_ctx* ctx, const blok_ray* rays_host, size_t n,
+                        blok_hit* out_hits_host);
+
+/* Shade first hits to RGBA8 (normal/albedo debug view through hit.rchit's material fetch,
+ * reference assets/shaders/hit.rchit:55-76): out_rgba8_host[w*h]. */
+int blok_hip_shade_rgba8(blok_hip_ctx* ctx, const blok_camera* cam,
+                         uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
+                         uint32_t* out_rgba8_host);
+
+/* = CudaTracer::resetAccum (reference blok/src/cuda_tracer.cu:450-454). */
+int blok_hip_reset_accum(blok_hip_ctx* ctx);
+
+/* Milliseconds of the most recent trace kernel, measured with HIP events recorded on the
+ * launch stream around the kernel only (valid after that stream has been synchronised). */
+int blok_hip_last_kernel_ms(blok_hip_ctx* ctx, float* out_ms);
+
+/* Enable/disable the per-launch HIP event pair (default off: nothing but the kernel is
+ * enqueued by the *_device entries). */
+int blok_hip_set_timing(blok_hip_ctx* ctx, int enabled);
+
+/* Library/ABI version: (major<<16)|minor. */
+uint32_t blok_hip_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BLOK_HIP_H */

@@ -1,0 +1,89 @@
+/*
+ * blok_world.h — C ABI of the host-side voxel data model that feeds the trace path:
+ * Morton codec, per-chunk sparse-voxel-octree build, sub-chunk packing, plus the
+ * synthetic scene / camera helpers the benchmark uses.  Host code only (no GPU).
+ *
+ * Each entry names the reference interface it stands in for.  Byte layout of the
+ * emitted records is the reference's (see blok_hip.h).  One documented deviation:
+ * chunks are packed in sorted (cz,cy,cx) order; the reference iterates an
+ * std::unordered_map (reference blok/src/chunk_manager.cpp:249), so its chunk order is
+ * unspecified.  Node order inside a chunk is the reference's.
+ */
+#ifndef BLOK_WORLD_H
+#define BLOK_WORLD_H
+
+#include "blok_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ----------------------------------------------------------------- morton */
+/* = blok::morton3d::encode / decode / octantFromCode
+ *   (reference blok/include/morton.hpp:23-33,46-53,55-58). */
+uint64_t blok_morton_encode(int32_t x, int32_t y, int32_t z);
+void     blok_morton_decode(uint64_t code, int32_t* x, int32_t* y, int32_t* z);
+uint32_t blok_morton_octant(uint64_t code, uint32_t max_depth, uint32_t level);
+
+/* ------------------------------------------------------------------ world */
+typedef struct blok_world blok_world;
+
+/* = ChunkManager::ChunkManager(C, voxelSize) (reference blok/src/chunk_manager.cpp:19-25).
+ * chunk_size must be a power of two >= 8 (the reference app uses 128, app.cpp:37). */
+int  blok_world_create(blok_world** out, uint32_t chunk_size, float voxel_size);
+void blok_world_destroy(blok_world* w);
+const char* blok_world_last_error(const blok_world* w);
+
+/* = ChunkManager::setVoxelMaterial(worldPos, materialId, density)
+ *   (reference blok/src/chunk_manager.cpp:316-328): floor -> chunk -> local, last write wins,
+ *   marks the chunk dirty. */
+int blok_world_set_voxel(blok_world* w, const float world_pos[3], uint32_t material_id, float density);
+/* Bulk integer form of the same write (global voxel coordinates, density 1). */
+int blok_world_set_voxels(blok_world* w, const int32_t* xyz, const uint32_t* material_ids, size_t n);
+/* = ChunkManager::getVoxelMaterial (reference blok/src/chunk_manager.cpp:330-348). */
+uint32_t blok_world_get_voxel_material(const blok_world* w, const float world_pos[3]);
+
+/* = rebuildDirtyChunks(mgr, maxPerFrame) (reference blok/src/chunk_manager.cpp:121-140):
+ *   clear + re-insert every density>0 voxel in z,y,x order (x fastest, :106-119) through
+ *   SvoTree::insertVoxel (reference blok/src/svo.cpp:59-101).  Returns chunks rebuilt (>=0). */
+int blok_world_rebuild_dirty(blok_world* w, int max_per_frame);
+
+/* = packChunksToGpuSvo (reference blok/src/chunk_manager.cpp:234-314). */
+int blok_world_pack(blok_world* w);
+size_t blok_world_node_count(const blok_world* w);
+size_t blok_world_sub_chunk_count(const blok_world* w);
+const blok_svo_node*  blok_world_nodes(const blok_world* w);
+const blok_sub_chunk* blok_world_sub_chunks(const blok_world* w);
+
+/* Per-chunk view (sorted order), for parity tests against the oracle's node arrays. */
+size_t blok_world_chunk_count(const blok_world* w);
+int    blok_world_chunk_info(const blok_world* w, size_t i, int32_t coord[3], uint64_t* n_nodes);
+const blok_svo_node* blok_world_chunk_nodes(const blok_world* w, size_t i);
+/* = SvoTree::findLeaf (reference blok/src/svo.cpp:103-130): node index in chunk i, or -1. */
+int64_t blok_world_find_leaf(const blok_world* w, size_t i, uint32_t x, uint32_t y, uint32_t z);
+
+/* ----------------------------------------------------------------- camera */
+/* = blok::Camera::forward/right/up + toDevice(Camera,w,h)
+ *   (reference blok/include/camera.hpp:25-42, blok/src/cuda_tracer.cu:404-415). */
+int blok_camera_from_yaw_pitch(const float pos[3], float yaw_deg, float pitch_deg, float fov_deg,
+                               uint32_t width, uint32_t height, blok_camera* out);
+/* Look-at convenience: derives yaw/pitch, then as above. */
+int blok_camera_look_at(const float pos[3], const float target[3], float fov_deg,
+                        uint32_t width, uint32_t height, blok_camera* out);
+
+/* ------------------------------------------------- synthetic benchmark scene */
+/* Integer-only generator G(N, seed) of SURVEY.md §8(d): terrain shell + 64 shell spheres,
+ * materialId in [1,255].  Writes into `w` (chunk size as created), then the caller
+ * rebuilds and packs.  Not reference behaviour — benchmark input synthesis. */
+int blok_scene_generate(blok_world* w, uint32_t n, uint32_t seed, uint64_t* out_n_voxels);
+/* Same voxel set as a dense id grid ids[x + y*n + z*n*n] (0 = empty); n <= 512. */
+int blok_scene_generate_dense(uint32_t n, uint32_t seed, uint32_t* ids, uint64_t* out_n_voxels);
+/* 256 hashed diffuse materials (roughness 0.5, metallic 0: reference material.cpp:102-106). */
+int blok_scene_materials(uint32_t seed, blok_material* out256);
+/* Poses A(0) outside-corner, B(1) inside-grazing, C(2) top-down of SURVEY.md §8(d). */
+int blok_scene_camera(uint32_t n, uint32_t seed, int pose, uint32_t width, uint32_t height, blok_camera* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BLOK_WORLD_H */

@@ -1,0 +1,813 @@
+// blok_oracle.cpp — CPU restatement of the reference's voxel trace path.
+//
+// TEST INFRASTRUCTURE ONLY.  Nothing shipped may import, link or call this file: only
+// tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg load liboracle.so.
+//
+// What is restated, and from where (paths relative to the reference tree):
+//   morton3d            blok/include/morton.hpp:12-58
+//   SvoTree             blok/src/svo.cpp:36-130, blok/include/svo.hpp:20-46
+//   ChunkManager        blok/src/chunk_manager.cpp:19-140,316-348 (dense per-chunk store, literal)
+//   packChunksToGpuSvo  blok/src/chunk_manager.cpp:144-314 (chunks visited in sorted (cz,cy,cx)
+//                       order; the reference's unordered_map order is unspecified)
+//   intersect.rint      assets/shaders/intersect.rint:47-68,70-206 (line for line)
+//   traceRayEXT         procedural-hit acceptance: a reported t is accepted iff
+//                       tmin <= t <= current tmax, and then becomes the current tmax;
+//                       closest hit = last accepted (Vulkan ray-tracing pipeline semantics,
+//                       call site assets/shaders/raygen.rgen:217-229)
+//   hit.rchit           assets/shaders/hit.rchit:46-76 (face LUT, material fetch, unpack)
+//   primary ray         blok/src/cuda_tracer.cu:276-282 with zero jitter (the compute backend's
+//                       matrix-free form; algebraically assets/shaders/raygen.rgen:201-205)
+//
+// PARITY PIN STATUS.  The reference holds no tests, golden vectors or fixtures for this path
+// (SURVEY.md §4, §8c), and nothing on it except morton.hpp compiles here: svo.hpp includes
+// <glm.hpp> and chunk_manager.hpp pulls vulkan.hpp/vk_mem_alloc.h, all absent from the tree
+// and the image, and the GLSL shaders have no compiler or device.  Therefore:
+//   - morton: PINNED against the reference header compiled in place (oracle/_ref, see Makefile);
+//   - everything else: "parity unpinned" — a line-by-line restatement, cross-validated only
+//     against independent brute-force formulations in this file (trace_voxels_bruteforce,
+//     get_voxel_material point queries).
+//
+// Build: g++ -O2 -ffp-contract=off (no fast-math): every float op below is one IEEE-754
+// binary32 operation, in the order written.
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <thread>
+#include <tuple>
+#include <vector>
+
+namespace {
+
+// ---------------------------------------------------------------- records (reference layouts)
+struct SvoNode {            // blok/include/svo.hpp:23-28
+    uint32_t childMask;
+    uint32_t firstChild;
+    uint32_t materialId;
+    float    occupancy;
+};
+static_assert(sizeof(SvoNode) == 16, "SvoNode is 16 bytes");
+
+struct SubChunkGpu {        // blok/include/resources.hpp:170-184
+    uint32_t nodeOffset, rootNodeIndex, nodeCount, startDepth;
+    float worldMin[3];
+    float subChunkSize;
+    float worldMax[3];
+    float pad0;
+};
+static_assert(sizeof(SubChunkGpu) == 48, "SubChunkGpu is 48 bytes");
+
+struct MaterialGpu {        // blok/include/material.hpp:88-114
+    float albedo[3];
+    uint32_t flags;
+    float emission[3];
+    float ior;
+};
+static_assert(sizeof(MaterialGpu) == 32, "MaterialGpu is 32 bytes");
+
+struct Camera {             // blok/src/cuda_tracer.cu:51-58
+    float pos[3], fwd[3], right[3], up[3];
+    float fovScale, aspect;
+};
+
+struct Ray { float org[3]; float tmin; float dir[3]; float tmax; };
+
+struct Hit {                // include/blok_hip.h: blok_hit
+    float t;
+    uint32_t materialId;
+    int16_t voxel[3];
+    uint8_t face;
+    uint8_t hit;
+};
+static_assert(sizeof(Hit) == 16, "hit record is 16 bytes");
+
+struct Counters {
+    uint64_t rays, hits;
+    uint64_t subChunksEntered;   // S: intersection-shader invocations whose root slab test passed
+    uint64_t nodesFetched;       // P: fetches at intersect.rint:133
+    uint64_t iterLimitHits;      // times the MAX_ITER guard ended a walk with work left
+    uint64_t stackLimitHits;     // pushes dropped by the MAX_STACK guard
+    uint64_t maxStack, maxIter;
+    uint64_t ties;               // brute-force formulations: rays whose minimum t is not unique
+};
+
+constexpr uint32_t INVALID_NODE_INDEX = 0xFFFFFFFFu;    // svo.hpp:20
+
+// ---------------------------------------------------------------- morton (morton.hpp:12-58)
+uint64_t spreadBits(uint32_t v) {
+    uint64_t x = v & 0x1fffff;
+    x = (x | (x << 32)) & 0x1f00000000ffffULL;
+    x = (x | (x << 16)) & 0x1f0000ff0000ffULL;
+    x = (x | (x << 8)) & 0x100f00f00f00f00fULL;
+    x = (x | (x << 4)) & 0x10c30c30c30c30c3ULL;
+    x = (x | (x << 2)) & 0x1249249249249249ULL;
+    return x;
+}
+uint64_t mortonEncode(int32_t x, int32_t y, int32_t z) {
+    const int32_t BIAS = 1 << 20;
+    uint32_t xs = x + BIAS, ys = y + BIAS, zs = z + BIAS;
+    return spreadBits(xs) | (spreadBits(ys) << 1) | (spreadBits(zs) << 2);
+}
+uint32_t compactBits(uint64_t v) {
+    v &= 0x1249249249249249ULL;
+    v = (v ^ (v >> 2)) & 0x10c30c30c30c30c3ULL;
+    v = (v ^ (v >> 4)) & 0x100f00f00f00f00fULL;
+    v = (v ^ (v >> 8)) & 0x1f0000ff0000ffULL;
+    v = (v ^ (v >> 16)) & 0x1f00000000ffffULL;
+    v = (v ^ (v >> 32)) & 0x1fffffULL;
+    return static_cast<uint32_t>(v);
+}
+uint32_t octantFromCode(uint64_t code, uint32_t maxDepth, uint32_t level) {
+    return static_cast<uint32_t>((code >> (3u * (maxDepth - 1u - level))) & 0x7ull);
+}
+
+// ---------------------------------------------------------------- SvoTree (svo.cpp)
+struct SvoTree {
+    std::vector<SvoNode> nodes;
+    uint32_t maxDepth = 0;
+
+    static SvoNode emptyNode() { return SvoNode{0u, INVALID_NODE_INDEX, 0u, 0.0f}; }   // :11-18
+    void clear() { nodes.clear(); nodes.push_back(emptyNode()); }                       // :27-31
+
+    uint32_t ensureChildren(uint32_t nodeIndex) {                                       // :36-57
+        if (nodes[nodeIndex].firstChild != INVALID_NODE_INDEX) return nodes[nodeIndex].firstChild;
+        const uint32_t firstChild = static_cast<uint32_t>(nodes.size());
+        nodes.resize(nodes.size() + 8);
+        for (uint32_t i = 0; i < 8; ++i) nodes[firstChild + i] = emptyNode();
+        nodes[nodeIndex].firstChild = firstChild;
+        return firstChild;
+    }
+    void insertVoxel(uint32_t x, uint32_t y, uint32_t z, uint32_t materialId, float density) {  // :59-101
+        if (density <= 0.0f) return;
+        const uint32_t dim = 1u << maxDepth;
+        if (x >= dim || y >= dim || z >= dim) return;
+        const uint64_t code = mortonEncode(x, y, z);
+        uint32_t nodeIndex = 0;
+        uint32_t pathNode[32], pathOct[32];
+        for (uint32_t level = 0; level < maxDepth; ++level) {
+            pathNode[level] = nodeIndex;
+            const uint32_t oct = octantFromCode(code, maxDepth, level);
+            pathOct[level] = oct;
+            nodeIndex = ensureChildren(nodeIndex) + oct;
+        }
+        nodes[nodeIndex].materialId = materialId;
+        nodes[nodeIndex].occupancy = density;
+        for (int level = static_cast<int>(maxDepth) - 1; level >= 0; --level)
+            nodes[pathNode[level]].childMask |= (1u << pathOct[level]);
+    }
+    int64_t findLeaf(uint32_t x, uint32_t y, uint32_t z) const {                         // :103-130
+        const uint32_t dim = 1u << maxDepth;
+        if (x >= dim || y >= dim || z >= dim) return -1;
+        const uint64_t code = mortonEncode(x, y, z);
+        uint32_t nodeIndex = 0;
+        for (uint32_t level = 0; level < maxDepth; ++level) {
+            const uint32_t oct = octantFromCode(code, maxDepth, level);
+            const SvoNode& node = nodes[nodeIndex];
+            if ((node.childMask & (1u << oct)) == 0u) return -1;
+            if (node.firstChild == INVALID_NODE_INDEX) return -1;
+            nodeIndex = node.firstChild + oct;
+        }
+        if (nodes[nodeIndex].occupancy <= 0.0f) return -1;
+        return nodeIndex;
+    }
+};
+
+// ---------------------------------------------------------------- ChunkManager (chunk_manager.cpp)
+constexpr uint32_t SUB_CHUNK_DIVISIONS = 8;     // :17
+
+struct Chunk {                                   // chunk.hpp:33-42
+    int32_t cx, cy, cz;
+    std::vector<float> density;
+    std::vector<uint32_t> materialIds;
+    bool dirty = true;
+    SvoTree svo;
+};
+
+struct World {
+    uint32_t C; float voxelSize; uint32_t maxDepth;
+    std::map<std::tuple<int32_t, int32_t, int32_t>, Chunk*> chunks;   // key (cz,cy,cx)
+    std::vector<SvoNode> globalNodes;
+    std::vector<SubChunkGpu> globalSubChunks;
+
+    World(uint32_t C_, float vs) : C(C_), voxelSize(vs), maxDepth(0) {
+        while ((1u << maxDepth) < C) maxDepth++;                        // :21-24
+    }
+    ~World() { for (auto& kv : chunks) delete kv.second; }
+
+    int32_t toChunk(int32_t g) const {                                  // :41-47
+        const int32_t c = static_cast<int32_t>(C);
+        return g >= 0 ? g / c : (g - c + 1) / c;
+    }
+    Chunk* getOrCreate(int32_t cx, int32_t cy, int32_t cz) {            // :61-75
+        auto key = std::make_tuple(cz, cy, cx);
+        auto it = chunks.find(key);
+        if (it != chunks.end()) return it->second;
+        Chunk* ch = new Chunk();
+        ch->cx = cx; ch->cy = cy; ch->cz = cz;
+        ch->density.assign(static_cast<size_t>(C) * C * C, 0.0f);
+        ch->materialIds.assign(static_cast<size_t>(C) * C * C, 0u);
+        ch->svo.maxDepth = maxDepth;
+        ch->svo.clear();
+        chunks[key] = ch;
+        return ch;
+    }
+    void setVoxelMaterial(float px, float py, float pz, uint32_t materialId, float density) {   // :316-328
+        const int32_t gx = int(std::floor(px)), gy = int(std::floor(py)), gz = int(std::floor(pz));
+        const int32_t cx = toChunk(gx), cy = toChunk(gy), cz = toChunk(gz);
+        const int32_t lx = gx - cx * int32_t(C), ly = gy - cy * int32_t(C), lz = gz - cz * int32_t(C);
+        Chunk* ch = getOrCreate(cx, cy, cz);
+        const size_t idx = size_t(lx) + size_t(ly) * C + size_t(lz) * C * C;   // :57-59
+        ch->density[idx] = density;
+        ch->materialIds[idx] = materialId;
+        ch->dirty = true;
+    }
+    uint32_t getVoxelMaterial(float px, float py, float pz) const {    // :330-348
+        const int32_t gx = int(std::floor(px)), gy = int(std::floor(py)), gz = int(std::floor(pz));
+        const int32_t cx = toChunk(gx), cy = toChunk(gy), cz = toChunk(gz);
+        auto it = chunks.find(std::make_tuple(cz, cy, cx));
+        if (it == chunks.end()) return 0;
+        const int32_t lx = gx - cx * int32_t(C), ly = gy - cy * int32_t(C), lz = gz - cz * int32_t(C);
+        const size_t idx = size_t(lx) + size_t(ly) * C + size_t(lz) * C * C;
+        const Chunk* ch = it->second;
+        if (ch->density[idx] <= 0.0f) return 0;
+        return ch->materialIds[idx];
+    }
+    int rebuildDirtyChunks(int maxPerFrame) {                           // :106-140
+        int count = 0;
+        for (auto& kv : chunks) {
+            Chunk* ch = kv.second;
+            if (!ch->dirty) continue;
+            if (count >= maxPerFrame) break;
+            ch->svo.clear();
+            for (uint32_t z = 0; z < C; ++z)
+                for (uint32_t y = 0; y < C; ++y)
+                    for (uint32_t x = 0; x < C; ++x) {
+                        const size_t idx = x + size_t(y) * C + size_t(z) * C * C;
+                        const float d = ch->density[idx];
+                        if (d > 0.0f) ch->svo.insertVoxel(x, y, z, ch->materialIds[idx], d);
+                    }
+            ch->dirty = false;
+            count++;
+        }
+        return count;
+    }
+
+    static bool subChunkHasGeometry(const std::vector<SvoNode>& nodes, uint32_t subX, uint32_t subY,
+                                    uint32_t subZ, uint32_t subDivisions) {     // :144-193
+        if (nodes.empty()) return false;
+        uint32_t subChunkDepth = 0;
+        while ((1u << subChunkDepth) < subDivisions) subChunkDepth++;
+        uint32_t nodeIndex = 0;
+        for (uint32_t level = 0; level < subChunkDepth; level++) {
+            const SvoNode& node = nodes[nodeIndex];
+            const uint32_t levelDivisions = 1u << (level + 1);
+            const uint32_t cellSize = subDivisions / levelDivisions;
+            const uint32_t octant = ((subX / cellSize) & 1) | (((subY / cellSize) & 1) << 1) |
+                                    (((subZ / cellSize) & 1) << 2);
+            if ((node.childMask & (1u << octant)) == 0) return false;
+            if (node.firstChild == 0xFFFFFFFFu) return false;
+            nodeIndex = node.firstChild + octant;
+            if (nodeIndex >= nodes.size()) return false;
+        }
+        const SvoNode& subRoot = nodes[nodeIndex];
+        return subRoot.childMask != 0 || subRoot.occupancy > 0.0f;
+    }
+    static uint32_t findSubChunkRootNode(const std::vector<SvoNode>& nodes, uint32_t subX, uint32_t subY,
+                                         uint32_t subZ, uint32_t subDivisions) { // :196-232
+        if (nodes.empty()) return 0;
+        uint32_t subChunkDepth = 0;
+        while ((1u << subChunkDepth) < subDivisions) subChunkDepth++;
+        uint32_t nodeIndex = 0;
+        for (uint32_t level = 0; level < subChunkDepth; level++) {
+            const SvoNode& node = nodes[nodeIndex];
+            const uint32_t levelDivisions = 1u << (level + 1);
+            const uint32_t cellSize = subDivisions / levelDivisions;
+            const uint32_t octant = ((subX / cellSize) & 1) | (((subY / cellSize) & 1) << 1) |
+                                    (((subZ / cellSize) & 1) << 2);
+            if (node.firstChild == 0xFFFFFFFFu) return nodeIndex;
+            nodeIndex = node.firstChild + octant;
+            if (nodeIndex >= nodes.size()) return 0;
+        }
+        return nodeIndex;
+    }
+    void pack() {                                                       // :234-314
+        globalNodes.clear();
+        globalSubChunks.clear();
+        uint32_t nodeOffset = 0;
+        uint32_t subChunkDepth = 0;
+        while ((1u << subChunkDepth) < SUB_CHUNK_DIVISIONS) subChunkDepth++;
+        for (auto& kv : chunks) {
+            const Chunk* ch = kv.second;
+            const auto& nodes = ch->svo.nodes;
+            if (nodes.empty()) continue;
+            float chunkOrigin[3] = {static_cast<float>(ch->cx * static_cast<int32_t>(C)),
+                                    static_cast<float>(ch->cy * static_cast<int32_t>(C)),
+                                    static_cast<float>(ch->cz * static_cast<int32_t>(C))};
+            for (float& o : chunkOrigin) o *= voxelSize;
+            const float chunkWorldSize = static_cast<float>(C) * voxelSize;
+            const float subChunkWorldSize = chunkWorldSize / static_cast<float>(SUB_CHUNK_DIVISIONS);
+            for (uint32_t sz = 0; sz < SUB_CHUNK_DIVISIONS; sz++)
+                for (uint32_t sy = 0; sy < SUB_CHUNK_DIVISIONS; sy++)
+                    for (uint32_t sx = 0; sx < SUB_CHUNK_DIVISIONS; sx++) {
+                        if (!subChunkHasGeometry(nodes, sx, sy, sz, SUB_CHUNK_DIVISIONS)) continue;
+                        const uint32_t subRootNode = findSubChunkRootNode(nodes, sx, sy, sz, SUB_CHUNK_DIVISIONS);
+                        SubChunkGpu sub{};
+                        sub.nodeOffset = nodeOffset;
+                        sub.rootNodeIndex = subRootNode;
+                        sub.nodeCount = static_cast<uint32_t>(nodes.size());
+                        sub.startDepth = subChunkDepth;
+                        sub.worldMin[0] = chunkOrigin[0] + static_cast<float>(sx) * subChunkWorldSize;
+                        sub.worldMin[1] = chunkOrigin[1] + static_cast<float>(sy) * subChunkWorldSize;
+                        sub.worldMin[2] = chunkOrigin[2] + static_cast<float>(sz) * subChunkWorldSize;
+                        sub.subChunkSize = subChunkWorldSize;
+                        for (int a = 0; a < 3; ++a) sub.worldMax[a] = sub.worldMin[a] + subChunkWorldSize;
+                        globalSubChunks.push_back(sub);
+                    }
+            globalNodes.insert(globalNodes.end(), nodes.begin(), nodes.end());
+            nodeOffset += static_cast<uint32_t>(nodes.size());
+        }
+    }
+};
+
+// ---------------------------------------------------------------- intersect.rint
+constexpr uint32_t MAX_STACK = 24u;     // :42
+constexpr uint32_t MAX_ITER = 256u;     // :43
+
+struct Vec3 { float x, y, z; };
+inline Vec3 sub3(Vec3 a, Vec3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline Vec3 add3(Vec3 a, Vec3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline Vec3 mul3(Vec3 a, Vec3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+inline Vec3 scale3(Vec3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+inline Vec3 min3v(Vec3 a, Vec3 b) { return {std::fmin(a.x, b.x), std::fmin(a.y, b.y), std::fmin(a.z, b.z)}; }
+inline Vec3 max3v(Vec3 a, Vec3 b) { return {std::fmax(a.x, b.x), std::fmax(a.y, b.y), std::fmax(a.z, b.z)}; }
+
+// :47-55
+inline void intersectAABB_Root(Vec3 origin, Vec3 invDir, Vec3 boxMin, Vec3 boxMax, float& tNear, float& tFar) {
+    const Vec3 t0 = mul3(sub3(boxMin, origin), invDir);
+    const Vec3 t1 = mul3(sub3(boxMax, origin), invDir);
+    const Vec3 tmin = min3v(t0, t1), tmax = max3v(t0, t1);
+    tNear = std::fmax(std::fmax(tmin.x, tmin.y), tmin.z);
+    tFar = std::fmin(std::fmin(tmax.x, tmax.y), tmax.z);
+}
+// :58-68
+inline uint32_t getHitFace(Vec3 hitPos, Vec3 center) {
+    const Vec3 diff = sub3(hitPos, center);
+    const Vec3 a = {std::fabs(diff.x), std::fabs(diff.y), std::fabs(diff.z)};
+    if (a.x >= a.y && a.x >= a.z) return diff.x > 0.0f ? 0u : 1u;
+    if (a.y >= a.z) return diff.y > 0.0f ? 2u : 3u;
+    return diff.z > 0.0f ? 4u : 5u;
+}
+// :79   1.0 / mix(rayDir, vec3(1e-6), lessThan(abs(rayDir), vec3(1e-6)))
+inline Vec3 safeInvDir(Vec3 d) {
+    auto one = [](float c) { return 1.0f / (std::fabs(c) < 1e-6f ? 1e-6f : c); };
+    return {one(d.x), one(d.y), one(d.z)};
+}
+
+// State of one traceRayEXT: the live interval and the committed procedural hit.
+struct RayQuery {
+    Vec3 org, dir;
+    float tmin, tmax;        // gl_RayTminEXT, gl_RayTmaxEXT (tmax shrinks on every accepted hit)
+    bool committed = false;
+    float hitT = -1.0f;
+    uint32_t hitKind = 0xFF, materialId = 0;
+    Vec3 leafCenter{0, 0, 0};
+    // reportIntersectionEXT
+    bool report(float t, uint32_t kind, uint32_t mat, Vec3 center) {
+        if (!(t >= tmin && t <= tmax)) return false;
+        tmax = t; committed = true; hitT = t; hitKind = kind; materialId = mat; leafCenter = center;
+        return true;
+    }
+};
+
+struct StackItem { uint32_t nodeIndex; Vec3 center; float halfSize, tEntry, tExit; };  // :100-106
+
+// main(), :70-206.  Returns true if the root slab test passed (the invocation "entered" the AABB).
+bool intersectSubChunk(RayQuery& q, const SubChunkGpu& sub, const SvoNode* nodes, Counters& c) {
+    const Vec3 rayOrg = q.org, rayDir = q.dir;
+    const Vec3 invDir = safeInvDir(rayDir);
+    const Vec3 wmin = {sub.worldMin[0], sub.worldMin[1], sub.worldMin[2]};
+    const Vec3 wmax = {sub.worldMax[0], sub.worldMax[1], sub.worldMax[2]};
+    float rootNear, rootFar;
+    intersectAABB_Root(rayOrg, invDir, wmin, wmax, rootNear, rootFar);          // :82
+    const float tMin = std::fmax(rootNear, q.tmin);                               // :85
+    const float tMax = std::fmin(rootFar, q.tmax);                                // :86
+    if (tMin > tMax) return false;                                                // :88
+
+    uint32_t octantMask = 0u;                                                     // :94-97
+    if (rayDir.x < 0.0f) octantMask |= 1u;
+    if (rayDir.y < 0.0f) octantMask |= 2u;
+    if (rayDir.z < 0.0f) octantMask |= 4u;
+
+    StackItem stack[MAX_STACK];
+    uint32_t stackPtr = 0u;
+    const Vec3 rootSize = sub3(wmax, wmin);                                       // :112
+    stack[stackPtr++] = StackItem{sub.nodeOffset + sub.rootNodeIndex,
+                                  add3(wmin, scale3(rootSize, 0.5f)), rootSize.x * 0.5f, tMin, tMax};
+    uint32_t iter = 0u;
+    while (stackPtr > 0u && iter++ < MAX_ITER) {                                  // :123
+        const StackItem item = stack[--stackPtr];
+        if (item.tEntry >= q.tmax) continue;                                      // :128
+        if (item.nodeIndex >= sub.nodeOffset + sub.nodeCount) continue;           // :132
+        const SvoNode node = nodes[item.nodeIndex];                               // :133
+        c.nodesFetched++;
+        if (node.childMask == 0u) {                                               // :136
+            if (node.occupancy > 0.0f) {
+                const Vec3 hitPos = add3(rayOrg, scale3(rayDir, item.tEntry));    // :138
+                const uint32_t faceID = getHitFace(hitPos, item.center);
+                q.report(item.tEntry, faceID, node.materialId, item.center);      // :139-141
+            }
+            continue;
+        }
+        // :148-160 compute tPlane/xIn/yIn/zIn/spans, none of which is read afterwards.
+        const float nextHalf = item.halfSize * 0.5f;                              // :162
+        for (int i = 7; i >= 0; i--) {                                            // :164
+            const uint32_t childIdx = uint32_t(i) ^ octantMask;
+            if ((node.childMask & (1u << childIdx)) == 0u) continue;              // :169
+            Vec3 childOff;
+            childOff.x = (childIdx & 1u) != 0u ? item.halfSize : -item.halfSize;  // :173-175
+            childOff.y = (childIdx & 2u) != 0u ? item.halfSize : -item.halfSize;
+            childOff.z = (childIdx & 4u) != 0u ? item.halfSize : -item.halfSize;
+            const Vec3 childCenter = add3(item.center, scale3(childOff, 0.5f));   // :177
+            const Vec3 nh = {nextHalf, nextHalf, nextHalf};
+            const Vec3 tC0 = mul3(sub3(sub3(childCenter, nh), rayOrg), invDir);   // :179
+            const Vec3 tC1 = mul3(sub3(add3(childCenter, nh), rayOrg), invDir);   // :180
+            const Vec3 tMinV = min3v(tC0, tC1), tMaxV = max3v(tC0, tC1);
+            float cTmin = std::fmax(std::fmax(tMinV.x, tMinV.y), tMinV.z);        // :185
+            float cTmax = std::fmin(std::fmin(tMaxV.x, tMaxV.y), tMaxV.z);        // :186
+            cTmin = std::fmax(cTmin, item.tEntry);                                // :189
+            cTmax = std::fmin(cTmax, item.tExit);                                 // :190
+            if (cTmin < cTmax) {                                                  // :193
+                if (stackPtr < MAX_STACK) {
+                    stack[stackPtr++] = StackItem{sub.nodeOffset + node.firstChild + childIdx,
+                                                  childCenter, nextHalf, cTmin, cTmax};
+                    if (stackPtr > c.maxStack) c.maxStack = stackPtr;
+                } else {
+                    c.stackLimitHits++;
+                }
+            }
+        }
+    }
+    if (iter > c.maxIter) c.maxIter = std::min(iter, MAX_ITER);
+    if (stackPtr > 0u) c.iterLimitHits++;
+    return true;
+}
+
+inline void commitHit(const RayQuery& q, Hit& out) {
+    if (!q.committed) {                                   // miss.rmiss:25-27
+        out.t = -1.0f; out.materialId = 0; out.voxel[0] = out.voxel[1] = out.voxel[2] = 0;
+        out.face = 0xFF; out.hit = 0;
+        return;
+    }
+    out.t = q.hitT;                                       // hit.rchit:74
+    out.materialId = q.materialId;                        // hit.rchit:62 input
+    out.voxel[0] = static_cast<int16_t>(std::floor(q.leafCenter.x));
+    out.voxel[1] = static_cast<int16_t>(std::floor(q.leafCenter.y));
+    out.voxel[2] = static_cast<int16_t>(std::floor(q.leafCenter.z));
+    out.face = static_cast<uint8_t>(q.hitKind);           // hit.rchit:58
+    out.hit = 1;
+}
+
+// -------- candidate generation ---------------------------------------------------------------
+// The reference leaves "which sub-chunk AABBs does the ray touch" to RT hardware.  Two stand-ins:
+//  (1) brute force: every sub-chunk, in array order (a BVH-less device) — the literal baseline;
+//  (2) a lattice of sub-chunk slots walked front to back — scalable, and it defines S_r
+//      (descriptors entered up to the hit) for the algorithmic byte count.
+struct Lattice {
+    float cell = 16.0f;
+    int32_t origin[3] = {0, 0, 0};     // world coordinate of slot (0,0,0), in voxels
+    int32_t dims[3] = {0, 0, 0};
+    std::vector<int32_t> slot;         // sub-chunk index or -1
+    int32_t at(int32_t x, int32_t y, int32_t z) const {
+        if (x < 0 || y < 0 || z < 0 || x >= dims[0] || y >= dims[1] || z >= dims[2]) return -1;
+        return slot[size_t(x) + size_t(dims[0]) * (size_t(y) + size_t(dims[1]) * size_t(z))];
+    }
+};
+
+// t of the axis-aligned plane at world coordinate p: same two operations, same order, as every
+// slab test in intersect.rint ((plane - rayOrg) * invDir, :48-49,:179-180).
+inline float planeT(float p, float o, float inv) { return (p - o) * inv; }
+
+void traceLattice(const Lattice& L, const SvoNode* nodes, const SubChunkGpu* subs, RayQuery& q, Counters& c) {
+    const Vec3 inv = safeInvDir(q.dir);
+    const float o[3] = {q.org.x, q.org.y, q.org.z};
+    const float iv[3] = {inv.x, inv.y, inv.z};
+    // entry/exit of the lattice box
+    float tEnter = -INFINITY, tExit = INFINITY;
+    for (int a = 0; a < 3; ++a) {
+        const float lo = planeT(float(L.origin[a]), o[a], iv[a]);
+        const float hi = planeT(float(L.origin[a]) + L.cell * float(L.dims[a]), o[a], iv[a]);
+        tEnter = std::fmax(tEnter, std::fmin(lo, hi));
+        tExit = std::fmin(tExit, std::fmax(lo, hi));
+    }
+    const float tStart = std::fmax(tEnter, q.tmin);
+    if (!(tStart <= std::fmin(tExit, q.tmax))) return;
+    // starting slot: per axis, count lattice planes already crossed at tStart (in ray order)
+    int32_t idx[3], step[3];
+    float tNext[3];
+    for (int a = 0; a < 3; ++a) {
+        step[a] = iv[a] > 0.0f ? 1 : -1;
+        // largest j in [0, dims-1] whose j-th interior plane (ray order) has t <= tStart; the
+        // plane t's are non-decreasing in ray order, so bisect
+        int32_t lo = 0, hi = L.dims[a] - 1;
+        while (lo < hi) {
+            const int32_t j = (lo + hi + 1) / 2;
+            const int32_t planeIdx = step[a] > 0 ? j : L.dims[a] - j;
+            if (planeT(float(L.origin[a]) + L.cell * float(planeIdx), o[a], iv[a]) <= tStart) lo = j; else hi = j - 1;
+        }
+        const int32_t crossed = lo;
+        idx[a] = step[a] > 0 ? crossed : L.dims[a] - 1 - crossed;
+        const int32_t farPlane = step[a] > 0 ? idx[a] + 1 : idx[a];
+        tNext[a] = planeT(float(L.origin[a]) + L.cell * float(farPlane), o[a], iv[a]);
+    }
+    float tCur = tStart;
+    for (;;) {
+        if (tCur >= q.tmax) break;     // later slots start at or beyond the committed hit (:128 drops them)
+        const int32_t s = L.at(idx[0], idx[1], idx[2]);
+        if (s >= 0 && intersectSubChunk(q, subs[s], nodes, c)) c.subChunksEntered++;
+        int a = 0;
+        if (tNext[1] < tNext[a]) a = 1;
+        if (tNext[2] < tNext[a]) a = 2;
+        tCur = tNext[a];
+        idx[a] += step[a];
+        if (idx[a] < 0 || idx[a] >= L.dims[a]) break;
+        const int32_t farPlane = step[a] > 0 ? idx[a] + 1 : idx[a];
+        tNext[a] = planeT(float(L.origin[a]) + L.cell * float(farPlane), o[a], iv[a]);
+    }
+}
+
+// Primary ray, blok/src/cuda_tracer.cu:276-282 with jx = jy = 0.
+inline Ray primaryRay(const Camera& cam, uint32_t width, uint32_t height, uint32_t x, uint32_t y) {
+    const float u = (2.0f * ((float(x) + 0.5f) / float(width)) - 1.0f) * cam.fovScale * cam.aspect;
+    const float v = (1.0f - 2.0f * ((float(y) + 0.5f) / float(height))) * cam.fovScale;
+    const Vec3 f = {cam.fwd[0], cam.fwd[1], cam.fwd[2]}, r = {cam.right[0], cam.right[1], cam.right[2]},
+               up = {cam.up[0], cam.up[1], cam.up[2]};
+    const Vec3 d = add3(add3(f, scale3(r, u)), scale3(up, v));
+    const float len = std::sqrt(d.x * d.x + d.y * d.y + d.z * d.z);            // normalize3, :61-64
+    Ray ray;
+    ray.org[0] = cam.pos[0]; ray.org[1] = cam.pos[1]; ray.org[2] = cam.pos[2];
+    ray.dir[0] = d.x / len; ray.dir[1] = d.y / len; ray.dir[2] = d.z / len;
+    ray.tmin = 0.001f;                                                           // raygen.rgen:225
+    ray.tmax = 10000.0f;                                                         // raygen.rgen:227
+    return ray;
+}
+
+inline RayQuery makeQuery(const Ray& r) {
+    RayQuery q;
+    q.org = {r.org[0], r.org[1], r.org[2]};
+    q.dir = {r.dir[0], r.dir[1], r.dir[2]};
+    q.tmin = r.tmin; q.tmax = r.tmax;
+    return q;
+}
+
+void addCounters(Counters& dst, const Counters& src) {
+    dst.rays += src.rays; dst.hits += src.hits;
+    dst.subChunksEntered += src.subChunksEntered; dst.nodesFetched += src.nodesFetched;
+    dst.iterLimitHits += src.iterLimitHits; dst.stackLimitHits += src.stackLimitHits;
+    dst.maxStack = std::max(dst.maxStack, src.maxStack); dst.maxIter = std::max(dst.maxIter, src.maxIter);
+    dst.ties += src.ties;
+}
+
+template <class Fn>
+void parallelFor(size_t n, int threads, Fn&& fn) {
+    threads = std::max(1, threads);
+    if (threads == 1) { fn(0, size_t(0), n); return; }
+    std::vector<std::thread> pool;
+    std::atomic<size_t> next{0};
+    const size_t grain = std::max<size_t>(256, n / (size_t(threads) * 16));
+    for (int t = 0; t < threads; ++t)
+        pool.emplace_back([&, t] {
+            for (;;) {
+                const size_t b = next.fetch_add(grain);
+                if (b >= n) break;
+                fn(t, b, std::min(n, b + grain));
+            }
+        });
+    for (auto& th : pool) th.join();
+}
+
+}  // namespace
+
+// =============================================================================== C interface
+extern "C" {
+
+uint64_t orc_morton_encode(int32_t x, int32_t y, int32_t z) { return mortonEncode(x, y, z); }
+void orc_morton_decode(uint64_t code, int32_t* x, int32_t* y, int32_t* z) {   // morton.hpp:46-53
+    const int32_t BIAS = 1 << 20;
+    *x = static_cast<int32_t>(compactBits(code)) - BIAS;
+    *y = static_cast<int32_t>(compactBits(code >> 1)) - BIAS;
+    *z = static_cast<int32_t>(compactBits(code >> 2)) - BIAS;
+}
+uint32_t orc_morton_octant(uint64_t code, uint32_t maxDepth, uint32_t level) {
+    return octantFromCode(code, maxDepth, level);
+}
+
+// ---- world (ChunkManager) ----
+void* orc_world_new(uint32_t C, float voxelSize) { return new World(C, voxelSize); }
+void orc_world_free(void* w) { delete static_cast<World*>(w); }
+void orc_world_set_voxel(void* w, float x, float y, float z, uint32_t mat, float density) {
+    static_cast<World*>(w)->setVoxelMaterial(x, y, z, mat, density);
+}
+void orc_world_set_voxels(void* w, const int32_t* xyz, const uint32_t* mats, size_t n) {
+    World* W = static_cast<World*>(w);
+    for (size_t i = 0; i < n; ++i)
+        W->setVoxelMaterial(float(xyz[3 * i]), float(xyz[3 * i + 1]), float(xyz[3 * i + 2]), mats[i], 1.0f);
+}
+uint32_t orc_world_get_voxel_material(const void* w, float x, float y, float z) {
+    return static_cast<const World*>(w)->getVoxelMaterial(x, y, z);
+}
+int orc_world_rebuild(void* w, int maxPerFrame) { return static_cast<World*>(w)->rebuildDirtyChunks(maxPerFrame); }
+void orc_world_pack(void* w) { static_cast<World*>(w)->pack(); }
+size_t orc_world_n_nodes(const void* w) { return static_cast<const World*>(w)->globalNodes.size(); }
+size_t orc_world_n_subs(const void* w) { return static_cast<const World*>(w)->globalSubChunks.size(); }
+const void* orc_world_nodes(const void* w) { return static_cast<const World*>(w)->globalNodes.data(); }
+const void* orc_world_subs(const void* w) { return static_cast<const World*>(w)->globalSubChunks.data(); }
+size_t orc_world_n_chunks(const void* w) { return static_cast<const World*>(w)->chunks.size(); }
+int orc_world_chunk_info(const void* w, size_t i, int32_t coord[3], uint64_t* nNodes) {
+    const World* W = static_cast<const World*>(w);
+    if (i >= W->chunks.size()) return -1;
+    auto it = W->chunks.begin();
+    std::advance(it, i);
+    coord[0] = it->second->cx; coord[1] = it->second->cy; coord[2] = it->second->cz;
+    *nNodes = it->second->svo.nodes.size();
+    return 0;
+}
+const void* orc_world_chunk_nodes(const void* w, size_t i) {
+    const World* W = static_cast<const World*>(w);
+    if (i >= W->chunks.size()) return nullptr;
+    auto it = W->chunks.begin();
+    std::advance(it, i);
+    return it->second->svo.nodes.data();
+}
+int64_t orc_world_find_leaf(const void* w, size_t i, uint32_t x, uint32_t y, uint32_t z) {
+    const World* W = static_cast<const World*>(w);
+    if (i >= W->chunks.size()) return -1;
+    auto it = W->chunks.begin();
+    std::advance(it, i);
+    return it->second->svo.findLeaf(x, y, z);
+}
+
+// ---- rays ----
+void orc_primary_rays(const void* cam, uint32_t width, uint32_t height, uint32_t x0, uint32_t y0,
+                      uint32_t w, uint32_t h, uint32_t stride, void* raysOut) {
+    const Camera& c = *static_cast<const Camera*>(cam);
+    Ray* out = static_cast<Ray*>(raysOut);
+    size_t k = 0;
+    for (uint32_t y = y0; y < y0 + h; y += stride)
+        for (uint32_t x = x0; x < x0 + w; x += stride) out[k++] = primaryRay(c, width, height, x, y);
+}
+
+// ---- trace: literal, every sub-chunk in array order ----
+void orc_trace_bruteforce(const void* nodes, const void* subs, size_t nSubs, const void* rays, size_t nRays,
+                          void* hitsOut, void* countersOut) {
+    const SvoNode* N = static_cast<const SvoNode*>(nodes);
+    const SubChunkGpu* S = static_cast<const SubChunkGpu*>(subs);
+    const Ray* R = static_cast<const Ray*>(rays);
+    Hit* H = static_cast<Hit*>(hitsOut);
+    Counters c{};
+    for (size_t i = 0; i < nRays; ++i) {
+        RayQuery q = makeQuery(R[i]);
+        for (size_t s = 0; s < nSubs; ++s)
+            if (intersectSubChunk(q, S[s], N, c)) c.subChunksEntered++;
+        commitHit(q, H[i]);
+        c.rays++; c.hits += H[i].hit;
+    }
+    if (countersOut) *static_cast<Counters*>(countersOut) = c;
+}
+
+// ---- trace: literal shader behind a front-to-back lattice of sub-chunk slots ----
+void* orc_lattice_build(const void* subs, size_t nSubs) {
+    const SubChunkGpu* S = static_cast<const SubChunkGpu*>(subs);
+    Lattice* L = new Lattice();
+    if (nSubs == 0) { L->dims[0] = L->dims[1] = L->dims[2] = 1; L->slot.assign(1, -1); return L; }
+    L->cell = S[0].subChunkSize;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (size_t s = 0; s < nSubs; ++s)
+        for (int a = 0; a < 3; ++a) { lo[a] = std::fmin(lo[a], S[s].worldMin[a]); hi[a] = std::fmax(hi[a], S[s].worldMax[a]); }
+    for (int a = 0; a < 3; ++a) {
+        L->origin[a] = int32_t(lo[a]);
+        L->dims[a] = int32_t((hi[a] - lo[a]) / L->cell + 0.5f);
+    }
+    L->slot.assign(size_t(L->dims[0]) * L->dims[1] * L->dims[2], -1);
+    for (size_t s = 0; s < nSubs; ++s) {
+        int32_t i[3];
+        for (int a = 0; a < 3; ++a) i[a] = int32_t((S[s].worldMin[a] - lo[a]) / L->cell + 0.5f);
+        L->slot[size_t(i[0]) + size_t(L->dims[0]) * (size_t(i[1]) + size_t(L->dims[1]) * size_t(i[2]))] = int32_t(s);
+    }
+    return L;
+}
+void orc_lattice_free(void* L) { delete static_cast<Lattice*>(L); }
+
+void orc_trace_lattice(const void* lattice, const void* nodes, const void* subs, const void* rays, size_t nRays,
+                       void* hitsOut, void* countersOut, int threads) {
+    const Lattice& L = *static_cast<const Lattice*>(lattice);
+    const SvoNode* N = static_cast<const SvoNode*>(nodes);
+    const SubChunkGpu* S = static_cast<const SubChunkGpu*>(subs);
+    const Ray* R = static_cast<const Ray*>(rays);
+    Hit* H = static_cast<Hit*>(hitsOut);
+    std::vector<Counters> per(std::max(1, threads), Counters{});
+    parallelFor(nRays, threads, [&](int t, size_t b, size_t e) {
+        Counters& c = per[t];
+        for (size_t i = b; i < e; ++i) {
+            RayQuery q = makeQuery(R[i]);
+            traceLattice(L, N, S, q, c);
+            commitHit(q, H[i]);
+            c.rays++; c.hits += H[i].hit;
+        }
+    });
+    if (countersOut) {
+        Counters total{};
+        for (auto& c : per) addCounters(total, c);
+        *static_cast<Counters*>(countersOut) = total;
+    }
+}
+
+// Primary rays generated on the fly (no ray buffer): the CPU-baseline entry.  Traces the pixels
+// (x0 + i*stride, y0 + j*stride) of the rectangle, row-major.
+void orc_trace_primary(const void* lattice, const void* nodes, const void* subs, const void* cam,
+                       uint32_t width, uint32_t height, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
+                       uint32_t stride, void* hitsOut, void* countersOut, int threads) {
+    const Lattice& L = *static_cast<const Lattice*>(lattice);
+    const SvoNode* N = static_cast<const SvoNode*>(nodes);
+    const SubChunkGpu* S = static_cast<const SubChunkGpu*>(subs);
+    const Camera& C = *static_cast<const Camera*>(cam);
+    Hit* H = static_cast<Hit*>(hitsOut);
+    const uint32_t cols = (w + stride - 1) / stride, rows = (h + stride - 1) / stride;
+    std::vector<Counters> per(std::max(1, threads), Counters{});
+    parallelFor(size_t(cols) * rows, threads, [&](int t, size_t b, size_t e) {
+        Counters& c = per[t];
+        for (size_t i = b; i < e; ++i) {
+            const uint32_t px = x0 + uint32_t(i % cols) * stride, py = y0 + uint32_t(i / cols) * stride;
+            RayQuery q = makeQuery(primaryRay(C, width, height, px, py));
+            traceLattice(L, N, S, q, c);
+            Hit hit;
+            commitHit(q, hit);
+            if (H) H[i] = hit;
+            c.rays++; c.hits += hit.hit;
+        }
+    });
+    if (countersOut) {
+        Counters total{};
+        for (auto& c : per) addCounters(total, c);
+        *static_cast<Counters*>(countersOut) = total;
+    }
+}
+
+// ---- independent formulation: minimum over ALL filled voxels of the leaf-level slab test ----
+// A filled unit voxel [v, v+1]^3 is reported by intersect.rint iff its own clipped interval is
+// non-empty (the intervals of its ancestors contain it), with t = max(slab entry, tmin); the
+// closest reported one wins.  Quadratic; tiny scenes only.  Counts rays whose minimum is not unique.
+void orc_trace_voxels_bruteforce(const int32_t* xyz, const uint32_t* mats, size_t nVox, const void* rays,
+                                 size_t nRays, void* hitsOut, void* countersOut) {
+    const Ray* R = static_cast<const Ray*>(rays);
+    Hit* H = static_cast<Hit*>(hitsOut);
+    Counters c{};
+    for (size_t i = 0; i < nRays; ++i) {
+        const Vec3 org = {R[i].org[0], R[i].org[1], R[i].org[2]}, dir = {R[i].dir[0], R[i].dir[1], R[i].dir[2]};
+        const Vec3 inv = safeInvDir(dir);
+        float best = INFINITY; size_t bestV = 0; uint32_t nBest = 0;
+        for (size_t v = 0; v < nVox; ++v) {
+            const Vec3 lo = {float(xyz[3 * v]), float(xyz[3 * v + 1]), float(xyz[3 * v + 2])};
+            const Vec3 hi = {lo.x + 1.0f, lo.y + 1.0f, lo.z + 1.0f};
+            float tn, tf;
+            intersectAABB_Root(org, inv, lo, hi, tn, tf);
+            const float a = std::fmax(tn, R[i].tmin), b = std::fmin(tf, R[i].tmax);
+            if (!(a < b)) continue;
+            if (a < best) { best = a; bestV = v; nBest = 1; }
+            else if (a == best) nBest++;
+        }
+        Hit& out = H[i];
+        if (nBest == 0) { out.t = -1.0f; out.materialId = 0; out.voxel[0] = out.voxel[1] = out.voxel[2] = 0; out.face = 0xFF; out.hit = 0; }
+        else {
+            const Vec3 center = {float(xyz[3 * bestV]) + 0.5f, float(xyz[3 * bestV + 1]) + 0.5f, float(xyz[3 * bestV + 2]) + 0.5f};
+            out.t = best; out.materialId = mats[bestV];
+            out.voxel[0] = int16_t(xyz[3 * bestV]); out.voxel[1] = int16_t(xyz[3 * bestV + 1]); out.voxel[2] = int16_t(xyz[3 * bestV + 2]);
+            out.face = uint8_t(getHitFace(add3(org, scale3(dir, best)), center));
+            out.hit = 1;
+            if (nBest > 1) c.ties++;
+        }
+        c.rays++; c.hits += out.hit;
+    }
+    if (countersOut) *static_cast<Counters*>(countersOut) = c;
+}
+
+// ---- hit.rchit: surface record for a hit (normal, albedo, roughness, metallic, emission) ----
+void orc_shade_surface(const void* hit, const void* materials, float out[12]) {
+    static const float FACE_NORMALS[6][3] = {{1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};  // :46-53
+    const Hit& h = *static_cast<const Hit*>(hit);
+    const MaterialGpu& mat = static_cast<const MaterialGpu*>(materials)[std::min(h.materialId, 65535u)];   // :62
+    const float metallic = float((mat.flags >> 24) & 0xFFu) / 255.0f;             // :65
+    const float roughness = float((mat.flags >> 16) & 0xFFu) / 255.0f;            // :66
+    for (int a = 0; a < 3; ++a) out[a] = FACE_NORMALS[h.face][a];
+    for (int a = 0; a < 3; ++a) out[3 + a] = mat.albedo[a];
+    out[6] = std::fmax(roughness, 0.04f);                                          // :72
+    out[7] = metallic;
+    out[8] = h.t;
+    for (int a = 0; a < 3; ++a) out[9 + a] = mat.emission[a];
+}
+
+uint32_t orc_sizeof_counters(void) { return sizeof(Counters); }
+
+}  // extern "C"

@@ -1,0 +1,207 @@
+"""ctypes bindings for oracle/liboracle.so and oracle/_ref/libref_morton.so — TESTS ONLY."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+ORACLE_LIB = ROOT / "oracle" / "liboracle.so"
+REF_MORTON_LIB = ROOT / "oracle" / "_ref" / "libref_morton.so"
+
+HIT = np.dtype([("t", "<f4"), ("material_id", "<u4"), ("voxel", "<i2", 3), ("face", "u1"), ("hit", "u1")])
+RAY = np.dtype([("org", "<f4", 3), ("tmin", "<f4"), ("dir", "<f4", 3), ("tmax", "<f4")])
+COUNTERS = np.dtype([(k, "<u8") for k in ("rays", "hits", "sub_chunks_entered", "nodes_fetched",
+                                           "iter_limit_hits", "stack_limit_hits", "max_stack", "max_iter", "ties")])
+SVO_NODE = np.dtype([("child_mask", "<u4"), ("first_child", "<u4"), ("material_id", "<u4"), ("occupancy", "<f4")])
+SUB_CHUNK = np.dtype([("node_offset", "<u4"), ("root_node_index", "<u4"), ("node_count", "<u4"),
+                      ("start_depth", "<u4"), ("world_min", "<f4", 3), ("sub_chunk_size", "<f4"),
+                      ("world_max", "<f4", 3), ("pad0", "<f4")])
+
+_lib = None
+_ref = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not ORACLE_LIB.exists():
+            raise RuntimeError(f"{ORACLE_LIB} not built: run `make -C oracle`")
+        L = C.CDLL(os.fspath(ORACLE_LIB))
+        L.orc_morton_encode.restype = C.c_uint64
+        L.orc_morton_encode.argtypes = [C.c_int32] * 3
+        L.orc_morton_decode.restype = None
+        L.orc_morton_decode.argtypes = [C.c_uint64] + [C.POINTER(C.c_int32)] * 3
+        L.orc_morton_octant.restype = C.c_uint32
+        L.orc_morton_octant.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
+        L.orc_world_new.restype = C.c_void_p
+        L.orc_world_new.argtypes = [C.c_uint32, C.c_float]
+        L.orc_world_free.argtypes = [C.c_void_p]
+        L.orc_world_set_voxel.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_float]
+        L.orc_world_set_voxels.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.orc_world_get_voxel_material.restype = C.c_uint32
+        L.orc_world_get_voxel_material.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float]
+        L.orc_world_rebuild.restype = C.c_int
+        L.orc_world_rebuild.argtypes = [C.c_void_p, C.c_int]
+        L.orc_world_pack.argtypes = [C.c_void_p]
+        for name in ("orc_world_n_nodes", "orc_world_n_subs", "orc_world_n_chunks"):
+            getattr(L, name).restype = C.c_size_t
+            getattr(L, name).argtypes = [C.c_void_p]
+        for name in ("orc_world_nodes", "orc_world_subs"):
+            getattr(L, name).restype = C.c_void_p
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.orc_world_chunk_info.restype = C.c_int
+        L.orc_world_chunk_info.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
+        L.orc_world_chunk_nodes.restype = C.c_void_p
+        L.orc_world_chunk_nodes.argtypes = [C.c_void_p, C.c_size_t]
+        L.orc_world_find_leaf.restype = C.c_int64
+        L.orc_world_find_leaf.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.orc_primary_rays.argtypes = [C.c_void_p] + [C.c_uint32] * 7 + [C.c_void_p]
+        L.orc_trace_bruteforce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                           C.c_void_p, C.c_void_p]
+        L.orc_lattice_build.restype = C.c_void_p
+        L.orc_lattice_build.argtypes = [C.c_void_p, C.c_size_t]
+        L.orc_lattice_free.argtypes = [C.c_void_p]
+        L.orc_trace_lattice.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                        C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_trace_primary.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_uint32] * 7 + \
+                                       [C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_trace_voxels_bruteforce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                                  C.c_void_p, C.c_void_p]
+        L.orc_shade_surface.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
+        L.orc_sizeof_counters.restype = C.c_uint32
+        assert L.orc_sizeof_counters() == COUNTERS.itemsize
+        _lib = L
+    return _lib
+
+
+def ref_morton():
+    """The reference's own morton.hpp, compiled in place (None when oracle/_ref is absent)."""
+    global _ref
+    if _ref is None and REF_MORTON_LIB.exists():
+        R = C.CDLL(os.fspath(REF_MORTON_LIB))
+        R.ref_morton_encode.restype = C.c_uint64
+        R.ref_morton_encode.argtypes = [C.c_int] * 3
+        R.ref_morton_decode.restype = None
+        R.ref_morton_decode.argtypes = [C.c_uint64] + [C.POINTER(C.c_int)] * 3
+        R.ref_morton_octant.restype = C.c_uint
+        R.ref_morton_octant.argtypes = [C.c_uint64, C.c_uint, C.c_uint]
+        _ref = R
+    return _ref
+
+
+def _p(a: np.ndarray):
+    return C.c_void_p(a.ctypes.data)
+
+
+def _copy(address, count, dtype):
+    if not count:
+        return np.zeros(0, dtype=dtype)
+    buf = (C.c_char * (count * dtype.itemsize)).from_address(address)
+    return np.frombuffer(buf, dtype=dtype, count=count).copy()
+
+
+class OracleWorld:
+    """Literal ChunkManager restatement (dense per-chunk store)."""
+
+    def __init__(self, chunk_size=128, voxel_size=1.0):
+        self.L = lib()
+        self.h = C.c_void_p(self.L.orc_world_new(chunk_size, voxel_size))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_world_free(self.h)
+            self.h = None
+
+    def set_voxel(self, p, mat, density=1.0):
+        self.L.orc_world_set_voxel(self.h, p[0], p[1], p[2], mat, density)
+
+    def set_voxels(self, xyz, mats):
+        xyz = np.ascontiguousarray(xyz, dtype=np.int32)
+        mats = np.ascontiguousarray(mats, dtype=np.uint32)
+        self.L.orc_world_set_voxels(self.h, _p(xyz), _p(mats), len(mats))
+
+    def get_voxel_material(self, p):
+        return int(self.L.orc_world_get_voxel_material(self.h, p[0], p[1], p[2]))
+
+    def rebuild(self, max_per_frame=1 << 30):
+        return self.L.orc_world_rebuild(self.h, max_per_frame)
+
+    def pack(self):
+        self.L.orc_world_pack(self.h)
+        nodes = _copy(self.L.orc_world_nodes(self.h), self.L.orc_world_n_nodes(self.h), SVO_NODE)
+        subs = _copy(self.L.orc_world_subs(self.h), self.L.orc_world_n_subs(self.h), SUB_CHUNK)
+        return nodes, subs
+
+    def n_chunks(self):
+        return self.L.orc_world_n_chunks(self.h)
+
+    def chunk(self, i):
+        coord = (C.c_int32 * 3)()
+        n = C.c_uint64()
+        assert self.L.orc_world_chunk_info(self.h, i, coord, C.byref(n)) == 0
+        return tuple(coord), _copy(self.L.orc_world_chunk_nodes(self.h, i), n.value, SVO_NODE)
+
+    def find_leaf(self, i, x, y, z):
+        return int(self.L.orc_world_find_leaf(self.h, i, x, y, z))
+
+
+def primary_rays(cam: np.ndarray, width, height, x0=0, y0=0, w=None, h=None, stride=1) -> np.ndarray:
+    w = width if w is None else w
+    h = height if h is None else h
+    n = ((w + stride - 1) // stride) * ((h + stride - 1) // stride)
+    rays = np.zeros(n, dtype=RAY)
+    lib().orc_primary_rays(_p(cam), width, height, x0, y0, w, h, stride, _p(rays))
+    return rays
+
+
+def trace_bruteforce(nodes, subs, rays):
+    hits = np.zeros(len(rays), dtype=HIT)
+    ctr = np.zeros(1, dtype=COUNTERS)
+    lib().orc_trace_bruteforce(_p(nodes), _p(subs), len(subs), _p(rays), len(rays), _p(hits), _p(ctr))
+    return hits, ctr[0]
+
+
+class Lattice:
+    def __init__(self, nodes, subs):
+        self.nodes = np.ascontiguousarray(nodes)
+        self.subs = np.ascontiguousarray(subs)
+        self.h = C.c_void_p(lib().orc_lattice_build(_p(self.subs), len(self.subs)))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_lattice_free(self.h)
+            self.h = None
+
+    def trace(self, rays, threads=1):
+        hits = np.zeros(len(rays), dtype=HIT)
+        ctr = np.zeros(1, dtype=COUNTERS)
+        lib().orc_trace_lattice(self.h, _p(self.nodes), _p(self.subs), _p(rays), len(rays), _p(hits), _p(ctr), threads)
+        return hits, ctr[0]
+
+    def trace_primary(self, cam, width, height, x0=0, y0=0, w=None, h=None, stride=1, threads=1, want_hits=True):
+        w = width if w is None else w
+        h = height if h is None else h
+        n = ((w + stride - 1) // stride) * ((h + stride - 1) // stride)
+        hits = np.zeros(n, dtype=HIT) if want_hits else None
+        ctr = np.zeros(1, dtype=COUNTERS)
+        lib().orc_trace_primary(self.h, _p(self.nodes), _p(self.subs), _p(cam), width, height, x0, y0, w, h,
+                                stride, _p(hits) if want_hits else None, _p(ctr), threads)
+        return hits, ctr[0]
+
+
+def trace_voxels_bruteforce(xyz, mats, rays):
+    xyz = np.ascontiguousarray(xyz, dtype=np.int32)
+    mats = np.ascontiguousarray(mats, dtype=np.uint32)
+    hits = np.zeros(len(rays), dtype=HIT)
+    ctr = np.zeros(1, dtype=COUNTERS)
+    lib().orc_trace_voxels_bruteforce(_p(xyz), _p(mats), len(mats), _p(rays), len(rays), _p(hits), _p(ctr))
+    return hits, ctr[0]
+
+
+def shade_surface(hit: np.ndarray, materials: np.ndarray) -> np.ndarray:
+    out = (C.c_float * 12)()
+    lib().orc_shade_surface(_p(hit), _p(materials), out)
+    return np.array(out[:], dtype=np.float32)
