@@ -1,0 +1,62 @@
+"""In-tree builds: libblok_host.so (g++), libblok_hip.so (hipcc, gfx950 only)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+ROOT = PKG.parent
+INCLUDE = ROOT / "include"
+
+HOST_SRC = [PKG / "csrc/host/world.cpp", PKG / "csrc/host/scene.cpp"]
+HIP_SRC = [PKG / "csrc/hip/api.hip", PKG / "csrc/hip/trace_kernels.hip", PKG / "csrc/hip/tree_build.cpp"]
+HIP_HDR = [PKG / "csrc/hip/tree.h", PKG / "csrc/hip/trace_kernels.h", PKG / "csrc/hip/reference_world.h",
+           INCLUDE / "blok_hip.h", INCLUDE / "blok_world.h"]
+
+
+def _stale(target: Path, deps) -> bool:
+    if not target.exists():
+        return True
+    t = target.stat().st_mtime
+    return any(Path(d).stat().st_mtime > t for d in deps)
+
+
+def _run(cmd):
+    proc = subprocess.run([os.fspath(c) for c in cmd], capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError("build failed: " + " ".join(map(str, cmd)) + "\n" + proc.stdout + proc.stderr)
+
+
+def hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def build_host(force: bool = False) -> Path:
+    out = PKG / "libblok_host.so"
+    if force or _stale(out, HOST_SRC + [INCLUDE / "blok_world.h", INCLUDE / "blok_hip.h"]):
+        _run(["g++", "-O2", "-std=c++20", "-fPIC", "-ffp-contract=off", "-Wall", "-Wextra", f"-I{INCLUDE}",
+              "-shared", "-o", out, *HOST_SRC])
+    return out
+
+
+def build_hip(force: bool = False) -> Path:
+    out = PKG / "libblok_hip.so"
+    if force or _stale(out, HIP_SRC + HIP_HDR):
+        _run([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++20", "-ffp-contract=off", "-fPIC", "-shared",
+              f"-I{INCLUDE}", f"-I{PKG / 'csrc/hip'}", "-o", out, *HIP_SRC])
+    return out
+
+
+def build_oracle() -> Path:
+    """Test infrastructure (tests/, smoke, cpu_baseline only)."""
+    _run(["make", "-C", ROOT / "oracle"])
+    return ROOT / "oracle" / "liboracle.so"
+
+
+def build_all(force: bool = False):
+    return build_host(force), build_hip(force), build_oracle()

@@ -1,0 +1,352 @@
+// C ABI of the gfx950 backend (include/blok_hip.h).  Owns device memory; every HIP call is checked.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "blok_hip.h"
+#include "reference_world.h"
+#include "trace_kernels.h"
+#include "tree.h"
+
+struct blok_hip_ctx {
+    int device = 0;
+    uint32_t width = 0, height = 0;
+    // derived structure in HBM
+    uint4* d_nodes = nullptr;
+    uint32_t* d_tree_materials = nullptr;
+    blok_material* d_materials = nullptr;
+    size_t n_materials = 0;
+    bool has_world = false;
+    blok_world_stats stats{};
+    // scratch frame for the host-output entry points
+    blok_hit* d_frame = nullptr;
+    size_t frame_capacity = 0;
+    // timing
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    bool timing = false, timed = false;
+    std::string error;
+};
+
+namespace {
+
+thread_local std::string g_create_error;
+
+int set_error(blok_hip_ctx* ctx, int status, const std::string& msg) {
+    if (ctx) ctx->error = msg; else g_create_error = msg;
+    return status;
+}
+
+#define BLOK_HIP_TRY(ctx, call)                                                                    \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return set_error(ctx, e_ == hipErrorOutOfMemory ? BLOK_ERR_OOM : BLOK_ERR_HIP,         \
+                             std::string(#call) + ": " + hipGetErrorString(e_));                   \
+    } while (0)
+
+void free_world(blok_hip_ctx* ctx) {
+    if (ctx->d_nodes) (void)hipFree(ctx->d_nodes);
+    if (ctx->d_tree_materials) (void)hipFree(ctx->d_tree_materials);
+    if (ctx->d_materials) (void)hipFree(ctx->d_materials);
+    ctx->d_nodes = nullptr; ctx->d_tree_materials = nullptr; ctx->d_materials = nullptr;
+    ctx->n_materials = 0; ctx->has_world = false; ctx->stats = blok_world_stats{};
+}
+
+int install_tree(blok_hip_ctx* ctx, const blok::HostTree& tree, const blok_material* materials, size_t n_materials) {
+    free_world(ctx);
+    const size_t node_bytes = tree.nodes.size() * sizeof(blok::TreeNode);
+    const size_t mat_bytes = std::max<size_t>(tree.materials.size(), 1) * sizeof(uint32_t);
+    BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_nodes), node_bytes));
+    BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_tree_materials), mat_bytes));
+    BLOK_HIP_TRY(ctx, hipMemcpy(ctx->d_nodes, tree.nodes.data(), node_bytes, hipMemcpyHostToDevice));
+    if (!tree.materials.empty())
+        BLOK_HIP_TRY(ctx, hipMemcpy(ctx->d_tree_materials, tree.materials.data(),
+                                    tree.materials.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (n_materials) {
+        BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_materials), n_materials * sizeof(blok_material)));
+        BLOK_HIP_TRY(ctx, hipMemcpy(ctx->d_materials, materials, n_materials * sizeof(blok_material), hipMemcpyHostToDevice));
+        ctx->n_materials = n_materials;
+    }
+    ctx->stats.n_voxels = tree.n_voxels;
+    ctx->stats.n_tree_nodes = tree.nodes.size();
+    ctx->stats.tree_bytes = node_bytes + tree.materials.size() * sizeof(uint32_t);
+    ctx->stats.levels = tree.levels;
+    for (int a = 0; a < 3; ++a) ctx->stats.origin[a] = tree.origin[a];
+    ctx->has_world = true;
+    return BLOK_OK;
+}
+
+int ensure_frame(blok_hip_ctx* ctx, size_t records) {
+    if (records <= ctx->frame_capacity) return BLOK_OK;
+    if (ctx->d_frame) (void)hipFree(ctx->d_frame);
+    ctx->d_frame = nullptr; ctx->frame_capacity = 0;
+    BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_frame), records * sizeof(blok_hit)));
+    ctx->frame_capacity = records;
+    return BLOK_OK;
+}
+
+blok::TraceArgs base_args(const blok_hip_ctx* ctx, const blok_camera* cam) {
+    blok::TraceArgs a{};
+    a.nodes = ctx->d_nodes;
+    a.materials = ctx->d_tree_materials;
+    for (int i = 0; i < 3; ++i) a.origin[i] = ctx->stats.origin[i];
+    a.levels = ctx->stats.levels;
+    if (cam) a.cam = *cam;
+    a.frame_w = ctx->width; a.frame_h = ctx->height;
+    a.tmin = BLOK_RAY_TMIN; a.tmax = BLOK_RAY_TMAX;
+    return a;
+}
+
+int launch_timed(blok_hip_ctx* ctx, blok::RayMode mode, const blok::TraceArgs& args, uint32_t blocks, hipStream_t stream) {
+    if (ctx->timing) BLOK_HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, stream));
+    blok::launch_trace(mode, args, blocks, stream);
+    BLOK_HIP_TRY(ctx, hipGetLastError());
+    if (ctx->timing) { BLOK_HIP_TRY(ctx, hipEventRecord(ctx->ev_end, stream)); ctx->timed = true; }
+    return BLOK_OK;
+}
+
+int check_trace(blok_hip_ctx* ctx, const blok_camera* cam) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    if (!cam) return set_error(ctx, BLOK_ERR_INVALID_ARG, "camera is null");
+    if (!ctx->has_world) return set_error(ctx, BLOK_ERR_NO_WORLD, "no world uploaded");
+    BLOK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return BLOK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t blok_hip_abi_version(void) { return (1u << 16) | 0u; }
+
+const char* blok_hip_last_error(const blok_hip_ctx* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+int blok_hip_create(blok_hip_ctx** out_ctx, int device_ordinal, uint32_t width, uint32_t height) {
+    if (!out_ctx) return BLOK_ERR_INVALID_ARG;
+    *out_ctx = nullptr;
+    if (!width || !height) return set_error(nullptr, BLOK_ERR_INVALID_ARG, "zero-sized frame");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return set_error(nullptr, BLOK_ERR_NO_DEVICE, std::string("no HIP device: ") + hipGetErrorString(e));
+    if (device_ordinal < 0 || device_ordinal >= count)
+        return set_error(nullptr, BLOK_ERR_INVALID_ARG, "device ordinal out of range");
+    hipDeviceProp_t prop{};
+    e = hipGetDeviceProperties(&prop, device_ordinal);
+    if (e != hipSuccess) return set_error(nullptr, BLOK_ERR_NO_DEVICE, std::string("hipGetDeviceProperties: ") + hipGetErrorString(e));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return set_error(nullptr, BLOK_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this backend is built for gfx950 only");
+    e = hipSetDevice(device_ordinal);
+    if (e != hipSuccess) return set_error(nullptr, BLOK_ERR_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    auto* ctx = new (std::nothrow) blok_hip_ctx();
+    if (!ctx) return set_error(nullptr, BLOK_ERR_OOM, "host allocation failed");
+    ctx->device = device_ordinal; ctx->width = width; ctx->height = height;
+    if (hipEventCreate(&ctx->ev_begin) != hipSuccess || hipEventCreate(&ctx->ev_end) != hipSuccess) {
+        delete ctx;
+        return set_error(nullptr, BLOK_ERR_HIP, "hipEventCreate failed");
+    }
+    *out_ctx = ctx;
+    return BLOK_OK;
+}
+
+int blok_hip_resize(blok_hip_ctx* ctx, uint32_t width, uint32_t height) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    if (!width || !height) return set_error(ctx, BLOK_ERR_INVALID_ARG, "zero-sized frame");
+    ctx->width = width; ctx->height = height;
+    return BLOK_OK;
+}
+
+void blok_hip_destroy(blok_hip_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    free_world(ctx);
+    if (ctx->d_frame) (void)hipFree(ctx->d_frame);
+    if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
+    if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
+    delete ctx;
+}
+
+int blok_hip_upload_world(blok_hip_ctx* ctx, const blok_svo_node* nodes, size_t n_nodes,
+                          const blok_sub_chunk* sub_chunks, size_t n_sub_chunks,
+                          const blok_material* materials, size_t n_materials) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    if ((n_nodes && !nodes) || (n_sub_chunks && !sub_chunks) || (n_materials && !materials))
+        return set_error(ctx, BLOK_ERR_INVALID_ARG, "null array with non-zero count");
+    BLOK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::vector<blok::VoxelRec> voxels;
+    const char* why = "";
+    if (!blok::extract_voxels(nodes, n_nodes, sub_chunks, n_sub_chunks, voxels, &why))
+        return set_error(ctx, BLOK_ERR_UNSUPPORTED, why);
+    blok::HostTree tree;
+    if (!blok::build_tree(voxels, tree, &why)) return set_error(ctx, BLOK_ERR_UNSUPPORTED, why);
+    const int rc = install_tree(ctx, tree, materials, n_materials);
+    if (rc != BLOK_OK) return rc;
+    ctx->stats.n_ref_nodes = n_nodes;
+    ctx->stats.n_sub_chunks = n_sub_chunks;
+    return BLOK_OK;
+}
+
+int blok_hip_upload_dense(blok_hip_ctx* ctx, const uint32_t* ids, uint32_t nx, uint32_t ny, uint32_t nz,
+                          const int32_t origin[3], const blok_material* materials, size_t n_materials) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    if (!ids || !nx || !ny || !nz || (n_materials && !materials))
+        return set_error(ctx, BLOK_ERR_INVALID_ARG, "bad dense grid arguments");
+    BLOK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int32_t o[3] = {origin ? origin[0] : 0, origin ? origin[1] : 0, origin ? origin[2] : 0};
+    std::vector<blok::VoxelRec> voxels;
+    for (uint32_t z = 0; z < nz; ++z)
+        for (uint32_t y = 0; y < ny; ++y) {
+            const uint32_t* row = ids + (static_cast<size_t>(z) * ny + y) * nx;
+            for (uint32_t x = 0; x < nx; ++x)
+                if (row[x]) voxels.push_back(blok::VoxelRec{o[0] + int32_t(x), o[1] + int32_t(y), o[2] + int32_t(z), row[x]});
+        }
+    blok::HostTree tree;
+    const char* why = "";
+    if (!blok::build_tree(voxels, tree, &why)) return set_error(ctx, BLOK_ERR_UNSUPPORTED, why);
+    return install_tree(ctx, tree, materials, n_materials);
+}
+
+int blok_hip_world_stats(const blok_hip_ctx* ctx, blok_world_stats* out) {
+    if (!ctx || !out) return BLOK_ERR_INVALID_ARG;
+    if (!ctx->has_world) return BLOK_ERR_NO_WORLD;
+    *out = ctx->stats;
+    return BLOK_OK;
+}
+
+int blok_hip_trace_primary_device(blok_hip_ctx* ctx, const blok_camera* cam, uint32_t x0, uint32_t y0,
+                                  uint32_t w, uint32_t h, void* out_hits_dev, void* hip_stream) {
+    int rc = check_trace(ctx, cam);
+    if (rc != BLOK_OK) return rc;
+    if (!out_hits_dev || !w || !h || x0 + w > ctx->width || y0 + h > ctx->height)
+        return set_error(ctx, BLOK_ERR_INVALID_ARG, "rectangle outside the frame or null output");
+    blok::TraceArgs a = base_args(ctx, cam);
+    a.x0 = x0; a.y0 = y0; a.w = w; a.h = h;
+    a.out = static_cast<blok_hit*>(out_hits_dev);
+    const uint32_t blocks = ((w + 15u) / 16u) * ((h + 15u) / 16u);
+    return launch_timed(ctx, blok::RayMode::Rect, a, blocks, static_cast<hipStream_t>(hip_stream));
+}
+
+int blok_hip_trace_primary(blok_hip_ctx* ctx, const blok_camera* cam, uint32_t x0, uint32_t y0,
+                           uint32_t w, uint32_t h, blok_hit* out_hits_host) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    if (!out_hits_host) return set_error(ctx, BLOK_ERR_INVALID_ARG, "null output");
+    int rc = check_trace(ctx, cam);
+    if (rc != BLOK_OK) return rc;
+    const size_t n = static_cast<size_t>(w) * h;
+    rc = ensure_frame(ctx, n);
+    if (rc != BLOK_OK) return rc;
+    rc = blok_hip_trace_primary_device(ctx, cam, x0, y0, w, h, ctx->d_frame, nullptr);
+    if (rc != BLOK_OK) return rc;
+    BLOK_HIP_TRY(ctx, hipMemcpy(out_hits_host, ctx->d_frame, n * sizeof(blok_hit), hipMemcpyDeviceToHost));
+    return BLOK_OK;
+}
+
+uint32_t blok_hip_tiles_for_rank(uint32_t width, uint32_t height, uint32_t tile, uint32_t rank, uint32_t n_ranks) {
+    if (!tile || !n_ranks || rank >= n_ranks) return 0;
+    const uint32_t total = ((width + tile - 1) / tile) * ((height + tile - 1) / tile);
+    return total > rank ? (total - rank + n_ranks - 1) / n_ranks : 0;
+}
+
+int blok_hip_trace_tiles_device(blok_hip_ctx* ctx, const blok_camera* cam, uint32_t tile, uint32_t rank,
+                                uint32_t n_ranks, void* out_hits_dev, void* hip_stream) {
+    int rc = check_trace(ctx, cam);
+    if (rc != BLOK_OK) return rc;
+    if (!out_hits_dev || tile < 16 || (tile & 15u) || !n_ranks || rank >= n_ranks)
+        return set_error(ctx, BLOK_ERR_INVALID_ARG, "tile must be a multiple of 16 and rank < n_ranks");
+    blok::TraceArgs a = base_args(ctx, cam);
+    a.tile = tile; a.rank = rank; a.n_ranks = n_ranks;
+    a.tiles_x = (ctx->width + tile - 1) / tile;
+    a.tiles_total = a.tiles_x * ((ctx->height + tile - 1) / tile);
+    a.out = static_cast<blok_hit*>(out_hits_dev);
+    const uint32_t mine = blok_hip_tiles_for_rank(ctx->width, ctx->height, tile, rank, n_ranks);
+    const uint32_t blocks = mine * (tile / 16u) * (tile / 16u);
+    return launch_timed(ctx, blok::RayMode::Tiles, a, blocks, static_cast<hipStream_t>(hip_stream));
+}
+
+int blok_hip_untile_device(blok_hip_ctx* ctx, const void* gathered_dev, uint32_t tile, uint32_t n_ranks,
+                           uint32_t tiles_per_rank_max, void* out_frame_dev, void* hip_stream) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    if (!gathered_dev || !out_frame_dev || !tile || !n_ranks || !tiles_per_rank_max)
+        return set_error(ctx, BLOK_ERR_INVALID_ARG, "bad untile arguments");
+    BLOK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    blok::UntileArgs u{};
+    u.gathered = static_cast<const uint4*>(gathered_dev);
+    u.frame = static_cast<uint4*>(out_frame_dev);
+    u.frame_w = ctx->width; u.frame_h = ctx->height; u.tile = tile; u.n_ranks = n_ranks;
+    u.tiles_per_rank_max = tiles_per_rank_max;
+    u.tiles_x = (ctx->width + tile - 1) / tile;
+    blok::launch_untile(u, static_cast<hipStream_t>(hip_stream));
+    BLOK_HIP_TRY(ctx, hipGetLastError());
+    return BLOK_OK;
+}
+
+int blok_hip_trace_rays(blok_hip_ctx* ctx, const blok_ray* rays_host, size_t n, blok_hit* out_hits_host) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    if (!ctx->has_world) return set_error(ctx, BLOK_ERR_NO_WORLD, "no world uploaded");
+    if (n == 0) return BLOK_OK;
+    if (!rays_host || !out_hits_host || n > 0x7FFFFFFFu) return set_error(ctx, BLOK_ERR_INVALID_ARG, "bad ray arguments");
+    BLOK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_frame(ctx, n);
+    if (rc != BLOK_OK) return rc;
+    blok_ray* d_rays = nullptr;
+    BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d_rays), n * sizeof(blok_ray)));
+    hipError_t e = hipMemcpy(d_rays, rays_host, n * sizeof(blok_ray), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        blok::TraceArgs a = base_args(ctx, nullptr);
+        a.rays = d_rays; a.n_rays = static_cast<uint32_t>(n); a.out = ctx->d_frame;
+        rc = launch_timed(ctx, blok::RayMode::Rays, a, static_cast<uint32_t>((n + blok::kBlock - 1) / blok::kBlock), nullptr);
+        if (rc == BLOK_OK) e = hipMemcpy(out_hits_host, ctx->d_frame, n * sizeof(blok_hit), hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d_rays);
+    if (rc != BLOK_OK) return rc;
+    if (e != hipSuccess) return set_error(ctx, BLOK_ERR_HIP, std::string("trace_rays copy: ") + hipGetErrorString(e));
+    return BLOK_OK;
+}
+
+int blok_hip_shade_rgba8(blok_hip_ctx* ctx, const blok_camera* cam, uint32_t x0, uint32_t y0, uint32_t w,
+                         uint32_t h, uint32_t* out_rgba8_host) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    if (!out_rgba8_host) return set_error(ctx, BLOK_ERR_INVALID_ARG, "null output");
+    int rc = check_trace(ctx, cam);
+    if (rc != BLOK_OK) return rc;
+    const size_t n = static_cast<size_t>(w) * h;
+    rc = ensure_frame(ctx, n);
+    if (rc != BLOK_OK) return rc;
+    rc = blok_hip_trace_primary_device(ctx, cam, x0, y0, w, h, ctx->d_frame, nullptr);
+    if (rc != BLOK_OK) return rc;
+    uint32_t* d_rgba = nullptr;
+    BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d_rgba), n * sizeof(uint32_t)));
+    blok::ShadeArgs s{ctx->d_frame, ctx->d_materials, static_cast<uint32_t>(ctx->n_materials), d_rgba, static_cast<uint32_t>(n)};
+    blok::launch_shade(s, nullptr);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(out_rgba8_host, d_rgba, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    (void)hipFree(d_rgba);
+    if (e != hipSuccess) return set_error(ctx, BLOK_ERR_HIP, std::string("shade: ") + hipGetErrorString(e));
+    return BLOK_OK;
+}
+
+int blok_hip_reset_accum(blok_hip_ctx* ctx) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    return BLOK_OK;   // primary-hit frames carry no accumulation state
+}
+
+int blok_hip_set_timing(blok_hip_ctx* ctx, int enabled) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    ctx->timing = enabled != 0;
+    ctx->timed = false;
+    return BLOK_OK;
+}
+
+int blok_hip_last_kernel_ms(blok_hip_ctx* ctx, float* out_ms) {
+    if (!ctx || !out_ms) return BLOK_ERR_INVALID_ARG;
+    if (!ctx->timed) return set_error(ctx, BLOK_ERR_INVALID_ARG, "no timed launch (enable with blok_hip_set_timing)");
+    BLOK_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_end));
+    BLOK_HIP_TRY(ctx, hipEventElapsedTime(out_ms, ctx->ev_begin, ctx->ev_end));
+    return BLOK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,77 @@
+// gfx950 trace kernels: one lane = one ray, walking the 64-tree (tree.h).
+//
+// SEMANTICS (what must equal the reference bit for bit).  For a ray (o, d, tmin, tmax), with
+//   inv_a = 1 / (|d_a| < 1e-6 ? 1e-6 : d_a)                        intersect.rint:79
+//   T(a, p) = fl( fl(p - o_a) * inv_a )      for an integer plane p  intersect.rint:48-49,179-180
+// a filled unit voxel v is REPORTED by the reference iff
+//   max(entry(v), tmin) < min(exit(v), tmax),   entry = max_a min(T(a,v_a), T(a,v_a+1)),
+//                                               exit  = min_a max(T(a,v_a), T(a,v_a+1))
+// (intersect.rint:179-193 at the leaf level; the same test on every ancestor box is implied, because
+// box planes are integers — exactly representable — and fl(p - o), fl(x * inv) are monotone in p, so
+// ancestor intervals contain the leaf's), and is reported with t = max(entry(v), tmin)
+// (intersect.rint:189,141).  The ray's result is the reported voxel of smallest t
+// (traceRayEXT closest-hit), which is unique.  The face is
+// getHitFace(o + d*t, centre) (intersect.rint:58-68,138), the material the leaf's materialId.
+//
+// TRAVERSAL.  Sort all integer planes the ray crosses by T (a 3-way merge, one sorted list per
+// axis).  Every reported voxel is a cell of that merge sequence (its near planes all have T strictly
+// below its far planes), and along the sequence the entry T never decreases.  The kernel walks the
+// sequence hierarchically: at level l it steps whole 4^l cells whose mask bit is clear, descends
+// into set ones, and picks the start cell of a node by counting which of its three interior planes
+// per axis have T <= current t.  All T's are evaluated with the formula above on integer planes
+// (never accumulated), so the walk visits exactly the reference's reported voxels in t order and
+// stops at the first.
+#ifndef BLOK_TRACE_KERNELS_H
+#define BLOK_TRACE_KERNELS_H
+
+#ifdef BLOK_TRACE_HOST_HARNESS
+#include "host_harness_shims.h"   // tests/host_harness: CPU stand-ins for the HIP types/intrinsics used
+#else
+#include <hip/hip_runtime.h>
+#endif
+#include <stdint.h>
+
+#include "blok_hip.h"
+#include "tree.h"
+
+namespace blok {
+
+constexpr int kBlock = 256;          // 4 waves; a 16x16 pixel tile, each wave an 8x8 sub-tile
+
+enum class RayMode : int { Rect = 0, Tiles = 1, Rays = 2 };
+
+struct TraceArgs {
+    const uint4*    nodes;
+    const uint32_t* materials;
+    int32_t  origin[3];
+    uint32_t levels;
+    blok_camera cam;
+    uint32_t frame_w, frame_h;
+    uint32_t x0, y0, w, h;                 // Rect
+    uint32_t tile, rank, n_ranks, tiles_x, tiles_total;   // Tiles
+    const blok_ray* rays;                  // Rays
+    uint32_t n_rays;
+    blok_hit* out;
+    float tmin, tmax;
+};
+
+struct UntileArgs {
+    const uint4* gathered;
+    uint4* frame;
+    uint32_t frame_w, frame_h, tile, n_ranks, tiles_per_rank_max, tiles_x;
+};
+
+struct ShadeArgs {
+    const blok_hit* hits;
+    const blok_material* materials;
+    uint32_t n_materials;
+    uint32_t* rgba;
+    uint32_t n;
+};
+
+void launch_trace(RayMode mode, const TraceArgs& args, uint32_t n_blocks, hipStream_t stream);
+void launch_untile(const UntileArgs& args, hipStream_t stream);
+void launch_shade(const ShadeArgs& args, hipStream_t stream);
+
+}  // namespace blok
+#endif

@@ -1,0 +1,108 @@
+// See trace_kernels.h for the semantics this file implements.
+// Compiled with -ffp-contract=off; the float ops that define results additionally use the
+// explicitly rounded intrinsics so that no flag can fuse them.
+#include "trace_kernels.h"
+#include "trace_core.h"
+
+namespace blok {
+
+namespace {
+
+template <RayMode MODE>
+__global__ __launch_bounds__(kBlock) void trace_kernel(const TraceArgs A) {
+    extern __shared__ uint4 lds_stack[];       // [levels-1][kBlock]
+    const uint32_t tid = threadIdx.x;
+    uint4* stk = lds_stack + tid;
+
+    if constexpr (MODE == RayMode::Rays) {
+        const uint32_t i = blockIdx.x * kBlock + tid;
+        if (i >= A.n_rays) return;
+        const blok_ray ray = A.rays[i];
+        RayIn r{ray.org[0], ray.org[1], ray.org[2], ray.dir[0], ray.dir[1], ray.dir[2], ray.tmin, ray.tmax};
+        trace_one(A, r, stk, A.out + i);
+        return;
+    } else {
+        // a block is a 16x16 pixel tile, a wave an 8x8 sub-tile (coherent rays per wave)
+        const uint32_t wave = tid >> 6, lane = tid & 63u;
+        const uint32_t lx = ((wave & 1u) << 3) | (lane & 7u);
+        const uint32_t ly = ((wave >> 1) << 3) | (lane >> 3);
+        uint32_t x, y;
+        size_t out_index;
+        bool inside;
+        if constexpr (MODE == RayMode::Rect) {
+            const uint32_t bx_count = (A.w + 15u) >> 4;
+            const uint32_t bx = blockIdx.x % bx_count, by = blockIdx.x / bx_count;
+            const uint32_t rx = (bx << 4) + lx, ry = (by << 4) + ly;
+            inside = rx < A.w && ry < A.h;
+            if (!inside) return;
+            x = A.x0 + rx; y = A.y0 + ry;
+            out_index = static_cast<size_t>(ry) * A.w + rx;
+        } else {
+            const uint32_t per_side = A.tile >> 4;                      // 16x16 blocks per tile side
+            const uint32_t per_tile = per_side * per_side;
+            const uint32_t local_tile = blockIdx.x / per_tile, sub = blockIdx.x % per_tile;
+            const uint32_t global_tile = A.rank + local_tile * A.n_ranks;
+            const uint32_t tx = global_tile % A.tiles_x, ty = global_tile / A.tiles_x;
+            const uint32_t ix = ((sub % per_side) << 4) + lx, iy = ((sub / per_side) << 4) + ly;
+            x = tx * A.tile + ix; y = ty * A.tile + iy;
+            out_index = static_cast<size_t>(local_tile) * A.tile * A.tile + static_cast<size_t>(iy) * A.tile + ix;
+            inside = global_tile < A.tiles_total && x < A.frame_w && y < A.frame_h;
+            if (!inside) { write_miss(A.out + out_index); return; }
+        }
+        const RayIn r = primary_ray(A, x, y);
+        trace_one(A, r, stk, A.out + out_index);
+    }
+}
+
+__global__ __launch_bounds__(256) void untile_kernel(const UntileArgs U) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= U.frame_w * U.frame_h) return;
+    const uint32_t x = i % U.frame_w, y = i / U.frame_w;
+    const uint32_t g = (y / U.tile) * U.tiles_x + x / U.tile;
+    const uint32_t rank = g % U.n_ranks, local = g / U.n_ranks;
+    const size_t src = (static_cast<size_t>(rank) * U.tiles_per_rank_max + local) * U.tile * U.tile +
+                       static_cast<size_t>(y % U.tile) * U.tile + (x % U.tile);
+    U.frame[i] = U.gathered[src];
+}
+
+// Debug view through hit.rchit's material fetch (hit.rchit:58-67): albedo lit by the face normal.
+__global__ __launch_bounds__(256) void shade_kernel(const ShadeArgs S) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= S.n) return;
+    const blok_hit h = S.hits[i];
+    uint32_t rgba = 0xFF000000u | (230u << 16) | (200u << 8) | 160u;   // sky
+    if (h.hit) {
+        const uint32_t id = min(h.material_id, 65535u);                 // hit.rchit:62
+        float r = 1.0f, g = 0.0f, b = 1.0f;
+        if (id < S.n_materials) { r = S.materials[id].albedo[0]; g = S.materials[id].albedo[1]; b = S.materials[id].albedo[2]; }
+        const float shade = h.face == 2 ? 1.0f : (h.face < 2 ? 0.8f : (h.face == 3 ? 0.4f : 0.6f));
+        const uint32_t R = static_cast<uint32_t>(fminf(r * shade, 1.0f) * 255.0f + 0.5f);
+        const uint32_t G = static_cast<uint32_t>(fminf(g * shade, 1.0f) * 255.0f + 0.5f);
+        const uint32_t B = static_cast<uint32_t>(fminf(b * shade, 1.0f) * 255.0f + 0.5f);
+        rgba = 0xFF000000u | (B << 16) | (G << 8) | R;
+    }
+    S.rgba[i] = rgba;
+}
+
+}  // namespace
+
+void launch_trace(RayMode mode, const TraceArgs& args, uint32_t n_blocks, hipStream_t stream) {
+    if (n_blocks == 0) return;
+    const size_t lds = static_cast<size_t>(args.levels > 1 ? args.levels - 1 : 1) * kBlock * sizeof(uint4);
+    switch (mode) {
+        case RayMode::Rect:  hipLaunchKernelGGL(trace_kernel<RayMode::Rect>,  dim3(n_blocks), dim3(kBlock), lds, stream, args); break;
+        case RayMode::Tiles: hipLaunchKernelGGL(trace_kernel<RayMode::Tiles>, dim3(n_blocks), dim3(kBlock), lds, stream, args); break;
+        case RayMode::Rays:  hipLaunchKernelGGL(trace_kernel<RayMode::Rays>,  dim3(n_blocks), dim3(kBlock), lds, stream, args); break;
+    }
+}
+
+void launch_untile(const UntileArgs& args, hipStream_t stream) {
+    const uint32_t n = args.frame_w * args.frame_h;
+    hipLaunchKernelGGL(untile_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, args);
+}
+
+void launch_shade(const ShadeArgs& args, hipStream_t stream) {
+    hipLaunchKernelGGL(shade_kernel, dim3((args.n + 255u) / 256u), dim3(256), 0, stream, args);
+}
+
+}  // namespace blok

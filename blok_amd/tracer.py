@@ -1,0 +1,138 @@
+"""HipTracer — host-side mirror of the reference's compute backend class (blok::CudaTracer,
+reference blok/include/cuda_tracer.hpp:23-58) over the C ABI in include/blok_hip.h.
+
+Lifecycle follows the reference: ``HipTracer(w, h)`` → ``init()`` → ``add_world()``
+(= Renderer::addWorld, reference blok/include/renderer.hpp:40-54) → ``draw_frame(cam)`` per frame →
+``resize`` / ``shutdown``.  ``begin_frame`` / ``end_frame`` are no-ops as in the reference
+(cuda_tracer.cu:450-456).  Errors raise ``BlokError`` (the reference throws std::runtime_error).
+There is no CPU path: constructing or tracing without libblok_hip.so and a gfx950 device raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import BlokError, CAMERA, HIT, MATERIAL, RAY, SUB_CHUNK, SVO_NODE, WorldStats
+
+
+class HipTracer:
+    def __init__(self, width: int, height: int, device: int = 0):
+        self.width, self.height, self.device = int(width), int(height), int(device)
+        self._lib = None
+        self._ctx = None
+
+    # -- lifecycle -------------------------------------------------------------------------
+    def init(self) -> "HipTracer":
+        self._lib = _ffi.hip_lib()
+        ctx = C.c_void_p()
+        rc = self._lib.blok_hip_create(C.byref(ctx), self.device, self.width, self.height)
+        if rc != 0:
+            raise BlokError(rc, self._lib.blok_hip_last_error(None).decode())
+        self._ctx = ctx
+        return self
+
+    def shutdown(self):
+        if self._ctx:
+            self._lib.blok_hip_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.shutdown()
+        except Exception:
+            pass
+
+    def begin_frame(self):
+        pass
+
+    def end_frame(self):
+        pass
+
+    def resize(self, width: int, height: int):
+        self._check(self._lib.blok_hip_resize(self._ctx, width, height))
+        self.width, self.height = int(width), int(height)
+
+    def reset_accum(self):
+        self._check(self._lib.blok_hip_reset_accum(self._ctx))
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise BlokError(rc, self._lib.blok_hip_last_error(self._ctx).decode())
+
+    # -- world -----------------------------------------------------------------------------
+    def add_world(self, world) -> WorldStats:
+        """world: blok_amd.world.PackedWorld (nodes, sub_chunks, materials)."""
+        nodes = np.ascontiguousarray(world.nodes, dtype=SVO_NODE)
+        subs = np.ascontiguousarray(world.sub_chunks, dtype=SUB_CHUNK)
+        mats = np.ascontiguousarray(world.materials, dtype=MATERIAL)
+        self._check(self._lib.blok_hip_upload_world(self._ctx, _ffi.ptr(nodes), len(nodes), _ffi.ptr(subs), len(subs),
+                                                    _ffi.ptr(mats), len(mats)))
+        return self.world_stats()
+
+    update_world = add_world
+
+    def add_dense(self, material_ids: np.ndarray, origin=(0, 0, 0), materials: np.ndarray | None = None) -> WorldStats:
+        """material_ids[z][y][x], 0 = empty."""
+        ids = np.ascontiguousarray(material_ids, dtype=np.uint32)
+        nz, ny, nx = ids.shape
+        mats = np.zeros(1, dtype=MATERIAL) if materials is None else np.ascontiguousarray(materials, dtype=MATERIAL)
+        o = (C.c_int32 * 3)(*origin)
+        self._check(self._lib.blok_hip_upload_dense(self._ctx, _ffi.ptr(ids), nx, ny, nz, o, _ffi.ptr(mats), len(mats)))
+        return self.world_stats()
+
+    def world_stats(self) -> WorldStats:
+        s = WorldStats()
+        self._check(self._lib.blok_hip_world_stats(self._ctx, C.byref(s)))
+        return s
+
+    # -- trace -----------------------------------------------------------------------------
+    def draw_frame(self, cam: np.ndarray, rect=None) -> np.ndarray:
+        """Primary first-hit records of the frame (or of rect = (x0, y0, w, h)), shape (h, w)."""
+        x0, y0, w, h = rect if rect is not None else (0, 0, self.width, self.height)
+        cam = np.ascontiguousarray(cam, dtype=CAMERA)
+        hits = np.zeros(w * h, dtype=HIT)
+        self._check(self._lib.blok_hip_trace_primary(self._ctx, _ffi.ptr(cam), x0, y0, w, h, _ffi.ptr(hits)))
+        return hits.reshape(h, w)
+
+    def draw_frame_device(self, cam: np.ndarray, out_ptr: int, rect=None, stream: int = 0):
+        x0, y0, w, h = rect if rect is not None else (0, 0, self.width, self.height)
+        cam = np.ascontiguousarray(cam, dtype=CAMERA)
+        self._check(self._lib.blok_hip_trace_primary_device(self._ctx, _ffi.ptr(cam), x0, y0, w, h,
+                                                            C.c_void_p(out_ptr), C.c_void_p(stream)))
+
+    def tiles_for_rank(self, tile: int, rank: int, n_ranks: int) -> int:
+        return int(_ffi.hip_lib().blok_hip_tiles_for_rank(self.width, self.height, tile, rank, n_ranks))
+
+    def draw_tiles_device(self, cam: np.ndarray, tile: int, rank: int, n_ranks: int, out_ptr: int, stream: int = 0):
+        cam = np.ascontiguousarray(cam, dtype=CAMERA)
+        self._check(self._lib.blok_hip_trace_tiles_device(self._ctx, _ffi.ptr(cam), tile, rank, n_ranks,
+                                                          C.c_void_p(out_ptr), C.c_void_p(stream)))
+
+    def untile_device(self, gathered_ptr: int, tile: int, n_ranks: int, tiles_per_rank_max: int, out_ptr: int,
+                      stream: int = 0):
+        self._check(self._lib.blok_hip_untile_device(self._ctx, C.c_void_p(gathered_ptr), tile, n_ranks,
+                                                     tiles_per_rank_max, C.c_void_p(out_ptr), C.c_void_p(stream)))
+
+    def trace_rays(self, rays: np.ndarray) -> np.ndarray:
+        rays = np.ascontiguousarray(rays, dtype=RAY)
+        hits = np.zeros(len(rays), dtype=HIT)
+        self._check(self._lib.blok_hip_trace_rays(self._ctx, _ffi.ptr(rays), len(rays), _ffi.ptr(hits)))
+        return hits
+
+    def shade_rgba8(self, cam: np.ndarray, rect=None) -> np.ndarray:
+        x0, y0, w, h = rect if rect is not None else (0, 0, self.width, self.height)
+        cam = np.ascontiguousarray(cam, dtype=CAMERA)
+        out = np.zeros(w * h, dtype=np.uint32)
+        self._check(self._lib.blok_hip_shade_rgba8(self._ctx, _ffi.ptr(cam), x0, y0, w, h, _ffi.ptr(out)))
+        return out.reshape(h, w)
+
+    # -- timing ----------------------------------------------------------------------------
+    def set_timing(self, enabled: bool):
+        self._check(self._lib.blok_hip_set_timing(self._ctx, int(enabled)))
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_float()
+        self._check(self._lib.blok_hip_last_kernel_ms(self._ctx, C.byref(ms)))
+        return ms.value

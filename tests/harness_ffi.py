@@ -1,0 +1,77 @@
+"""ctypes bindings for tests/host_harness/libhost_harness.so (the kernel body compiled for the CPU) — TESTS ONLY."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+SRC = ROOT / "tests" / "host_harness"
+LIB = SRC / "libhost_harness.so"
+HIT = np.dtype([("t", "<f4"), ("material_id", "<u4"), ("voxel", "<i2", 3), ("face", "u1"), ("hit", "u1")])
+
+
+def build(sanitize: bool = False) -> Path:
+    out = SRC / ("libhost_harness_asan.so" if sanitize else "libhost_harness.so")
+    deps = [SRC / "harness.cpp", SRC / "host_harness_shims.h", ROOT / "blok_amd/csrc/hip/trace_core.h",
+            ROOT / "blok_amd/csrc/hip/trace_kernels.h", ROOT / "blok_amd/csrc/hip/tree_build.cpp",
+            ROOT / "blok_amd/csrc/hip/tree.h"]
+    if out.exists() and all(d.stat().st_mtime <= out.stat().st_mtime for d in deps):
+        return out
+    cmd = ["g++", "-O1", "-g", "-std=c++20", "-fPIC", "-ffp-contract=off", "-Wall", f"-I{ROOT / 'include'}",
+           f"-I{ROOT / 'blok_amd/csrc/hip'}", f"-I{SRC}", "-shared", "-o", os.fspath(out),
+           os.fspath(SRC / "harness.cpp"), os.fspath(ROOT / "blok_amd/csrc/hip/tree_build.cpp")]
+    if sanitize:
+        cmd[1:1] = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer"]
+    subprocess.run(cmd, check=True)
+    return out
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(os.fspath(build()))
+        L.hh_build.restype = C.c_void_p
+        L.hh_build.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_char_p)]
+        L.hh_free.argtypes = [C.c_void_p]
+        L.hh_levels.restype = C.c_uint32
+        L.hh_levels.argtypes = [C.c_void_p]
+        L.hh_voxels.restype = C.c_uint64
+        L.hh_voxels.argtypes = [C.c_void_p]
+        L.hh_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.hh_trace_primary.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+class HostKernel:
+    def __init__(self, nodes: np.ndarray, subs: np.ndarray):
+        why = C.c_char_p()
+        self.h = lib().hh_build(C.c_void_p(nodes.ctypes.data), len(nodes), C.c_void_p(subs.ctypes.data), len(subs),
+                                C.byref(why))
+        if not self.h:
+            raise RuntimeError(why.value.decode())
+        self.h = C.c_void_p(self.h)
+        self.levels = lib().hh_levels(self.h)
+        self.n_voxels = lib().hh_voxels(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().hh_free(self.h)
+            self.h = None
+
+    def trace_rays(self, rays: np.ndarray) -> np.ndarray:
+        out = np.zeros(len(rays), dtype=HIT)
+        lib().hh_trace_rays(self.h, C.c_void_p(rays.ctypes.data), len(rays), C.c_void_p(out.ctypes.data))
+        return out
+
+    def trace_primary(self, cam: np.ndarray, width: int, height: int) -> np.ndarray:
+        out = np.zeros(width * height, dtype=HIT)
+        lib().hh_trace_primary(self.h, C.c_void_p(cam.ctypes.data), width, height, C.c_void_p(out.ctypes.data))
+        return out

@@ -1,0 +1,68 @@
+// TEST INFRASTRUCTURE: runs the kernel's per-ray body on the CPU (one "lane" at a time) over a tree
+// built by the product's host tree builder.  Never linked into the shipped libraries.
+#define BLOK_TRACE_HOST_HARNESS 1
+#include "trace_core.h"
+#include "reference_world.h"
+
+#include <vector>
+
+using namespace blok;
+
+namespace {
+struct Harness {
+    HostTree tree;
+    std::vector<uint4> nodes;
+};
+}
+
+extern "C" {
+
+void* hh_build(const blok_svo_node* nodes, size_t n_nodes, const blok_sub_chunk* subs, size_t n_subs, const char** why) {
+    static const char* none = "";
+    *why = none;
+    std::vector<VoxelRec> voxels;
+    if (!extract_voxels(nodes, n_nodes, subs, n_subs, voxels, why)) return nullptr;
+    auto* h = new Harness();
+    if (!build_tree(voxels, h->tree, why)) { delete h; return nullptr; }
+    h->nodes.resize(h->tree.nodes.size());
+    std::memcpy(h->nodes.data(), h->tree.nodes.data(), h->nodes.size() * sizeof(uint4));
+    return h;
+}
+void hh_free(void* h) { delete static_cast<Harness*>(h); }
+uint32_t hh_levels(const void* h) { return static_cast<const Harness*>(h)->tree.levels; }
+uint64_t hh_voxels(const void* h) { return static_cast<const Harness*>(h)->tree.n_voxels; }
+
+static TraceArgs make_args(const Harness* H) {
+    TraceArgs a{};
+    a.nodes = H->nodes.data();
+    a.materials = H->tree.materials.data();
+    for (int i = 0; i < 3; ++i) a.origin[i] = H->tree.origin[i];
+    a.levels = H->tree.levels;
+    a.tmin = BLOK_RAY_TMIN; a.tmax = BLOK_RAY_TMAX;
+    return a;
+}
+
+void hh_trace_rays(const void* h, const blok_ray* rays, size_t n, blok_hit* out) {
+    const Harness* H = static_cast<const Harness*>(h);
+    TraceArgs a = make_args(H);
+    std::vector<uint4> stack(size_t(kMaxLevels) * kBlock);
+    for (size_t i = 0; i < n; ++i) {
+        RayIn r{rays[i].org[0], rays[i].org[1], rays[i].org[2], rays[i].dir[0], rays[i].dir[1], rays[i].dir[2],
+                rays[i].tmin, rays[i].tmax};
+        trace_one(a, r, stack.data(), out + i);
+    }
+}
+
+void hh_trace_primary(const void* h, const blok_camera* cam, uint32_t width, uint32_t height, blok_hit* out) {
+    const Harness* H = static_cast<const Harness*>(h);
+    TraceArgs a = make_args(H);
+    a.cam = *cam; a.frame_w = width; a.frame_h = height;
+    std::vector<uint4> stack(size_t(kMaxLevels) * kBlock);
+    for (uint32_t y = 0; y < height; ++y)
+        for (uint32_t x = 0; x < width; ++x) {
+            const RayIn r = primary_ray(a, x, y);
+            trace_one(a, r, stack.data(), out + size_t(y) * width + x);
+        }
+}
+
+}
