@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: primary first-hit rays at 3840x2160 over the synthetic 1024^3 SVO
+(BASELINE.json configs[2], the configuration the metric is quoted on).
+
+One step = one full frame.  N = 1: one launch of the trace kernel over the whole frame.
+N > 1 (one process per GPU, launched by torch.distributed.run): the frame is cut into 32x32 tiles dealt
+round-robin to the ranks, every rank traces its tiles from its own replica of the world, one RCCL
+all-gather assembles the tile buffers and every rank un-permutes them into the frame (the reference has no
+multi-GPU path).  Total work per step is fixed as N grows -> "scaling": "strong".
+
+Prints ONE JSON line on rank 0.  Inputs are synthetic (generator G(N, seed) of SURVEY.md §8(d)) and are
+resident in HBM before the timed region.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--n", type=int, default=1024, help="world edge in voxels")
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--pose", type=int, default=0, help="camera pose A/B/C = 0/1/2 (SURVEY.md §8(d))")
+    ap.add_argument("--tile", type=int, default=32)
+    ap.add_argument("--seed", type=lambda s: int(s, 0), default=0xB10C0001)
+    ap.add_argument("--cpu-stride", type=int, default=2, help="CPU baseline traces every stride-th pixel in x and y")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def build_world(n: int, seed: int):
+    from blok_amd import world as W
+    cm = W.ChunkManager(128, 1.0)
+    cm.generate_scene(n, seed)
+    cm.rebuild_dirty_chunks()
+    return cm.pack_chunks_to_gpu_svo(W.scene_materials(seed))
+
+
+def cpu_baseline(packed, cam, width, height, stride):
+    """The oracle (oracle/blok_oracle.cpp: restated intersect.rint behind a front-to-back slot lattice)
+    timed on this box's host cores, on a strided sample of the same frame.  Baseline only."""
+    from tests import oracle_ffi as O
+    threads = max(1, min(16, os.cpu_count() or 1))
+    lattice = O.Lattice(packed.nodes, packed.sub_chunks)
+    lattice.trace_primary(cam, width, height, stride=max(stride * 4, 8), threads=threads, want_hits=False)  # warm
+    t0 = time.perf_counter()
+    _, ctr = lattice.trace_primary(cam, width, height, stride=stride, threads=threads, want_hits=False)
+    dt = time.perf_counter() - t0
+    rays = int(ctr["rays"])
+    alg_bytes = 48 * int(ctr["sub_chunks_entered"]) + 16 * int(ctr["nodes_fetched"]) + 32 * int(ctr["hits"]) + 16 * rays
+    return {
+        "value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+        "sample": f"every {stride}th pixel in x and y of the {width}x{height} frame ({rays} rays, {dt:.2f} s wall)",
+    }, {
+        "bytes_per_ray": alg_bytes / rays,
+        "sub_chunks_per_ray": int(ctr["sub_chunks_entered"]) / rays,
+        "nodes_per_ray": int(ctr["nodes_fetched"]) / rays,
+        "hit_fraction": int(ctr["hits"]) / rays,
+    }
+
+
+def main():
+    args = parse()
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_size != args.gpus:
+        if world_size == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world_size
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a gfx950 GPU (no CPU fallback exists)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world_size > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from blok_amd import world as W
+    from blok_amd.tracer import HipTracer
+
+    W_, H_ = args.width, args.height
+    packed = build_world(args.n, args.seed)
+    cam = W.scene_camera(args.n, args.pose, W_, H_, args.seed)
+    tracer = HipTracer(W_, H_, device=local_rank).init()
+    stats = tracer.add_world(packed)                      # world resident in HBM from here on
+
+    stream = torch.cuda.current_stream()
+    frame = torch.empty((H_ * W_, 4), dtype=torch.int32, device="cuda")       # 16-B first-hit records
+    if world_size > 1:
+        tile = args.tile
+        per_rank = tracer.tiles_for_rank(tile, 0, world_size)                # rank 0 holds the maximum
+        mine = torch.empty((per_rank * tile * tile, 4), dtype=torch.int32, device="cuda")
+        gathered = torch.empty((world_size * per_rank * tile * tile, 4), dtype=torch.int32, device="cuda")
+
+    def step():
+        if world_size == 1:
+            tracer.draw_frame_device(cam, frame.data_ptr(), stream=stream.cuda_stream)
+        else:
+            tracer.draw_tiles_device(cam, tile, rank, world_size, mine.data_ptr(), stream=stream.cuda_stream)
+            dist.all_gather_into_tensor(gathered, mine)
+            tracer.untile_device(gathered.data_ptr(), tile, world_size, per_rank, frame.data_ptr(),
+                                 stream=stream.cuda_stream)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        step()
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    fence()
+    device_ms = ev0.elapsed_time(ev1)          # HIP events on the launch stream, whole timed region
+    if dist is not None:
+        t = torch.tensor([elapsed, device_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, device_ms = float(t[0]), float(t[1])
+
+    # dominant kernel's average launch duration: HIP events around single launches on the same stream
+    tracer.set_timing(True)
+    kernel_ms = []
+    for _ in range(min(args.steps, 20)):
+        if world_size == 1:
+            tracer.draw_frame_device(cam, frame.data_ptr(), stream=stream.cuda_stream)
+        else:
+            tracer.draw_tiles_device(cam, tile, rank, world_size, mine.data_ptr(), stream=stream.cuda_stream)
+        torch.cuda.synchronize()
+        kernel_ms.append(tracer.last_kernel_ms())
+    tracer.set_timing(False)
+    kernel_ms_avg = float(np.mean(kernel_ms))
+    hits = int((frame[:, 3] >> 24).sum().item()) if rank == 0 else 0
+
+    if rank == 0:
+        rays_per_step = W_ * H_
+        value = rays_per_step * args.steps / elapsed / 1e6
+        out = {
+            "metric": "Mrays/sec, primary first-hit rays at 4K over a 1024^3 SVO",
+            "value": value, "unit": "Mrays/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.n}^3 synthetic SVO (G(N,seed) terrain shell + 64 spheres, "
+                                   f"{stats.n_voxels} voxels, {stats.n_ref_nodes} reference SvoNodes, "
+                                   f"{stats.n_sub_chunks} sub-chunks), {W_}x{H_} primary rays, camera pose "
+                                   f"{'ABC'[args.pose]}, first-hit records 16 B/ray",
+                       "parallelism": "single GPU" if world_size == 1 else f"{args.tile}x{args.tile} screen tiles round-robin over {world_size} GPUs + RCCL all-gather",
+                       "hits_per_frame": hits, "device_ms_per_step": device_ms / args.steps},
+        }
+        alg = None
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"], alg = cpu_baseline(packed, cam, W_, H_, args.cpu_stride)
+        rays_per_launch = rays_per_step / world_size
+        if alg is not None:
+            achieved = alg["bytes_per_ray"] * rays_per_launch / (kernel_ms_avg * 1e-3) / 1e9
+            traffic = None
+            pmc = ROOT / "profiles" / "pmc_traffic.json"
+            if pmc.exists() and world_size == 1 and (args.n, W_, H_, args.pose) == (1024, 3840, 2160, 0):
+                traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
+            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                               "kernel": "trace_kernel", "kernel_ms": kernel_ms_avg,
+                               "algorithmic_bytes_per_ray": alg["bytes_per_ray"],
+                               "rays_per_launch": rays_per_launch,
+                               "sub_chunks_per_ray": alg["sub_chunks_per_ray"], "nodes_per_ray": alg["nodes_per_ray"],
+                               "hit_fraction": alg["hit_fraction"]}
+        print(json.dumps(out))
+    tracer.shutdown()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

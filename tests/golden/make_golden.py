@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Generates the committed golden fixtures.  Run HERE (authoring container):
+
+    python tests/golden/make_golden.py
+
+* morton_reference.json  — outputs of the REFERENCE's own morton.hpp (compiled in place as
+  oracle/_ref/libref_morton.so; needs /root/reference).  These are true reference vectors.
+* svo_builder.json       — per-chunk node-array digests of the oracle's SvoTree/ChunkManager restatement for
+  seeded voxel sets ("parity unpinned": the reference's svo.cpp cannot be compiled here, it needs glm).
+* first_hit_64.npz       — oracle first-hit records, 64^3 scene, 256x256 (BASELINE.json configs[0]): a 64x64
+  centre crop of each pose + SHA-256 of the full buffers.
+The fixtures are data (inputs + expected outputs); no reference source text is stored.
+"""
+import hashlib
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+from blok_amd import world as W  # noqa: E402  (scene generator = input synthesis only)
+from tests import oracle_ffi as O  # noqa: E402
+
+OUT = Path(__file__).resolve().parent
+SEED = 0xB10C0001
+
+
+def morton():
+    ref = O.ref_morton()
+    if ref is None:
+        print("oracle/_ref/libref_morton.so missing: keeping existing morton_reference.json")
+        return
+    rng = np.random.default_rng(7)
+    pts = [(0, 0, 0), (1, 2, 3), (127, 127, 127), (-1, -1, -1), (-5, 7, 1000), (1048575, 0, -1048576),
+           (1 << 19, 1 << 18, 1 << 17), (5, 5, 5), (64, 32, 16)]
+    pts += [tuple(int(v) for v in rng.integers(-(1 << 20), 1 << 20, 3)) for _ in range(200)]
+    vec = []
+    for x, y, z in pts:
+        code = int(ref.ref_morton_encode(x, y, z))
+        octs = [int(ref.ref_morton_octant(code, 7, lvl)) for lvl in range(7)]
+        vec.append({"xyz": [x, y, z], "code": f"{code:#018x}", "octants_depth7": octs})
+    (OUT / "morton_reference.json").write_text(json.dumps({"source": "blok/include/morton.hpp compiled in place",
+                                                           "vectors": vec}, indent=0))
+
+
+def svo_builder():
+    cases = []
+    for seed, count, span in [(1, 50, 16), (2, 2000, 128), (3, 5000, 200), (4, 300, 128)]:
+        rng = np.random.default_rng(seed)
+        xyz = rng.integers(-span if seed == 3 else 0, span, size=(count, 3)).astype(np.int32)
+        mats = rng.integers(1, 1 << 16, size=count).astype(np.uint32)
+        ow = O.OracleWorld(128, 1.0)
+        ow.set_voxels(xyz, mats)
+        ow.rebuild()
+        nodes, subs = ow.pack()
+        chunks = []
+        for i in range(ow.n_chunks()):
+            coord, cn = ow.chunk(i)
+            chunks.append({"coord": list(coord), "n_nodes": int(len(cn)),
+                           "sha256": hashlib.sha256(cn.tobytes()).hexdigest()})
+        cases.append({"seed": seed, "count": count, "span": span, "n_nodes": int(len(nodes)), "n_sub_chunks": int(len(subs)),
+                      "nodes_sha256": hashlib.sha256(nodes.tobytes()).hexdigest(),
+                      "sub_chunks_sha256": hashlib.sha256(subs.tobytes()).hexdigest(), "chunks": chunks})
+    (OUT / "svo_builder.json").write_text(json.dumps({"generator": "numpy default_rng(seed): integers(lo, span, (count,3)) then integers(1, 65536, count); lo = -span for seed 3 else 0",
+                                                      "cases": cases}, indent=1))
+
+
+def first_hit():
+    n, w, h = 64, 256, 256
+    cm = W.ChunkManager(128, 1.0)
+    cm.generate_scene(n, SEED)
+    cm.rebuild_dirty_chunks()
+    pw = cm.pack_chunks_to_gpu_svo()
+    lat = O.Lattice(pw.nodes, pw.sub_chunks)
+    out = {}
+    meta = {}
+    for pose in (0, 1, 2):
+        cam = W.scene_camera(n, pose, w, h, SEED)
+        hits, ctr = lat.trace(O.primary_rays(cam, w, h))
+        img = hits.reshape(h, w)
+        out[f"crop_pose{pose}"] = img[96:160, 96:160].copy()
+        out[f"cam_pose{pose}"] = cam
+        meta[f"pose{pose}"] = {"sha256_full": hashlib.sha256(hits.tobytes()).hexdigest(), "hits": int(ctr["hits"]),
+                               "sub_chunks_entered": int(ctr["sub_chunks_entered"]), "nodes_fetched": int(ctr["nodes_fetched"])}
+    np.savez_compressed(OUT / "first_hit_64.npz", **out)
+    (OUT / "first_hit_64.json").write_text(json.dumps({"scene": "G(64, 0xB10C0001)", "frame": [w, h], "crop": [96, 96, 64, 64], **meta}, indent=1))
+
+
+if __name__ == "__main__":
+    morton()
+    svo_builder()
+    first_hit()
+    print("golden fixtures written to", OUT)

@@ -1,0 +1,180 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against the oracle — bit-exact first-hit records."""
+import hashlib
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from blok_amd import tiles as T
+from blok_amd import world as W
+from tests import oracle_ffi as O
+from tests.conftest import SEED, edge_case_rays, make_scene_world, random_rays, records_equal
+
+pytestmark = pytest.mark.gpu
+GOLDEN = Path(__file__).resolve().parent / "golden"
+
+
+@pytest.fixture(scope="module")
+def tracer_cls():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from blok_amd.tracer import HipTracer
+    from blok_amd import _ffi
+    assert _ffi.HIP_LIB.exists(), "libblok_hip.so must be built in-tree"
+    return HipTracer
+
+
+def test_config1_golden_first_hits(tracer_cls, scene64):
+    """64^3, 256x256: committed golden crops + digests of the full buffers."""
+    cm, pw = scene64
+    meta = json.loads((GOLDEN / "first_hit_64.json").read_text())
+    gold = np.load(GOLDEN / "first_hit_64.npz")
+    tr = tracer_cls(256, 256).init()
+    st = tr.add_world(pw)
+    assert st.n_voxels == 10082 and st.levels == 3
+    for pose in (0, 1, 2):
+        cam = W.scene_camera(64, pose, 256, 256, SEED)
+        hits = tr.draw_frame(cam)
+        assert records_equal(hits[96:160, 96:160], gold[f"crop_pose{pose}"]).all()
+        assert hashlib.sha256(hits.tobytes()).hexdigest() == meta[f"pose{pose}"]["sha256_full"]
+    tr.shutdown()
+
+
+def test_explicit_rays_edge_cases(tracer_cls, scene64):
+    cm, pw = scene64
+    tr = tracer_cls(64, 64).init()
+    tr.add_world(pw)
+    rays = np.concatenate([edge_case_rays(), random_rays(64, 20000, 31)])
+    ref, ctr = O.Lattice(pw.nodes, pw.sub_chunks).trace(rays, threads=8)
+    got = tr.trace_rays(rays)
+    assert ctr["hits"] > 3000
+    assert records_equal(got, ref).all()
+    assert len(tr.trace_rays(rays[:0])) == 0
+    tr.shutdown()
+
+
+def test_config2_dense_256_1080p(tracer_cls, scene256):
+    """BASELINE.json configs[1]: 256^3 dense grid upload, 1920x1080.  Full frame vs oracle."""
+    cm, pw = scene256
+    ids = W.scene_dense(256, SEED)
+    tr = tracer_cls(1920, 1080).init()
+    st = tr.add_dense(ids, (0, 0, 0), W.scene_materials(SEED))
+    assert st.n_voxels == int((ids != 0).sum())
+    cam = W.scene_camera(256, 0, 1920, 1080, SEED)
+    dense_hits = tr.draw_frame(cam)
+    ref, ctr = O.Lattice(pw.nodes, pw.sub_chunks).trace_primary(cam, 1920, 1080, threads=16)
+    assert ctr["hits"] > 100000
+    assert records_equal(dense_hits.reshape(-1), ref).all()
+    # the same voxels through the reference-format upload give the same frame
+    tr.add_world(pw)
+    assert records_equal(tr.draw_frame(cam).reshape(-1), ref).all()
+    # every hit names a filled voxel with its material; t is positive and below tmax
+    h = dense_hits.reshape(-1)
+    hit = h[h["hit"] == 1]
+    v = hit["voxel"].astype(np.int64)
+    assert (ids[v[:, 2], v[:, 1], v[:, 0]] == hit["material_id"]).all()
+    assert (hit["t"] >= np.float32(0.001)).all() and (hit["t"] < 10000).all() and (hit["face"] < 6).all()
+    miss = h[h["hit"] == 0]
+    assert (miss["t"] == -1).all() and (miss["face"] == 0xFF).all() and (miss["material_id"] == 0).all()
+    tr.shutdown()
+
+
+@pytest.fixture(scope="module")
+def scene1024():
+    return make_scene_world(1024)
+
+
+def test_config3_1024_svo_4k(tracer_cls, scene1024):
+    """BASELINE.json configs[2] at full size: 4K over the 1024^3 SVO.  Oracle on a strided sample of every
+    pose; rectangle tiling, tile partition + untile, and determinism on the full frame."""
+    import torch
+    cm, pw = scene1024
+    Wd, Ht = 3840, 2160
+    tr = tracer_cls(Wd, Ht).init()
+    st = tr.add_world(pw)
+    assert st.levels == 5 and st.n_sub_chunks == len(pw.sub_chunks)
+    lat = O.Lattice(pw.nodes, pw.sub_chunks)
+    frames = {}
+    for pose in (0, 1, 2):
+        cam = W.scene_camera(1024, pose, Wd, Ht, SEED)
+        full = tr.draw_frame(cam)
+        frames[pose] = full
+        stride = 5
+        ref, ctr = lat.trace_primary(cam, Wd, Ht, stride=stride, threads=16)
+        assert ctr["hits"] > 20000 and ctr["iter_limit_hits"] == 0 and ctr["stack_limit_hits"] == 0
+        assert records_equal(full[::stride, ::stride].reshape(-1), ref).all(), f"pose {pose}"
+    cam = W.scene_camera(1024, 0, Wd, Ht, SEED)
+    full = frames[0]
+    # idempotence / determinism
+    assert records_equal(tr.draw_frame(cam).reshape(-1), full.reshape(-1)).all()
+    # any rectangle of the frame equals the same pixels of the full frame (tile-able entry point)
+    for rect in [(0, 0, 17, 9), (1000, 700, 333, 211), (3840 - 50, 2160 - 30, 50, 30)]:
+        x0, y0, w, h = rect
+        assert records_equal(tr.draw_frame(cam, rect).reshape(-1), full[y0:y0 + h, x0:x0 + w].reshape(-1)).all()
+    # multi-GPU partition rehearsed on one device: n virtual ranks -> gathered buffer -> untile == full frame
+    for n_ranks, tile in [(8, 32), (3, 64)]:
+        per = tr.tiles_for_rank(tile, 0, n_ranks)
+        gathered = torch.zeros((n_ranks * per * tile * tile, 4), dtype=torch.int32, device="cuda")
+        for r in range(n_ranks):
+            assert tr.tiles_for_rank(tile, r, n_ranks) == T.tiles_for_rank(Wd, Ht, tile, r, n_ranks)
+            tr.draw_tiles_device(cam, tile, r, n_ranks, gathered[r * per * tile * tile:].data_ptr())
+        out = torch.empty((Ht * Wd, 4), dtype=torch.int32, device="cuda")
+        tr.untile_device(gathered.data_ptr(), tile, n_ranks, per, out.data_ptr())
+        torch.cuda.synchronize()
+        assert (out.cpu().numpy().view(np.uint8).reshape(-1, 16) == full.reshape(-1).view(np.uint8).reshape(-1, 16)).all()
+        host = T.untile(gathered.cpu().numpy().view(O.HIT).reshape(-1), Wd, Ht, tile, n_ranks, per)
+        assert records_equal(host.reshape(-1), full.reshape(-1)).all()
+    tr.shutdown()
+
+
+def test_world_edge_cases(tracer_cls):
+    """Empty world, single voxel, negative coordinates, material ids above 65535, replace-world, errors."""
+    from blok_amd._ffi import BlokError
+    tr = tracer_cls(32, 32).init()
+    cam = W.camera_look_at((5.5, 20, 7.5), (5.5, 0, 7.5), 60.0, 32, 32)
+    with pytest.raises(BlokError) as e:
+        tr.draw_frame(cam)
+    assert e.value.status == -4                                    # BLOK_ERR_NO_WORLD
+    empty = W.ChunkManager(128, 1.0).pack_chunks_to_gpu_svo()
+    tr.add_world(empty)
+    assert (tr.draw_frame(cam)["hit"] == 0).all()
+    cm = W.ChunkManager(128, 1.0)
+    rng = np.random.default_rng(4)
+    xyz = rng.integers(-150, 150, size=(6000, 3)).astype(np.int32)
+    cm.set_voxels(xyz, rng.integers(1, 70000, size=len(xyz)).astype(np.uint32))
+    cm.rebuild_dirty_chunks()
+    pw = cm.pack_chunks_to_gpu_svo()
+    tr.add_world(pw)
+    rays = random_rays(300, 5000, 12)
+    rays["org"] -= 150
+    ref, ctr = O.Lattice(pw.nodes, pw.sub_chunks).trace(rays, threads=4)
+    got = tr.trace_rays(rays)
+    assert ctr["hits"] > 200 and records_equal(got, ref).all()
+    assert got["material_id"].max() > 65535
+    bad = pw.sub_chunks.copy()
+    bad["world_min"][0, 1] += 0.25
+    with pytest.raises(BlokError) as e:
+        tr.add_world(W.PackedWorld(pw.nodes, bad, pw.materials))
+    assert e.value.status == -5 and "lattice" in str(e.value)     # BLOK_ERR_UNSUPPORTED
+    with pytest.raises(BlokError):
+        tr.draw_frame(cam, (0, 0, 64, 64))                          # rectangle outside the frame
+    tr.resize(64, 48)
+    assert tr.draw_frame(W.camera_look_at((0, 200, 0), (0, 0, 0), 60.0, 64, 48)).shape == (48, 64)
+    tr.shutdown()
+
+
+def test_shaded_debug_view_and_timing(tracer_cls, scene64):
+    cm, pw = scene64
+    tr = tracer_cls(128, 128).init()
+    tr.add_world(pw)
+    cam = W.scene_camera(64, 0, 128, 128, SEED)
+    hits = tr.draw_frame(cam)
+    rgba = tr.shade_rgba8(cam)
+    assert rgba.shape == (128, 128)
+    assert ((rgba >> 24) == 0xFF).all()
+    assert (rgba[hits["hit"] == 0] == rgba[hits["hit"] == 0][0]).all()
+    tr.set_timing(True)
+    tr.draw_frame(cam)
+    assert 0.0 < tr.last_kernel_ms() < 1000.0
+    tr.shutdown()

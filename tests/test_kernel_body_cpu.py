@@ -1,0 +1,131 @@
+"""CPU: the trace kernel's per-ray body (blok_amd/csrc/hip/trace_core.h) compiled for the host by the test
+harness, against the oracle.  This is how the walk is debugged and sanitised without a GPU; the shipped
+library contains no host build of it."""
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from blok_amd import world as W
+from tests import harness_ffi as H
+from tests import oracle_ffi as O
+from tests.conftest import SEED, edge_case_rays, random_rays, records_equal
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+@pytest.mark.parametrize("pose", [0, 1, 2])
+def test_primary_rays_bit_exact_64(scene64, pose):
+    cm, pw = scene64
+    cam = W.scene_camera(64, pose, 160, 120, SEED)
+    ref, ctr = O.Lattice(pw.nodes, pw.sub_chunks).trace(O.primary_rays(cam, 160, 120))
+    got = H.HostKernel(pw.nodes, pw.sub_chunks).trace_primary(cam, 160, 120)
+    assert ctr["hits"] > 1000
+    assert records_equal(got, ref).all()
+
+
+def test_edge_case_and_random_rays_bit_exact(scene64):
+    cm, pw = scene64
+    rays = np.concatenate([edge_case_rays(), random_rays(64, 4000, 9)])
+    ref, ctr = O.Lattice(pw.nodes, pw.sub_chunks).trace(rays)
+    got = H.HostKernel(pw.nodes, pw.sub_chunks).trace_rays(rays)
+    assert ctr["hits"] > 500
+    assert records_equal(got, ref).all()
+
+
+def test_world_with_negative_coordinates_and_several_chunks():
+    rng = np.random.default_rng(4)
+    xyz = rng.integers(-150, 150, size=(6000, 3)).astype(np.int32)
+    mats = rng.integers(1, 70000, size=len(xyz)).astype(np.uint32)       # ids above 65535 travel unclamped
+    cm = W.ChunkManager(128, 1.0)
+    cm.set_voxels(xyz, mats)
+    cm.rebuild_dirty_chunks()
+    pw = cm.pack_chunks_to_gpu_svo()
+    hk = H.HostKernel(pw.nodes, pw.sub_chunks)
+    assert hk.n_voxels == len(np.unique(xyz, axis=0))
+    rays = random_rays(300, 3000, 12)
+    rays["org"] -= 150
+    ref, ctr = O.Lattice(pw.nodes, pw.sub_chunks).trace(rays)
+    assert ctr["hits"] > 100
+    assert records_equal(hk.trace_rays(rays), ref).all()
+
+
+def test_single_voxel_and_empty_worlds():
+    cm = W.ChunkManager(128, 1.0)
+    cm.set_voxels(np.array([[5, 6, 7]], dtype=np.int32), np.array([9], dtype=np.uint32))
+    cm.rebuild_dirty_chunks()
+    pw = cm.pack_chunks_to_gpu_svo()
+    hk = H.HostKernel(pw.nodes, pw.sub_chunks)
+    rays = np.zeros(4, dtype=O.RAY)
+    rays["tmin"], rays["tmax"] = 0.001, 10000.0
+    rays["org"] = [(5.5, 20, 7.5), (5.5, 6.5, 7.5), (0, 0, 0), (5.5, 20, 7.5)]
+    rays["dir"] = [(0, -1, 0), (0, -1, 0), (1, 0, 0), (0, 1, 0)]
+    ref, _ = O.trace_bruteforce(pw.nodes, pw.sub_chunks, rays)
+    got = hk.trace_rays(rays)
+    assert records_equal(got, ref).all()
+    assert got[0]["hit"] == 1 and got[0]["face"] == 2 and got[0]["t"] == np.float32(13.0) and tuple(got[0]["voxel"]) == (5, 6, 7)
+    assert got[1]["hit"] == 1 and got[1]["t"] == np.float32(0.001)        # origin inside the voxel: t = tmin
+    assert got[2]["hit"] == 0 and got[2]["t"] == -1.0 and got[2]["face"] == 0xFF
+    empty = H.HostKernel(np.zeros(0, dtype=O.SVO_NODE), np.zeros(0, dtype=O.SUB_CHUNK))
+    assert (empty.trace_rays(rays)["hit"] == 0).all()
+
+
+def test_unsupported_worlds_are_rejected():
+    cm = W.ChunkManager(128, 1.0)
+    cm.set_voxels(np.array([[1, 1, 1]], dtype=np.int32), np.array([1], dtype=np.uint32))
+    cm.rebuild_dirty_chunks()
+    pw = cm.pack_chunks_to_gpu_svo()
+    subs = pw.sub_chunks.copy()
+    subs["world_min"][0, 0] += 0.5
+    with pytest.raises(RuntimeError, match="lattice"):
+        H.HostKernel(pw.nodes, subs)
+    nodes = pw.nodes.copy()
+    root = subs_root = int(pw.sub_chunks[0]["root_node_index"])
+    nodes[root]["child_mask"] = 0
+    nodes[root]["occupancy"] = 1.0                     # a filled 16^3 leaf: never produced by insertVoxel
+    with pytest.raises(RuntimeError, match="leaf above voxel level"):
+        H.HostKernel(nodes, pw.sub_chunks)
+
+
+def test_config2_dense_256_sample(scene256):
+    """BASELINE.json configs[1] geometry (256^3, 1920x1080) on a strided pixel sample."""
+    cm, pw = scene256
+    cam = W.scene_camera(256, 0, 1920, 1080, SEED)
+    rays = O.primary_rays(cam, 1920, 1080, stride=12)
+    ref, ctr = O.Lattice(pw.nodes, pw.sub_chunks).trace(rays, threads=4)
+    got = H.HostKernel(pw.nodes, pw.sub_chunks).trace_rays(rays)
+    assert ctr["hits"] > 2000
+    assert records_equal(got, ref).all()
+
+
+def test_kernel_body_under_address_and_ub_sanitizers(tmp_path):
+    """ASan/UBSan run of the kernel body + tree builder (GPU sanitizers are unavailable on this pool)."""
+    lib = H.build(sanitize=True)
+    code = f"""
+import sys, ctypes as C, numpy as np
+sys.path.insert(0, {str(ROOT)!r})
+from blok_amd import world as W
+from tests import oracle_ffi as O
+from tests.conftest import edge_case_rays, random_rays
+L = C.CDLL({str(lib)!r})
+L.hh_build.restype = C.c_void_p
+L.hh_build.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_char_p)]
+L.hh_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+cm = W.ChunkManager(128, 1.0); cm.generate_scene(64); cm.rebuild_dirty_chunks(); pw = cm.pack_chunks_to_gpu_svo()
+why = C.c_char_p()
+h = L.hh_build(C.c_void_p(pw.nodes.ctypes.data), len(pw.nodes), C.c_void_p(pw.sub_chunks.ctypes.data), len(pw.sub_chunks), C.byref(why))
+rays = np.concatenate([edge_case_rays(), random_rays(64, 2000, 5)])
+out = np.zeros(len(rays), dtype=O.HIT)
+L.hh_trace_rays(C.c_void_p(h), C.c_void_p(rays.ctypes.data), len(rays), C.c_void_p(out.ctypes.data))
+print('hits', int(out['hit'].sum()))
+"""
+    import os
+    env = dict(os.environ)
+    asan = subprocess.run(["g++", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    env["LD_PRELOAD"] = asan
+    env["ASAN_OPTIONS"] = "detect_leaks=0"
+    proc = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    assert "hits" in proc.stdout and "runtime error" not in proc.stderr and "AddressSanitizer" not in proc.stderr

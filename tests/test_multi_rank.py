@@ -1,0 +1,76 @@
+"""CPU, world_size 2 over gloo: the screen-tile partition, the gather and the un-permute reproduce the
+single-rank frame.  Ranks produce their tiles with the kernel body compiled for the host (test harness)."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world_size, port, out_dir):
+    sys.path.insert(0, str(ROOT))
+    import torch
+    import torch.distributed as dist
+    from blok_amd import tiles as T
+    from blok_amd import world as W
+    from tests import harness_ffi as H
+    from tests import oracle_ffi as O
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    n, width, height, tile = 64, 200, 136, 32            # ragged: 7x5 tiles, edge tiles padded
+    cm = W.ChunkManager(128, 1.0)
+    cm.generate_scene(n)
+    cm.rebuild_dirty_chunks()
+    pw = cm.pack_chunks_to_gpu_svo()                      # world replicated on every rank
+    cam = W.scene_camera(n, 0, width, height)
+    hk = H.HostKernel(pw.nodes, pw.sub_chunks)
+    full = hk.trace_primary(cam, width, height).reshape(height, width)
+    per = T.tiles_for_rank(width, height, tile, 0, world_size)
+    mine = np.zeros(per * tile * tile, dtype=O.HIT)
+    mine["t"], mine["face"] = -1.0, 0xFF                  # padding = miss records
+    for k, (x0, y0) in enumerate(T.rank_tile_origins(width, height, tile, rank, world_size)):
+        block = mine[k * tile * tile:(k + 1) * tile * tile].reshape(tile, tile)
+        h, w = min(tile, height - y0), min(tile, width - x0)
+        block[:h, :w] = full[y0:y0 + h, x0:x0 + w]        # this rank only keeps its own tiles
+    send = torch.from_numpy(mine.view(np.int32).reshape(-1, 4).copy())
+    gathered = torch.empty((world_size * len(send), 4), dtype=torch.int32)
+    dist.all_gather_into_tensor(gathered, send)
+    frame = T.untile(gathered.numpy().view(O.HIT).reshape(-1), width, height, tile, world_size, per)
+    ok = frame.tobytes() == full.tobytes()
+    t = torch.tensor([1.0 + rank])
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)              # the bench's max-over-ranks timing reduction
+    (Path(out_dir) / f"rank{rank}.txt").write_text(f"{int(ok)} {float(t[0])} {T.tiles_for_rank(width, height, tile, rank, world_size)}")
+    dist.destroy_process_group()
+
+
+def test_tile_partition_gather_untile_world_size_2(tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = (tmp_path / "rank0.txt").read_text().split()
+    r1 = (tmp_path / "rank1.txt").read_text().split()
+    assert r0[0] == "1" and r1[0] == "1"
+    assert float(r0[1]) == 2.0 and float(r1[1]) == 2.0
+    assert int(r0[2]) + int(r1[2]) == 35 and int(r0[2]) == 18
+
+
+def test_tile_math_matches_c_abi():
+    from blok_amd import _ffi
+    from blok_amd import tiles as T
+    lib = _ffi.hip_lib()
+    for (w, h, tile, n) in [(3840, 2160, 32, 8), (3840, 2160, 32, 1), (200, 136, 32, 2), (100, 70, 64, 3), (16, 16, 16, 4)]:
+        for r in range(n):
+            assert lib.blok_hip_tiles_for_rank(w, h, tile, r, n) == T.tiles_for_rank(w, h, tile, r, n)
+            assert len(T.rank_tile_origins(w, h, tile, r, n)) == T.tiles_for_rank(w, h, tile, r, n)
