@@ -58,5 +58,17 @@ def build_oracle() -> Path:
     return ROOT / "oracle" / "liboracle.so"
 
 
+def build_tools(force: bool = False) -> Path:
+    """Headless C++ driver (tools/blok_headless.cpp) over include/blok/hip_tracer.hpp."""
+    out = ROOT / "tools" / "blok_headless"
+    src = ROOT / "tools" / "blok_headless.cpp"
+    if force or _stale(out, [src, INCLUDE / "blok" / "hip_tracer.hpp", INCLUDE / "blok_hip.h", INCLUDE / "blok_world.h"]):
+        _run(["g++", "-O2", "-std=c++20", "-Wall", "-Wextra", f"-I{INCLUDE}", "-o", out, src, f"-L{PKG}",
+              "-lblok_hip", "-lblok_host", "-Wl,-rpath,$ORIGIN/../blok_amd"])
+    return out
+
+
 def build_all(force: bool = False):
-    return build_host(force), build_hip(force), build_oracle()
+    host, hip = build_host(force), build_hip(force)
+    build_tools(force)
+    return host, hip, build_oracle()

@@ -13,6 +13,11 @@
 #define BLOK_DEV __device__ __forceinline__
 #endif
 
+// Optional event hook, defined only by the host harness' statistics build.
+#ifndef BLOK_STAT
+#define BLOK_STAT(event, level)
+#endif
+
 #if defined(__clang__)
 #pragma clang fp contract(off)
 #endif
@@ -111,6 +116,7 @@ BLOK_DEV void trace_one(const TraceArgs& A, const RayIn& r, uint4* stk, blok_hit
     }
 
     for (uint32_t guard = 0; guard < (1u << 20); ++guard) {
+        BLOK_STAT(0, lvl);
         const uint32_t shift = 2 * lvl;
         const uint32_t bit = ((px >> shift) & 3) | (((py >> shift) & 3) << 2) | (((pz >> shift) & 3) << 4);
         if (mask_bit(node, bit)) {
@@ -142,6 +148,7 @@ BLOK_DEV void trace_one(const TraceArgs& A, const RayIn& r, uint4* stk, blok_hit
                 }
             } else {
                 // descend: remember the node we are leaving, fetch the child, pick its start cell
+                BLOK_STAT(1, lvl);
                 stk[(lvl - 1) * kBlock] = make_uint4(node.lo, node.hi, node.base, 0u);   // slot of level lvl+1
                 const uint4 q = A.nodes[node.base + mask_rank(node, bit)];
                 node.lo = q.x; node.hi = q.y; node.base = q.z;
@@ -155,6 +162,7 @@ BLOK_DEV void trace_one(const TraceArgs& A, const RayIn& r, uint4* stk, blok_hit
             }
         }
         // step to the next cell of the merge sequence: cross the nearest far plane (x, then y, then z on ties)
+        BLOK_STAT(2, lvl);
         const bool sx = tFx <= tFy && tFx <= tFz;
         const bool sy = !sx && tFy <= tFz;
         tCur = sx ? tFx : (sy ? tFy : tFz);
@@ -168,6 +176,7 @@ BLOK_DEV void trace_one(const TraceArgs& A, const RayIn& r, uint4* stk, blok_hit
         const uint32_t crossed = static_cast<uint32_t>(pold ^ pnew) >> (shift + 2);
         if (crossed != 0u) {
             // left the parent node: climb to the level whose cell boundary was crossed
+            BLOK_STAT(3, lvl);
             const uint32_t k = ((31u - __clz(crossed)) >> 1) + 1u;
             lvl += k;
             const uint32_t ns = 2 * lvl;

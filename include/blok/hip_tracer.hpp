@@ -1,0 +1,182 @@
+// C++20 host side of the gfx950 backend, above the C ABI (blok_hip.h / blok_world.h).
+//
+// Mirrors the reference's own types so that an `App`-like driver calls it the way blok's App calls its
+// backends (reference blok/src/app.cpp:73-128,130-192):
+//   blok::GraphicsApi      reference blok/include/backend.hpp:9-12, plus the third enumerator HIP
+//   blok::Camera           reference blok/include/camera.hpp:15-84 (same fields, defaults, key/mouse steps)
+//   blok::WorldSvoGpu      reference blok/include/resources.hpp:195-203 (the three host arrays only)
+//   blok::ChunkManager     reference blok/include/chunk_manager.hpp:18-52 (+ rebuildDirtyChunks, packChunksToGpuSvo)
+//   blok::HipTracer        reference blok/include/cuda_tracer.hpp:23-58 (lifecycle) and
+//                          blok/include/renderer.hpp:40-72 (addWorld / updateWorld / cleanupWorld)
+// Failures throw std::runtime_error, as the reference's backends do (caught once in main,
+// reference blok/src/main.cpp:19-22).  Header-only; link libblok_hip.so and libblok_host.so.
+#ifndef BLOK_HIP_TRACER_HPP
+#define BLOK_HIP_TRACER_HPP
+
+#include <cmath>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../blok_hip.h"
+#include "../blok_world.h"
+
+namespace blok {
+
+enum class GraphicsApi { OpenGL, Vulkan, HIP };
+
+struct Camera {
+    float position[3] = {0.0f, 10.0f, -5.0f};
+    float yaw = 0.0f;
+    float pitch = 0.0f;
+    float fov = 60.0f;
+    mutable bool cameraChanged = false;
+
+    // basis through the same code the tests pin (blok_camera_from_yaw_pitch)
+    blok_camera basis(unsigned width, unsigned height) const {
+        blok_camera c{};
+        if (blok_camera_from_yaw_pitch(position, yaw, pitch, fov, width, height, &c) != BLOK_OK)
+            throw std::runtime_error("Camera::basis: bad frame size");
+        return c;
+    }
+    void processKeyboard(char key, float dt) {           // reference camera.hpp:61-71
+        const blok_camera c = basis(1, 1);
+        const float speed = 40.0f * dt;
+        auto move = [&](const float d[3], float s) { for (int a = 0; a < 3; ++a) position[a] += d[a] * s; };
+        const float worldUp[3] = {0.0f, 1.0f, 0.0f};
+        if (key == 'W') move(c.fwd, speed);
+        if (key == 'S') move(c.fwd, -speed);
+        if (key == 'A') move(c.right, -speed);
+        if (key == 'D') move(c.right, speed);
+        if (key == 'X') move(worldUp, speed);
+        if (key == 'Z') move(worldUp, -speed);
+        cameraChanged = true;
+    }
+    void processMouse(float dx, float dy) {               // reference camera.hpp:72-81
+        const float sens = 0.01f;
+        yaw += dx * sens;
+        pitch += dy * sens;
+        if (pitch > 89.0f) pitch = 89.0f;
+        if (pitch < -89.0f) pitch = -89.0f;
+        cameraChanged = true;
+    }
+};
+
+struct WorldSvoGpu {
+    std::vector<blok_svo_node> globalNodes;
+    std::vector<blok_sub_chunk> globalSubChunks;
+    std::vector<blok_material> materials;
+};
+
+class ChunkManager {
+public:
+    uint32_t C;
+    float voxelSize;
+
+    ChunkManager(uint32_t C_, float voxelSize_) : C(C_), voxelSize(voxelSize_) {
+        if (blok_world_create(&w_, C_, voxelSize_) != BLOK_OK) throw std::runtime_error("ChunkManager: bad chunk size");
+    }
+    ~ChunkManager() { blok_world_destroy(w_); }
+    ChunkManager(const ChunkManager&) = delete;
+    ChunkManager& operator=(const ChunkManager&) = delete;
+
+    void setVoxelMaterial(const float worldPos[3], uint32_t materialId, float density = 1.0f) {
+        check(blok_world_set_voxel(w_, worldPos, materialId, density));
+    }
+    uint32_t getVoxelMaterial(const float worldPos[3]) const { return blok_world_get_voxel_material(w_, worldPos); }
+    blok_world* handle() { return w_; }
+
+    friend int rebuildDirtyChunks(ChunkManager& mgr, int maxPerFrame) {
+        const int n = blok_world_rebuild_dirty(mgr.w_, maxPerFrame);
+        if (n < 0) mgr.check(n);
+        return n;
+    }
+    friend void packChunksToGpuSvo(ChunkManager& mgr, WorldSvoGpu& gpuWorld) {
+        mgr.check(blok_world_pack(mgr.w_));
+        const blok_svo_node* n = blok_world_nodes(mgr.w_);
+        const blok_sub_chunk* s = blok_world_sub_chunks(mgr.w_);
+        gpuWorld.globalNodes.assign(n, n + blok_world_node_count(mgr.w_));
+        gpuWorld.globalSubChunks.assign(s, s + blok_world_sub_chunk_count(mgr.w_));
+    }
+
+private:
+    void check(int rc) const { if (rc < 0) throw std::runtime_error(std::string("ChunkManager: ") + blok_world_last_error(w_)); }
+    blok_world* w_ = nullptr;
+};
+
+class HipTracer {
+public:
+    HipTracer(unsigned int width, unsigned int height, int device = 0) : m_width(width), m_height(height), m_device(device) {}
+    ~HipTracer() { shutdown(); }
+    HipTracer(const HipTracer&) = delete;
+    HipTracer& operator=(const HipTracer&) = delete;
+
+    void init() {
+        if (m_ctx) return;
+        if (blok_hip_create(&m_ctx, m_device, m_width, m_height) != BLOK_OK)
+            throw std::runtime_error(std::string("HipTracer::init: ") + blok_hip_last_error(nullptr));
+        m_hits.resize(static_cast<size_t>(m_width) * m_height);
+    }
+    void shutdown() { if (m_ctx) { blok_hip_destroy(m_ctx); m_ctx = nullptr; } m_world = nullptr; }
+    void beginFrame() {}
+    void endFrame() {}
+    void resize(unsigned int w, unsigned int h) {
+        check(blok_hip_resize(m_ctx, w, h));
+        m_width = w; m_height = h;
+        m_hits.assign(static_cast<size_t>(w) * h, blok_hit{});
+    }
+    void resetAccum() { check(blok_hip_reset_accum(m_ctx)); m_frameIndex = 0; }
+
+    // = Renderer::addWorld: keeps a non-owning pointer to the caller's world, owns the device copies
+    void addWorld(WorldSvoGpu& gpuWorld) { m_world = &gpuWorld; updateWorld(); }
+    void updateWorld() {
+        if (!m_world) return;
+        check(blok_hip_upload_world(m_ctx, m_world->globalNodes.data(), m_world->globalNodes.size(),
+                                    m_world->globalSubChunks.data(), m_world->globalSubChunks.size(),
+                                    m_world->materials.data(), m_world->materials.size()));
+    }
+    void cleanupWorld() {
+        check(blok_hip_upload_world(m_ctx, nullptr, 0, nullptr, 0, nullptr, 0));
+        m_world = nullptr;
+    }
+
+    // = CudaTracer::drawFrame(cam, ...): one frame of primary first-hit records, blocking
+    void drawFrame(Camera& cam) {
+        const blok_camera c = cam.basis(m_width, m_height);
+        check(blok_hip_trace_primary(m_ctx, &c, 0, 0, m_width, m_height, m_hits.data()));
+        cam.cameraChanged = false;
+        ++m_frameIndex;
+    }
+    // RGBA8 view of the same frame (the CUDA backend's output format, reference cuda_tracer.cu:385-386)
+    const std::vector<uint32_t>& drawFrameRgba8(Camera& cam) {
+        const blok_camera c = cam.basis(m_width, m_height);
+        m_pixels.resize(static_cast<size_t>(m_width) * m_height);
+        check(blok_hip_shade_rgba8(m_ctx, &c, 0, 0, m_width, m_height, m_pixels.data()));
+        return m_pixels;
+    }
+
+    const std::vector<blok_hit>& hits() const { return m_hits; }     // output accessor (getGLTex analogue)
+    unsigned int width() const { return m_width; }
+    unsigned int height() const { return m_height; }
+    blok_hip_ctx* handle() { return m_ctx; }
+    blok_world_stats worldStats() const {
+        blok_world_stats s{};
+        if (blok_hip_world_stats(m_ctx, &s) != BLOK_OK) throw std::runtime_error("HipTracer: no world");
+        return s;
+    }
+
+private:
+    void check(int rc) const { if (rc != BLOK_OK) throw std::runtime_error(std::string("HipTracer: ") + blok_hip_last_error(m_ctx)); }
+
+    unsigned int m_width = 0, m_height = 0;
+    int m_device = 0;
+    blok_hip_ctx* m_ctx = nullptr;
+    WorldSvoGpu* m_world = nullptr;       // non-owning, like reference renderer.hpp:195
+    uint32_t m_frameIndex = 0;
+    std::vector<blok_hit> m_hits;
+    std::vector<uint32_t> m_pixels;
+};
+
+}  // namespace blok
+#endif

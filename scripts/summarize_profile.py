@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Condenses gpurun_out/prof_<tag>/ (rocprofv3 csv output) into profiles/<tag>_kernel_stats.csv,
+profiles/<tag>_pmc.json and profiles/pmc_traffic.json (HBM bytes per launch of the dominant kernel, with the
+gfx950 FETCH_SIZE correction of /opt/skills/guides/MI355X_MICROARCH.md §HBM applied)."""
+import csv
+import json
+import sys
+from collections import defaultdict
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = ROOT / "gpurun_out" / f"prof_{tag}"
+dst = ROOT / "profiles"
+dst.mkdir(exist_ok=True)
+
+stats = list(src.glob("trace/**/*kernel_stats.csv"))
+if stats:
+    text = stats[0].read_text()
+    (dst / f"{tag}_kernel_stats.csv").write_text(text)
+    print(text)
+trace = list(src.glob("trace/**/*kernel_trace.csv"))
+durations = defaultdict(list)
+if trace:
+    for row in csv.DictReader(trace[0].open()):
+        durations[row["Kernel_Name"]].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+
+pmc = defaultdict(lambda: defaultdict(list))
+for f in sorted(src.glob("pmc*/**/*counter_collection.csv")):
+    for row in csv.DictReader(f.open()):
+        pmc[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+summary = {}
+for kernel, counters in pmc.items():
+    if "trace_kernel" not in kernel:
+        continue
+    summary[kernel] = {c: {"mean": sum(v) / len(v), "n": len(v)} for c, v in counters.items()}
+    d = durations.get(kernel)
+    if d:
+        summary[kernel]["duration_ns_mean_unprofiled_pass"] = sum(d) / len(d)
+        summary[kernel]["launches"] = len(d)
+(dst / f"{tag}_pmc.json").write_text(json.dumps(summary, indent=1))
+print(json.dumps(summary, indent=1))
+for kernel, s in summary.items():
+    if "FETCH_SIZE" in s and "WRITE_SIZE" in s and "RayModeE0" in kernel:
+        # FETCH_SIZE / WRITE_SIZE are in KiB... rocprofv3 reports them in kilobytes (derived: *64/1024).
+        fetch_kb, write_kb = s["FETCH_SIZE"]["mean"], s["WRITE_SIZE"]["mean"]
+        out = {"kernel": kernel, "fetch_size_kb_raw": fetch_kb, "write_size_kb": write_kb,
+               "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM only for wide coalesced streams; this kernel's reads are "
+                       "16-B node gathers (uncalibrated width), so the raw value is reported as a lower bound and 2x as an upper bound",
+               "hbm_bytes_per_launch": (fetch_kb + write_kb) * 1024.0,
+               "hbm_bytes_per_launch_upper": (2 * fetch_kb + write_kb) * 1024.0}
+        (dst / "pmc_traffic.json").write_text(json.dumps(out, indent=1))
+        print(json.dumps(out, indent=1))

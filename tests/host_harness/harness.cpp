@@ -1,6 +1,10 @@
 // TEST INFRASTRUCTURE: runs the kernel's per-ray body on the CPU (one "lane" at a time) over a tree
 // built by the product's host tree builder.  Never linked into the shipped libraries.
 #define BLOK_TRACE_HOST_HARNESS 1
+#include <cstdint>
+// statistics build: events 0 iteration, 1 descend, 2 step, 3 ascend, per level
+static thread_local uint64_t g_stat[4][8];
+#define BLOK_STAT(event, level) (++g_stat[event][level])
 #include "trace_core.h"
 #include "reference_world.h"
 
@@ -51,6 +55,27 @@ void hh_trace_rays(const void* h, const blok_ray* rays, size_t n, blok_hit* out)
                 rays[i].tmin, rays[i].tmax};
         trace_one(a, r, stack.data(), out + i);
     }
+}
+
+// Per-ray iteration counts for a frame (row-major), plus the event totals [4][8].
+void hh_trace_primary_stats(const void* h, const blok_camera* cam, uint32_t width, uint32_t height, blok_hit* out,
+                            uint32_t* iters_per_ray, uint64_t* totals) {
+    const Harness* H = static_cast<const Harness*>(h);
+    TraceArgs a = make_args(H);
+    a.cam = *cam; a.frame_w = width; a.frame_h = height;
+    std::vector<uint4> stack(size_t(kMaxLevels) * kBlock);
+    std::memset(g_stat, 0, sizeof(g_stat));
+    for (uint32_t y = 0; y < height; ++y)
+        for (uint32_t x = 0; x < width; ++x) {
+            uint64_t before = 0;
+            for (int l = 0; l < 8; ++l) before += g_stat[0][l];
+            const RayIn r = primary_ray(a, x, y);
+            trace_one(a, r, stack.data(), out + size_t(y) * width + x);
+            uint64_t after = 0;
+            for (int l = 0; l < 8; ++l) after += g_stat[0][l];
+            iters_per_ray[size_t(y) * width + x] = uint32_t(after - before);
+        }
+    std::memcpy(totals, g_stat, sizeof(g_stat));
 }
 
 void hh_trace_primary(const void* h, const blok_camera* cam, uint32_t width, uint32_t height, blok_hit* out) {
