@@ -12,8 +12,7 @@ INCLUDE = ROOT / "include"
 
 HOST_SRC = [PKG / "csrc/host/world.cpp", PKG / "csrc/host/scene.cpp"]
 HIP_SRC = [PKG / "csrc/hip/api.hip", PKG / "csrc/hip/trace_kernels.hip", PKG / "csrc/hip/tree_build.cpp"]
-HIP_HDR = [PKG / "csrc/hip/tree.h", PKG / "csrc/hip/trace_kernels.h", PKG / "csrc/hip/reference_world.h",
-           INCLUDE / "blok_hip.h", INCLUDE / "blok_world.h"]
+HIP_HDR = sorted((PKG / "csrc/hip").glob("*.h")) + [INCLUDE / "blok_hip.h", INCLUDE / "blok_world.h"]
 
 
 def _stale(target: Path, deps) -> bool:

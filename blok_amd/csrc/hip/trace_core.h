@@ -34,11 +34,6 @@ BLOK_DEV float rn_mul(float a, float b) { return a * b; }
 BLOK_DEV float rn_div(float a, float b) { return a / b; }
 BLOK_DEV float rn_sqrt(float a) { return __builtin_sqrtf(a); }
 
-// T(a, p): t at which the ray crosses the plane  axis_a = p  (p a world integer).
-BLOK_DEV float plane_t(int p_world, float o, float inv) {
-    return rn_mul(rn_sub(static_cast<float>(p_world), o), inv);
-}
-
 // intersect.rint:79
 BLOK_DEV float safe_inv(float d) {
     return rn_div(1.0f, fabsf(d) < 1e-6f ? 1e-6f : d);
@@ -62,139 +57,142 @@ BLOK_DEV uint32_t mask_rank(const NodeRec& n, uint32_t bit) {
     return __popc(below_lo) + __popc(below_hi);
 }
 
-// One axis of "enter a node": which of the node's 4 child slabs contains the ray at tS, and the T of
-// that slab's far plane.  p = node corner (local), s = child size = 1 << shift.
-BLOK_DEV void enter_axis(int& p, float& t_far, int org, float o, float inv, bool pos,
-                                           uint32_t shift, float tS) {
-    const int base = p + org;
-    const float m2 = plane_t(base + (2 << shift), o, inv);          // middle plane (ray order j = 2)
-    const bool g = m2 <= tS;
-    const int jq = g ? 3 : 1;                                        // next plane to test, ray order
-    const float mq = plane_t(base + ((pos ? jq : 4 - jq) << shift), o, inv);
-    const bool g2 = mq <= tS;
-    const int n = (g ? 2 : 0) + (g2 ? 1 : 0);                        // interior planes already crossed
-    t_far = g ? (g2 ? t_far : mq) : (g2 ? m2 : mq);
-    p += (pos ? n : 3 - n) << shift;
-}
-
 struct RayIn { float ox, oy, oz, dx, dy, dz, tmin, tmax; };
 
+// The walk runs in MIRRORED tree coordinates: on an axis the ray travels in the negative direction the
+// coordinate is reflected (q = W - p), so in q-space every ray travels towards +q on every axis, the far
+// plane of a cell is always q + size and a step is always +size.  A mirrored plane q maps back to the
+// world plane  base + sgn * q  (sgn = +1: base = origin; sgn = -1: base = origin + W) before T is
+// evaluated, so T is the same canonical function of the same world integer as without mirroring, and
+// a node's child bit is the mirrored digit triple XOR a per-ray constant.
+struct Axis {
+    float o, inv;     // ray origin component, safe inverse direction (intersect.rint:79)
+    int base, sgn;    // mirrored plane q  ->  world plane base + sgn * q
+};
+
+// T(a, q) for a mirrored plane q: t = fl(fl(float(world plane) - o) * inv), intersect.rint:48-49,179-180.
+BLOK_DEV float plane_t(const Axis& a, int q) {
+    return rn_mul(rn_sub(static_cast<float>(__mul24(a.sgn, q) + a.base), a.o), a.inv);
+}
+
+// One axis of "enter a node" whose near corner is q and whose children have size s = 1 << shift: how many
+// of the three interior planes have T <= tS (binary search, T is monotone in q), i.e. which child slab
+// holds the ray at tS, and the T of that slab's far plane.  t_far comes in as the node's own far plane.
+BLOK_DEV void enter_axis(const Axis& a, int& q, float& t_far, uint32_t shift, float tS) {
+    const float m2 = plane_t(a, q + (2 << shift));
+    const bool g = m2 <= tS;
+    const float mq = plane_t(a, q + ((g ? 3 : 1) << shift));
+    const bool g2 = mq <= tS;
+    const float inner = g ? t_far : m2;          // far plane if mq is already crossed
+    t_far = g2 ? inner : mq;
+    q += ((g ? 2 : 0) + (g2 ? 1 : 0)) << shift;
+}
+
 // Walks one ray; writes the 16-byte record.  `stk` points at this lane's slot of the LDS node stack
-// (stride kBlock entries between levels).
+// (stride kBlock entries between levels; slot l-2 holds the node of level l on the current path).
 BLOK_DEV void trace_one(const TraceArgs& A, const RayIn& r, uint4* stk, blok_hit* dst) {
-    const float ix = safe_inv(r.dx), iy = safe_inv(r.dy), iz = safe_inv(r.dz);
-    const bool posx = ix > 0.0f, posy = iy > 0.0f, posz = iz > 0.0f;
-    const int orgx = A.origin[0], orgy = A.origin[1], orgz = A.origin[2];
     const uint32_t L = A.levels;
-    const int world = 1 << (2 * L);
+    const int W = 1 << (2 * L);
+    Axis ax, ay, az;
+    ax.o = r.ox; ay.o = r.oy; az.o = r.oz;
+    ax.inv = safe_inv(r.dx); ay.inv = safe_inv(r.dy); az.inv = safe_inv(r.dz);
+    const bool negx = !(ax.inv > 0.0f), negy = !(ay.inv > 0.0f), negz = !(az.inv > 0.0f);
+    ax.sgn = negx ? -1 : 1; ay.sgn = negy ? -1 : 1; az.sgn = negz ? -1 : 1;
+    ax.base = A.origin[0] + (negx ? W : 0); ay.base = A.origin[1] + (negy ? W : 0); az.base = A.origin[2] + (negz ? W : 0);
+    const uint32_t mirror = (negx ? 3u : 0u) | (negy ? 12u : 0u) | (negz ? 48u : 0u);
 
-    // world box
-    float tFx, tFy, tFz, tCur;
-    {
-        const float x0 = plane_t(orgx, r.ox, ix), x1 = plane_t(orgx + world, r.ox, ix);
-        const float y0 = plane_t(orgy, r.oy, iy), y1 = plane_t(orgy + world, r.oy, iy);
-        const float z0 = plane_t(orgz, r.oz, iz), z1 = plane_t(orgz + world, r.oz, iz);
-        const float t_in = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
-        tFx = fmaxf(x0, x1); tFy = fmaxf(y0, y1); tFz = fmaxf(z0, z1);
-        tCur = fmaxf(t_in, r.tmin);
-        if (!(tCur < fminf(fminf(fminf(tFx, tFy), tFz), r.tmax))) { write_miss(dst); return; }
-    }
+    // world box: near planes q = 0, far planes q = W (T is monotone in q, so no min/max is needed)
+    float tFx = plane_t(ax, W), tFy = plane_t(ay, W), tFz = plane_t(az, W);
+    float tCur = fmaxf(fmaxf(fmaxf(plane_t(ax, 0), plane_t(ay, 0)), plane_t(az, 0)), r.tmin);
+    if (!(tCur < fminf(fminf(fminf(tFx, tFy), tFz), r.tmax))) { write_miss(dst); return; }
 
-    int px = 0, py = 0, pz = 0;          // min corner of the current cell, tree-local voxel units
-    NodeRec node;                         // node whose children are the cells of level `lvl`
+    int qx = 0, qy = 0, qz = 0;          // mirrored min corner of the current cell
+    uint32_t lvl = L - 1;                // current cells have size 4^lvl; `node` is their parent
+    NodeRec node;
     {
         const uint4 q = A.nodes[0];
         node.lo = q.x; node.hi = q.y; node.base = q.z;
-    }
-    uint32_t lvl = L - 1;
-    {
-        const uint32_t shift = 2 * lvl;
-        const float tS = tCur;            // already >= tmin
-        enter_axis(px, tFx, orgx, r.ox, ix, posx, shift, tS);
-        enter_axis(py, tFy, orgy, r.oy, iy, posy, shift, tS);
-        enter_axis(pz, tFz, orgz, r.oz, iz, posz, shift, tS);
+        const uint32_t cs = 2 * lvl;
+        enter_axis(ax, qx, tFx, cs, tCur);
+        enter_axis(ay, qy, tFy, cs, tCur);
+        enter_axis(az, qz, tFz, cs, tCur);
     }
 
-    for (uint32_t guard = 0; guard < (1u << 20); ++guard) {
+    bool found = false;
+    uint32_t bit = 0;
+    for (;;) {
         BLOK_STAT(0, lvl);
         const uint32_t shift = 2 * lvl;
-        const uint32_t bit = ((px >> shift) & 3) | (((py >> shift) & 3) << 2) | (((pz >> shift) & 3) << 4);
-        if (mask_bit(node, bit)) {
-            if (lvl == 0) {
-                const float tc = fmaxf(tCur, r.tmin);
-                const float lim = fminf(fminf(fminf(tFx, tFy), tFz), r.tmax);
-                if (tc < lim) {
-                    // reported: intersect.rint:136-141, hit.rchit:58-74
-                    const uint32_t material = A.materials[node.base + mask_rank(node, bit)];
-                    const int vx = px + orgx, vy = py + orgy, vz = pz + orgz;
-                    const float hx = rn_add(r.ox, rn_mul(r.dx, tc));
-                    const float hy = rn_add(r.oy, rn_mul(r.dy, tc));
-                    const float hz = rn_add(r.oz, rn_mul(r.dz, tc));
-                    const float ex = rn_sub(hx, rn_add(static_cast<float>(vx), 0.5f));
-                    const float ey = rn_sub(hy, rn_add(static_cast<float>(vy), 0.5f));
-                    const float ez = rn_sub(hz, rn_add(static_cast<float>(vz), 0.5f));
-                    const float ax = fabsf(ex), ay = fabsf(ey), az = fabsf(ez);
-                    uint32_t face;
-                    if (ax >= ay && ax >= az) face = ex > 0.0f ? 0u : 1u;
-                    else if (ay >= az)        face = ey > 0.0f ? 2u : 3u;
-                    else                      face = ez > 0.0f ? 4u : 5u;
-                    uint4 rec;
-                    rec.x = __float_as_uint(tc);
-                    rec.y = material;
-                    rec.z = (static_cast<uint32_t>(vx) & 0xFFFFu) | (static_cast<uint32_t>(vy) << 16);
-                    rec.w = (static_cast<uint32_t>(vz) & 0xFFFFu) | (face << 16) | (1u << 24);
-                    *reinterpret_cast<uint4*>(dst) = rec;
-                    return;
-                }
-            } else {
-                // descend: remember the node we are leaving, fetch the child, pick its start cell
-                BLOK_STAT(1, lvl);
-                stk[(lvl - 1) * kBlock] = make_uint4(node.lo, node.hi, node.base, 0u);   // slot of level lvl+1
-                const uint4 q = A.nodes[node.base + mask_rank(node, bit)];
-                node.lo = q.x; node.hi = q.y; node.base = q.z;
-                lvl -= 1;
-                const uint32_t cs = 2 * lvl;
-                const float tS = fmaxf(tCur, r.tmin);
-                enter_axis(px, tFx, orgx, r.ox, ix, posx, cs, tS);
-                enter_axis(py, tFy, orgy, r.oy, iy, posy, cs, tS);
-                enter_axis(pz, tFz, orgz, r.oz, iz, posz, cs, tS);
-                continue;
-            }
+        bit = ((static_cast<uint32_t>(qx >> shift) & 3u) | ((static_cast<uint32_t>(qy >> shift) & 3u) << 2) |
+               ((static_cast<uint32_t>(qz >> shift) & 3u) << 4)) ^ mirror;
+        const bool occupied = mask_bit(node, bit);
+        if (occupied && lvl != 0) {
+            // descend: remember the node we are leaving, fetch the child, pick its start cell
+            BLOK_STAT(1, lvl);
+            stk[(lvl - 1) * kBlock] = make_uint4(node.lo, node.hi, node.base, 0u);     // node of level lvl+1
+            const uint4 c = A.nodes[node.base + mask_rank(node, bit)];
+            node.lo = c.x; node.hi = c.y; node.base = c.z;
+            lvl -= 1;
+            const uint32_t cs = 2 * lvl;
+            const float tS = fmaxf(tCur, r.tmin);
+            enter_axis(ax, qx, tFx, cs, tS);
+            enter_axis(ay, qy, tFy, cs, tS);
+            enter_axis(az, qz, tFz, cs, tS);
+            continue;
         }
-        // step to the next cell of the merge sequence: cross the nearest far plane (x, then y, then z on ties)
+        const float tExit = fminf(fminf(tFx, tFy), tFz);
+        if (occupied) {
+            // a filled voxel: reported iff its clipped interval is non-empty (intersect.rint:189-193)
+            if (fmaxf(tCur, r.tmin) < fminf(tExit, r.tmax)) { found = true; break; }
+        }
+        // step: cross the nearest far plane (x, then y, then z on ties)
         BLOK_STAT(2, lvl);
-        const bool sx = tFx <= tFy && tFx <= tFz;
-        const bool sy = !sx && tFy <= tFz;
-        tCur = sx ? tFx : (sy ? tFy : tFz);
+        tCur = tExit;
         if (!(tCur < r.tmax)) break;
+        const bool sx = tFx == tExit;
+        const bool sy = !sx && tFy == tExit;
+        const bool sz = !sx && !sy;
         const int size = 1 << shift;
-        const int pold = sx ? px : (sy ? py : pz);
-        const bool pos = sx ? posx : (sy ? posy : posz);
-        const int pnew = pos ? pold + size : pold - size;
-        if (pnew < 0 || pnew >= world) break;
-        if (sx) px = pnew; else if (sy) py = pnew; else pz = pnew;
-        const uint32_t crossed = static_cast<uint32_t>(pold ^ pnew) >> (shift + 2);
-        if (crossed != 0u) {
-            // left the parent node: climb to the level whose cell boundary was crossed
+        qx += sx ? size : 0; qy += sy ? size : 0; qz += sz ? size : 0;
+        // the stepped coordinate is now a multiple of 4^k for the level k whose cell boundary was crossed
+        const uint32_t up = static_cast<uint32_t>(__ffs(sx ? qx : (sy ? qy : qz)) - 1) >> 1;
+        if (up != lvl) {
             BLOK_STAT(3, lvl);
-            const uint32_t k = ((31u - __clz(crossed)) >> 1) + 1u;
-            lvl += k;
-            const uint32_t ns = 2 * lvl;
-            const int keep = ~((1 << ns) - 1);
-            px &= keep; py &= keep; pz &= keep;
-            const uint4 q = stk[(lvl - 1) * kBlock];                 // node of level lvl+1
-            node.lo = q.x; node.hi = q.y; node.base = q.z;
-            const int far = 1 << ns;
-            tFx = plane_t(px + orgx + (posx ? far : 0), r.ox, ix);
-            tFy = plane_t(py + orgy + (posy ? far : 0), r.oy, iy);
-            tFz = plane_t(pz + orgz + (posz ? far : 0), r.oz, iz);
-        } else {
-            const float tn = plane_t(pnew + (sx ? orgx : (sy ? orgy : orgz)) + (pos ? size : 0),
-                                     sx ? r.ox : (sy ? r.oy : r.oz), sx ? ix : (sy ? iy : iz));
-            if (sx) tFx = tn; else if (sy) tFy = tn; else tFz = tn;
+            if (up >= L) break;                                    // left the world box
+            lvl = up;
+            const int keep = ~((1 << (2 * up)) - 1);
+            qx &= keep; qy &= keep; qz &= keep;
+            const uint4 c = stk[(lvl - 1) * kBlock];               // node of level lvl+1
+            node.lo = c.x; node.hi = c.y; node.base = c.z;
         }
+        const int far = 1 << (2 * lvl);
+        tFx = plane_t(ax, qx + far); tFy = plane_t(ay, qy + far); tFz = plane_t(az, qz + far);
     }
-    write_miss(dst);
+    if (!found) { write_miss(dst); return; }
+
+    // reported: intersect.rint:136-141, hit.rchit:58-74
+    const float tc = fmaxf(tCur, r.tmin);
+    const uint32_t material = A.materials[node.base + mask_rank(node, bit)];
+    const int vx = ax.base + ax.sgn * qx - (negx ? 1 : 0);          // world voxel = mirrored cell un-mirrored
+    const int vy = ay.base + ay.sgn * qy - (negy ? 1 : 0);
+    const int vz = az.base + az.sgn * qz - (negz ? 1 : 0);
+    const float hx = rn_add(r.ox, rn_mul(r.dx, tc));
+    const float hy = rn_add(r.oy, rn_mul(r.dy, tc));
+    const float hz = rn_add(r.oz, rn_mul(r.dz, tc));
+    const float ex = rn_sub(hx, rn_add(static_cast<float>(vx), 0.5f));
+    const float ey = rn_sub(hy, rn_add(static_cast<float>(vy), 0.5f));
+    const float ez = rn_sub(hz, rn_add(static_cast<float>(vz), 0.5f));
+    const float fx = fabsf(ex), fy = fabsf(ey), fz = fabsf(ez);
+    uint32_t face;                                                   // getHitFace, intersect.rint:58-68
+    if (fx >= fy && fx >= fz) face = ex > 0.0f ? 0u : 1u;
+    else if (fy >= fz)        face = ey > 0.0f ? 2u : 3u;
+    else                      face = ez > 0.0f ? 4u : 5u;
+    uint4 rec;
+    rec.x = __float_as_uint(tc);
+    rec.y = material;
+    rec.z = (static_cast<uint32_t>(vx) & 0xFFFFu) | (static_cast<uint32_t>(vy) << 16);
+    rec.w = (static_cast<uint32_t>(vz) & 0xFFFFu) | (face << 16) | (1u << 24);
+    *reinterpret_cast<uint4*>(dst) = rec;
 }
 
 // Primary ray of pixel (x, y): reference blok/src/cuda_tracer.cu:276-282 with zero jitter

@@ -41,7 +41,7 @@ for kernel, counters in pmc.items():
 (dst / f"{tag}_pmc.json").write_text(json.dumps(summary, indent=1))
 print(json.dumps(summary, indent=1))
 for kernel, s in summary.items():
-    if "FETCH_SIZE" in s and "WRITE_SIZE" in s and "RayModeE0" in kernel:
+    if "FETCH_SIZE" in s and "WRITE_SIZE" in s and ("RayModeE0" in kernel or "(blok::RayMode)0" in kernel):
         # FETCH_SIZE / WRITE_SIZE are in KiB... rocprofv3 reports them in kilobytes (derived: *64/1024).
         fetch_kb, write_kb = s["FETCH_SIZE"]["mean"], s["WRITE_SIZE"]["mean"]
         out = {"kernel": kernel, "fetch_size_kb_raw": fetch_kb, "write_size_kb": write_kb,

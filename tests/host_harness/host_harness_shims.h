@@ -10,6 +10,8 @@ struct uint4 { uint32_t x, y, z, w; };
 inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
 typedef void* hipStream_t;
 
+inline int __mul24(int a, int b) { return a * b; }
+inline int __ffs(int v) { return __builtin_ffs(v); }
 inline int __popc(uint32_t v) { return __builtin_popcount(v); }
 inline uint32_t __clz(uint32_t v) { return v ? static_cast<uint32_t>(__builtin_clz(v)) : 32u; }
 inline uint32_t __float_as_uint(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
