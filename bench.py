@@ -3,10 +3,12 @@
 (BASELINE.json configs[2], the configuration the metric is quoted on).
 
 One step = one full frame.  N = 1: one launch of the trace kernel over the whole frame.
+A step produces the 16-B first-hit records and the RGBA8 framebuffer of the frame.
 N > 1 (one process per GPU, launched by torch.distributed.run): the frame is cut into 32x32 tiles dealt
-round-robin to the ranks, every rank traces its tiles from its own replica of the world, one RCCL
-all-gather assembles the tile buffers and every rank un-permutes them into the frame (the reference has no
-multi-GPU path).  Total work per step is fixed as N grows -> "scaling": "strong".
+round-robin to the ranks, every rank traces its tiles from its own replica of the world (hit records stay on
+the rank), one RCCL gather per frame brings the RGBA8 tiles to rank 0, which un-permutes them into the
+framebuffer; the gather of frame k runs under the trace of frame k+1 (blok_amd/multi_gpu.py; the reference
+has no multi-GPU path).  Total work per step is fixed as N grows -> "scaling": "strong".
 
 Prints ONE JSON line on rank 0.  Inputs are synthetic (generator G(N, seed) of SURVEY.md §8(d)) and are
 resident in HBM before the timed region.
@@ -114,22 +116,10 @@ def main():
     tracer = HipTracer(W_, H_, device=local_rank).init()
     stats = tracer.add_world(packed)                      # world resident in HBM from here on
 
+    from blok_amd.multi_gpu import FramePipeline, HipBackend
     stream = torch.cuda.current_stream()
-    frame = torch.empty((H_ * W_, 4), dtype=torch.int32, device="cuda")       # 16-B first-hit records
-    if world_size > 1:
-        tile = args.tile
-        per_rank = tracer.tiles_for_rank(tile, 0, world_size)                # rank 0 holds the maximum
-        mine = torch.empty((per_rank * tile * tile, 4), dtype=torch.int32, device="cuda")
-        gathered = torch.empty((world_size * per_rank * tile * tile, 4), dtype=torch.int32, device="cuda")
-
-    def step():
-        if world_size == 1:
-            tracer.draw_frame_device(cam, frame.data_ptr(), stream=stream.cuda_stream)
-        else:
-            tracer.draw_tiles_device(cam, tile, rank, world_size, mine.data_ptr(), stream=stream.cuda_stream)
-            dist.all_gather_into_tensor(gathered, mine)
-            tracer.untile_device(gathered.data_ptr(), tile, world_size, per_rank, frame.data_ptr(),
-                                 stream=stream.cuda_stream)
+    pipe = FramePipeline(HipBackend(tracer, cam), W_, H_, rank, world_size, dist, tile=args.tile,
+                         stream_handle=lambda: stream.cuda_stream)
 
     def fence():
         if dist is not None:
@@ -137,13 +127,15 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step()
+        pipe.step()
+    pipe.flush()
     fence()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record(stream)
     for _ in range(args.steps):
-        step()
+        pipe.step()
+    pipe.flush()                                 # the last frame's gather + un-permute are inside the timed region
     ev1.record(stream)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -159,14 +151,19 @@ def main():
     kernel_ms = []
     for _ in range(min(args.steps, 20)):
         if world_size == 1:
-            tracer.draw_frame_device(cam, frame.data_ptr(), stream=stream.cuda_stream)
+            pipe.backend.trace_full(pipe.hits, pipe.frame_rgba, stream.cuda_stream)
         else:
-            tracer.draw_tiles_device(cam, tile, rank, world_size, mine.data_ptr(), stream=stream.cuda_stream)
+            pipe.backend.trace_tiles(args.tile, rank, world_size, pipe.hits, pipe.rgba[0], stream.cuda_stream)
         torch.cuda.synchronize()
         kernel_ms.append(tracer.last_kernel_ms())
     tracer.set_timing(False)
     kernel_ms_avg = float(np.mean(kernel_ms))
-    hits = int((frame[:, 3] >> 24).sum().item()) if rank == 0 else 0
+    local_hits = (pipe.hits[:, 3] >> 24).sum()
+    if dist is not None:
+        dist.all_reduce(local_hits)
+    hits = int(local_hits.item())
+    sky = 0xFF000000 | (230 << 16) | (200 << 8) | 160
+    lit_pixels = int((pipe.frame_rgba != (sky - (1 << 32))).sum().item()) if rank == 0 else 0
 
     if rank == 0:
         rays_per_step = W_ * H_
@@ -180,8 +177,10 @@ def main():
                                    f"{stats.n_voxels} voxels, {stats.n_ref_nodes} reference SvoNodes, "
                                    f"{stats.n_sub_chunks} sub-chunks), {W_}x{H_} primary rays, camera pose "
                                    f"{'ABC'[args.pose]}, first-hit records 16 B/ray",
-                       "parallelism": "single GPU" if world_size == 1 else f"{args.tile}x{args.tile} screen tiles round-robin over {world_size} GPUs + RCCL all-gather",
-                       "hits_per_frame": hits, "device_ms_per_step": device_ms / args.steps},
+                       "parallelism": "single GPU" if world_size == 1 else f"{args.tile}x{args.tile} screen tiles round-robin over {world_size} GPUs, RCCL gather of RGBA8 tiles to rank 0, 2-deep pipeline",
+                       "hits_per_frame": hits, "framebuffer_pixels_hit": lit_pixels,
+                       "outputs": "16-B first-hit records (kept on the tracing GPU) + RGBA8 framebuffer on rank 0",
+                       "device_ms_per_step": device_ms / args.steps},
         }
         alg = None
         if not args.no_cpu_baseline:

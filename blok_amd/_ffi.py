@@ -93,11 +93,11 @@ HIP_SYMBOLS = {
     "blok_hip_trace_primary": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
                                          C.c_uint32, C.c_void_p]),
     "blok_hip_trace_primary_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
-                                                C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+                                                C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "blok_hip_tiles_for_rank": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "blok_hip_trace_tiles_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
-                                              C.c_void_p, C.c_void_p]),
-    "blok_hip_untile_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                              C.c_void_p, C.c_void_p, C.c_void_p]),
+    "blok_hip_untile_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                          C.c_void_p, C.c_void_p]),
     "blok_hip_trace_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "blok_hip_shade_rgba8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,

@@ -97,6 +97,8 @@ blok::TraceArgs base_args(const blok_hip_ctx* ctx, const blok_camera* cam) {
     a.levels = ctx->stats.levels;
     if (cam) a.cam = *cam;
     a.frame_w = ctx->width; a.frame_h = ctx->height;
+    a.mat_table = ctx->d_materials;
+    a.n_materials = static_cast<uint32_t>(ctx->n_materials);
     a.tmin = BLOK_RAY_TMIN; a.tmax = BLOK_RAY_TMAX;
     return a;
 }
@@ -218,14 +220,15 @@ int blok_hip_world_stats(const blok_hip_ctx* ctx, blok_world_stats* out) {
 }
 
 int blok_hip_trace_primary_device(blok_hip_ctx* ctx, const blok_camera* cam, uint32_t x0, uint32_t y0,
-                                  uint32_t w, uint32_t h, void* out_hits_dev, void* hip_stream) {
+                                  uint32_t w, uint32_t h, void* out_hits_dev, void* out_rgba_dev, void* hip_stream) {
     int rc = check_trace(ctx, cam);
     if (rc != BLOK_OK) return rc;
-    if (!out_hits_dev || !w || !h || x0 + w > ctx->width || y0 + h > ctx->height)
-        return set_error(ctx, BLOK_ERR_INVALID_ARG, "rectangle outside the frame or null output");
+    if ((!out_hits_dev && !out_rgba_dev) || !w || !h || x0 + w > ctx->width || y0 + h > ctx->height)
+        return set_error(ctx, BLOK_ERR_INVALID_ARG, "rectangle outside the frame or no output");
     blok::TraceArgs a = base_args(ctx, cam);
     a.x0 = x0; a.y0 = y0; a.w = w; a.h = h;
     a.out = static_cast<blok_hit*>(out_hits_dev);
+    a.out_rgba = static_cast<uint32_t*>(out_rgba_dev);
     const uint32_t blocks = ((w + 15u) / 16u) * ((h + 15u) / 16u);
     return launch_timed(ctx, blok::RayMode::Rect, a, blocks, static_cast<hipStream_t>(hip_stream));
 }
@@ -239,7 +242,7 @@ int blok_hip_trace_primary(blok_hip_ctx* ctx, const blok_camera* cam, uint32_t x
     const size_t n = static_cast<size_t>(w) * h;
     rc = ensure_frame(ctx, n);
     if (rc != BLOK_OK) return rc;
-    rc = blok_hip_trace_primary_device(ctx, cam, x0, y0, w, h, ctx->d_frame, nullptr);
+    rc = blok_hip_trace_primary_device(ctx, cam, x0, y0, w, h, ctx->d_frame, nullptr, nullptr);
     if (rc != BLOK_OK) return rc;
     BLOK_HIP_TRY(ctx, hipMemcpy(out_hits_host, ctx->d_frame, n * sizeof(blok_hit), hipMemcpyDeviceToHost));
     return BLOK_OK;
@@ -252,30 +255,32 @@ uint32_t blok_hip_tiles_for_rank(uint32_t width, uint32_t height, uint32_t tile,
 }
 
 int blok_hip_trace_tiles_device(blok_hip_ctx* ctx, const blok_camera* cam, uint32_t tile, uint32_t rank,
-                                uint32_t n_ranks, void* out_hits_dev, void* hip_stream) {
+                                uint32_t n_ranks, void* out_hits_dev, void* out_rgba_dev, void* hip_stream) {
     int rc = check_trace(ctx, cam);
     if (rc != BLOK_OK) return rc;
-    if (!out_hits_dev || tile < 16 || (tile & 15u) || !n_ranks || rank >= n_ranks)
+    if ((!out_hits_dev && !out_rgba_dev) || tile < 16 || (tile & 15u) || !n_ranks || rank >= n_ranks)
         return set_error(ctx, BLOK_ERR_INVALID_ARG, "tile must be a multiple of 16 and rank < n_ranks");
     blok::TraceArgs a = base_args(ctx, cam);
     a.tile = tile; a.rank = rank; a.n_ranks = n_ranks;
     a.tiles_x = (ctx->width + tile - 1) / tile;
     a.tiles_total = a.tiles_x * ((ctx->height + tile - 1) / tile);
     a.out = static_cast<blok_hit*>(out_hits_dev);
+    a.out_rgba = static_cast<uint32_t*>(out_rgba_dev);
     const uint32_t mine = blok_hip_tiles_for_rank(ctx->width, ctx->height, tile, rank, n_ranks);
     const uint32_t blocks = mine * (tile / 16u) * (tile / 16u);
     return launch_timed(ctx, blok::RayMode::Tiles, a, blocks, static_cast<hipStream_t>(hip_stream));
 }
 
-int blok_hip_untile_device(blok_hip_ctx* ctx, const void* gathered_dev, uint32_t tile, uint32_t n_ranks,
-                           uint32_t tiles_per_rank_max, void* out_frame_dev, void* hip_stream) {
+int blok_hip_untile_device(blok_hip_ctx* ctx, const void* gathered_dev, uint32_t elem_bytes, uint32_t tile,
+                           uint32_t n_ranks, uint32_t tiles_per_rank_max, void* out_frame_dev, void* hip_stream) {
     if (!ctx) return BLOK_ERR_INVALID_ARG;
-    if (!gathered_dev || !out_frame_dev || !tile || !n_ranks || !tiles_per_rank_max)
-        return set_error(ctx, BLOK_ERR_INVALID_ARG, "bad untile arguments");
+    if (!gathered_dev || !out_frame_dev || !tile || !n_ranks || !tiles_per_rank_max || (elem_bytes != 16 && elem_bytes != 4))
+        return set_error(ctx, BLOK_ERR_INVALID_ARG, "bad untile arguments (elem_bytes must be 16 or 4)");
     BLOK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     blok::UntileArgs u{};
-    u.gathered = static_cast<const uint4*>(gathered_dev);
-    u.frame = static_cast<uint4*>(out_frame_dev);
+    u.gathered = gathered_dev;
+    u.frame = out_frame_dev;
+    u.elem_bytes = elem_bytes;
     u.frame_w = ctx->width; u.frame_h = ctx->height; u.tile = tile; u.n_ranks = n_ranks;
     u.tiles_per_rank_max = tiles_per_rank_max;
     u.tiles_x = (ctx->width + tile - 1) / tile;
@@ -314,18 +319,11 @@ int blok_hip_shade_rgba8(blok_hip_ctx* ctx, const blok_camera* cam, uint32_t x0,
     int rc = check_trace(ctx, cam);
     if (rc != BLOK_OK) return rc;
     const size_t n = static_cast<size_t>(w) * h;
-    rc = ensure_frame(ctx, n);
+    rc = ensure_frame(ctx, (n + 3) / 4);                       // n RGBA8 pixels fit in n/4 16-byte records
     if (rc != BLOK_OK) return rc;
-    rc = blok_hip_trace_primary_device(ctx, cam, x0, y0, w, h, ctx->d_frame, nullptr);
+    rc = blok_hip_trace_primary_device(ctx, cam, x0, y0, w, h, nullptr, ctx->d_frame, nullptr);
     if (rc != BLOK_OK) return rc;
-    uint32_t* d_rgba = nullptr;
-    BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d_rgba), n * sizeof(uint32_t)));
-    blok::ShadeArgs s{ctx->d_frame, ctx->d_materials, static_cast<uint32_t>(ctx->n_materials), d_rgba, static_cast<uint32_t>(n)};
-    blok::launch_shade(s, nullptr);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpy(out_rgba8_host, d_rgba, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
-    (void)hipFree(d_rgba);
-    if (e != hipSuccess) return set_error(ctx, BLOK_ERR_HIP, std::string("shade: ") + hipGetErrorString(e));
+    BLOK_HIP_TRY(ctx, hipMemcpy(out_rgba8_host, ctx->d_frame, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return BLOK_OK;
 }
 

@@ -39,9 +39,27 @@ BLOK_DEV float safe_inv(float d) {
     return rn_div(1.0f, fabsf(d) < 1e-6f ? 1e-6f : d);
 }
 
-BLOK_DEV void write_miss(blok_hit* dst) {
+// RGBA8 of a first hit through hit.rchit's material fetch (hit.rchit:58-67): albedo of
+// materials[min(id, 65535)] scaled by a fixed per-face factor; a constant sky colour on a miss.
+constexpr uint32_t kSkyRgba = 0xFF000000u | (230u << 16) | (200u << 8) | 160u;
+BLOK_DEV uint32_t shade_rgba(const blok_material* table, uint32_t n_materials, uint32_t material_id, uint32_t face) {
+    const uint32_t id = material_id < 65535u ? material_id : 65535u;
+    float r = 1.0f, g = 0.0f, b = 1.0f;                              // out-of-table ids show magenta
+    if (id < n_materials) { r = table[id].albedo[0]; g = table[id].albedo[1]; b = table[id].albedo[2]; }
+    const float k = face == 2u ? 1.0f : (face < 2u ? 0.8f : (face == 3u ? 0.4f : 0.6f));
+    const uint32_t R = static_cast<uint32_t>(fminf(r * k, 1.0f) * 255.0f + 0.5f);
+    const uint32_t G = static_cast<uint32_t>(fminf(g * k, 1.0f) * 255.0f + 0.5f);
+    const uint32_t B = static_cast<uint32_t>(fminf(b * k, 1.0f) * 255.0f + 0.5f);
+    return 0xFF000000u | (B << 16) | (G << 8) | R;
+}
+
+// Where a lane's results go; either pointer may be null.
+struct Sink { blok_hit* hit; uint32_t* rgba; };
+
+BLOK_DEV void write_miss(const Sink& dst) {
     // t = -1 (miss.rmiss:25-27), material 0, voxel 0, face 0xFF, hit 0
-    *reinterpret_cast<uint4*>(dst) = make_uint4(0xBF800000u, 0u, 0u, 0x00FF0000u);
+    if (dst.hit) *reinterpret_cast<uint4*>(dst.hit) = make_uint4(0xBF800000u, 0u, 0u, 0x00FF0000u);
+    if (dst.rgba) *dst.rgba = kSkyRgba;
 }
 
 struct NodeRec { uint32_t lo, hi, base; };
@@ -90,7 +108,7 @@ BLOK_DEV void enter_axis(const Axis& a, int& q, float& t_far, uint32_t shift, fl
 
 // Walks one ray; writes the 16-byte record.  `stk` points at this lane's slot of the LDS node stack
 // (stride kBlock entries between levels; slot l-2 holds the node of level l on the current path).
-BLOK_DEV void trace_one(const TraceArgs& A, const RayIn& r, uint4* stk, blok_hit* dst) {
+BLOK_DEV void trace_one(const TraceArgs& A, const RayIn& r, uint4* stk, const Sink& dst) {
     const uint32_t L = A.levels;
     const int W = 1 << (2 * L);
     Axis ax, ay, az;
@@ -192,7 +210,8 @@ BLOK_DEV void trace_one(const TraceArgs& A, const RayIn& r, uint4* stk, blok_hit
     rec.y = material;
     rec.z = (static_cast<uint32_t>(vx) & 0xFFFFu) | (static_cast<uint32_t>(vy) << 16);
     rec.w = (static_cast<uint32_t>(vz) & 0xFFFFu) | (face << 16) | (1u << 24);
-    *reinterpret_cast<uint4*>(dst) = rec;
+    if (dst.hit) *reinterpret_cast<uint4*>(dst.hit) = rec;
+    if (dst.rgba) *dst.rgba = shade_rgba(A.mat_table, A.n_materials, material, face);
 }
 
 // Primary ray of pixel (x, y): reference blok/src/cuda_tracer.cu:276-282 with zero jitter

@@ -51,27 +51,21 @@ struct TraceArgs {
     uint32_t tile, rank, n_ranks, tiles_x, tiles_total;   // Tiles
     const blok_ray* rays;                  // Rays
     uint32_t n_rays;
-    blok_hit* out;
+    blok_hit* out;                         // may be null
+    uint32_t* out_rgba;                    // may be null: RGBA8 through the material table
+    const blok_material* mat_table;
+    uint32_t n_materials;
     float tmin, tmax;
 };
 
 struct UntileArgs {
-    const uint4* gathered;
-    uint4* frame;
-    uint32_t frame_w, frame_h, tile, n_ranks, tiles_per_rank_max, tiles_x;
-};
-
-struct ShadeArgs {
-    const blok_hit* hits;
-    const blok_material* materials;
-    uint32_t n_materials;
-    uint32_t* rgba;
-    uint32_t n;
+    const void* gathered;
+    void* frame;
+    uint32_t frame_w, frame_h, tile, n_ranks, tiles_per_rank_max, tiles_x, elem_bytes;
 };
 
 void launch_trace(RayMode mode, const TraceArgs& args, uint32_t n_blocks, hipStream_t stream);
 void launch_untile(const UntileArgs& args, hipStream_t stream);
-void launch_shade(const ShadeArgs& args, hipStream_t stream);
 
 }  // namespace blok
 #endif

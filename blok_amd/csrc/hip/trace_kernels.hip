@@ -19,7 +19,7 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const TraceArgs A) {
         if (i >= A.n_rays) return;
         const blok_ray ray = A.rays[i];
         RayIn r{ray.org[0], ray.org[1], ray.org[2], ray.dir[0], ray.dir[1], ray.dir[2], ray.tmin, ray.tmax};
-        trace_one(A, r, stk, A.out + i);
+        trace_one(A, r, stk, Sink{A.out ? A.out + i : nullptr, A.out_rgba ? A.out_rgba + i : nullptr});
         return;
     } else {
         // a block is a 16x16 pixel tile, a wave an 8x8 sub-tile (coherent rays per wave)
@@ -47,13 +47,14 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const TraceArgs A) {
             x = tx * A.tile + ix; y = ty * A.tile + iy;
             out_index = static_cast<size_t>(local_tile) * A.tile * A.tile + static_cast<size_t>(iy) * A.tile + ix;
             inside = global_tile < A.tiles_total && x < A.frame_w && y < A.frame_h;
-            if (!inside) { write_miss(A.out + out_index); return; }
+            if (!inside) { write_miss(Sink{A.out ? A.out + out_index : nullptr, A.out_rgba ? A.out_rgba + out_index : nullptr}); return; }
         }
         const RayIn r = primary_ray(A, x, y);
-        trace_one(A, r, stk, A.out + out_index);
+        trace_one(A, r, stk, Sink{A.out ? A.out + out_index : nullptr, A.out_rgba ? A.out_rgba + out_index : nullptr});
     }
 }
 
+template <typename Elem>
 __global__ __launch_bounds__(256) void untile_kernel(const UntileArgs U) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= U.frame_w * U.frame_h) return;
@@ -62,26 +63,7 @@ __global__ __launch_bounds__(256) void untile_kernel(const UntileArgs U) {
     const uint32_t rank = g % U.n_ranks, local = g / U.n_ranks;
     const size_t src = (static_cast<size_t>(rank) * U.tiles_per_rank_max + local) * U.tile * U.tile +
                        static_cast<size_t>(y % U.tile) * U.tile + (x % U.tile);
-    U.frame[i] = U.gathered[src];
-}
-
-// Debug view through hit.rchit's material fetch (hit.rchit:58-67): albedo lit by the face normal.
-__global__ __launch_bounds__(256) void shade_kernel(const ShadeArgs S) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= S.n) return;
-    const blok_hit h = S.hits[i];
-    uint32_t rgba = 0xFF000000u | (230u << 16) | (200u << 8) | 160u;   // sky
-    if (h.hit) {
-        const uint32_t id = min(h.material_id, 65535u);                 // hit.rchit:62
-        float r = 1.0f, g = 0.0f, b = 1.0f;
-        if (id < S.n_materials) { r = S.materials[id].albedo[0]; g = S.materials[id].albedo[1]; b = S.materials[id].albedo[2]; }
-        const float shade = h.face == 2 ? 1.0f : (h.face < 2 ? 0.8f : (h.face == 3 ? 0.4f : 0.6f));
-        const uint32_t R = static_cast<uint32_t>(fminf(r * shade, 1.0f) * 255.0f + 0.5f);
-        const uint32_t G = static_cast<uint32_t>(fminf(g * shade, 1.0f) * 255.0f + 0.5f);
-        const uint32_t B = static_cast<uint32_t>(fminf(b * shade, 1.0f) * 255.0f + 0.5f);
-        rgba = 0xFF000000u | (B << 16) | (G << 8) | R;
-    }
-    S.rgba[i] = rgba;
+    static_cast<Elem*>(U.frame)[i] = static_cast<const Elem*>(U.gathered)[src];
 }
 
 }  // namespace
@@ -98,11 +80,8 @@ void launch_trace(RayMode mode, const TraceArgs& args, uint32_t n_blocks, hipStr
 
 void launch_untile(const UntileArgs& args, hipStream_t stream) {
     const uint32_t n = args.frame_w * args.frame_h;
-    hipLaunchKernelGGL(untile_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, args);
-}
-
-void launch_shade(const ShadeArgs& args, hipStream_t stream) {
-    hipLaunchKernelGGL(shade_kernel, dim3((args.n + 255u) / 256u), dim3(256), 0, stream, args);
+    if (args.elem_bytes == 16) hipLaunchKernelGGL(untile_kernel<uint4>, dim3((n + 255u) / 256u), dim3(256), 0, stream, args);
+    else hipLaunchKernelGGL(untile_kernel<uint32_t>, dim3((n + 255u) / 256u), dim3(256), 0, stream, args);
 }
 
 }  // namespace blok

@@ -96,23 +96,27 @@ class HipTracer:
         self._check(self._lib.blok_hip_trace_primary(self._ctx, _ffi.ptr(cam), x0, y0, w, h, _ffi.ptr(hits)))
         return hits.reshape(h, w)
 
-    def draw_frame_device(self, cam: np.ndarray, out_ptr: int, rect=None, stream: int = 0):
+    def draw_frame_device(self, cam: np.ndarray, hits_ptr: int = 0, rgba_ptr: int = 0, rect=None, stream: int = 0):
+        """Asynchronous, device-resident outputs (either pointer may be 0, not both)."""
         x0, y0, w, h = rect if rect is not None else (0, 0, self.width, self.height)
         cam = np.ascontiguousarray(cam, dtype=CAMERA)
         self._check(self._lib.blok_hip_trace_primary_device(self._ctx, _ffi.ptr(cam), x0, y0, w, h,
-                                                            C.c_void_p(out_ptr), C.c_void_p(stream)))
+                                                            C.c_void_p(hits_ptr), C.c_void_p(rgba_ptr),
+                                                            C.c_void_p(stream)))
 
     def tiles_for_rank(self, tile: int, rank: int, n_ranks: int) -> int:
         return int(_ffi.hip_lib().blok_hip_tiles_for_rank(self.width, self.height, tile, rank, n_ranks))
 
-    def draw_tiles_device(self, cam: np.ndarray, tile: int, rank: int, n_ranks: int, out_ptr: int, stream: int = 0):
+    def draw_tiles_device(self, cam: np.ndarray, tile: int, rank: int, n_ranks: int, hits_ptr: int = 0,
+                          rgba_ptr: int = 0, stream: int = 0):
         cam = np.ascontiguousarray(cam, dtype=CAMERA)
         self._check(self._lib.blok_hip_trace_tiles_device(self._ctx, _ffi.ptr(cam), tile, rank, n_ranks,
-                                                          C.c_void_p(out_ptr), C.c_void_p(stream)))
+                                                          C.c_void_p(hits_ptr), C.c_void_p(rgba_ptr),
+                                                          C.c_void_p(stream)))
 
-    def untile_device(self, gathered_ptr: int, tile: int, n_ranks: int, tiles_per_rank_max: int, out_ptr: int,
-                      stream: int = 0):
-        self._check(self._lib.blok_hip_untile_device(self._ctx, C.c_void_p(gathered_ptr), tile, n_ranks,
+    def untile_device(self, gathered_ptr: int, elem_bytes: int, tile: int, n_ranks: int, tiles_per_rank_max: int,
+                      out_ptr: int, stream: int = 0):
+        self._check(self._lib.blok_hip_untile_device(self._ctx, C.c_void_p(gathered_ptr), elem_bytes, tile, n_ranks,
                                                      tiles_per_rank_max, C.c_void_p(out_ptr), C.c_void_p(stream)))
 
     def trace_rays(self, rays: np.ndarray) -> np.ndarray:

@@ -174,26 +174,29 @@ int blok_hip_trace_primary(blok_hip_ctx* ctx, const blok_camera* cam,
                            uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
                            blok_hit* out_hits_host);
 
-/* Same work, device-resident output, asynchronous on `hip_stream` (a hipStream_t, or NULL
- * for the default stream).  `out_hits_dev` is a device pointer to w*h records.
- * This is the entry the benchmark times and the one a graph capture may record
- * (no allocation, no host sync inside). */
+/* Same work, device-resident outputs, asynchronous on `hip_stream` (a hipStream_t, or NULL for the default
+ * stream).  `out_hits_dev` (w*h 16-B records) and `out_rgba_dev` (w*h RGBA8 pixels: the frame through
+ * hit.rchit's material fetch, reference assets/shaders/hit.rchit:58-67; the CUDA backend's output format,
+ * reference blok/src/cuda_tracer.cu:385-386) are device pointers; either may be NULL, not both.
+ * This is the entry the benchmark times and the one a graph capture may record (no allocation, no host
+ * sync inside). */
 int blok_hip_trace_primary_device(blok_hip_ctx* ctx, const blok_camera* cam,
                                   uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
-                                  void* out_hits_dev, void* hip_stream);
+                                  void* out_hits_dev, void* out_rgba_dev, void* hip_stream);
 
 /* Interleaved-tile form of the multi-GPU partition: rank r of n traces the tiles
  * (tile x tile pixels, row-major tile index i) with i % n == r and writes them densely,
- * tile after tile, each tile row-major; out_hits_dev holds
- * blok_hip_tiles_for_rank(...) * tile*tile records (edge tiles are padded with misses). */
+ * tile after tile, each tile row-major; each output holds
+ * blok_hip_tiles_for_rank(...) * tile*tile elements (edge tiles are padded with misses / sky). */
 uint32_t blok_hip_tiles_for_rank(uint32_t width, uint32_t height, uint32_t tile,
                                  uint32_t rank, uint32_t n_ranks);
 int blok_hip_trace_tiles_device(blok_hip_ctx* ctx, const blok_camera* cam,
                                 uint32_t tile, uint32_t rank, uint32_t n_ranks,
-                                void* out_hits_dev, void* hip_stream);
-/* Root side: scatter n_ranks gathered tile buffers (rank-major, each padded to
- * `tiles_per_rank_max` tiles) back into a row-major width*height frame. */
-int blok_hip_untile_device(blok_hip_ctx* ctx, const void* gathered_dev, uint32_t tile,
+                                void* out_hits_dev, void* out_rgba_dev, void* hip_stream);
+/* Root side: scatter n_ranks gathered tile buffers (rank-major, each padded to `tiles_per_rank_max`
+ * tiles) of `elem_bytes`-sized elements (16: hit records, 4: RGBA8) back into a row-major
+ * width*height frame. */
+int blok_hip_untile_device(blok_hip_ctx* ctx, const void* gathered_dev, uint32_t elem_bytes, uint32_t tile,
                            uint32_t n_ranks, uint32_t tiles_per_rank_max,
                            void* out_frame_dev, void* hip_stream);
 

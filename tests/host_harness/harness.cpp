@@ -53,7 +53,7 @@ void hh_trace_rays(const void* h, const blok_ray* rays, size_t n, blok_hit* out)
     for (size_t i = 0; i < n; ++i) {
         RayIn r{rays[i].org[0], rays[i].org[1], rays[i].org[2], rays[i].dir[0], rays[i].dir[1], rays[i].dir[2],
                 rays[i].tmin, rays[i].tmax};
-        trace_one(a, r, stack.data(), out + i);
+        trace_one(a, r, stack.data(), Sink{out + i, nullptr});
     }
 }
 
@@ -70,7 +70,7 @@ void hh_trace_primary_stats(const void* h, const blok_camera* cam, uint32_t widt
             uint64_t before = 0;
             for (int l = 0; l < 8; ++l) before += g_stat[0][l];
             const RayIn r = primary_ray(a, x, y);
-            trace_one(a, r, stack.data(), out + size_t(y) * width + x);
+            trace_one(a, r, stack.data(), Sink{out + size_t(y) * width + x, nullptr});
             uint64_t after = 0;
             for (int l = 0; l < 8; ++l) after += g_stat[0][l];
             iters_per_ray[size_t(y) * width + x] = uint32_t(after - before);
@@ -86,7 +86,7 @@ void hh_trace_primary(const void* h, const blok_camera* cam, uint32_t width, uin
     for (uint32_t y = 0; y < height; ++y)
         for (uint32_t x = 0; x < width; ++x) {
             const RayIn r = primary_ray(a, x, y);
-            trace_one(a, r, stack.data(), out + size_t(y) * width + x);
+            trace_one(a, r, stack.data(), Sink{out + size_t(y) * width + x, nullptr});
         }
 }
 

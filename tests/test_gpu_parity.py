@@ -118,13 +118,39 @@ def test_config3_1024_svo_4k(tracer_cls, scene1024):
         gathered = torch.zeros((n_ranks * per * tile * tile, 4), dtype=torch.int32, device="cuda")
         for r in range(n_ranks):
             assert tr.tiles_for_rank(tile, r, n_ranks) == T.tiles_for_rank(Wd, Ht, tile, r, n_ranks)
-            tr.draw_tiles_device(cam, tile, r, n_ranks, gathered[r * per * tile * tile:].data_ptr())
+            tr.draw_tiles_device(cam, tile, r, n_ranks, hits_ptr=gathered[r * per * tile * tile:].data_ptr())
         out = torch.empty((Ht * Wd, 4), dtype=torch.int32, device="cuda")
-        tr.untile_device(gathered.data_ptr(), tile, n_ranks, per, out.data_ptr())
+        tr.untile_device(gathered.data_ptr(), 16, tile, n_ranks, per, out.data_ptr())
         torch.cuda.synchronize()
         assert (out.cpu().numpy().view(np.uint8).reshape(-1, 16) == full.reshape(-1).view(np.uint8).reshape(-1, 16)).all()
         host = T.untile(gathered.cpu().numpy().view(O.HIT).reshape(-1), Wd, Ht, tile, n_ranks, per)
         assert records_equal(host.reshape(-1), full.reshape(-1)).all()
+    # RGBA8 framebuffer: fused output == shading of the records; tiles -> gather layout -> un-permute == full frame
+    rgba_full = tr.shade_rgba8(cam)
+    mats = pw.materials
+    flat = full.reshape(-1)
+    face_k = np.array([0.8, 0.8, 1.0, 0.4, 0.6, 0.6], dtype=np.float32)
+    alb = mats["albedo"][np.minimum(flat["material_id"], len(mats) - 1)] * face_k[np.minimum(flat["face"], 5)][:, None]
+    q = (np.minimum(alb, np.float32(1.0)) * np.float32(255.0) + np.float32(0.5)).astype(np.uint32)
+    expect = np.where(flat["hit"] == 1, 0xFF000000 | (q[:, 2] << 16) | (q[:, 1] << 8) | q[:, 0],
+                      0xFF000000 | (230 << 16) | (200 << 8) | 160).astype(np.uint32)
+    assert (rgba_full.reshape(-1) == expect).all()
+    n_ranks, tile = 8, 32
+    per = tr.tiles_for_rank(tile, 0, n_ranks)
+    g = torch.zeros((n_ranks, per * tile * tile), dtype=torch.int32, device="cuda")
+    for r in range(n_ranks):
+        tr.draw_tiles_device(cam, tile, r, n_ranks, rgba_ptr=g[r].data_ptr())
+    out = torch.empty(Ht * Wd, dtype=torch.int32, device="cuda")
+    tr.untile_device(g.data_ptr(), 4, tile, n_ranks, per, out.data_ptr())
+    torch.cuda.synchronize()
+    assert (out.cpu().numpy().view(np.uint32) == rgba_full.reshape(-1)).all()
+    # the bench's frame pipeline at N = 1
+    from blok_amd.multi_gpu import FramePipeline, HipBackend
+    pipe = FramePipeline(HipBackend(tr, cam), Wd, Ht)
+    pipe.step(); pipe.flush()
+    torch.cuda.synchronize()
+    assert (pipe.frame_rgba.cpu().numpy().view(np.uint32) == rgba_full.reshape(-1)).all()
+    assert records_equal(pipe.hits.cpu().numpy().view(O.HIT).reshape(-1), flat).all()
     tr.shutdown()
 
 
