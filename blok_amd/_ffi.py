@@ -44,6 +44,11 @@ assert SVO_NODE.itemsize == 16 and SUB_CHUNK.itemsize == 48 and MATERIAL.itemsiz
 assert CAMERA.itemsize == 56 and HIT.itemsize == 16 and RAY.itemsize == 32
 
 
+class GBuffer(C.Structure):
+    _fields_ = [("color", C.c_void_p), ("world_pos", C.c_void_p), ("normal_roughness", C.c_void_p),
+                ("albedo_metallic", C.c_void_p)]
+
+
 class WorldStats(C.Structure):
     _fields_ = [("n_voxels", C.c_uint64), ("n_ref_nodes", C.c_uint64), ("n_sub_chunks", C.c_uint64),
                 ("n_tree_nodes", C.c_uint64), ("tree_bytes", C.c_uint64), ("levels", C.c_uint32),
@@ -99,6 +104,8 @@ HIP_SYMBOLS = {
                                               C.c_void_p, C.c_void_p, C.c_void_p]),
     "blok_hip_untile_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                          C.c_void_p, C.c_void_p]),
+    "blok_hip_trace_paths_device": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_uint32] * 7 + [C.POINTER(GBuffer), C.c_void_p]),
+    "blok_hip_trace_paths": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_uint32] * 7 + [C.POINTER(GBuffer)]),
     "blok_hip_trace_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "blok_hip_shade_rgba8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
                                        C.c_uint32, C.c_void_p]),

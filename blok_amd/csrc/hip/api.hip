@@ -10,6 +10,7 @@
 #include "blok_hip.h"
 #include "reference_world.h"
 #include "trace_kernels.h"
+#include "path_args.h"
 #include "tree.h"
 
 struct blok_hip_ctx {
@@ -324,6 +325,53 @@ int blok_hip_shade_rgba8(blok_hip_ctx* ctx, const blok_camera* cam, uint32_t x0,
     rc = blok_hip_trace_primary_device(ctx, cam, x0, y0, w, h, nullptr, ctx->d_frame, nullptr);
     if (rc != BLOK_OK) return rc;
     BLOK_HIP_TRY(ctx, hipMemcpy(out_rgba8_host, ctx->d_frame, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return BLOK_OK;
+}
+
+int blok_hip_trace_paths_device(blok_hip_ctx* ctx, const blok_camera* cam, uint32_t x0, uint32_t y0, uint32_t w,
+                                uint32_t h, uint32_t spp, uint32_t max_bounces, uint32_t frame_index,
+                                const blok_gbuffer* planes, void* hip_stream) {
+    int rc = check_trace(ctx, cam);
+    if (rc != BLOK_OK) return rc;
+    if (!planes || !w || !h || x0 + w > ctx->width || y0 + h > ctx->height || !spp || !max_bounces)
+        return set_error(ctx, BLOK_ERR_INVALID_ARG, "bad path-trace arguments");
+    if (!ctx->n_materials) return set_error(ctx, BLOK_ERR_INVALID_ARG, "path tracing needs a material table");
+    blok::PathArgs p{};
+    p.trace = base_args(ctx, cam);
+    p.trace.x0 = x0; p.trace.y0 = y0; p.trace.w = w; p.trace.h = h;
+    p.spp = spp; p.max_bounces = max_bounces; p.frame_count = frame_index;
+    p.color = planes->color; p.world_pos = planes->world_pos;
+    p.normal_roughness = planes->normal_roughness; p.albedo_metallic = planes->albedo_metallic;
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    if (ctx->timing) BLOK_HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, stream));
+    blok::launch_paths(p, ((w + 15u) / 16u) * ((h + 15u) / 16u), stream);
+    BLOK_HIP_TRY(ctx, hipGetLastError());
+    if (ctx->timing) { BLOK_HIP_TRY(ctx, hipEventRecord(ctx->ev_end, stream)); ctx->timed = true; }
+    return BLOK_OK;
+}
+
+int blok_hip_trace_paths(blok_hip_ctx* ctx, const blok_camera* cam, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
+                         uint32_t spp, uint32_t max_bounces, uint32_t frame_index, const blok_gbuffer* planes_host) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    if (!planes_host) return set_error(ctx, BLOK_ERR_INVALID_ARG, "null planes");
+    int rc = check_trace(ctx, cam);
+    if (rc != BLOK_OK) return rc;
+    const size_t n = static_cast<size_t>(w) * h, bytes = n * 4 * sizeof(float);
+    float* host[4] = {planes_host->color, planes_host->world_pos, planes_host->normal_roughness, planes_host->albedo_metallic};
+    float* dev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 4 && e == hipSuccess; ++i)
+        if (host[i]) e = hipMalloc(reinterpret_cast<void**>(&dev[i]), bytes);
+    if (e == hipSuccess) {
+        const blok_gbuffer planes_dev{dev[0], dev[1], dev[2], dev[3]};
+        rc = blok_hip_trace_paths_device(ctx, cam, x0, y0, w, h, spp, max_bounces, frame_index, &planes_dev, nullptr);
+        for (int i = 0; i < 4 && rc == BLOK_OK && e == hipSuccess; ++i)
+            if (host[i]) e = hipMemcpy(host[i], dev[i], bytes, hipMemcpyDeviceToHost);
+    }
+    for (float* d : dev) if (d) (void)hipFree(d);
+    if (rc != BLOK_OK) return rc;
+    if (e != hipSuccess) return set_error(ctx, e == hipErrorOutOfMemory ? BLOK_ERR_OOM : BLOK_ERR_HIP,
+                                          std::string("trace_paths: ") + hipGetErrorString(e));
     return BLOK_OK;
 }
 

@@ -1,0 +1,253 @@
+// Per-pixel sample / bounce loop on top of walk(): the reference's ray-generation shader
+// (assets/shaders/raygen.rgen:77-165 RNG, sampling, sky; :167-414 main) with hit.rchit / miss.rmiss /
+// shadow.rmiss folded in.  One lane = one pixel.  Operation order follows the shader statement by statement;
+// every float op is a single rounded op (no contraction), sqrt and divide are correctly rounded, and
+// sin / cos / pow come from the device math library (a few ulp from any other implementation — the tolerance
+// the parity tests state).  Compiles for the host under BLOK_TRACE_HOST_HARNESS like trace_core.h.
+//
+// Deliberate, documented differences from the shader:
+//  - the primary ray is formed from the camera basis (cuda_tracer.cu:276-282) instead of invProj/invView
+//    (raygen.rgen:204-205): glm, which would fix those matrices' arithmetic, is absent from the reference tree;
+//  - MAX_BOUNCES (raygen.rgen:211, = 2) and sampleCount (forced to 8 by the host, renderer_denoising.cpp:683)
+//    are parameters, as BASELINE.json configs[4] needs 64 spp and deeper paths;
+//  - planes are written as float4 (the reference narrows normal+roughness to RGBA16F and albedo+metallic to
+//    RGBA8, raygen.rgen:57-58), and motion vectors (raygen.rgen:409-413) are not produced.
+#ifndef BLOK_PATH_CORE_H
+#define BLOK_PATH_CORE_H
+
+#include "trace_core.h"
+
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+
+namespace blok {
+
+struct PathArgs {
+    TraceArgs trace;                 // tree, camera, frame size, rectangle (x0, y0, w, h)
+    uint32_t spp, max_bounces, frame_count;
+    float* color;                    // float4 per pixel of the rectangle, row-major; any plane may be null
+    float* world_pos;
+    float* normal_roughness;
+    float* albedo_metallic;
+};
+
+struct V3 { float x, y, z; };
+BLOK_DEV V3 v3(float x, float y, float z) { V3 v; v.x = x; v.y = y; v.z = z; return v; }
+BLOK_DEV V3 vadd(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+BLOK_DEV V3 vsub(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+BLOK_DEV V3 vmul(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+BLOK_DEV V3 vscale(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+BLOK_DEV V3 vdivs(V3 a, float s) { return v3(a.x / s, a.y / s, a.z / s); }
+BLOK_DEV V3 vneg(V3 a) { return v3(-a.x, -a.y, -a.z); }
+BLOK_DEV float vdot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+BLOK_DEV V3 vnormalize(V3 v) { return vdivs(v, rn_sqrt(vdot(v, v))); }
+BLOK_DEV V3 vcross(V3 a, V3 b) { return v3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
+BLOK_DEV V3 vmix(V3 a, V3 b, float t) { return vadd(vscale(a, 1.0f - t), vscale(b, t)); }
+BLOK_DEV float max3f(V3 a) { return fmaxf(fmaxf(a.x, a.y), a.z); }
+
+constexpr float kPi = 3.14159265359f;        // raygen.rgen:74
+constexpr float kInvPi = 0.31830988618f;     // raygen.rgen:75
+
+BLOK_DEV uint32_t pcg(uint32_t& state) {      // raygen.rgen:77-82
+    const uint32_t old = state;
+    state = old * 747796405u + 2891336453u;
+    const uint32_t word = ((old >> ((old >> 28u) + 4u)) ^ old) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+BLOK_DEV float random_float(uint32_t& state) { return static_cast<float>(pcg(state)) / 4294967295.0f; }   // :84-86
+BLOK_DEV uint32_t init_rng(uint32_t px, uint32_t py, uint32_t width, uint32_t frame, uint32_t sample) {   // :92-99
+    uint32_t seed = px + py * width;
+    seed ^= frame * 747796405u;
+    seed ^= sample * 1664525u;
+    pcg(seed);
+    pcg(seed);
+    return seed;
+}
+BLOK_DEV void tangent_frame(V3 n, V3& tangent, V3& bitangent) {       // :108-110, :125-127
+    const V3 up = fabsf(n.z) < 0.999f ? v3(0.0f, 0.0f, 1.0f) : v3(1.0f, 0.0f, 0.0f);
+    tangent = vnormalize(vcross(up, n));
+    bitangent = vcross(n, tangent);
+}
+BLOK_DEV V3 sample_cosine_hemisphere(float ux, float uy, V3 n) {       // :101-113
+    const float r = rn_sqrt(ux);
+    const float phi = 2.0f * kPi * uy;
+    const float x = r * cosf(phi);
+    const float y = r * sinf(phi);
+    const float z = rn_sqrt(fmaxf(0.0f, 1.0f - ux));
+    V3 t, b;
+    tangent_frame(n, t, b);
+    return vnormalize(vadd(vadd(vscale(t, x), vscale(b, y)), vscale(n, z)));
+}
+BLOK_DEV V3 sample_ggx(float ux, float uy, V3 n, float roughness) {    // :115-130
+    const float a = roughness * roughness;
+    const float a2 = a * a;
+    const float phi = 2.0f * kPi * ux;
+    const float cos_theta = rn_sqrt((1.0f - uy) / (1.0f + (a2 - 1.0f) * uy));
+    const float sin_theta = rn_sqrt(fmaxf(0.0f, 1.0f - cos_theta * cos_theta));
+    const V3 h = v3(sin_theta * cosf(phi), sin_theta * sinf(phi), cos_theta);
+    V3 t, b;
+    tangent_frame(n, t, b);
+    return vnormalize(vadd(vadd(vscale(t, h.x), vscale(b, h.y)), vscale(n, h.z)));
+}
+BLOK_DEV V3 fresnel_schlick(float cos_theta, V3 f0) {                  // :132-134
+    const float w = powf(fmaxf(1.0f - cos_theta, 0.0f), 5.0f);
+    return v3(f0.x + (1.0f - f0.x) * w, f0.y + (1.0f - f0.y) * w, f0.z + (1.0f - f0.z) * w);
+}
+BLOK_DEV V3 sun_direction() { return vnormalize(v3(0.5f, 0.8f, 0.3f)); }   // :142, :185
+BLOK_DEV V3 sky_color(V3 dir) {                                         // :136-148
+    const float t = 0.5f * (dir.y + 1.0f);
+    const V3 sky = vmix(v3(0.8f, 0.85f, 0.95f), v3(0.4f, 0.6f, 0.9f), t);
+    const float sun_dot = fmaxf(vdot(dir, sun_direction()), 0.0f);
+    const V3 sun = vscale(vscale(v3(1.0f, 0.95f, 0.8f), powf(sun_dot, 128.0f)), 5.0f);
+    const V3 glow = vscale(vscale(v3(1.0f, 0.9f, 0.7f), powf(sun_dot, 8.0f)), 0.3f);
+    return vadd(vadd(sky, sun), glow);
+}
+BLOK_DEV bool is_emissive(V3 e) { return vdot(e, v3(1.0f, 1.0f, 1.0f)) > 0.01f; }                // :158-160
+BLOK_DEV float luminance(V3 c) { return vdot(c, v3(0.2126f, 0.7152f, 0.0722f)); }                // :163-165
+
+BLOK_DEV void store4(float* plane, size_t i, float a, float b, float c, float d) {
+    if (!plane) return;
+    float* p = plane + 4 * i;
+    p[0] = a; p[1] = b; p[2] = c; p[3] = d;
+}
+
+// raygen.rgen:167-414 for pixel (px, py) of the full frame; `index` is its slot in the output planes.
+BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t index, uint4* stk) {
+    const TraceArgs& A = P.trace;
+    const blok_camera& cam = A.cam;
+    const V3 cam_pos = v3(cam.pos[0], cam.pos[1], cam.pos[2]);
+    const V3 cam_f = v3(cam.fwd[0], cam.fwd[1], cam.fwd[2]);
+    const V3 cam_r = v3(cam.right[0], cam.right[1], cam.right[2]);
+    const V3 cam_u = v3(cam.up[0], cam.up[1], cam.up[2]);
+    V3 first_pos = v3(0, 0, 0), first_normal = v3(0, 0, 0), first_albedo = v3(0, 0, 0), first_emission = v3(0, 0, 0);
+    float first_roughness = 0.0f, first_metallic = 0.0f, first_depth = 0.0f;
+    bool had_first_hit = false, first_was_emissive = false;
+    V3 accumulated = v3(0, 0, 0);
+    const V3 sun_dir = sun_direction();
+    const V3 sun_radiance = v3(3.0f, 2.9f, 2.7f);
+
+    for (uint32_t s = 0u; s < P.spp; ++s) {                                                  // :188
+        uint32_t rng = init_rng(px, py, A.frame_w, P.frame_count, s);
+        float pcx, pcy;                                                                        // :193-199
+        if (s == 0u) { pcx = static_cast<float>(px) + 0.5f; pcy = static_cast<float>(py) + 0.5f; }
+        else {
+            const float jx = random_float(rng) - 0.5f;
+            const float jy = random_float(rng) - 0.5f;
+            pcx = static_cast<float>(px) + 0.5f + jx * 0.5f;
+            pcy = static_cast<float>(py) + 0.5f + jy * 0.5f;
+        }
+        const float u = (2.0f * (pcx / static_cast<float>(A.frame_w)) - 1.0f) * cam.tan_half_fov * cam.aspect;
+        const float v = (1.0f - 2.0f * (pcy / static_cast<float>(A.frame_h))) * cam.tan_half_fov;
+        V3 ray_dir = vnormalize(vadd(vadd(cam_f, vscale(cam_r, u)), vscale(cam_u, v)));
+        V3 ray_org = cam_pos;
+        V3 radiance = v3(0, 0, 0), throughput = v3(1, 1, 1);
+
+        for (uint32_t bounce = 0u; bounce < P.max_bounces; ++bounce) {                        // :212
+            RayIn r;
+            r.ox = ray_org.x; r.oy = ray_org.y; r.oz = ray_org.z;
+            r.dx = ray_dir.x; r.dy = ray_dir.y; r.dz = ray_dir.z;
+            r.tmin = 0.001f; r.tmax = 10000.0f;                                               // :225,:227
+            const HitInfo hit = walk(A, r, stk);
+            if (!hit.found) {                                                                 // :232-235, miss.rmiss
+                radiance = vadd(radiance, vmul(throughput, sky_color(ray_dir)));
+                break;
+            }
+            const V3 hit_pos = vadd(ray_org, vscale(ray_dir, hit.t));                         // :238
+            // hit.rchit:58-75
+            const uint32_t id = hit.material < 65535u ? hit.material : 65535u;
+            const blok_material mat = A.mat_table[id < A.n_materials ? id : 0u];
+            V3 n = v3(hit.face == 0u ? 1.0f : (hit.face == 1u ? -1.0f : 0.0f),
+                      hit.face == 2u ? 1.0f : (hit.face == 3u ? -1.0f : 0.0f),
+                      hit.face == 4u ? 1.0f : (hit.face == 5u ? -1.0f : 0.0f));
+            const V3 albedo = v3(mat.albedo[0], mat.albedo[1], mat.albedo[2]);
+            const V3 emission = v3(mat.emission[0], mat.emission[1], mat.emission[2]);
+            const float metallic = static_cast<float>((mat.flags >> 24) & 0xFFu) / 255.0f;
+            const float roughness = fmaxf(static_cast<float>((mat.flags >> 16) & 0xFFu) / 255.0f, 0.04f);
+            if (vdot(n, ray_dir) > 0.0f) n = vneg(n);                                         // :248-250
+            if (bounce == 0u && s == 0u && !had_first_hit) {                                  // :253-263
+                had_first_hit = true;
+                first_pos = hit_pos; first_normal = n; first_albedo = albedo; first_emission = emission;
+                first_roughness = roughness; first_metallic = metallic; first_depth = hit.t;
+                first_was_emissive = is_emissive(emission);
+            }
+            if (is_emissive(emission)) {                                                      // :265-277
+                radiance = vadd(radiance, vmul(throughput, emission));
+                if (luminance(emission) > 5.0f || bounce > 0u) break;
+            }
+            const float n_dot_l = fmaxf(vdot(n, sun_dir), 0.0f);                              // :280
+            if (n_dot_l > 0.0f && bounce == 0u) {
+                const V3 so = vadd(hit_pos, vscale(n, 0.001f));
+                RayIn sr;
+                sr.ox = so.x; sr.oy = so.y; sr.oz = so.z;
+                sr.dx = sun_dir.x; sr.dy = sun_dir.y; sr.dz = sun_dir.z;
+                sr.tmin = 0.001f; sr.tmax = 1000.0f;                                          // :294,:296
+                const bool shadowed = walk(A, sr, stk).found;                                 // any accepted hit
+                if (!shadowed) {                                                              // :300-325
+                    const V3 diffuse = vscale(albedo, 1.0f - metallic);
+                    radiance = vadd(radiance, vscale(vscale(vmul(vmul(throughput, diffuse), sun_radiance), n_dot_l), kInvPi));
+                    if (roughness < 0.9f) {
+                        const V3 h = vnormalize(vsub(sun_dir, ray_dir));
+                        const float n_dot_h = fmaxf(vdot(n, h), 0.0f);
+                        const float v_dot_h = fmaxf(vdot(vneg(ray_dir), h), 0.0f);
+                        const float a = roughness * roughness;
+                        const float a2 = a * a;
+                        const float denom = n_dot_h * n_dot_h * (a2 - 1.0f) + 1.0f;
+                        const float d = a2 / (kPi * denom * denom);
+                        const V3 f0 = vmix(v3(0.04f, 0.04f, 0.04f), albedo, metallic);
+                        const V3 f = fresnel_schlick(v_dot_h, f0);
+                        radiance = vadd(radiance, vscale(vmul(vscale(vscale(vmul(throughput, f), d), 0.25f), sun_radiance), n_dot_l));
+                    }
+                }
+            }
+            if (bounce > 0u) {                                                                // :329-335
+                const float p = fminf(max3f(throughput), 0.95f);
+                if (random_float(rng) > p) break;
+                throughput = vdivs(throughput, p);
+            }
+            const float ux = random_float(rng);                                               // :338
+            const float uy = random_float(rng);
+            const V3 f0 = vmix(v3(0.04f, 0.04f, 0.04f), albedo, metallic);                    // :341-347
+            const V3 view = vneg(ray_dir);
+            const float n_dot_v = fmaxf(vdot(n, view), 0.001f);
+            const V3 f = fresnel_schlick(n_dot_v, f0);
+            float spec_w = (f.x + f.y + f.z) / 3.0f;
+            spec_w = spec_w * (1.0f - metallic) + 1.0f * metallic;
+            if (random_float(rng) < spec_w) {                                                 // :349-360
+                const V3 h = sample_ggx(ux, uy, n, fmaxf(roughness, 0.04f));
+                const V3 new_dir = vsub(ray_dir, vscale(h, 2.0f * vdot(h, ray_dir)));
+                if (vdot(new_dir, n) <= 0.0f) break;
+                const float h_dot_v = fmaxf(vdot(h, view), 0.0f);
+                const V3 fh = fresnel_schlick(h_dot_v, f0);
+                throughput = vmul(throughput, vdivs(fh, fmaxf(spec_w, 0.001f)));
+                ray_dir = new_dir;
+            } else {                                                                          // :361-367
+                const V3 new_dir = sample_cosine_hemisphere(ux, uy, n);
+                const V3 diffuse = vscale(albedo, 1.0f - metallic);
+                throughput = vmul(throughput, vdivs(diffuse, fmaxf(1.0f - spec_w, 0.001f)));
+                ray_dir = new_dir;
+            }
+            const float max_t = max3f(throughput);                                            // :370-373
+            if (max_t > 10.0f) throughput = vscale(throughput, 10.0f / max_t);
+            ray_org = vadd(hit_pos, vscale(n, 0.002f));                                       // :376
+        }
+        accumulated = vadd(accumulated, radiance);                                            // :379
+    }
+    V3 color = vdivs(accumulated, static_cast<float>(P.spp));                                 // :383
+    const float max_val = max3f(color);                                                       // :386-389
+    if (max_val > 100.0f) color = vscale(color, 100.0f / max_val);
+    if (!had_first_hit) {                                                                     // :395-400
+        first_depth = 10000.0f;
+        first_pos = vadd(cam_pos, vscale(vnormalize(cam_f), 10000.0f));
+        first_normal = v3(0.0f, 1.0f, 0.0f);
+        first_albedo = sky_color(vnormalize(vsub(first_pos, cam_pos)));
+    }
+    const V3 final_albedo = first_was_emissive ? first_emission : first_albedo;               // :403
+    store4(P.color, index, color.x, color.y, color.z, 1.0f);                                  // :392
+    store4(P.world_pos, index, first_pos.x, first_pos.y, first_pos.z, first_depth);           // :405
+    store4(P.normal_roughness, index, first_normal.x, first_normal.y, first_normal.z, first_roughness);   // :406
+    store4(P.albedo_metallic, index, final_albedo.x, final_albedo.y, final_albedo.z, first_metallic);    // :407
+}
+
+}  // namespace blok
+#endif

@@ -106,9 +106,19 @@ BLOK_DEV void enter_axis(const Axis& a, int& q, float& t_far, uint32_t shift, fl
     q += ((g ? 2 : 0) + (g2 ? 1 : 0)) << shift;
 }
 
-// Walks one ray; writes the 16-byte record.  `stk` points at this lane's slot of the LDS node stack
-// (stride kBlock entries between levels; slot l-2 holds the node of level l on the current path).
-BLOK_DEV void trace_one(const TraceArgs& A, const RayIn& r, uint4* stk, const Sink& dst) {
+// What closest-hit sees of a procedural hit (intersect.rint:138-141, hit.rchit:58-74), in registers.
+struct HitInfo {
+    bool found;
+    float t;
+    uint32_t material, face;
+    int vx, vy, vz;          // world voxel
+};
+
+// Walks one ray.  `stk` points at this lane's slot of the LDS node stack (stride kBlock entries between
+// levels; slot l-2 holds the node of level l on the current path).
+BLOK_DEV HitInfo walk(const TraceArgs& A, const RayIn& r, uint4* stk) {
+    HitInfo out;
+    out.found = false; out.t = -1.0f; out.material = 0u; out.face = 0xFFu; out.vx = out.vy = out.vz = 0;
     const uint32_t L = A.levels;
     const int W = 1 << (2 * L);
     Axis ax, ay, az;
@@ -122,7 +132,7 @@ BLOK_DEV void trace_one(const TraceArgs& A, const RayIn& r, uint4* stk, const Si
     // world box: near planes q = 0, far planes q = W (T is monotone in q, so no min/max is needed)
     float tFx = plane_t(ax, W), tFy = plane_t(ay, W), tFz = plane_t(az, W);
     float tCur = fmaxf(fmaxf(fmaxf(plane_t(ax, 0), plane_t(ay, 0)), plane_t(az, 0)), r.tmin);
-    if (!(tCur < fminf(fminf(fminf(tFx, tFy), tFz), r.tmax))) { write_miss(dst); return; }
+    if (!(tCur < fminf(fminf(fminf(tFx, tFy), tFz), r.tmax))) return out;
 
     int qx = 0, qy = 0, qz = 0;          // mirrored min corner of the current cell
     uint32_t lvl = L - 1;                // current cells have size 4^lvl; `node` is their parent
@@ -186,7 +196,7 @@ BLOK_DEV void trace_one(const TraceArgs& A, const RayIn& r, uint4* stk, const Si
         const int far = 1 << (2 * lvl);
         tFx = plane_t(ax, qx + far); tFy = plane_t(ay, qy + far); tFz = plane_t(az, qz + far);
     }
-    if (!found) { write_miss(dst); return; }
+    if (!found) return out;
 
     // reported: intersect.rint:136-141, hit.rchit:58-74
     const float tc = fmaxf(tCur, r.tmin);
@@ -205,13 +215,22 @@ BLOK_DEV void trace_one(const TraceArgs& A, const RayIn& r, uint4* stk, const Si
     if (fx >= fy && fx >= fz) face = ex > 0.0f ? 0u : 1u;
     else if (fy >= fz)        face = ey > 0.0f ? 2u : 3u;
     else                      face = ez > 0.0f ? 4u : 5u;
+    out.found = true; out.t = tc; out.material = material; out.face = face;
+    out.vx = vx; out.vy = vy; out.vz = vz;
+    return out;
+}
+
+// Walks one ray and writes its 16-byte record and/or RGBA8 pixel.
+BLOK_DEV void trace_one(const TraceArgs& A, const RayIn& r, uint4* stk, const Sink& dst) {
+    const HitInfo h = walk(A, r, stk);
+    if (!h.found) { write_miss(dst); return; }
     uint4 rec;
-    rec.x = __float_as_uint(tc);
-    rec.y = material;
-    rec.z = (static_cast<uint32_t>(vx) & 0xFFFFu) | (static_cast<uint32_t>(vy) << 16);
-    rec.w = (static_cast<uint32_t>(vz) & 0xFFFFu) | (face << 16) | (1u << 24);
+    rec.x = __float_as_uint(h.t);
+    rec.y = h.material;
+    rec.z = (static_cast<uint32_t>(h.vx) & 0xFFFFu) | (static_cast<uint32_t>(h.vy) << 16);
+    rec.w = (static_cast<uint32_t>(h.vz) & 0xFFFFu) | (h.face << 16) | (1u << 24);
     if (dst.hit) *reinterpret_cast<uint4*>(dst.hit) = rec;
-    if (dst.rgba) *dst.rgba = shade_rgba(A.mat_table, A.n_materials, material, face);
+    if (dst.rgba) *dst.rgba = shade_rgba(A.mat_table, A.n_materials, h.material, h.face);
 }
 
 // Primary ray of pixel (x, y): reference blok/src/cuda_tracer.cu:276-282 with zero jitter

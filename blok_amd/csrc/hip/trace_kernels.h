@@ -64,6 +64,8 @@ struct UntileArgs {
     uint32_t frame_w, frame_h, tile, n_ranks, tiles_per_rank_max, tiles_x, elem_bytes;
 };
 
+struct PathArgs;
+void launch_paths(const PathArgs& args, uint32_t n_blocks, hipStream_t stream);
 void launch_trace(RayMode mode, const TraceArgs& args, uint32_t n_blocks, hipStream_t stream);
 void launch_untile(const UntileArgs& args, hipStream_t stream);
 

@@ -3,6 +3,7 @@
 // explicitly rounded intrinsics so that no flag can fuse them.
 #include "trace_kernels.h"
 #include "trace_core.h"
+#include "path_core.h"
 
 namespace blok {
 
@@ -54,6 +55,21 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const TraceArgs A) {
     }
 }
 
+// raygen.rgen main(): one lane per pixel of the rectangle, same 16x16 / 8x8 pixel mapping as the trace kernel.
+__global__ __launch_bounds__(kBlock) void path_kernel(const PathArgs P) {
+    extern __shared__ uint4 lds_stack[];
+    const TraceArgs& A = P.trace;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t wave = tid >> 6, lane = tid & 63u;
+    const uint32_t lx = ((wave & 1u) << 3) | (lane & 7u);
+    const uint32_t ly = ((wave >> 1) << 3) | (lane >> 3);
+    const uint32_t bx_count = (A.w + 15u) >> 4;
+    const uint32_t bx = blockIdx.x % bx_count, by = blockIdx.x / bx_count;
+    const uint32_t rx = (bx << 4) + lx, ry = (by << 4) + ly;
+    if (rx >= A.w || ry >= A.h) return;
+    shade_pixel(P, A.x0 + rx, A.y0 + ry, static_cast<size_t>(ry) * A.w + rx, lds_stack + tid);
+}
+
 template <typename Elem>
 __global__ __launch_bounds__(256) void untile_kernel(const UntileArgs U) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -76,6 +92,13 @@ void launch_trace(RayMode mode, const TraceArgs& args, uint32_t n_blocks, hipStr
         case RayMode::Tiles: hipLaunchKernelGGL(trace_kernel<RayMode::Tiles>, dim3(n_blocks), dim3(kBlock), lds, stream, args); break;
         case RayMode::Rays:  hipLaunchKernelGGL(trace_kernel<RayMode::Rays>,  dim3(n_blocks), dim3(kBlock), lds, stream, args); break;
     }
+}
+
+void launch_paths(const PathArgs& args, uint32_t n_blocks, hipStream_t stream) {
+    if (n_blocks == 0) return;
+    const uint32_t levels = args.trace.levels;
+    const size_t lds = static_cast<size_t>(levels > 1 ? levels - 1 : 1) * kBlock * sizeof(uint4);
+    hipLaunchKernelGGL(path_kernel, dim3(n_blocks), dim3(kBlock), lds, stream, args);
 }
 
 void launch_untile(const UntileArgs& args, hipStream_t stream) {

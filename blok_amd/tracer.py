@@ -14,7 +14,7 @@ import ctypes as C
 import numpy as np
 
 from . import _ffi
-from ._ffi import BlokError, CAMERA, HIT, MATERIAL, RAY, SUB_CHUNK, SVO_NODE, WorldStats
+from ._ffi import BlokError, CAMERA, GBuffer, HIT, MATERIAL, RAY, SUB_CHUNK, SVO_NODE, WorldStats
 
 
 class HipTracer:
@@ -124,6 +124,26 @@ class HipTracer:
         hits = np.zeros(len(rays), dtype=HIT)
         self._check(self._lib.blok_hip_trace_rays(self._ctx, _ffi.ptr(rays), len(rays), _ffi.ptr(hits)))
         return hits
+
+    def trace_paths(self, cam: np.ndarray, spp: int = 8, max_bounces: int = 2, frame_index: int = 0, rect=None):
+        """raygen.rgen's sample/bounce loop: dict of (h, w, 4) float32 planes
+        color, world_pos, normal_roughness, albedo_metallic."""
+        x0, y0, w, h = rect if rect is not None else (0, 0, self.width, self.height)
+        cam = np.ascontiguousarray(cam, dtype=CAMERA)
+        planes = {k: np.zeros((h, w, 4), dtype=np.float32) for k in ("color", "world_pos", "normal_roughness", "albedo_metallic")}
+        g = GBuffer(*[planes[k].ctypes.data for k in ("color", "world_pos", "normal_roughness", "albedo_metallic")])
+        self._check(self._lib.blok_hip_trace_paths(self._ctx, _ffi.ptr(cam), x0, y0, w, h, spp, max_bounces, frame_index,
+                                                   C.byref(g)))
+        return planes
+
+    def trace_paths_device(self, cam: np.ndarray, color_ptr: int, spp: int = 8, max_bounces: int = 2,
+                           frame_index: int = 0, rect=None, world_pos_ptr: int = 0, normal_roughness_ptr: int = 0,
+                           albedo_metallic_ptr: int = 0, stream: int = 0):
+        x0, y0, w, h = rect if rect is not None else (0, 0, self.width, self.height)
+        cam = np.ascontiguousarray(cam, dtype=CAMERA)
+        g = GBuffer(color_ptr, world_pos_ptr, normal_roughness_ptr, albedo_metallic_ptr)
+        self._check(self._lib.blok_hip_trace_paths_device(self._ctx, _ffi.ptr(cam), x0, y0, w, h, spp, max_bounces,
+                                                          frame_index, C.byref(g), C.c_void_p(stream)))
 
     def shade_rgba8(self, cam: np.ndarray, rect=None) -> np.ndarray:
         x0, y0, w, h = rect if rect is not None else (0, 0, self.width, self.height)

@@ -200,6 +200,28 @@ int blok_hip_untile_device(blok_hip_ctx* ctx, const void* gathered_dev, uint32_t
                            uint32_t n_ranks, uint32_t tiles_per_rank_max,
                            void* out_frame_dev, void* hip_stream);
 
+/* The reference's per-pixel sample / bounce loop and G-buffer: raygen.rgen:167-414 with hit.rchit, miss.rmiss
+ * and shadow.rmiss (reference assets/shaders/).  Planes are float4 per pixel of the rectangle, row-major; any
+ * pointer may be NULL.  color = (rgb, 1); world_pos = (first-hit position, depth); normal_roughness;
+ * albedo_metallic (raygen.rgen:392-407; the reference stores the last two as RGBA16F / RGBA8).
+ * spp = FrameUBO.sampleCount (8 in the reference, renderer_denoising.cpp:683), max_bounces = MAX_BOUNCES
+ * (2, raygen.rgen:211), frame_index = FrameUBO.frameCount (seeds the RNG, raygen.rgen:92-99). */
+typedef struct blok_gbuffer {
+    float* color;
+    float* world_pos;
+    float* normal_roughness;
+    float* albedo_metallic;
+} blok_gbuffer;
+int blok_hip_trace_paths_device(blok_hip_ctx* ctx, const blok_camera* cam,
+                                uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
+                                uint32_t spp, uint32_t max_bounces, uint32_t frame_index,
+                                const blok_gbuffer* planes_dev, void* hip_stream);
+/* Blocking form with host planes. */
+int blok_hip_trace_paths(blok_hip_ctx* ctx, const blok_camera* cam,
+                         uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
+                         uint32_t spp, uint32_t max_bounces, uint32_t frame_index,
+                         const blok_gbuffer* planes_host);
+
 /* Explicit rays (secondary rays; edge-case tests). n rays in, n records out, host arrays. */
 int blok_hip_trace_rays(blok_hip_ctx* ctx, const blok_ray* rays_host, size_t n,
                         blok_hit* out_hits_host);

@@ -808,6 +808,282 @@ void orc_shade_surface(const void* hit, const void* materials, float out[12]) {
     for (int a = 0; a < 3; ++a) out[9 + a] = mat.emission[a];
 }
 
+}  // extern "C"
+
+// =============================================================================================
+// raygen.rgen:77-165,167-414 — RNG, sampling, sky, the per-pixel sample/bounce loop and the G-buffer.
+// Vector helpers spell out GLSL's definitions: dot = x*x'+y*y'+z*z' left to right, normalize = v / sqrt(dot),
+// mix(a,b,t) = a*(1-t) + b*t, reflect(I,N) = I - 2*dot(N,I)*N.  The primary ray uses the camera-basis form
+// (see primaryRay) with the reference's pixel-centre jitter (raygen.rgen:193-202).
+// Reference formats not reproduced: outNormalRoughness is RGBA16F, outAlbedoMetallic RGBA8, motion vectors RG16F
+// (raygen.rgen:57-59); here every plane is float4 and motion vectors are not produced (they need prevViewProj,
+// i.e. glm matrices that are absent from the reference tree).
+namespace {
+
+inline float dot3(Vec3 a, Vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline Vec3 normalize3(Vec3 v) { const float len = std::sqrt(dot3(v, v)); return {v.x / len, v.y / len, v.z / len}; }
+inline Vec3 cross3(Vec3 a, Vec3 b) { return {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y}; }
+inline Vec3 mix3(Vec3 a, Vec3 b, float t) { return add3(scale3(a, 1.0f - t), scale3(b, t)); }
+inline Vec3 neg3(Vec3 a) { return {-a.x, -a.y, -a.z}; }
+
+constexpr float PI = 3.14159265359f;         // :74
+constexpr float INV_PI = 0.31830988618f;     // :75
+
+inline uint32_t pcg(uint32_t& state) {        // :77-82
+    const uint32_t oldState = state;
+    state = oldState * 747796405u + 2891336453u;
+    const uint32_t word = ((oldState >> ((oldState >> 28u) + 4u)) ^ oldState) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+inline float randomFloat(uint32_t& state) { return float(pcg(state)) / 4294967295.0f; }      // :84-86
+inline uint32_t initRNG(uint32_t px, uint32_t py, uint32_t screenWidth, uint32_t frameIndex, uint32_t sampleIndex) {  // :92-99
+    uint32_t seed = px + py * screenWidth;
+    seed ^= frameIndex * 747796405u;
+    seed ^= sampleIndex * 1664525u;
+    pcg(seed);
+    pcg(seed);
+    return seed;
+}
+inline Vec3 sampleCosineHemisphere(float ux, float uy, Vec3 N) {      // :101-113
+    const float r = std::sqrt(ux);
+    const float phi = 2.0f * PI * uy;
+    const float x = r * std::cos(phi);
+    const float y = r * std::sin(phi);
+    const float z = std::sqrt(std::fmax(0.0f, 1.0f - ux));
+    const Vec3 up = std::fabs(N.z) < 0.999f ? Vec3{0.0f, 0.0f, 1.0f} : Vec3{1.0f, 0.0f, 0.0f};
+    const Vec3 tangent = normalize3(cross3(up, N));
+    const Vec3 bitangent = cross3(N, tangent);
+    return normalize3(add3(add3(scale3(tangent, x), scale3(bitangent, y)), scale3(N, z)));
+}
+inline Vec3 sampleGGX(float ux, float uy, Vec3 N, float roughness) {   // :115-130
+    const float a = roughness * roughness;
+    const float a2 = a * a;
+    const float phi = 2.0f * PI * ux;
+    const float cosTheta = std::sqrt((1.0f - uy) / (1.0f + (a2 - 1.0f) * uy));
+    const float sinTheta = std::sqrt(std::fmax(0.0f, 1.0f - cosTheta * cosTheta));
+    const Vec3 H = {sinTheta * std::cos(phi), sinTheta * std::sin(phi), cosTheta};
+    const Vec3 up = std::fabs(N.z) < 0.999f ? Vec3{0.0f, 0.0f, 1.0f} : Vec3{1.0f, 0.0f, 0.0f};
+    const Vec3 tangent = normalize3(cross3(up, N));
+    const Vec3 bitangent = cross3(N, tangent);
+    return normalize3(add3(add3(scale3(tangent, H.x), scale3(bitangent, H.y)), scale3(N, H.z)));
+}
+inline Vec3 fresnelSchlick(float cosTheta, Vec3 F0) {                   // :132-134
+    const float w = std::pow(std::fmax(1.0f - cosTheta, 0.0f), 5.0f);
+    return {F0.x + (1.0f - F0.x) * w, F0.y + (1.0f - F0.y) * w, F0.z + (1.0f - F0.z) * w};
+}
+inline Vec3 sunDirection() { return normalize3({0.5f, 0.8f, 0.3f}); }  // :142,185
+inline Vec3 getSkyColor(Vec3 dir) {                                     // :136-148
+    const float t = 0.5f * (dir.y + 1.0f);
+    const Vec3 skyColor = mix3({0.8f, 0.85f, 0.95f}, {0.4f, 0.6f, 0.9f}, t);
+    const float sunDot = std::fmax(dot3(dir, sunDirection()), 0.0f);
+    const Vec3 sunColor = scale3(scale3({1.0f, 0.95f, 0.8f}, std::pow(sunDot, 128.0f)), 5.0f);
+    const Vec3 sunGlow = scale3(scale3({1.0f, 0.9f, 0.7f}, std::pow(sunDot, 8.0f)), 0.3f);
+    return add3(add3(skyColor, sunColor), sunGlow);
+}
+inline bool isEmissive(Vec3 e) { return dot3(e, {1.0f, 1.0f, 1.0f}) > 0.01f; }                 // :158-160
+inline float luminance(Vec3 c) { return dot3(c, {0.2126f, 0.7152f, 0.0722f}); }                // :163-165
+
+struct Payload { Vec3 radiance, normal, albedo; float roughness, metallic, hitT; };           // :62-69
+
+// traceRayEXT + hit.rchit / miss.rmiss for the radiance payload (:217-229, hit.rchit:55-76, miss.rmiss:25-27)
+inline void traceRadiance(const Lattice& L, const SvoNode* nodes, const SubChunkGpu* subs, const MaterialGpu* materials,
+                          Vec3 org, Vec3 dir, Payload& payload, Counters& c) {
+    RayQuery q;
+    q.org = org; q.dir = dir; q.tmin = 0.001f; q.tmax = 10000.0f;
+    traceLattice(L, nodes, subs, q, c);
+    c.rays++;
+    if (!q.committed) { payload.hitT = -1.0f; return; }
+    c.hits++;
+    static const Vec3 FACE_NORMALS[6] = {{1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
+    const MaterialGpu& mat = materials[std::min(q.materialId, 65535u)];
+    payload.normal = FACE_NORMALS[q.hitKind];
+    payload.albedo = {mat.albedo[0], mat.albedo[1], mat.albedo[2]};
+    payload.roughness = std::fmax(float((mat.flags >> 16) & 0xFFu) / 255.0f, 0.04f);
+    payload.metallic = float((mat.flags >> 24) & 0xFFu) / 255.0f;
+    payload.hitT = q.hitT;
+    payload.radiance = {mat.emission[0], mat.emission[1], mat.emission[2]};
+}
+// shadow ray: TerminateOnFirstHit | SkipClosestHit, miss shader clears the flag (:283-298, shadow.rmiss:13-15)
+inline bool traceShadow(const Lattice& L, const SvoNode* nodes, const SubChunkGpu* subs, Vec3 org, Vec3 dir, Counters& c) {
+    RayQuery q;
+    q.org = org; q.dir = dir; q.tmin = 0.001f; q.tmax = 1000.0f;
+    traceLattice(L, nodes, subs, q, c);
+    c.rays++;
+    return q.committed;
+}
+
+struct GBufferPixel { float color[4], worldPos[4], normalRoughness[4], albedoMetallic[4]; };
+
+GBufferPixel shadePixel(const Lattice& L, const SvoNode* nodes, const SubChunkGpu* subs, const MaterialGpu* materials,
+                        const Camera& cam, uint32_t width, uint32_t height, uint32_t px, uint32_t py,
+                        uint32_t sampleCount, uint32_t maxBounces, uint32_t frameCount, Counters& c) {
+    const Vec3 camPos = {cam.pos[0], cam.pos[1], cam.pos[2]};
+    const Vec3 camF = {cam.fwd[0], cam.fwd[1], cam.fwd[2]}, camR = {cam.right[0], cam.right[1], cam.right[2]},
+               camU = {cam.up[0], cam.up[1], cam.up[2]};
+    Vec3 firstHitPos{0, 0, 0}, firstHitNormal{0, 0, 0}, firstHitAlbedo{0, 0, 0}, firstHitEmission{0, 0, 0};   // :173-181
+    float firstHitRoughness = 0.0f, firstHitMetallic = 0.0f, firstHitDepth = 0.0f;
+    bool hadFirstHit = false, firstHitWasEmissive = false;
+    Vec3 accumulatedColor{0, 0, 0};
+    const Vec3 sunDir = sunDirection();
+    const Vec3 sunRadiance = {3.0f, 2.9f, 2.7f};
+
+    for (uint32_t sampleIdx = 0u; sampleIdx < sampleCount; sampleIdx++) {                                     // :188
+        uint32_t rng = initRNG(px, py, width, frameCount, sampleIdx);
+        float pcx, pcy;                                                                                        // :193-199
+        if (sampleIdx == 0u) { pcx = float(px) + 0.5f; pcy = float(py) + 0.5f; }
+        else {
+            const float jx = randomFloat(rng) - 0.5f;
+            const float jy = randomFloat(rng) - 0.5f;
+            pcx = float(px) + 0.5f + jx * 0.5f;
+            pcy = float(py) + 0.5f + jy * 0.5f;
+        }
+        // :201-206 in camera-basis form (cuda_tracer.cu:276-282)
+        const float u = (2.0f * (pcx / float(width)) - 1.0f) * cam.fovScale * cam.aspect;
+        const float v = (1.0f - 2.0f * (pcy / float(height))) * cam.fovScale;
+        Vec3 rayDir = normalize3(add3(add3(camF, scale3(camR, u)), scale3(camU, v)));
+        Vec3 rayOrigin = camPos;
+        Vec3 radiance{0, 0, 0}, throughput{1, 1, 1};
+
+        for (uint32_t bounce = 0u; bounce < maxBounces; bounce++) {                                            // :212
+            Payload payload{};
+            payload.radiance = {0, 0, 0};
+            payload.hitT = -1.0f;
+            traceRadiance(L, nodes, subs, materials, rayOrigin, rayDir, payload, c);
+            if (payload.hitT < 0.0f) {                                                                         // :232-235
+                radiance = add3(radiance, mul3(throughput, getSkyColor(rayDir)));
+                break;
+            }
+            const Vec3 hitPos = add3(rayOrigin, scale3(rayDir, payload.hitT));                                 // :238
+            Vec3 N = payload.normal;
+            const Vec3 albedo = payload.albedo, emission = payload.radiance;
+            const float roughness = payload.roughness, metallic = payload.metallic;
+            if (dot3(N, rayDir) > 0.0f) N = neg3(N);                                                           // :248-250
+            if (bounce == 0u && sampleIdx == 0u && !hadFirstHit) {                                             // :253-263
+                hadFirstHit = true;
+                firstHitPos = hitPos; firstHitNormal = N; firstHitAlbedo = albedo; firstHitEmission = emission;
+                firstHitRoughness = roughness; firstHitMetallic = metallic; firstHitDepth = payload.hitT;
+                firstHitWasEmissive = isEmissive(emission);
+            }
+            if (isEmissive(emission)) {                                                                        // :265-277
+                radiance = add3(radiance, mul3(throughput, emission));
+                if (luminance(emission) > 5.0f || bounce > 0u) break;
+            }
+            const float NdotL = std::fmax(dot3(N, sunDir), 0.0f);                                              // :280
+            if (NdotL > 0.0f && bounce == 0u) {
+                const Vec3 shadowOrigin = add3(hitPos, scale3(N, 0.001f));
+                const bool isShadowed = traceShadow(L, nodes, subs, shadowOrigin, sunDir, c);
+                if (!isShadowed) {                                                                             // :300-325
+                    const Vec3 diffuseColor = scale3(albedo, 1.0f - metallic);
+                    radiance = add3(radiance, scale3(scale3(mul3(mul3(throughput, diffuseColor), sunRadiance), NdotL), INV_PI));
+                    if (roughness < 0.9f) {
+                        const Vec3 H = normalize3(sub3(sunDir, rayDir));
+                        const float NdotH = std::fmax(dot3(N, H), 0.0f);
+                        const float VdotH = std::fmax(dot3(neg3(rayDir), H), 0.0f);
+                        const float a = roughness * roughness;
+                        const float a2 = a * a;
+                        const float denom = NdotH * NdotH * (a2 - 1.0f) + 1.0f;
+                        const float D = a2 / (PI * denom * denom);
+                        const Vec3 F0 = mix3({0.04f, 0.04f, 0.04f}, albedo, metallic);
+                        const Vec3 F = fresnelSchlick(VdotH, F0);
+                        const float Vis = 0.25f;
+                        radiance = add3(radiance, scale3(mul3(scale3(scale3(mul3(throughput, F), D), Vis), sunRadiance), NdotL));
+                    }
+                }
+            }
+            if (bounce > 0u) {                                                                                 // :329-335
+                const float p = std::fmin(std::fmax(std::fmax(throughput.x, throughput.y), throughput.z), 0.95f);
+                if (randomFloat(rng) > p) break;
+                throughput = {throughput.x / p, throughput.y / p, throughput.z / p};
+            }
+            const float ux = randomFloat(rng);                                                                 // :338
+            const float uy = randomFloat(rng);
+            const Vec3 F0 = mix3({0.04f, 0.04f, 0.04f}, albedo, metallic);                                     // :341-347
+            const Vec3 V = neg3(rayDir);
+            const float NdotV = std::fmax(dot3(N, V), 0.001f);
+            const Vec3 F = fresnelSchlick(NdotV, F0);
+            float specularWeight = (F.x + F.y + F.z) / 3.0f;
+            specularWeight = specularWeight * (1.0f - metallic) + 1.0f * metallic;
+            if (randomFloat(rng) < specularWeight) {                                                           // :349-360
+                const Vec3 H = sampleGGX(ux, uy, N, std::fmax(roughness, 0.04f));
+                const Vec3 newDir = sub3(rayDir, scale3(H, 2.0f * dot3(H, rayDir)));
+                if (dot3(newDir, N) <= 0.0f) break;
+                const float HdotV = std::fmax(dot3(H, V), 0.0f);
+                const Vec3 Fh = fresnelSchlick(HdotV, F0);
+                const float w = std::fmax(specularWeight, 0.001f);
+                throughput = mul3(throughput, {Fh.x / w, Fh.y / w, Fh.z / w});
+                rayDir = newDir;
+            } else {                                                                                           // :361-367
+                const Vec3 newDir = sampleCosineHemisphere(ux, uy, N);
+                const Vec3 diffuseColor = scale3(albedo, 1.0f - metallic);
+                const float w = std::fmax(1.0f - specularWeight, 0.001f);
+                throughput = mul3(throughput, {diffuseColor.x / w, diffuseColor.y / w, diffuseColor.z / w});
+                rayDir = newDir;
+            }
+            const float maxThroughput = std::fmax(std::fmax(throughput.x, throughput.y), throughput.z);       // :370-373
+            if (maxThroughput > 10.0f) throughput = scale3(throughput, 10.0f / maxThroughput);
+            rayOrigin = add3(hitPos, scale3(N, 0.002f));                                                       // :376
+        }
+        accumulatedColor = add3(accumulatedColor, radiance);                                                   // :379
+    }
+    const float n = float(sampleCount);
+    Vec3 color = {accumulatedColor.x / n, accumulatedColor.y / n, accumulatedColor.z / n};                    // :383
+    const float maxVal = std::fmax(std::fmax(color.x, color.y), color.z);                                     // :386-389
+    if (maxVal > 100.0f) color = scale3(color, 100.0f / maxVal);
+    if (!hadFirstHit) {                                                                                        // :395-400
+        firstHitDepth = 10000.0f;
+        firstHitPos = add3(camPos, scale3(normalize3(camF), 10000.0f));
+        firstHitNormal = {0.0f, 1.0f, 0.0f};
+        firstHitAlbedo = getSkyColor(normalize3(sub3(firstHitPos, camPos)));
+    }
+    const Vec3 finalAlbedo = firstHitWasEmissive ? firstHitEmission : firstHitAlbedo;                         // :403
+    GBufferPixel g;
+    g.color[0] = color.x; g.color[1] = color.y; g.color[2] = color.z; g.color[3] = 1.0f;                      // :392
+    g.worldPos[0] = firstHitPos.x; g.worldPos[1] = firstHitPos.y; g.worldPos[2] = firstHitPos.z; g.worldPos[3] = firstHitDepth;
+    g.normalRoughness[0] = firstHitNormal.x; g.normalRoughness[1] = firstHitNormal.y; g.normalRoughness[2] = firstHitNormal.z;
+    g.normalRoughness[3] = firstHitRoughness;
+    g.albedoMetallic[0] = finalAlbedo.x; g.albedoMetallic[1] = finalAlbedo.y; g.albedoMetallic[2] = finalAlbedo.z;
+    g.albedoMetallic[3] = firstHitMetallic;
+    return g;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Renders the pixels (x0 + i*stride, y0 + j*stride) of the rectangle; four float4 planes, row-major.
+void orc_render_paths(const void* lattice, const void* nodes, const void* subs, const void* materials, const void* cam,
+                      uint32_t width, uint32_t height, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint32_t stride,
+                      uint32_t sampleCount, uint32_t maxBounces, uint32_t frameCount,
+                      float* color, float* worldPos, float* normalRoughness, float* albedoMetallic,
+                      void* countersOut, int threads) {
+    const Lattice& L = *static_cast<const Lattice*>(lattice);
+    const SvoNode* N = static_cast<const SvoNode*>(nodes);
+    const SubChunkGpu* S = static_cast<const SubChunkGpu*>(subs);
+    const MaterialGpu* M = static_cast<const MaterialGpu*>(materials);
+    const Camera& C = *static_cast<const Camera*>(cam);
+    const uint32_t cols = (w + stride - 1) / stride, rows = (h + stride - 1) / stride;
+    std::vector<Counters> per(std::max(1, threads), Counters{});
+    parallelFor(size_t(cols) * rows, threads, [&](int t, size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) {
+            const uint32_t px = x0 + uint32_t(i % cols) * stride, py = y0 + uint32_t(i / cols) * stride;
+            const GBufferPixel g = shadePixel(L, N, S, M, C, width, height, px, py, sampleCount, maxBounces, frameCount, per[t]);
+            std::memcpy(color + 4 * i, g.color, 16);
+            std::memcpy(worldPos + 4 * i, g.worldPos, 16);
+            std::memcpy(normalRoughness + 4 * i, g.normalRoughness, 16);
+            std::memcpy(albedoMetallic + 4 * i, g.albedoMetallic, 16);
+        }
+    });
+    if (countersOut) {
+        Counters total{};
+        for (auto& c : per) addCounters(total, c);
+        *static_cast<Counters*>(countersOut) = total;
+    }
+}
+
+}  // extern "C"
+
+extern "C" {
+
 uint32_t orc_sizeof_counters(void) { return sizeof(Counters); }
 
 }  // extern "C"

@@ -17,6 +17,7 @@ HIT = np.dtype([("t", "<f4"), ("material_id", "<u4"), ("voxel", "<i2", 3), ("fac
 def build(sanitize: bool = False) -> Path:
     out = SRC / ("libhost_harness_asan.so" if sanitize else "libhost_harness.so")
     deps = [SRC / "harness.cpp", SRC / "host_harness_shims.h", ROOT / "blok_amd/csrc/hip/trace_core.h",
+            ROOT / "blok_amd/csrc/hip/path_core.h",
             ROOT / "blok_amd/csrc/hip/trace_kernels.h", ROOT / "blok_amd/csrc/hip/tree_build.cpp",
             ROOT / "blok_amd/csrc/hip/tree.h"]
     if out.exists() and all(d.stat().st_mtime <= out.stat().st_mtime for d in deps):
@@ -46,6 +47,7 @@ def lib():
         L.hh_voxels.argtypes = [C.c_void_p]
         L.hh_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.hh_trace_primary.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.hh_render_paths.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_uint32] * 6 + [C.c_void_p] * 4
         _lib = L
     return _lib
 
@@ -75,3 +77,13 @@ class HostKernel:
         out = np.zeros(width * height, dtype=HIT)
         lib().hh_trace_primary(self.h, C.c_void_p(cam.ctypes.data), width, height, C.c_void_p(out.ctypes.data))
         return out
+
+
+    def render_paths(self, cam, materials, width, height, spp=8, max_bounces=2, frame_index=0):
+        materials = np.ascontiguousarray(materials)
+        planes = {k: np.zeros((height, width, 4), dtype=np.float32)
+                  for k in ("color", "world_pos", "normal_roughness", "albedo_metallic")}
+        lib().hh_render_paths(self.h, C.c_void_p(cam.ctypes.data), C.c_void_p(materials.ctypes.data), len(materials),
+                              width, height, spp, max_bounces, frame_index,
+                              *[C.c_void_p(planes[k].ctypes.data) for k in ("color", "world_pos", "normal_roughness", "albedo_metallic")])
+        return planes

@@ -6,6 +6,7 @@
 static thread_local uint64_t g_stat[4][8];
 #define BLOK_STAT(event, level) (++g_stat[event][level])
 #include "trace_core.h"
+#include "path_core.h"
 #include "reference_world.h"
 
 #include <vector>
@@ -55,6 +56,22 @@ void hh_trace_rays(const void* h, const blok_ray* rays, size_t n, blok_hit* out)
                 rays[i].tmin, rays[i].tmax};
         trace_one(a, r, stack.data(), Sink{out + i, nullptr});
     }
+}
+
+// raygen.rgen loop of the kernel, on the CPU: four float4 planes of the full frame.
+void hh_render_paths(const void* h, const blok_camera* cam, const blok_material* materials, uint32_t n_materials,
+                     uint32_t width, uint32_t height, uint32_t spp, uint32_t max_bounces, uint32_t frame_index,
+                     float* color, float* world_pos, float* normal_roughness, float* albedo_metallic) {
+    const Harness* H = static_cast<const Harness*>(h);
+    PathArgs p{};
+    p.trace = make_args(H);
+    p.trace.cam = *cam; p.trace.frame_w = width; p.trace.frame_h = height;
+    p.trace.mat_table = materials; p.trace.n_materials = n_materials;
+    p.spp = spp; p.max_bounces = max_bounces; p.frame_count = frame_index;
+    p.color = color; p.world_pos = world_pos; p.normal_roughness = normal_roughness; p.albedo_metallic = albedo_metallic;
+    std::vector<uint4> stack(size_t(kMaxLevels) * kBlock);
+    for (uint32_t y = 0; y < height; ++y)
+        for (uint32_t x = 0; x < width; ++x) shade_pixel(p, x, y, size_t(y) * width + x, stack.data());
 }
 
 // Per-ray iteration counts for a frame (row-major), plus the event totals [4][8].

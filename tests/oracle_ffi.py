@@ -70,6 +70,7 @@ def lib() -> C.CDLL:
                                        [C.c_void_p, C.c_void_p, C.c_int]
         L.orc_trace_voxels_bruteforce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                                   C.c_void_p, C.c_void_p]
+        L.orc_render_paths.argtypes = [C.c_void_p] * 5 + [C.c_uint32] * 10 + [C.c_void_p] * 5 + [C.c_int]
         L.orc_shade_surface.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
         L.orc_sizeof_counters.restype = C.c_uint32
         assert L.orc_sizeof_counters() == COUNTERS.itemsize
@@ -171,8 +172,8 @@ class Lattice:
         self.h = C.c_void_p(lib().orc_lattice_build(_p(self.subs), len(self.subs)))
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().orc_lattice_free(self.h)
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.orc_lattice_free(self.h)
             self.h = None
 
     def trace(self, rays, threads=1):
@@ -190,6 +191,21 @@ class Lattice:
         lib().orc_trace_primary(self.h, _p(self.nodes), _p(self.subs), _p(cam), width, height, x0, y0, w, h,
                                 stride, _p(hits) if want_hits else None, _p(ctr), threads)
         return hits, ctr[0]
+
+
+def render_paths(lattice: "Lattice", materials, cam, width, height, spp=8, max_bounces=2, frame_index=0, rect=None,
+                 stride=1, threads=1):
+    """raygen.rgen restatement: dict of (rows, cols, 4) float32 planes + counters."""
+    x0, y0, w, h = rect if rect is not None else (0, 0, width, height)
+    cols, rows = (w + stride - 1) // stride, (h + stride - 1) // stride
+    materials = np.ascontiguousarray(materials)
+    planes = {k: np.zeros((rows, cols, 4), dtype=np.float32) for k in ("color", "world_pos", "normal_roughness", "albedo_metallic")}
+    ctr = np.zeros(1, dtype=COUNTERS)
+    lib().orc_render_paths(lattice.h, _p(lattice.nodes), _p(lattice.subs), _p(materials), _p(cam), width, height,
+                           x0, y0, w, h, stride, spp, max_bounces, frame_index, _p(planes["color"]),
+                           _p(planes["world_pos"]), _p(planes["normal_roughness"]), _p(planes["albedo_metallic"]),
+                           _p(ctr), threads)
+    return planes, ctr[0]
 
 
 def trace_voxels_bruteforce(xyz, mats, rays):
