@@ -4,7 +4,10 @@
 #include <cstdint>
 // statistics build: events 0 iteration, 1 descend, 2 step, 3 ascend, per level
 static thread_local uint64_t g_stat[4][8];
-#define BLOK_STAT(event, level) (++g_stat[event][level])
+static thread_local unsigned char* g_seq = nullptr;      // optional per-ray event log: 1 descend, 2 step (+level*4)
+static thread_local uint32_t g_seq_len = 0, g_seq_cap = 0;
+#define BLOK_STAT(event, level) do { ++g_stat[event][level]; \
+    if (g_seq && (event == 1 || event == 2) && g_seq_len < g_seq_cap) g_seq[g_seq_len++] = (unsigned char)(event | ((level) << 2)); } while (0)
 #include "trace_core.h"
 #include "path_core.h"
 #include "reference_world.h"
@@ -72,6 +75,23 @@ void hh_render_paths(const void* h, const blok_camera* cam, const blok_material*
     std::vector<uint4> stack(size_t(kMaxLevels) * kBlock);
     for (uint32_t y = 0; y < height; ++y)
         for (uint32_t x = 0; x < width; ++x) shade_pixel(p, x, y, size_t(y) * width + x, stack.data());
+}
+
+// Event log per ray (cap bytes each, zero padded) for an 8x8-tile wave simulation.
+void hh_trace_primary_events(const void* h, const blok_camera* cam, uint32_t width, uint32_t height, uint32_t x0, uint32_t y0,
+                             uint32_t w, uint32_t hgt, uint32_t cap, unsigned char* events) {
+    const Harness* H = static_cast<const Harness*>(h);
+    TraceArgs a = make_args(H);
+    a.cam = *cam; a.frame_w = width; a.frame_h = height;
+    std::vector<uint4> stack(size_t(kMaxLevels) * kBlock);
+    blok_hit tmp;
+    for (uint32_t y = 0; y < hgt; ++y)
+        for (uint32_t x = 0; x < w; ++x) {
+            g_seq = events + (size_t(y) * w + x) * cap; g_seq_len = 0; g_seq_cap = cap;
+            const RayIn r = primary_ray(a, x0 + x, y0 + y);
+            trace_one(a, r, stack.data(), Sink{&tmp, nullptr});
+        }
+    g_seq = nullptr;
 }
 
 // Per-ray iteration counts for a frame (row-major), plus the event totals [4][8].
