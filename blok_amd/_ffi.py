@@ -75,6 +75,35 @@ HOST_SYMBOLS = {
     "blok_world_chunk_info": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]),
     "blok_world_chunk_nodes": (C.c_void_p, [C.c_void_p, C.c_size_t]),
     "blok_world_find_leaf": (C.c_int64, [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "blok_material_desc_init": (None, [C.c_void_p]),
+    "blok_material_pack": (None, [C.c_void_p, C.c_void_p]),
+    "blok_material_library_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "blok_material_library_destroy": (None, [C.c_void_p]),
+    "blok_material_library_size": (C.c_uint32, [C.c_void_p]),
+    "blok_material_library_add": (C.c_uint32, [C.c_void_p, C.c_void_p]),
+    "blok_material_library_add_or_find": (C.c_uint32, [C.c_void_p, C.c_void_p]),
+    "blok_material_library_get": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
+    "blok_material_library_id_by_name": (C.c_uint32, [C.c_void_p, C.c_char_p]),
+    "blok_material_library_from_color": (C.c_uint32, [C.c_void_p, C.c_uint8, C.c_uint8, C.c_uint8]),
+    "blok_material_library_set_vox_palette": (None, [C.c_void_p, C.c_uint8, C.c_uint32]),
+    "blok_material_library_from_vox_palette": (C.c_uint32, [C.c_void_p, C.c_uint8]),
+    "blok_material_library_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "blok_material_library_clear": (None, [C.c_void_p]),
+    "blok_world_set_material_library": (None, [C.c_void_p, C.c_void_p]),
+    "blok_world_get_material_library": (C.c_void_p, [C.c_void_p]),
+    "blok_world_set_voxel_rgb": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_uint8, C.c_uint8, C.c_uint8, C.c_float]),
+    "blok_vox_load_file": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]),
+    "blok_vox_load_memory": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]),
+    "blok_vox_free": (None, [C.c_void_p]),
+    "blok_vox_model_count": (C.c_uint32, [C.c_void_p]),
+    "blok_vox_model_info": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "blok_vox_model_voxels": (C.c_void_p, [C.c_void_p, C.c_uint32]),
+    "blok_vox_palette": (C.c_void_p, [C.c_void_p]),
+    "blok_vox_get_material": (C.c_int, [C.c_void_p, C.c_uint8, C.c_void_p]),
+    "blok_vox_import_materials": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "blok_vox_import_to_world": (C.c_uint32, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_uint32]),
+    "blok_load_and_import_vox": (C.c_int, [C.c_char_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_uint32,
+                                           C.c_char_p, C.c_size_t]),
     "blok_camera_from_yaw_pitch": (C.c_int, [C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float,
                                              C.c_uint32, C.c_uint32, C.c_void_p]),
     "blok_camera_look_at": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float,

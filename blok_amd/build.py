@@ -10,7 +10,7 @@ PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
 INCLUDE = ROOT / "include"
 
-HOST_SRC = [PKG / "csrc/host/world.cpp", PKG / "csrc/host/scene.cpp"]
+HOST_SRC = [PKG / "csrc/host/world.cpp", PKG / "csrc/host/scene.cpp", PKG / "csrc/host/vox.cpp"]
 HIP_SRC = [PKG / "csrc/hip/api.hip", PKG / "csrc/hip/trace_kernels.hip", PKG / "csrc/hip/tree_build.cpp"]
 HIP_HDR = sorted((PKG / "csrc/hip").glob("*.h")) + [INCLUDE / "blok_hip.h", INCLUDE / "blok_world.h"]
 

@@ -141,6 +141,7 @@ struct blok_world {
     std::vector<ChunkRec*> order;  // sorted view, rebuilt on demand
     std::vector<blok_svo_node> packed_nodes;
     std::vector<blok_sub_chunk> packed_subs;
+    blok_material_library* material_lib = nullptr;   // non-owning, reference chunk_manager.hpp:24,30
     std::string error;
 
     // reference blok/src/chunk_manager.cpp:41-47 (floor division for negatives)
@@ -277,6 +278,18 @@ int blok_world_set_voxel(blok_world* w, const float p[3], uint32_t material_id, 
              static_cast<int32_t>(std::floor(p[2])), material_id, density);
     return BLOK_OK;
 }
+void blok_world_set_material_library(blok_world* w, blok_material_library* lib) { if (w) w->material_lib = lib; }
+blok_material_library* blok_world_get_material_library(const blok_world* w) { return w ? w->material_lib : nullptr; }
+
+// reference blok/src/chunk_manager.cpp:91-102
+int blok_world_set_voxel_rgb(blok_world* w, const float p[3], uint8_t r, uint8_t g, uint8_t b, float density) {
+    if (!w || !p) return fail(w, "set_voxel_rgb: null argument");
+    const uint32_t id = w->material_lib
+        ? blok_material_library_from_color(w->material_lib, r, g, b)
+        : (static_cast<uint32_t>(r) << 16) | (static_cast<uint32_t>(g) << 8) | static_cast<uint32_t>(b);
+    return blok_world_set_voxel(w, p, id, density);
+}
+
 int blok_world_set_voxels(blok_world* w, const int32_t* xyz, const uint32_t* mats, size_t n) {
     if (!w || (n && (!xyz || !mats))) return fail(w, "set_voxels: null argument");
     for (size_t i = 0; i < n; ++i) w->write(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], mats[i], 1.0f);

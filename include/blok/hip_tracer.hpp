@@ -105,6 +105,37 @@ private:
     blok_world* w_ = nullptr;
 };
 
+// = blok::MaterialLibrary (reference blok/include/material.hpp:116-163), RAII over the C ABI.
+class MaterialLibrary {
+public:
+    MaterialLibrary() { if (blok_material_library_create(&lib_) != BLOK_OK) throw std::runtime_error("MaterialLibrary: allocation failed"); }
+    ~MaterialLibrary() { blok_material_library_destroy(lib_); }
+    MaterialLibrary(const MaterialLibrary&) = delete;
+    MaterialLibrary& operator=(const MaterialLibrary&) = delete;
+    uint32_t addMaterial(const blok_material_desc& m) { return blok_material_library_add(lib_, &m); }
+    uint32_t getOrCreateFromColor(uint8_t r, uint8_t g, uint8_t b) { return blok_material_library_from_color(lib_, r, g, b); }
+    uint32_t getMaterialFromVoxPalette(uint8_t i) const { return blok_material_library_from_vox_palette(lib_, i); }
+    size_t size() const { return blok_material_library_size(lib_); }
+    std::vector<blok_material> packForGpu() const {
+        std::vector<blok_material> out(size());
+        if (blok_material_library_pack(lib_, out.data(), out.size()) != BLOK_OK) throw std::runtime_error("MaterialLibrary::packForGpu");
+        return out;
+    }
+    blok_material_library* handle() { return lib_; }
+private:
+    blok_material_library* lib_ = nullptr;
+};
+
+// = loadAndImportVox (reference blok/src/vox_loader.cpp:432-462)
+inline bool loadAndImportVox(const std::string& filepath, ChunkManager& chunkMgr, MaterialLibrary* materialLib = nullptr,
+                             const float worldOffset[3] = nullptr, uint32_t modelIndex = 0, std::string* errorMsg = nullptr) {
+    char err[256] = {0};
+    const int rc = blok_load_and_import_vox(filepath.c_str(), chunkMgr.handle(), materialLib ? materialLib->handle() : nullptr,
+                                            worldOffset, modelIndex, err, sizeof(err));
+    if (rc != BLOK_OK && errorMsg) *errorMsg = err;
+    return rc == BLOK_OK;
+}
+
 class HipTracer {
 public:
     HipTracer(unsigned int width, unsigned int height, int device = 0) : m_width(width), m_height(height), m_device(device) {}

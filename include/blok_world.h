@@ -62,6 +62,68 @@ const blok_svo_node* blok_world_chunk_nodes(const blok_world* w, size_t i);
 /* = SvoTree::findLeaf (reference blok/src/svo.cpp:103-130): node index in chunk i, or -1. */
 int64_t blok_world_find_leaf(const blok_world* w, size_t i, uint32_t x, uint32_t y, uint32_t z);
 
+/* -------------------------------------------------------------- materials */
+/* = blok::Material (reference blok/include/material.hpp:27-44), C layout. */
+typedef struct blok_material_desc {
+    float   albedo[3];        /* default 1,1,1 */
+    float   alpha;            /* 1 */
+    float   metallic;         /* 0 */
+    float   roughness;        /* 0.5 */
+    float   ior;              /* 1.5 */
+    float   specular;         /* 0.5 */
+    float   emission[3];      /* 0 */
+    float   emission_power;   /* 0 */
+    uint8_t type;             /* MaterialType: 0 diffuse, 1 metallic, 2 glass, 3 emissive (material.hpp:18-24) */
+    int16_t vox_palette_index;/* -1 */
+    char    name[32];
+} blok_material_desc;
+void blok_material_desc_init(blok_material_desc* m);           /* the defaults above */
+/* = MaterialGpu::pack (reference blok/include/material.hpp:96-112). */
+void blok_material_pack(const blok_material_desc* m, blok_material* out);
+
+/* = blok::MaterialLibrary (reference blok/include/material.hpp:116-163, blok/src/material.cpp):
+ * id 0 is the default grey diffuse material; ids are indices into the packed GPU table. */
+typedef struct blok_material_library blok_material_library;
+int      blok_material_library_create(blok_material_library** out);
+void     blok_material_library_destroy(blok_material_library* lib);
+uint32_t blok_material_library_size(const blok_material_library* lib);
+uint32_t blok_material_library_add(blok_material_library* lib, const blok_material_desc* m);          /* addMaterial */
+uint32_t blok_material_library_add_or_find(blok_material_library* lib, const blok_material_desc* m);  /* addOrFindMaterial */
+int      blok_material_library_get(const blok_material_library* lib, uint32_t id, blok_material_desc* out); /* getMaterial (id clamps to 0) */
+uint32_t blok_material_library_id_by_name(const blok_material_library* lib, const char* name);        /* getMaterialIdByName */
+uint32_t blok_material_library_from_color(blok_material_library* lib, uint8_t r, uint8_t g, uint8_t b); /* getOrCreateFromColor */
+void     blok_material_library_set_vox_palette(blok_material_library* lib, uint8_t palette_index, uint32_t material_id);
+uint32_t blok_material_library_from_vox_palette(const blok_material_library* lib, uint8_t palette_index);
+int      blok_material_library_pack(const blok_material_library* lib, blok_material* out, size_t capacity); /* packForGpu */
+void     blok_material_library_clear(blok_material_library* lib);
+/* = ChunkManager::setMaterialLibrary (reference blok/include/chunk_manager.hpp:30): with a library
+ * attached, colour writes go through getOrCreateFromColor, otherwise the id is r<<16|g<<8|b
+ * (reference blok/src/chunk_manager.cpp:91-102). */
+void blok_world_set_material_library(blok_world* w, blok_material_library* lib);
+blok_material_library* blok_world_get_material_library(const blok_world* w);
+int  blok_world_set_voxel_rgb(blok_world* w, const float world_pos[3], uint8_t r, uint8_t g, uint8_t b, float density);
+
+/* ------------------------------------------------------------ .vox import */
+/* MagicaVoxel .vox reader = loadVoxFile (reference blok/src/vox_loader.cpp:151-368): SIZE / XYZI / RGBA / MATL. */
+typedef struct blok_vox blok_vox;
+int  blok_vox_load_file(const char* path, blok_vox** out, char* err, size_t err_len);
+int  blok_vox_load_memory(const void* data, size_t size, blok_vox** out, char* err, size_t err_len);
+void blok_vox_free(blok_vox* v);
+uint32_t blok_vox_model_count(const blok_vox* v);
+int  blok_vox_model_info(const blok_vox* v, uint32_t model, uint32_t size_xyz[3], uint32_t* n_voxels);
+/* voxels of a model as (x, y, z, colorIndex) bytes, file order */
+const uint8_t* blok_vox_model_voxels(const blok_vox* v, uint32_t model);
+const uint32_t* blok_vox_palette(const blok_vox* v);            /* 256 entries, ABGR */
+/* = VoxFile::getMaterial (reference blok/src/vox_loader.cpp:116-149) */
+int  blok_vox_get_material(const blok_vox* v, uint8_t palette_index, blok_material_desc* out);
+/* = importVoxMaterials (reference blok/src/vox_loader.cpp:370-388) */
+int  blok_vox_import_materials(const blok_vox* v, blok_material_library* lib, uint32_t palette_to_material[256]);
+/* = importVoxToChunks (reference blok/src/vox_loader.cpp:390-430): VOX z is up -> world y. Returns voxels imported. */
+uint32_t blok_vox_import_to_world(const blok_vox* v, blok_world* w, const float world_offset[3], uint32_t model_index);
+/* = loadAndImportVox (reference blok/src/vox_loader.cpp:432-462); lib may be NULL. */
+int  blok_load_and_import_vox(const char* path, blok_world* w, blok_material_library* lib,
+                              const float world_offset[3], uint32_t model_index, char* err, size_t err_len);
+
 /* ----------------------------------------------------------------- camera */
 /* = blok::Camera::forward/right/up + toDevice(Camera,w,h)
  *   (reference blok/include/camera.hpp:25-42, blok/src/cuda_tracer.cu:404-415). */

@@ -1084,6 +1084,319 @@ void orc_render_paths(const void* lattice, const void* nodes, const void* subs, 
 
 extern "C" {
 
+// =============================================================================================
+// material.hpp:17-114, material.cpp, vox_loader.cpp:60-462 — materials and the MagicaVoxel importer.
+// The default palette (vox_loader.cpp:22-55, a 256-entry literal there) is produced from its construction rule;
+// tests compare it with the reference's table read as text when the reference tree is present.
+}  // extern "C"  (closed for the C++ section below)
+
+#include <array>
+#include <cstdio>
+#include <istream>
+#include <sstream>
+#include <string>
+#include <unordered_map>
+
+namespace {
+
+enum class MaterialType : uint8_t { Diffuse = 0, Metallic = 1, Glass = 2, Emissive = 3, Count = 4 };   // material.hpp:18-24
+
+struct Material {                                   // material.hpp:27-44
+    std::string name;
+    float albedo[3] = {1.0f, 1.0f, 1.0f};
+    float alpha = 1.0f, metallic = 0.0f, roughness = 0.5f, ior = 1.5f, specular = 0.5f;
+    float emission[3] = {0.0f, 0.0f, 0.0f};
+    float emissionPower = 0.0f;
+    MaterialType type = MaterialType::Diffuse;
+    int16_t voxPaletteIndex = -1;
+};
+
+inline float clampf(float v, float lo, float hi) { return std::min(std::max(v, lo), hi); }
+
+MaterialGpu packMaterial(const Material& mat) {      // material.hpp:96-112
+    MaterialGpu gpu;
+    for (int a = 0; a < 3; ++a) gpu.albedo[a] = mat.albedo[a];
+    const uint32_t metalBits = static_cast<uint32_t>(clampf(mat.metallic, 0.0f, 1.0f) * 255.0f);
+    const uint32_t roughBits = static_cast<uint32_t>(clampf(mat.roughness, 0.0f, 1.0f) * 255.0f);
+    const uint32_t typeBits = static_cast<uint32_t>(mat.type);
+    const uint32_t alphaBits = static_cast<uint32_t>(clampf(mat.alpha, 0.0f, 1.0f) * 15.0f);
+    const uint32_t specBits = static_cast<uint32_t>(clampf(mat.specular, 0.0f, 1.0f) * 255.0f);
+    gpu.flags = (metalBits << 24) | (roughBits << 16) | (typeBits << 12) | (alphaBits << 8) | specBits;
+    for (int a = 0; a < 3; ++a) gpu.emission[a] = mat.emission[a] * mat.emissionPower;
+    gpu.ior = (mat.type == MaterialType::Glass) ? mat.ior : mat.emissionPower;
+    return gpu;
+}
+
+struct MaterialLibrary {                             // material.cpp
+    std::vector<Material> m_materials;
+    std::unordered_map<std::string, uint32_t> m_nameToId;
+    std::unordered_map<uint32_t, uint32_t> m_colorToId;
+    std::array<uint32_t, 256> m_voxPaletteMap{};
+    MaterialLibrary() { m_voxPaletteMap.fill(0); createDefaultMaterials(); }                 // :12-15
+    void createDefaultMaterials() {                                                          // :17-28
+        Material d;
+        d.name = "default";
+        d.albedo[0] = d.albedo[1] = d.albedo[2] = 0.8f;
+        d.roughness = 0.5f; d.metallic = 0.0f; d.type = MaterialType::Diffuse;
+        m_materials.push_back(d);
+        m_nameToId["default"] = 0;
+    }
+    uint32_t addMaterial(const Material& mat) {                                              // :30-39
+        const uint32_t id = static_cast<uint32_t>(m_materials.size());
+        m_materials.push_back(mat);
+        if (!mat.name.empty()) m_nameToId[mat.name] = id;
+        return id;
+    }
+    uint32_t getOrCreateFromColor(uint32_t packedRGB) {                                      // :89-117
+        auto it = m_colorToId.find(packedRGB);
+        if (it != m_colorToId.end()) return it->second;
+        Material mat;
+        mat.albedo[0] = static_cast<float>((packedRGB >> 16) & 0xFF) / 255.0f;
+        mat.albedo[1] = static_cast<float>((packedRGB >> 8) & 0xFF) / 255.0f;
+        mat.albedo[2] = static_cast<float>(packedRGB & 0xFF) / 255.0f;
+        mat.roughness = 0.5f; mat.metallic = 0.0f; mat.type = MaterialType::Diffuse;
+        char nameBuf[32];
+        snprintf(nameBuf, sizeof(nameBuf), "color_%06X", packedRGB);
+        mat.name = nameBuf;
+        const uint32_t id = addMaterial(mat);
+        m_colorToId[packedRGB] = id;
+        return id;
+    }
+    uint32_t getOrCreateFromColor(uint8_t r, uint8_t g, uint8_t b) {                          // :81-87
+        return getOrCreateFromColor((uint32_t(r) << 16) | (uint32_t(g) << 8) | uint32_t(b));
+    }
+};
+
+struct VoxVoxel { uint8_t x, y, z, colorIndex; };                                            // vox_loader.hpp:20-23
+struct VoxMaterial {                                                                         // vox_loader.hpp:26-37
+    MaterialType type{MaterialType::Diffuse};
+    float roughness{0.5f}, metallic{0.0f}, ior{1.5f}, emission{0.0f}, flux{0.0f}, alpha{1.0f}, glow{0.0f}, specular{0.5f};
+    bool hasProperties{false};
+};
+struct VoxModel { uint32_t sizeX = 0, sizeY = 0, sizeZ = 0; std::vector<VoxVoxel> voxels; };
+struct VoxFile {
+    std::vector<VoxModel> models;
+    uint32_t palette[256];
+    VoxMaterial materials[256];
+    Material getMaterial(uint8_t paletteIndex) const {                                       // vox_loader.cpp:116-149
+        Material mat;
+        const uint32_t c = palette[paletteIndex];
+        const uint8_t r = (c >> 0) & 0xFF, g = (c >> 8) & 0xFF, b = (c >> 16) & 0xFF, a = (c >> 24) & 0xFF;
+        mat.albedo[0] = r / 255.0f; mat.albedo[1] = g / 255.0f; mat.albedo[2] = b / 255.0f;
+        mat.alpha = a / 255.0f;
+        const VoxMaterial& voxMat = materials[paletteIndex];
+        if (voxMat.hasProperties) {
+            mat.type = voxMat.type; mat.roughness = voxMat.roughness; mat.metallic = voxMat.metallic;
+            mat.ior = voxMat.ior; mat.specular = voxMat.specular; mat.alpha = voxMat.alpha;
+            if (voxMat.type == MaterialType::Emissive) {
+                for (int k = 0; k < 3; ++k) mat.emission[k] = mat.albedo[k];
+                mat.emissionPower = voxMat.emission > 0 ? voxMat.emission : voxMat.flux;
+                if (mat.emissionPower <= 0) mat.emissionPower = 5.0f;
+            }
+        } else {
+            mat.type = MaterialType::Diffuse; mat.roughness = 0.5f; mat.metallic = 0.0f;
+        }
+        mat.voxPaletteIndex = static_cast<int16_t>(paletteIndex);
+        return mat;
+    }
+};
+
+void defaultPalette(uint32_t pal[256]) {     // values of vox_loader.cpp:22-55, from MagicaVoxel's construction rule
+    const uint32_t lv[6] = {0xff, 0xcc, 0x99, 0x66, 0x33, 0x00};
+    const uint32_t rp[10] = {0xee, 0xdd, 0xbb, 0xaa, 0x88, 0x77, 0x55, 0x44, 0x22, 0x11};
+    int k = 0;
+    pal[k++] = 0x00000000;
+    for (int r = 0; r < 6; ++r) for (int g = 0; g < 6; ++g) for (int b = 0; b < 6; ++b) {
+        if (r == 5 && g == 5 && b == 5) continue;
+        pal[k++] = 0xff000000u | (lv[b] << 16) | (lv[g] << 8) | lv[r];
+    }
+    for (int i = 0; i < 10; ++i) pal[k++] = 0xff000000u | rp[i];
+    for (int i = 0; i < 10; ++i) pal[k++] = 0xff000000u | (rp[i] << 8);
+    for (int i = 0; i < 10; ++i) pal[k++] = 0xff000000u | (rp[i] << 16);
+    for (int i = 0; i < 10; ++i) pal[k++] = 0xff000000u | (rp[i] << 16) | (rp[i] << 8) | rp[i];
+}
+
+template <typename T> bool readValue(std::istream& file, T& value) {                         // vox_loader.cpp:58-62
+    file.read(reinterpret_cast<char*>(&value), sizeof(T));
+    return file.good();
+}
+bool readBytes(std::istream& file, void* buffer, size_t count) {                             // :63-66
+    file.read(reinterpret_cast<char*>(buffer), static_cast<std::streamsize>(count));
+    return file.good();
+}
+std::string readString(std::istream& file) {                                                 // :68-74
+    int32_t len;
+    if (!readValue(file, len) || len <= 0 || len > 1024) return "";
+    std::string str(len, '\0');
+    readBytes(file, str.data(), len);
+    return str;
+}
+std::unordered_map<std::string, std::string> readDict(std::istream& file) {                  // :76-90
+    std::unordered_map<std::string, std::string> dict;
+    int32_t numPairs;
+    if (!readValue(file, numPairs)) return dict;
+    for (int32_t i = 0; i < numPairs; ++i) {
+        std::string key = readString(file);
+        std::string value = readString(file);
+        if (!key.empty()) dict[key] = value;
+    }
+    return dict;
+}
+MaterialType parseVoxMaterialType(const std::string& t) {                                    // :98-105
+    if (t == "_diffuse") return MaterialType::Diffuse;
+    if (t == "_metal") return MaterialType::Metallic;
+    if (t == "_glass") return MaterialType::Glass;
+    if (t == "_emit") return MaterialType::Emissive;
+    return MaterialType::Diffuse;
+}
+float parseFloat(const std::string& str, float defaultVal = 0.0f) {                          // :107-113
+    try { return std::stof(str); } catch (...) { return defaultVal; }
+}
+
+bool loadVoxFile(std::istream& file, VoxFile& outVox, std::string& errorMsg) {               // :151-368
+    char magic[4];
+    if (!readBytes(file, magic, 4) || std::memcmp(magic, "VOX ", 4) != 0) { errorMsg = "Invalid VOX file: bad magic number"; return false; }
+    int32_t version;
+    if (!readValue(file, version)) { errorMsg = "Failed to read VOX version"; return false; }
+    if (version < 150) { errorMsg = "Unsupported VOX version: " + std::to_string(version) + " (need >= 150)"; return false; }
+    defaultPalette(outVox.palette);
+    outVox.models.clear();
+    VoxModel currentModel{};
+    bool hasSize = false;
+    char id[4];
+    int32_t contentSize, childrenSize;
+    if (!readBytes(file, id, 4) || std::memcmp(id, "MAIN", 4) != 0) { errorMsg = "Invalid VOX file: missing MAIN chunk"; return false; }
+    if (!readValue(file, contentSize) || !readValue(file, childrenSize)) { errorMsg = "Failed to read MAIN chunk header"; return false; }
+    if (contentSize > 0) file.seekg(contentSize, std::ios::cur);
+    std::streampos endPos = file.tellg();
+    endPos += childrenSize;
+    while (file.tellg() < endPos && file.good()) {
+        char cid[4];
+        int32_t cContent, cChildren;
+        if (!readBytes(file, cid, 4)) break;
+        if (!readValue(file, cContent)) break;
+        if (!readValue(file, cChildren)) break;
+        std::streampos chunkEnd = file.tellg();
+        chunkEnd += cContent;
+        if (std::memcmp(cid, "SIZE", 4) == 0) {
+            if (hasSize && !currentModel.voxels.empty()) { outVox.models.push_back(std::move(currentModel)); currentModel = VoxModel{}; }
+            int32_t x = 0, y = 0, z = 0;
+            readValue(file, x); readValue(file, y); readValue(file, z);
+            currentModel.sizeX = static_cast<uint32_t>(x); currentModel.sizeY = static_cast<uint32_t>(y); currentModel.sizeZ = static_cast<uint32_t>(z);
+            hasSize = true;
+        } else if (std::memcmp(cid, "XYZI", 4) == 0) {
+            int32_t numVoxels;
+            if (!readValue(file, numVoxels)) { errorMsg = "Failed to read voxel count"; return false; }
+            for (int32_t i = 0; i < numVoxels; ++i) {
+                uint8_t x = 0, y = 0, z = 0, colorIndex = 0;
+                readValue(file, x); readValue(file, y); readValue(file, z);
+                if (!readValue(file, colorIndex)) break;   // the reference keeps pushing here (uninitialised bytes)
+                currentModel.voxels.push_back(VoxVoxel{x, y, z, colorIndex});
+            }
+        } else if (std::memcmp(cid, "RGBA", 4) == 0) {
+            for (int i = 0; i < 255; ++i) {
+                uint32_t rgba;
+                if (readValue(file, rgba)) outVox.palette[i + 1] = rgba;
+            }
+            uint32_t unused;
+            readValue(file, unused);
+        } else if (std::memcmp(cid, "MATL", 4) == 0) {
+            int32_t materialId;
+            if (!readValue(file, materialId)) { file.seekg(chunkEnd); continue; }
+            auto props = readDict(file);
+            if (materialId >= 0 && materialId < 256) {
+                VoxMaterial& mat = outVox.materials[materialId];
+                mat.hasProperties = true;
+                auto it = props.find("_type");  if (it != props.end()) mat.type = parseVoxMaterialType(it->second);
+                it = props.find("_rough");      if (it != props.end()) mat.roughness = parseFloat(it->second, 0.5f);
+                it = props.find("_metal");      if (it != props.end()) mat.metallic = parseFloat(it->second, 0.0f);
+                it = props.find("_ior");        if (it != props.end()) mat.ior = parseFloat(it->second, 1.5f);
+                it = props.find("_emit");       if (it != props.end()) mat.emission = parseFloat(it->second, 0.0f);
+                it = props.find("_flux");       if (it != props.end()) mat.flux = parseFloat(it->second, 0.0f);
+                it = props.find("_alpha");      if (it != props.end()) mat.alpha = parseFloat(it->second, 1.0f);
+                it = props.find("_sp");         if (it != props.end()) mat.specular = parseFloat(it->second, 0.5f);
+                it = props.find("_g");          if (it != props.end()) mat.glow = parseFloat(it->second, 0.0f);
+            }
+        }
+        file.seekg(chunkEnd);
+        if (cChildren > 0) file.seekg(cChildren, std::ios::cur);
+    }
+    if (hasSize || !currentModel.voxels.empty()) outVox.models.push_back(std::move(currentModel));
+    if (outVox.models.empty()) { errorMsg = "No models found in VOX file"; return false; }
+    return true;
+}
+
+void importVoxMaterials(const VoxFile& vox, MaterialLibrary& matLib, uint32_t paletteToMaterial[256]) {   // :370-388
+    for (int i = 1; i < 256; ++i) {
+        Material mat = vox.getMaterial(static_cast<uint8_t>(i));
+        char nameBuf[32];
+        snprintf(nameBuf, sizeof(nameBuf), "vox_mat_%d", i);
+        mat.name = nameBuf;
+        const uint32_t matId = matLib.addMaterial(mat);
+        paletteToMaterial[i] = matId;
+        matLib.m_voxPaletteMap[static_cast<uint8_t>(i)] = matId;
+    }
+    paletteToMaterial[0] = 0;
+}
+
+uint32_t importVoxToChunks(const VoxFile& vox, World& chunkMgr, MaterialLibrary* matLib, float ox, float oy, float oz,
+                           uint32_t modelIndex) {                                            // :390-430
+    if (modelIndex >= vox.models.size()) return 0;
+    const VoxModel& model = vox.models[modelIndex];
+    uint32_t count = 0;
+    for (const auto& v : model.voxels) {
+        const float wx = ox + static_cast<float>(v.x), wy = oy + static_cast<float>(v.z), wz = oz + static_cast<float>(v.y);
+        if (matLib) {
+            chunkMgr.setVoxelMaterial(wx, wy, wz, matLib->m_voxPaletteMap[v.colorIndex], 1.0f);
+        } else {
+            const uint32_t c = vox.palette[v.colorIndex];
+            const uint8_t r = (c >> 0) & 0xFF, g = (c >> 8) & 0xFF, b = (c >> 16) & 0xFF;
+            // ChunkManager::setVoxel(worldPos, r, g, b) without a library: chunk_manager.cpp:91-102
+            const uint32_t materialId = (uint32_t(r) << 16) | (uint32_t(g) << 8) | uint32_t(b);
+            chunkMgr.setVoxelMaterial(wx, wy, wz, materialId, 1.0f);
+        }
+        count++;
+    }
+    return count;
+}
+
+}  // namespace
+
+extern "C" {
+
+void* orc_vox_load(const void* data, size_t n, char* err, size_t errLen) {
+    std::istringstream in(std::string(static_cast<const char*>(data), n), std::ios::binary);
+    auto* v = new VoxFile();
+    std::string msg;
+    if (!loadVoxFile(in, *v, msg)) { if (err && errLen) snprintf(err, errLen, "%s", msg.c_str()); delete v; return nullptr; }
+    return v;
+}
+void orc_vox_free(void* v) { delete static_cast<VoxFile*>(v); }
+uint32_t orc_vox_n_models(const void* v) { return uint32_t(static_cast<const VoxFile*>(v)->models.size()); }
+void orc_vox_model_info(const void* v, uint32_t i, uint32_t size[3], uint32_t* nVoxels) {
+    const VoxModel& m = static_cast<const VoxFile*>(v)->models[i];
+    size[0] = m.sizeX; size[1] = m.sizeY; size[2] = m.sizeZ; *nVoxels = uint32_t(m.voxels.size());
+}
+const void* orc_vox_model_voxels(const void* v, uint32_t i) { return static_cast<const VoxFile*>(v)->models[i].voxels.data(); }
+const uint32_t* orc_vox_palette(const void* v) { return static_cast<const VoxFile*>(v)->palette; }
+void orc_default_palette(uint32_t out[256]) { defaultPalette(out); }
+void* orc_matlib_new() { return new MaterialLibrary(); }
+void orc_matlib_free(void* l) { delete static_cast<MaterialLibrary*>(l); }
+uint32_t orc_matlib_size(const void* l) { return uint32_t(static_cast<const MaterialLibrary*>(l)->m_materials.size()); }
+uint32_t orc_matlib_from_color(void* l, uint8_t r, uint8_t g, uint8_t b) { return static_cast<MaterialLibrary*>(l)->getOrCreateFromColor(r, g, b); }
+void orc_matlib_pack(const void* l, void* out) {                                             // material.cpp:127-135
+    const MaterialLibrary* lib = static_cast<const MaterialLibrary*>(l);
+    MaterialGpu* o = static_cast<MaterialGpu*>(out);
+    for (size_t i = 0; i < lib->m_materials.size(); ++i) o[i] = packMaterial(lib->m_materials[i]);
+}
+void orc_vox_import_materials(const void* v, void* l, uint32_t map[256]) {
+    importVoxMaterials(*static_cast<const VoxFile*>(v), *static_cast<MaterialLibrary*>(l), map);
+}
+uint32_t orc_vox_import_to_world(const void* v, void* world, void* libOrNull, float ox, float oy, float oz, uint32_t model) {
+    return importVoxToChunks(*static_cast<const VoxFile*>(v), *static_cast<World*>(world),
+                             static_cast<MaterialLibrary*>(libOrNull), ox, oy, oz, model);
+}
+
 uint32_t orc_sizeof_counters(void) { return sizeof(Counters); }
 
 }  // extern "C"

@@ -71,6 +71,27 @@ def lib() -> C.CDLL:
         L.orc_trace_voxels_bruteforce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                                   C.c_void_p, C.c_void_p]
         L.orc_render_paths.argtypes = [C.c_void_p] * 5 + [C.c_uint32] * 10 + [C.c_void_p] * 5 + [C.c_int]
+        L.orc_vox_load.restype = C.c_void_p
+        L.orc_vox_load.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t]
+        L.orc_vox_free.argtypes = [C.c_void_p]
+        L.orc_vox_n_models.restype = C.c_uint32
+        L.orc_vox_n_models.argtypes = [C.c_void_p]
+        L.orc_vox_model_info.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.orc_vox_model_voxels.restype = C.c_void_p
+        L.orc_vox_model_voxels.argtypes = [C.c_void_p, C.c_uint32]
+        L.orc_vox_palette.restype = C.c_void_p
+        L.orc_vox_palette.argtypes = [C.c_void_p]
+        L.orc_default_palette.argtypes = [C.c_void_p]
+        L.orc_matlib_new.restype = C.c_void_p
+        L.orc_matlib_free.argtypes = [C.c_void_p]
+        L.orc_matlib_size.restype = C.c_uint32
+        L.orc_matlib_size.argtypes = [C.c_void_p]
+        L.orc_matlib_from_color.restype = C.c_uint32
+        L.orc_matlib_from_color.argtypes = [C.c_void_p, C.c_uint8, C.c_uint8, C.c_uint8]
+        L.orc_matlib_pack.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_vox_import_materials.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_vox_import_to_world.restype = C.c_uint32
+        L.orc_vox_import_to_world.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_uint32]
         L.orc_shade_surface.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
         L.orc_sizeof_counters.restype = C.c_uint32
         assert L.orc_sizeof_counters() == COUNTERS.itemsize
@@ -221,3 +242,69 @@ def shade_surface(hit: np.ndarray, materials: np.ndarray) -> np.ndarray:
     out = (C.c_float * 12)()
     lib().orc_shade_surface(_p(hit), _p(materials), out)
     return np.array(out[:], dtype=np.float32)
+
+
+MATERIAL = np.dtype([("albedo", "<f4", 3), ("flags", "<u4"), ("emission", "<f4", 3), ("ior", "<f4")])
+
+
+class OracleVox:
+    def __init__(self, data: bytes):
+        buf = np.frombuffer(data, dtype=np.uint8)
+        err = C.create_string_buffer(256)
+        h = lib().orc_vox_load(_p(buf) if len(buf) else None, len(buf), err, len(err))
+        self.error = err.value.decode()
+        self.h = C.c_void_p(h) if h else None
+
+    def __del__(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.orc_vox_free(self.h)
+            self.h = None
+
+    def n_models(self):
+        return lib().orc_vox_n_models(self.h)
+
+    def model(self, i):
+        size = (C.c_uint32 * 3)()
+        n = C.c_uint32()
+        lib().orc_vox_model_info(self.h, i, size, C.byref(n))
+        return tuple(size), _copy(lib().orc_vox_model_voxels(self.h, i), n.value * 4, np.dtype("u1")).reshape(-1, 4)
+
+    def palette(self):
+        return _copy(lib().orc_vox_palette(self.h), 256, np.dtype("<u4"))
+
+
+class OracleMaterialLibrary:
+    def __init__(self):
+        self.h = C.c_void_p(lib().orc_matlib_new())
+
+    def __del__(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.orc_matlib_free(self.h)
+            self.h = None
+
+    def __len__(self):
+        return lib().orc_matlib_size(self.h)
+
+    def from_color(self, r, g, b):
+        return lib().orc_matlib_from_color(self.h, r, g, b)
+
+    def pack(self):
+        out = np.zeros(len(self), dtype=MATERIAL)
+        lib().orc_matlib_pack(self.h, _p(out))
+        return out
+
+    def import_vox(self, vox: OracleVox):
+        mapping = np.zeros(256, dtype=np.uint32)
+        lib().orc_vox_import_materials(vox.h, self.h, _p(mapping))
+        return mapping
+
+
+def vox_import_to_world(vox: OracleVox, world: "OracleWorld", matlib, offset=(0.0, 0.0, 0.0), model=0):
+    return lib().orc_vox_import_to_world(vox.h, world.h, matlib.h if matlib is not None else None,
+                                         offset[0], offset[1], offset[2], model)
+
+
+def default_palette():
+    out = np.zeros(256, dtype=np.uint32)
+    lib().orc_default_palette(_p(out))
+    return out

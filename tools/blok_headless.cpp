@@ -1,7 +1,7 @@
 // Headless driver shaped like the reference's App (reference blok/src/app.cpp:65-192) with the backend
 // switch extended by GraphicsApi::HIP: build a world through ChunkManager, rebuildDirtyChunks,
 // packChunksToGpuSvo, addWorld, then a frame loop of drawFrame; writes the last frame as a PPM.
-//   blok_headless [--n 256] [--size 1280x720] [--pose 0|1|2] [--frames 10] [--out frame.ppm]
+//   blok_headless [--n 256 | --vox model.vox] [--size 1280x720] [--pose 0|1|2] [--frames 10] [--out frame.ppm]
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -18,6 +18,7 @@ struct Options {
     uint32_t n = 256, width = 1280, height = 720, frames = 10;     // reference window: 1280x720, app.cpp:95
     int pose = 0;
     std::string out = "frame.ppm";
+    std::string vox;                      // optional .vox model instead of the synthetic scene (app.cpp:105-113)
 };
 
 class App {
@@ -32,13 +33,23 @@ private:
             case blok::GraphicsApi::HIP: {
                 m_tracer = std::make_unique<blok::HipTracer>(m_opt.width, m_opt.height);
                 m_tracer->init();
-                uint64_t writes = 0;
-                if (blok_scene_generate(m_mgr.handle(), m_opt.n, 0xB10C0001u, &writes) != BLOK_OK)
-                    throw std::runtime_error("scene generation failed (n must be a power of two in [16, 4096])");
+                if (!m_opt.vox.empty()) {
+                    std::string err;
+                    if (!blok::loadAndImportVox(m_opt.vox, m_mgr, &m_materials, nullptr, 0, &err))   // app.cpp:105-113
+                        throw std::runtime_error("Failed to load VOX: " + err);
+                    m_opt.n = 128;
+                } else {
+                    uint64_t writes = 0;
+                    if (blok_scene_generate(m_mgr.handle(), m_opt.n, 0xB10C0001u, &writes) != BLOK_OK)
+                        throw std::runtime_error("scene generation failed (n must be a power of two in [16, 4096])");
+                }
                 rebuildDirtyChunks(m_mgr, 1 << 30);                                       // app.cpp:120
                 packChunksToGpuSvo(m_mgr, m_world);                                       // app.cpp:121
-                m_world.materials.resize(256);
-                blok_scene_materials(0xB10C0001u, m_world.materials.data());
+                if (!m_opt.vox.empty()) m_world.materials = m_materials.packForGpu();
+                else {
+                    m_world.materials.resize(256);
+                    blok_scene_materials(0xB10C0001u, m_world.materials.data());
+                }
                 m_tracer->addWorld(m_world);                                              // app.cpp:122-124
                 const blok_world_stats s = m_tracer->worldStats();
                 std::cout << "world: " << s.n_voxels << " voxels, " << s.n_ref_nodes << " SVO nodes, " << s.n_sub_chunks
@@ -78,6 +89,7 @@ private:
     blok::GraphicsApi m_backend;
     Options m_opt;
     blok::ChunkManager m_mgr;
+    blok::MaterialLibrary m_materials;
     blok::WorldSvoGpu m_world;                     // App owns the world, the tracer its device copy (app.hpp:40)
     blok::Camera m_camera;
     std::unique_ptr<blok::HipTracer> m_tracer;
@@ -94,6 +106,7 @@ int main(int argc, char** argv) {
         else if (!std::strcmp(argv[i], "--pose")) opt.pose = std::atoi(next());
         else if (!std::strcmp(argv[i], "--frames")) opt.frames = std::strtoul(next(), nullptr, 10);
         else if (!std::strcmp(argv[i], "--out")) opt.out = next();
+        else if (!std::strcmp(argv[i], "--vox")) opt.vox = next();
         else { std::fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
     }
     try {
