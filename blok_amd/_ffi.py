@@ -16,7 +16,7 @@ import numpy as np
 
 PKG_DIR = Path(__file__).resolve().parent
 HOST_LIB = PKG_DIR / "libblok_host.so"
-HIP_LIB = PKG_DIR / "libblok_hip.so"
+HIP_LIB = Path(os.environ.get("BLOK_HIP_LIB", PKG_DIR / "libblok_hip.so"))   # override: A/B builds of the kernels
 
 
 class BlokLibraryError(RuntimeError):

@@ -230,7 +230,7 @@ int blok_hip_trace_primary_device(blok_hip_ctx* ctx, const blok_camera* cam, uin
     a.x0 = x0; a.y0 = y0; a.w = w; a.h = h;
     a.out = static_cast<blok_hit*>(out_hits_dev);
     a.out_rgba = static_cast<uint32_t*>(out_rgba_dev);
-    const uint32_t blocks = ((w + 15u) / 16u) * ((h + 15u) / 16u);
+    const uint32_t blocks = ((w + blok::kTileW - 1u) / blok::kTileW) * ((h + blok::kTileH - 1u) / blok::kTileH);
     return launch_timed(ctx, blok::RayMode::Rect, a, blocks, static_cast<hipStream_t>(hip_stream));
 }
 
@@ -268,7 +268,7 @@ int blok_hip_trace_tiles_device(blok_hip_ctx* ctx, const blok_camera* cam, uint3
     a.out = static_cast<blok_hit*>(out_hits_dev);
     a.out_rgba = static_cast<uint32_t*>(out_rgba_dev);
     const uint32_t mine = blok_hip_tiles_for_rank(ctx->width, ctx->height, tile, rank, n_ranks);
-    const uint32_t blocks = mine * (tile / 16u) * (tile / 16u);
+    const uint32_t blocks = mine * (tile / blok::kTileW) * (tile / blok::kTileH);
     return launch_timed(ctx, blok::RayMode::Tiles, a, blocks, static_cast<hipStream_t>(hip_stream));
 }
 
@@ -344,7 +344,7 @@ int blok_hip_trace_paths_device(blok_hip_ctx* ctx, const blok_camera* cam, uint3
     p.normal_roughness = planes->normal_roughness; p.albedo_metallic = planes->albedo_metallic;
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     if (ctx->timing) BLOK_HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, stream));
-    blok::launch_paths(p, ((w + 15u) / 16u) * ((h + 15u) / 16u), stream);
+    blok::launch_paths(p, ((w + blok::kTileW - 1u) / blok::kTileW) * ((h + blok::kTileH - 1u) / blok::kTileH), stream);
     BLOK_HIP_TRY(ctx, hipGetLastError());
     if (ctx->timing) { BLOK_HIP_TRY(ctx, hipEventRecord(ctx->ev_end, stream)); ctx->timed = true; }
     return BLOK_OK;

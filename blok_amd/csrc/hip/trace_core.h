@@ -77,6 +77,15 @@ BLOK_DEV uint32_t mask_rank(const NodeRec& n, uint32_t bit) {
 
 struct RayIn { float ox, oy, oz, dx, dy, dz, tmin, tmax; };
 
+// Two-bit digit of a (non-negative) tree coordinate at bit offset `shift`: one v_bfe_u32.
+BLOK_DEV uint32_t digit2(int q, uint32_t shift) {
+#ifdef BLOK_TRACE_HOST_HARNESS
+    return (static_cast<uint32_t>(q) >> shift) & 3u;
+#else
+    return __builtin_amdgcn_ubfe(static_cast<uint32_t>(q), shift, 2u);
+#endif
+}
+
 // The walk runs in MIRRORED tree coordinates: on an axis the ray travels in the negative direction the
 // coordinate is reflected (q = W - p), so in q-space every ray travels towards +q on every axis, the far
 // plane of a cell is always q + size and a step is always +size.  A mirrored plane q maps back to the
@@ -146,13 +155,16 @@ BLOK_DEV HitInfo walk(const TraceArgs& A, const RayIn& r, uint4* stk) {
         enter_axis(az, qz, tFz, cs, tCur);
     }
 
+    // Invariant: tCur starts at max(world entry, tmin) and never decreases — a cell's far planes are never
+    // before the plane through which it was entered (T is monotone along each axis and the start cell of a
+    // node only counts planes with T <= tCur as crossed) — so max(tCur, tmin) == tCur throughout and the
+    // reported t of a voxel, max(entry, tmin), is tCur itself.
     bool found = false;
     uint32_t bit = 0;
     for (;;) {
         BLOK_STAT(0, lvl);
         const uint32_t shift = 2 * lvl;
-        bit = ((static_cast<uint32_t>(qx >> shift) & 3u) | ((static_cast<uint32_t>(qy >> shift) & 3u) << 2) |
-               ((static_cast<uint32_t>(qz >> shift) & 3u) << 4)) ^ mirror;
+        bit = (digit2(qx, shift) | (digit2(qy, shift) << 2) | (digit2(qz, shift) << 4)) ^ mirror;
         const bool occupied = mask_bit(node, bit);
         if (occupied && lvl != 0) {
             // descend: remember the node we are leaving, fetch the child, pick its start cell
@@ -162,16 +174,15 @@ BLOK_DEV HitInfo walk(const TraceArgs& A, const RayIn& r, uint4* stk) {
             node.lo = c.x; node.hi = c.y; node.base = c.z;
             lvl -= 1;
             const uint32_t cs = 2 * lvl;
-            const float tS = fmaxf(tCur, r.tmin);
-            enter_axis(ax, qx, tFx, cs, tS);
-            enter_axis(ay, qy, tFy, cs, tS);
-            enter_axis(az, qz, tFz, cs, tS);
+            enter_axis(ax, qx, tFx, cs, tCur);     // tCur >= tmin always (see the invariant above the loop)
+            enter_axis(ay, qy, tFy, cs, tCur);
+            enter_axis(az, qz, tFz, cs, tCur);
             continue;
         }
         const float tExit = fminf(fminf(tFx, tFy), tFz);
         if (occupied) {
             // a filled voxel: reported iff its clipped interval is non-empty (intersect.rint:189-193)
-            if (fmaxf(tCur, r.tmin) < fminf(tExit, r.tmax)) { found = true; break; }
+            if (tCur < fminf(tExit, r.tmax)) { found = true; break; }
         }
         // step: cross the nearest far plane (x, then y, then z on ties)
         BLOK_STAT(2, lvl);
@@ -199,7 +210,7 @@ BLOK_DEV HitInfo walk(const TraceArgs& A, const RayIn& r, uint4* stk) {
     if (!found) return out;
 
     // reported: intersect.rint:136-141, hit.rchit:58-74
-    const float tc = fmaxf(tCur, r.tmin);
+    const float tc = tCur;                                            // = max(entry, tmin), intersect.rint:189,141
     const uint32_t material = A.materials[node.base + mask_rank(node, bit)];
     const int vx = ax.base + ax.sgn * qx - (negx ? 1 : 0);          // world voxel = mirrored cell un-mirrored
     const int vy = ay.base + ay.sgn * qy - (negy ? 1 : 0);

@@ -31,20 +31,20 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const TraceArgs A) {
         size_t out_index;
         bool inside;
         if constexpr (MODE == RayMode::Rect) {
-            const uint32_t bx_count = (A.w + 15u) >> 4;
+            const uint32_t bx_count = (A.w + kTileW - 1u) / kTileW;
             const uint32_t bx = blockIdx.x % bx_count, by = blockIdx.x / bx_count;
-            const uint32_t rx = (bx << 4) + lx, ry = (by << 4) + ly;
+            const uint32_t rx = bx * kTileW + lx, ry = by * kTileH + ly;
             inside = rx < A.w && ry < A.h;
             if (!inside) return;
             x = A.x0 + rx; y = A.y0 + ry;
             out_index = static_cast<size_t>(ry) * A.w + rx;
         } else {
-            const uint32_t per_side = A.tile >> 4;                      // 16x16 blocks per tile side
-            const uint32_t per_tile = per_side * per_side;
+            const uint32_t per_side = A.tile / kTileW;                  // blocks per tile row
+            const uint32_t per_tile = per_side * (A.tile / kTileH);
             const uint32_t local_tile = blockIdx.x / per_tile, sub = blockIdx.x % per_tile;
             const uint32_t global_tile = A.rank + local_tile * A.n_ranks;
             const uint32_t tx = global_tile % A.tiles_x, ty = global_tile / A.tiles_x;
-            const uint32_t ix = ((sub % per_side) << 4) + lx, iy = ((sub / per_side) << 4) + ly;
+            const uint32_t ix = (sub % per_side) * kTileW + lx, iy = (sub / per_side) * kTileH + ly;
             x = tx * A.tile + ix; y = ty * A.tile + iy;
             out_index = static_cast<size_t>(local_tile) * A.tile * A.tile + static_cast<size_t>(iy) * A.tile + ix;
             inside = global_tile < A.tiles_total && x < A.frame_w && y < A.frame_h;
@@ -63,9 +63,9 @@ __global__ __launch_bounds__(kBlock) void path_kernel(const PathArgs P) {
     const uint32_t wave = tid >> 6, lane = tid & 63u;
     const uint32_t lx = ((wave & 1u) << 3) | (lane & 7u);
     const uint32_t ly = ((wave >> 1) << 3) | (lane >> 3);
-    const uint32_t bx_count = (A.w + 15u) >> 4;
+    const uint32_t bx_count = (A.w + kTileW - 1u) / kTileW;
     const uint32_t bx = blockIdx.x % bx_count, by = blockIdx.x / bx_count;
-    const uint32_t rx = (bx << 4) + lx, ry = (by << 4) + ly;
+    const uint32_t rx = bx * kTileW + lx, ry = by * kTileH + ly;
     if (rx >= A.w || ry >= A.h) return;
     shade_pixel(P, A.x0 + rx, A.y0 + ry, static_cast<size_t>(ry) * A.w + rx, lds_stack + tid);
 }
