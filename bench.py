@@ -54,7 +54,7 @@ def build_world(n: int, seed: int):
     return cm.pack_chunks_to_gpu_svo(W.scene_materials(seed))
 
 
-def cpu_baseline(packed, cam, width, height, stride):
+def cpu_baseline(packed, cam, width, height, stride, min_seconds=1.0):
     """The oracle (oracle/blok_oracle.cpp: restated intersect.rint behind a front-to-back slot lattice)
     timed on this box's host cores, on a strided sample of the same frame.  Baseline only."""
     from tests import oracle_ffi as O
@@ -68,7 +68,7 @@ def cpu_baseline(packed, cam, width, height, stride):
         _, c = lattice.trace_primary(cam, width, height, stride=stride, threads=threads, want_hits=False)
         frames += 1
         totals = {k: int(c[k]) + (totals[k] if totals else 0) for k in c.dtype.names}
-        if time.perf_counter() - t0 >= 1.0 or frames >= 64:
+        if time.perf_counter() - t0 >= min_seconds or frames >= 64:
             break
     dt = time.perf_counter() - t0
     ctr = totals
@@ -99,13 +99,14 @@ def main():
         args.gpus = world_size
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a gfx950 GPU (no CPU fallback exists)")
-    torch.cuda.set_device(local_rank)
+    device_index = local_rank % torch.cuda.device_count()      # a launcher may expose one device per rank
+    torch.cuda.set_device(device_index)
     dist = None
     if world_size > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
 
     from blok_amd import world as W
     from blok_amd.tracer import HipTracer
@@ -113,7 +114,7 @@ def main():
     W_, H_ = args.width, args.height
     packed = build_world(args.n, args.seed)
     cam = W.scene_camera(args.n, args.pose, W_, H_, args.seed)
-    tracer = HipTracer(W_, H_, device=local_rank).init()
+    tracer = HipTracer(W_, H_, device=device_index).init()
     stats = tracer.add_world(packed)                      # world resident in HBM from here on
 
     from blok_amd.multi_gpu import FramePipeline, HipBackend
@@ -184,7 +185,10 @@ def main():
         }
         alg = None
         if not args.no_cpu_baseline:
-            out["cpu_baseline"], alg = cpu_baseline(packed, cam, W_, H_, args.cpu_stride)
+            if world_size == 1:
+                out["cpu_baseline"], alg = cpu_baseline(packed, cam, W_, H_, args.cpu_stride)
+            else:      # N > 1: only the per-ray byte counters (a quick strided oracle pass), no baseline object
+                _, alg = cpu_baseline(packed, cam, W_, H_, 4, min_seconds=0.0)
         rays_per_launch = rays_per_step / world_size
         if alg is not None:
             achieved = alg["bytes_per_ray"] * rays_per_launch / (kernel_ms_avg * 1e-3) / 1e9

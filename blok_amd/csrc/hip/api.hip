@@ -259,7 +259,7 @@ int blok_hip_trace_tiles_device(blok_hip_ctx* ctx, const blok_camera* cam, uint3
                                 uint32_t n_ranks, void* out_hits_dev, void* out_rgba_dev, void* hip_stream) {
     int rc = check_trace(ctx, cam);
     if (rc != BLOK_OK) return rc;
-    if ((!out_hits_dev && !out_rgba_dev) || tile < 16 || (tile & 15u) || !n_ranks || rank >= n_ranks)
+    if ((!out_hits_dev && !out_rgba_dev) || tile < 16 || (tile % blok::kTileW) || (tile % blok::kTileH) || (tile & 15u) || !n_ranks || rank >= n_ranks)
         return set_error(ctx, BLOK_ERR_INVALID_ARG, "tile must be a multiple of 16 and rank < n_ranks");
     blok::TraceArgs a = base_args(ctx, cam);
     a.tile = tile; a.rank = rank; a.n_ranks = n_ranks;

@@ -25,8 +25,8 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const TraceArgs A) {
     } else {
         // a block is a 16x16 pixel tile, a wave an 8x8 sub-tile (coherent rays per wave)
         const uint32_t wave = tid >> 6, lane = tid & 63u;
-        const uint32_t lx = ((wave & 1u) << 3) | (lane & 7u);
-        const uint32_t ly = ((wave >> 1) << 3) | (lane >> 3);
+        const uint32_t lx = (wave & 1u) * kWaveW + (lane % kWaveW);
+        const uint32_t ly = (wave >> 1) * kWaveH + (lane / kWaveW);
         uint32_t x, y;
         size_t out_index;
         bool inside;
@@ -61,8 +61,8 @@ __global__ __launch_bounds__(kBlock) void path_kernel(const PathArgs P) {
     const TraceArgs& A = P.trace;
     const uint32_t tid = threadIdx.x;
     const uint32_t wave = tid >> 6, lane = tid & 63u;
-    const uint32_t lx = ((wave & 1u) << 3) | (lane & 7u);
-    const uint32_t ly = ((wave >> 1) << 3) | (lane >> 3);
+    const uint32_t lx = (wave & 1u) * kWaveW + (lane % kWaveW);
+    const uint32_t ly = (wave >> 1) * kWaveH + (lane / kWaveW);
     const uint32_t bx_count = (A.w + kTileW - 1u) / kTileW;
     const uint32_t bx = blockIdx.x % bx_count, by = blockIdx.x / bx_count;
     const uint32_t rx = bx * kTileW + lx, ry = by * kTileH + ly;
