@@ -123,6 +123,9 @@ HIP_SYMBOLS = {
                                         C.c_void_p, C.c_size_t]),
     "blok_hip_upload_dense": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
                                         C.POINTER(C.c_int32), C.c_void_p, C.c_size_t]),
+    "blok_hip_set_host_build": (C.c_int, [C.c_void_p, C.c_int]),
+    "blok_hip_world_built_on_device": (C.c_int, [C.c_void_p]),
+    "blok_hip_download_tree": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
     "blok_hip_world_stats": (C.c_int, [C.c_void_p, C.POINTER(WorldStats)]),
     "blok_hip_trace_primary": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
                                          C.c_uint32, C.c_void_p]),

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "blok_hip.h"
+#include "gpu_build.h"
 #include "reference_world.h"
 #include "trace_kernels.h"
 #include "path_args.h"
@@ -22,6 +23,8 @@ struct blok_hip_ctx {
     blok_material* d_materials = nullptr;
     size_t n_materials = 0;
     bool has_world = false;
+    bool built_on_device = false;     // structure built by gpu_build.hip (else tree_build.cpp on the host)
+    bool force_host_build = false;
     blok_world_stats stats{};
     // scratch frame for the host-output entry points
     blok_hit* d_frame = nullptr;
@@ -54,7 +57,15 @@ void free_world(blok_hip_ctx* ctx) {
     if (ctx->d_tree_materials) (void)hipFree(ctx->d_tree_materials);
     if (ctx->d_materials) (void)hipFree(ctx->d_materials);
     ctx->d_nodes = nullptr; ctx->d_tree_materials = nullptr; ctx->d_materials = nullptr;
-    ctx->n_materials = 0; ctx->has_world = false; ctx->stats = blok_world_stats{};
+    ctx->n_materials = 0; ctx->has_world = false; ctx->built_on_device = false; ctx->stats = blok_world_stats{};
+}
+
+int install_materials(blok_hip_ctx* ctx, const blok_material* materials, size_t n_materials) {
+    if (!n_materials) return BLOK_OK;
+    BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_materials), n_materials * sizeof(blok_material)));
+    BLOK_HIP_TRY(ctx, hipMemcpy(ctx->d_materials, materials, n_materials * sizeof(blok_material), hipMemcpyHostToDevice));
+    ctx->n_materials = n_materials;
+    return BLOK_OK;
 }
 
 int install_tree(blok_hip_ctx* ctx, const blok::HostTree& tree, const blok_material* materials, size_t n_materials) {
@@ -67,11 +78,8 @@ int install_tree(blok_hip_ctx* ctx, const blok::HostTree& tree, const blok_mater
     if (!tree.materials.empty())
         BLOK_HIP_TRY(ctx, hipMemcpy(ctx->d_tree_materials, tree.materials.data(),
                                     tree.materials.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    if (n_materials) {
-        BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_materials), n_materials * sizeof(blok_material)));
-        BLOK_HIP_TRY(ctx, hipMemcpy(ctx->d_materials, materials, n_materials * sizeof(blok_material), hipMemcpyHostToDevice));
-        ctx->n_materials = n_materials;
-    }
+    const int rc_mat = install_materials(ctx, materials, n_materials);
+    if (rc_mat != BLOK_OK) return rc_mat;
     ctx->stats.n_voxels = tree.n_voxels;
     ctx->stats.n_tree_nodes = tree.nodes.size();
     ctx->stats.tree_bytes = node_bytes + tree.materials.size() * sizeof(uint32_t);
@@ -180,6 +188,32 @@ int blok_hip_upload_world(blok_hip_ctx* ctx, const blok_svo_node* nodes, size_t 
     if ((n_nodes && !nodes) || (n_sub_chunks && !sub_chunks) || (n_materials && !materials))
         return set_error(ctx, BLOK_ERR_INVALID_ARG, "null array with non-zero count");
     BLOK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // device-side build (gpu_build.hip); worlds it does not cover take the general host path below
+    if (!ctx->force_host_build) {
+        blok::GpuTree gpu;
+        std::string reason;
+        const blok::GpuBuildStatus st = blok::gpu_build_tree(nodes, n_nodes, sub_chunks, n_sub_chunks, &gpu, &reason);
+        if (st == blok::GpuBuildStatus::Unsupported) return set_error(ctx, BLOK_ERR_UNSUPPORTED, reason);
+        if (st == blok::GpuBuildStatus::HipError) return set_error(ctx, BLOK_ERR_HIP, reason);
+        if (st == blok::GpuBuildStatus::OutOfMemory) return set_error(ctx, BLOK_ERR_OOM, reason);
+        if (st == blok::GpuBuildStatus::Ok) {
+            free_world(ctx);
+            ctx->d_nodes = gpu.d_nodes;
+            ctx->d_tree_materials = gpu.d_materials;
+            const int rc = install_materials(ctx, materials, n_materials);
+            if (rc != BLOK_OK) { free_world(ctx); return rc; }
+            ctx->stats.n_voxels = gpu.n_voxels;
+            ctx->stats.n_tree_nodes = gpu.n_nodes;
+            ctx->stats.tree_bytes = gpu.n_nodes * sizeof(blok::TreeNode) + gpu.n_voxels * sizeof(uint32_t);
+            ctx->stats.levels = gpu.levels;
+            for (int a = 0; a < 3; ++a) ctx->stats.origin[a] = gpu.origin[a];
+            ctx->stats.n_ref_nodes = n_nodes;
+            ctx->stats.n_sub_chunks = n_sub_chunks;
+            ctx->has_world = true;
+            ctx->built_on_device = true;
+            return BLOK_OK;
+        }
+    }
     std::vector<blok::VoxelRec> voxels;
     const char* why = "";
     if (!blok::extract_voxels(nodes, n_nodes, sub_chunks, n_sub_chunks, voxels, &why))
@@ -190,6 +224,27 @@ int blok_hip_upload_world(blok_hip_ctx* ctx, const blok_svo_node* nodes, size_t 
     if (rc != BLOK_OK) return rc;
     ctx->stats.n_ref_nodes = n_nodes;
     ctx->stats.n_sub_chunks = n_sub_chunks;
+    return BLOK_OK;
+}
+
+int blok_hip_set_host_build(blok_hip_ctx* ctx, int enabled) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    ctx->force_host_build = enabled != 0;
+    return BLOK_OK;
+}
+
+int blok_hip_world_built_on_device(const blok_hip_ctx* ctx) { return ctx && ctx->has_world && ctx->built_on_device ? 1 : 0; }
+
+int blok_hip_download_tree(const blok_hip_ctx* ctx, void* nodes_out, size_t node_capacity, uint32_t* materials_out,
+                           size_t material_capacity) {
+    if (!ctx || !ctx->has_world) return BLOK_ERR_NO_WORLD;
+    if ((nodes_out && node_capacity < ctx->stats.n_tree_nodes) || (materials_out && material_capacity < ctx->stats.n_voxels))
+        return BLOK_ERR_INVALID_ARG;
+    if (nodes_out && hipMemcpy(nodes_out, ctx->d_nodes, ctx->stats.n_tree_nodes * sizeof(blok::TreeNode), hipMemcpyDeviceToHost) != hipSuccess)
+        return BLOK_ERR_HIP;
+    if (materials_out && ctx->stats.n_voxels &&
+        hipMemcpy(materials_out, ctx->d_tree_materials, ctx->stats.n_voxels * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)
+        return BLOK_ERR_HIP;
     return BLOK_OK;
 }
 

@@ -1,0 +1,301 @@
+// Device-side build of the 64-tree from the reference's world arrays (the work of Renderer::addWorld's
+// uploadSvoBuffers + buildChunkBlas/Tlas, reference blok/src/renderer_upload.cpp:237-312,
+// blok/src/renderer_raytracing.cpp:15-254, on this backend).
+//
+//   1. copy SvoNode[] / SubChunkGpu[] to HBM (coalesced memcpy, 149 MB for the 1024^3 scene);
+//   2. brick_mask_kernel: one lane per 4x4x4 brick of every sub-chunk walks the sub-chunk's binary octree
+//      (same visibility rules as the shader: only through set childMask bits, out-of-range indices skipped,
+//      childMask == 0 is a leaf that counts iff occupancy > 0; intersect.rint:132-137,169) and emits the
+//      brick's 64-bit voxel mask;
+//   3. compaction of non-empty bricks (hipcub scan), Morton-digit keys, radix sort -> level-1 order;
+//   4. popcount scan -> material offsets; material_kernel: one lane per voxel re-walks to the leaf and stores
+//      its materialId;
+//   5. the few thousand nodes above brick level are grouped on the host from the sorted brick keys
+//      (tree_build.cpp: build_upper_levels) and copied in front of the bricks.
+// Integer / byte work, HBM- and latency-bound; no MFMA.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <string>
+#include <vector>
+
+#include "gpu_build.h"
+
+namespace blok {
+
+namespace {
+
+struct WalkCtx {
+    const blok_svo_node* nodes;
+    uint32_t n_nodes;
+    const blok_sub_chunk* subs;
+    uint32_t n_subs;
+    uint32_t sub_size;        // voxels per sub-chunk edge (power of two >= 4)
+    uint32_t bricks_side;     // sub_size / 4
+    uint32_t bricks_per_sub;  // bricks_side^3
+    uint32_t sub_shift;       // log2(sub_size)
+};
+
+__device__ __forceinline__ uint32_t node_limit(const WalkCtx& c, const blok_sub_chunk& s) {
+    const uint64_t end = static_cast<uint64_t>(s.node_offset) + s.node_count;
+    return static_cast<uint32_t>(end < c.n_nodes ? end : c.n_nodes);
+}
+
+// Error bits raised by the walks.
+enum : uint32_t { kErrLeafAboveVoxel = 1u, kErrInteriorBelowVoxel = 2u };
+
+__global__ __launch_bounds__(256) void brick_mask_kernel(const WalkCtx c, uint64_t* masks, uint32_t* non_empty, uint32_t* error) {
+    const uint64_t tid = static_cast<uint64_t>(blockIdx.x) * 256u + threadIdx.x;
+    if (tid >= static_cast<uint64_t>(c.n_subs) * c.bricks_per_sub) return;
+    const uint32_t s = static_cast<uint32_t>(tid / c.bricks_per_sub), b = static_cast<uint32_t>(tid % c.bricks_per_sub);
+    const uint32_t vx = (b % c.bricks_side) * 4u, vy = ((b / c.bricks_side) % c.bricks_side) * 4u,
+                   vz = (b / (c.bricks_side * c.bricks_side)) * 4u;
+    const blok_sub_chunk sub = c.subs[s];
+    const uint32_t limit = node_limit(c, sub);
+    uint32_t at = sub.node_offset + sub.root_node_index;
+    uint64_t mask = 0;
+    bool alive = true;
+    for (uint32_t shift = c.sub_shift; shift > 2u && alive; --shift) {       // down to the node covering the brick
+        if (at >= limit) { alive = false; break; }
+        const blok_svo_node nd = c.nodes[at];
+        if (nd.child_mask == 0u) { if (nd.occupancy > 0.0f) atomicOr(error, kErrLeafAboveVoxel); alive = false; break; }
+        const uint32_t h = shift - 1u;
+        const uint32_t oct = ((vx >> h) & 1u) | (((vy >> h) & 1u) << 1) | (((vz >> h) & 1u) << 2);
+        if (!(nd.child_mask & (1u << oct))) { alive = false; break; }
+        at = sub.node_offset + nd.first_child + oct;
+    }
+    if (alive && at < limit) {
+        const blok_svo_node n4 = c.nodes[at];
+        if (n4.child_mask == 0u) { if (n4.occupancy > 0.0f) atomicOr(error, kErrLeafAboveVoxel); }
+        else
+            for (uint32_t ci = 0; ci < 8u; ++ci) {
+                if (!(n4.child_mask & (1u << ci))) continue;
+                const uint32_t a2 = sub.node_offset + n4.first_child + ci;
+                if (a2 >= limit) continue;
+                const blok_svo_node n2 = c.nodes[a2];
+                if (n2.child_mask == 0u) { if (n2.occupancy > 0.0f) atomicOr(error, kErrLeafAboveVoxel); continue; }
+                for (uint32_t gi = 0; gi < 8u; ++gi) {
+                    if (!(n2.child_mask & (1u << gi))) continue;
+                    const uint32_t a1 = sub.node_offset + n2.first_child + gi;
+                    if (a1 >= limit) continue;
+                    const blok_svo_node n1 = c.nodes[a1];
+                    if (n1.child_mask != 0u) { atomicOr(error, kErrInteriorBelowVoxel); continue; }
+                    if (!(n1.occupancy > 0.0f)) continue;
+                    const uint32_t x = ((ci & 1u) << 1) | (gi & 1u), y = (ci & 2u) | ((gi >> 1) & 1u), z = ((ci >> 2) << 1) | (gi >> 2);
+                    mask |= 1ull << (x | (y << 2) | (z << 4));
+                }
+            }
+    }
+    masks[tid] = mask;
+    non_empty[tid] = mask != 0ull;
+}
+
+struct KeyCtx { int32_t origin[3]; uint32_t levels; };
+
+// Key of a brick: the 2-bit digit triples of levels 1..L-1 of its corner, least significant level first.
+__global__ __launch_bounds__(256) void brick_key_kernel(const WalkCtx c, const KeyCtx k, const uint64_t* masks,
+                                                        const uint32_t* slot_of, uint64_t total, uint64_t* keys, uint32_t* src) {
+    const uint64_t tid = static_cast<uint64_t>(blockIdx.x) * 256u + threadIdx.x;
+    if (tid >= total || masks[tid] == 0ull) return;
+    const uint32_t s = static_cast<uint32_t>(tid / c.bricks_per_sub), b = static_cast<uint32_t>(tid % c.bricks_per_sub);
+    const blok_sub_chunk& sub = c.subs[s];
+    const uint32_t x = static_cast<uint32_t>(static_cast<int32_t>(sub.world_min[0]) - k.origin[0]) + (b % c.bricks_side) * 4u;
+    const uint32_t y = static_cast<uint32_t>(static_cast<int32_t>(sub.world_min[1]) - k.origin[1]) + ((b / c.bricks_side) % c.bricks_side) * 4u;
+    const uint32_t z = static_cast<uint32_t>(static_cast<int32_t>(sub.world_min[2]) - k.origin[2]) + (b / (c.bricks_side * c.bricks_side)) * 4u;
+    uint64_t key = 0;
+    for (uint32_t l = 1; l < k.levels; ++l) {
+        const uint64_t digit = ((x >> (2 * l)) & 3u) | (((y >> (2 * l)) & 3u) << 2) | (((z >> (2 * l)) & 3u) << 4);
+        key |= digit << (6 * (l - 1));
+    }
+    const uint32_t slot = slot_of[tid];
+    keys[slot] = key;
+    src[slot] = static_cast<uint32_t>(tid);
+}
+
+__global__ __launch_bounds__(256) void gather_mask_kernel(const uint64_t* masks, const uint32_t* src_sorted, uint32_t n,
+                                                          uint64_t* masks_sorted, uint32_t* counts) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t m = masks[src_sorted[i]];
+    masks_sorted[i] = m;
+    counts[i] = __popcll(m);
+}
+
+// One lane per (brick, voxel bit): find the leaf again and store its material id at its rank.
+__global__ __launch_bounds__(256) void material_kernel(const WalkCtx c, const uint64_t* masks_sorted, const uint32_t* src_sorted,
+                                                       const uint32_t* mat_base, uint32_t n_bricks, uint32_t* materials) {
+    const uint64_t tid = static_cast<uint64_t>(blockIdx.x) * 256u + threadIdx.x;
+    const uint32_t i = static_cast<uint32_t>(tid >> 6), bit = static_cast<uint32_t>(tid & 63u);
+    if (i >= n_bricks) return;
+    const uint64_t mask = masks_sorted[i];
+    if (!((mask >> bit) & 1ull)) return;
+    const uint32_t g = src_sorted[i];
+    const uint32_t s = g / c.bricks_per_sub, b = g % c.bricks_per_sub;
+    const uint32_t vx = (b % c.bricks_side) * 4u + (bit & 3u), vy = ((b / c.bricks_side) % c.bricks_side) * 4u + ((bit >> 2) & 3u),
+                   vz = (b / (c.bricks_side * c.bricks_side)) * 4u + (bit >> 4);
+    const blok_sub_chunk sub = c.subs[s];
+    uint32_t at = sub.node_offset + sub.root_node_index;
+    for (uint32_t shift = c.sub_shift; shift > 0u; --shift) {
+        const blok_svo_node nd = c.nodes[at];
+        const uint32_t h = shift - 1u;
+        const uint32_t oct = ((vx >> h) & 1u) | (((vy >> h) & 1u) << 1) | (((vz >> h) & 1u) << 2);
+        at = sub.node_offset + nd.first_child + oct;        // the mask bit proves this path exists and is in range
+    }
+    materials[mat_base[i] + __popcll(mask & ((1ull << bit) - 1ull))] = c.nodes[at].material_id;
+}
+
+__global__ __launch_bounds__(256) void brick_node_kernel(const uint64_t* masks_sorted, const uint32_t* mat_base, uint32_t n, uint4* out) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t m = masks_sorted[i];
+    out[i] = make_uint4(static_cast<uint32_t>(m), static_cast<uint32_t>(m >> 32), mat_base[i], 0u);
+}
+
+struct DeviceBuffers {          // frees everything it still owns on scope exit
+    std::vector<void*> ptrs;
+    ~DeviceBuffers() { for (void* p : ptrs) if (p) (void)hipFree(p); }
+    template <class T> hipError_t alloc(T** p, size_t count) {
+        *p = nullptr;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(count, 1) * sizeof(T));
+        if (e == hipSuccess) ptrs.push_back(*p);
+        return e;
+    }
+    void release(void* p) { for (void*& q : ptrs) if (q == p) q = nullptr; }
+};
+
+#define GB_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { *why = std::string(#call) + ": " + hipGetErrorString(e_); \
+                          return e_ == hipErrorOutOfMemory ? GpuBuildStatus::OutOfMemory : GpuBuildStatus::HipError; } } while (0)
+
+inline uint32_t blocks_for(uint64_t n) { return static_cast<uint32_t>((n + 255u) / 256u); }
+
+}  // namespace
+
+GpuBuildStatus gpu_build_tree(const blok_svo_node* nodes, size_t n_nodes, const blok_sub_chunk* subs, size_t n_subs,
+                              GpuTree* out, std::string* why) {
+    *out = GpuTree{};
+    if (n_subs == 0 || n_nodes == 0) return GpuBuildStatus::UseHostBuilder;          // trivial / empty worlds
+    if (n_nodes > 0xFFFFFFFFull || n_subs > 0x7FFFFFFFull) return GpuBuildStatus::UseHostBuilder;
+    // ---- host: descriptor validation (same rules as extract_voxels) and the lattice of the tree
+    const float size_f = subs[0].sub_chunk_size;
+    const uint32_t S = static_cast<uint32_t>(size_f);
+    if (!(size_f >= 1.0f) || static_cast<float>(S) != size_f || (S & (S - 1)) != 0 || S > 1024) {
+        *why = "sub-chunk size is not a power-of-two number of unit voxels (voxelSize must be 1)";
+        return GpuBuildStatus::Unsupported;
+    }
+    if (S < 4 || S > 64) return GpuBuildStatus::UseHostBuilder;
+    int32_t lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+    for (size_t s = 0; s < n_subs; ++s) {
+        if (subs[s].sub_chunk_size != size_f) return GpuBuildStatus::UseHostBuilder;  // mixed sizes: general path
+        for (int a = 0; a < 3; ++a) {
+            const float m = subs[s].world_min[a];
+            if (std::floor(m) != m || std::fabs(m) > 32768.0f || subs[s].world_max[a] != m + size_f) {
+                *why = "sub-chunk bounds are not on the integer voxel lattice";
+                return GpuBuildStatus::Unsupported;
+            }
+            lo[a] = std::min(lo[a], static_cast<int32_t>(m));
+            hi[a] = std::max(hi[a], static_cast<int32_t>(m) + static_cast<int32_t>(S));
+        }
+    }
+    for (int a = 0; a < 3; ++a)
+        if (lo[a] < -32768 || hi[a] > 32768) { *why = "world voxel coordinates exceed int16 (hit records carry int16)"; return GpuBuildStatus::Unsupported; }
+    for (size_t s = 0; s < n_subs; ++s)
+        for (int a = 0; a < 3; ++a)
+            if ((static_cast<int32_t>(subs[s].world_min[a]) - lo[a]) % 4 != 0) return GpuBuildStatus::UseHostBuilder;
+    int64_t extent = 1;
+    for (int a = 0; a < 3; ++a) extent = std::max<int64_t>(extent, int64_t(hi[a]) - lo[a]);
+    uint32_t levels = 1;
+    while ((int64_t(1) << (2 * levels)) < extent) ++levels;
+    if (levels > kMaxLevels) { *why = "world extent exceeds 4^7 voxels per axis"; return GpuBuildStatus::Unsupported; }
+
+    WalkCtx c{};
+    c.n_nodes = static_cast<uint32_t>(n_nodes); c.n_subs = static_cast<uint32_t>(n_subs);
+    c.sub_size = S; c.bricks_side = S / 4; c.bricks_per_sub = c.bricks_side * c.bricks_side * c.bricks_side;
+    c.sub_shift = 0; while ((1u << c.sub_shift) < S) ++c.sub_shift;
+    const uint64_t total = static_cast<uint64_t>(n_subs) * c.bricks_per_sub;
+    if (total > 0x7FFFFFFFull) return GpuBuildStatus::UseHostBuilder;
+
+    DeviceBuffers mem;
+    blok_svo_node* d_nodes_ref; blok_sub_chunk* d_subs; uint64_t* d_masks; uint32_t *d_flag, *d_slot, *d_error;
+    GB_TRY(mem.alloc(&d_nodes_ref, n_nodes));
+    GB_TRY(mem.alloc(&d_subs, n_subs));
+    GB_TRY(mem.alloc(&d_masks, total));
+    GB_TRY(mem.alloc(&d_flag, total + 1));
+    GB_TRY(mem.alloc(&d_slot, total + 1));
+    GB_TRY(mem.alloc(&d_error, 1));
+    GB_TRY(hipMemcpy(d_nodes_ref, nodes, n_nodes * sizeof(blok_svo_node), hipMemcpyHostToDevice));
+    GB_TRY(hipMemcpy(d_subs, subs, n_subs * sizeof(blok_sub_chunk), hipMemcpyHostToDevice));
+    GB_TRY(hipMemset(d_error, 0, sizeof(uint32_t)));
+    GB_TRY(hipMemset(d_flag + total, 0, sizeof(uint32_t)));
+    c.nodes = d_nodes_ref; c.subs = d_subs;
+
+    hipLaunchKernelGGL(brick_mask_kernel, dim3(blocks_for(total)), dim3(256), 0, nullptr, c, d_masks, d_flag, d_error);
+    GB_TRY(hipGetLastError());
+    // exclusive scan of the non-empty flags (one extra element = total count)
+    void* d_temp = nullptr; size_t temp_bytes = 0;
+    GB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, temp_bytes, d_flag, d_slot, static_cast<int>(total + 1)));
+    size_t scan_bytes = temp_bytes;
+    uint8_t* d_scratch;
+    GB_TRY(mem.alloc(&d_scratch, scan_bytes));
+    d_temp = d_scratch;
+    GB_TRY(hipcub::DeviceScan::ExclusiveSum(d_temp, temp_bytes, d_flag, d_slot, static_cast<int>(total + 1)));
+    uint32_t n_bricks = 0, error = 0;
+    GB_TRY(hipMemcpy(&n_bricks, d_slot + total, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    GB_TRY(hipMemcpy(&error, d_error, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (error & kErrLeafAboveVoxel) { *why = "filled leaf above voxel level (not produced by SvoTree::insertVoxel)"; return GpuBuildStatus::Unsupported; }
+    if (error & kErrInteriorBelowVoxel) { *why = "interior node below voxel level"; return GpuBuildStatus::Unsupported; }
+    if (n_bricks == 0) return GpuBuildStatus::UseHostBuilder;
+
+    uint64_t *d_keys, *d_keys_sorted, *d_masks_sorted; uint32_t *d_src, *d_src_sorted, *d_counts, *d_mat_base;
+    GB_TRY(mem.alloc(&d_keys, n_bricks)); GB_TRY(mem.alloc(&d_keys_sorted, n_bricks));
+    GB_TRY(mem.alloc(&d_src, n_bricks)); GB_TRY(mem.alloc(&d_src_sorted, n_bricks));
+    GB_TRY(mem.alloc(&d_masks_sorted, n_bricks));
+    GB_TRY(mem.alloc(&d_counts, n_bricks + 1)); GB_TRY(mem.alloc(&d_mat_base, n_bricks + 1));
+    KeyCtx k{}; for (int a = 0; a < 3; ++a) k.origin[a] = lo[a]; k.levels = levels;
+    hipLaunchKernelGGL(brick_key_kernel, dim3(blocks_for(total)), dim3(256), 0, nullptr, c, k, d_masks, d_slot, total, d_keys, d_src);
+    GB_TRY(hipGetLastError());
+    const int key_bits = std::max(1, static_cast<int>(6 * (levels - 1)));
+    temp_bytes = 0;
+    GB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, d_keys, d_keys_sorted, d_src, d_src_sorted, static_cast<int>(n_bricks), 0, key_bits));
+    uint8_t* d_sort_scratch;
+    GB_TRY(mem.alloc(&d_sort_scratch, temp_bytes));
+    GB_TRY(hipcub::DeviceRadixSort::SortPairs(d_sort_scratch, temp_bytes, d_keys, d_keys_sorted, d_src, d_src_sorted, static_cast<int>(n_bricks), 0, key_bits));
+    hipLaunchKernelGGL(gather_mask_kernel, dim3(blocks_for(n_bricks)), dim3(256), 0, nullptr, d_masks, d_src_sorted, n_bricks, d_masks_sorted, d_counts);
+    GB_TRY(hipGetLastError());
+    GB_TRY(hipMemset(d_counts + n_bricks, 0, sizeof(uint32_t)));
+    temp_bytes = 0;
+    GB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, temp_bytes, d_counts, d_mat_base, static_cast<int>(n_bricks + 1)));
+    if (temp_bytes > scan_bytes) { GB_TRY(mem.alloc(&d_scratch, temp_bytes)); scan_bytes = temp_bytes; }
+    GB_TRY(hipcub::DeviceScan::ExclusiveSum(d_scratch, temp_bytes, d_counts, d_mat_base, static_cast<int>(n_bricks + 1)));
+    uint32_t n_voxels = 0;
+    GB_TRY(hipMemcpy(&n_voxels, d_mat_base + n_bricks, sizeof(uint32_t), hipMemcpyDeviceToHost));
+
+    uint32_t* d_materials;
+    GB_TRY(mem.alloc(&d_materials, n_voxels));
+    hipLaunchKernelGGL(material_kernel, dim3(blocks_for(static_cast<uint64_t>(n_bricks) * 64u)), dim3(256), 0, nullptr,
+                       c, d_masks_sorted, d_src_sorted, d_mat_base, n_bricks, d_materials);
+    GB_TRY(hipGetLastError());
+
+    // ---- the levels above the bricks, on the host, from the sorted keys
+    std::vector<uint64_t> keys(n_bricks);
+    GB_TRY(hipMemcpy(keys.data(), d_keys_sorted, n_bricks * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    std::vector<TreeNode> upper;
+    if (!build_upper_levels(keys, levels, upper)) return GpuBuildStatus::UseHostBuilder;    // duplicate bricks: general path
+    uint4* d_tree;
+    const size_t n_tree = upper.size() + n_bricks;
+    GB_TRY(mem.alloc(&d_tree, n_tree));
+    GB_TRY(hipMemcpy(d_tree, upper.data(), upper.size() * sizeof(TreeNode), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(brick_node_kernel, dim3(blocks_for(n_bricks)), dim3(256), 0, nullptr, d_masks_sorted, d_mat_base, n_bricks,
+                       d_tree + upper.size());
+    GB_TRY(hipGetLastError());
+    GB_TRY(hipDeviceSynchronize());
+
+    mem.release(d_tree); mem.release(d_materials);
+    out->d_nodes = d_tree; out->d_materials = d_materials;
+    out->n_nodes = n_tree; out->n_voxels = n_voxels; out->levels = levels;
+    for (int a = 0; a < 3; ++a) out->origin[a] = lo[a];
+    return GpuBuildStatus::Ok;
+}
+
+}  // namespace blok

@@ -44,5 +44,10 @@ struct VoxelRec { int32_t x, y, z; uint32_t material; };
 // `why` if the extent does not fit kMaxLevels / int16.
 bool build_tree(std::vector<VoxelRec>& voxels, HostTree& out, const char** why);
 
+// Levels L..2 (root first) from the sorted, strictly increasing keys of the level-1 bricks, for a tree whose
+// bricks are stored right after these nodes (level-2 nodes' `base` already includes upper.size()).
+// Returns false if the keys are not strictly increasing (duplicate bricks).
+bool build_upper_levels(const std::vector<uint64_t>& brick_keys, uint32_t levels, std::vector<TreeNode>& upper);
+
 }  // namespace blok
 #endif

@@ -107,6 +107,39 @@ bool build_tree(std::vector<VoxelRec>& voxels, HostTree& out, const char** why) 
     return true;
 }
 
+bool build_upper_levels(const std::vector<uint64_t>& brick_keys, uint32_t levels, std::vector<TreeNode>& upper) {
+    upper.clear();
+    for (size_t i = 1; i < brick_keys.size(); ++i)
+        if (brick_keys[i] <= brick_keys[i - 1]) return false;
+    if (levels <= 1) return brick_keys.size() == 1;              // the single brick is the root
+    std::vector<std::vector<TreeNode>> level_nodes(levels + 1);
+    std::vector<uint64_t> cur = brick_keys, next;
+    for (uint32_t l = 2; l <= levels; ++l) {
+        next.clear();
+        std::vector<TreeNode>& nodes = level_nodes[l];
+        for (size_t i = 0; i < cur.size(); ++i) {
+            const uint64_t parent = cur[i] >> 6;
+            const uint32_t bit = uint32_t(cur[i] & 63u);
+            if (next.empty() || next.back() != parent) { next.push_back(parent); nodes.push_back(TreeNode{0, 0, uint32_t(i), 0}); }
+            if (bit < 32) nodes.back().mask_lo |= 1u << bit; else nodes.back().mask_hi |= 1u << (bit - 32);
+        }
+        cur.swap(next);
+    }
+    std::vector<uint32_t> start(levels + 2, 0);
+    uint64_t total = 0;
+    for (uint32_t l = levels; l >= 2; --l) { start[l] = uint32_t(total); total += level_nodes[l].size(); }
+    if (total + brick_keys.size() > 0xFFFFFFFFull) return false;
+    start[1] = uint32_t(total);                                   // bricks follow the upper levels
+    upper.resize(total);
+    for (uint32_t l = levels; l >= 2; --l)
+        for (size_t i = 0; i < level_nodes[l].size(); ++i) {
+            TreeNode n = level_nodes[l][i];
+            n.base += start[l - 1];
+            upper[start[l] + i] = n;
+        }
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Reading the reference's world: every sub-chunk's octree is expanded to its filled unit leaves.
 // Visibility rules follow the shader that consumes these arrays: a child is only ever visited through

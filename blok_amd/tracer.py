@@ -82,6 +82,20 @@ class HipTracer:
         self._check(self._lib.blok_hip_upload_dense(self._ctx, _ffi.ptr(ids), nx, ny, nz, o, _ffi.ptr(mats), len(mats)))
         return self.world_stats()
 
+    def set_host_build(self, enabled: bool):
+        self._check(self._lib.blok_hip_set_host_build(self._ctx, int(enabled)))
+
+    def built_on_device(self) -> bool:
+        return bool(self._lib.blok_hip_world_built_on_device(self._ctx))
+
+    def download_tree(self):
+        """(nodes as (n, 4) uint32, material ids) of the device-resident structure."""
+        st = self.world_stats()
+        nodes = np.zeros((st.n_tree_nodes, 4), dtype=np.uint32)
+        mats = np.zeros(max(st.n_voxels, 1), dtype=np.uint32)
+        self._check(self._lib.blok_hip_download_tree(self._ctx, _ffi.ptr(nodes), len(nodes), _ffi.ptr(mats), len(mats)))
+        return nodes, mats[:st.n_voxels]
+
     def world_stats(self) -> WorldStats:
         s = WorldStats()
         self._check(self._lib.blok_hip_world_stats(self._ctx, C.byref(s)))

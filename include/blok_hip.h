@@ -149,6 +149,16 @@ int blok_hip_upload_dense(blok_hip_ctx* ctx, const uint32_t* material_ids,
                           uint32_t nx, uint32_t ny, uint32_t nz, const int32_t origin[3],
                           const blok_material* materials, size_t n_materials);
 
+/* The traversal structure is built on the device (blok_amd/csrc/hip/gpu_build.hip).  Worlds outside what those
+ * kernels cover (empty worlds, sub-chunks smaller than 4 voxels or of mixed sizes) are built by the general host
+ * path instead; blok_hip_set_host_build(ctx, 1) forces that path (used by tests to compare the two). */
+int blok_hip_set_host_build(blok_hip_ctx* ctx, int enabled);
+int blok_hip_world_built_on_device(const blok_hip_ctx* ctx);   /* 1 / 0 */
+/* Copies the device-resident structure back: n_tree_nodes 16-byte nodes and n_voxels material ids
+ * (see blok_world_stats); either output may be NULL.  For tests and debugging. */
+int blok_hip_download_tree(const blok_hip_ctx* ctx, void* nodes_out, size_t node_capacity,
+                           uint32_t* materials_out, size_t material_capacity);
+
 /* Sizes of the device-resident world, for accounting (bytes). */
 typedef struct blok_world_stats {
     uint64_t n_voxels;          /* filled leaves */

@@ -204,3 +204,66 @@ def test_shaded_debug_view_and_timing(tracer_cls, scene64):
     tr.draw_frame(cam)
     assert 0.0 < tr.last_kernel_ms() < 1000.0
     tr.shutdown()
+
+
+def test_device_build_equals_host_build(tracer_cls, scene64, scene256, scene1024):
+    """blok_hip_upload_world builds the 64-tree on the device (gpu_build.hip); the general host builder
+    (tree_build.cpp) must produce the same structure and the same frames."""
+    import time
+    for n, (cm, pw) in ((64, scene64), (256, scene256), (1024, scene1024)):
+        tr = tracer_cls(640, 360).init()
+        t0 = time.perf_counter(); st_dev = tr.add_world(pw); t_dev = time.perf_counter() - t0
+        assert tr.built_on_device()
+        nodes_dev, mats_dev = tr.download_tree()
+        cam = W.scene_camera(n, 0, 640, 360, SEED)
+        frame_dev = tr.draw_frame(cam)
+        tr.set_host_build(True)
+        t0 = time.perf_counter(); st_host = tr.add_world(pw); t_host = time.perf_counter() - t0
+        assert not tr.built_on_device()
+        nodes_host, mats_host = tr.download_tree()
+        frame_host = tr.draw_frame(cam)
+        assert (st_dev.n_voxels, st_dev.levels, list(st_dev.origin)) == (st_host.n_voxels, st_host.levels, list(st_host.origin))
+        assert np.array_equal(nodes_dev, nodes_host) and np.array_equal(mats_dev, mats_host)
+        assert records_equal(frame_dev.reshape(-1), frame_host.reshape(-1)).all()
+        print(f"upload {n}^3: device build {t_dev * 1e3:.1f} ms, host build {t_host * 1e3:.1f} ms")
+        tr.shutdown()
+
+
+def test_device_build_odd_worlds(tracer_cls):
+    """Negative coordinates / several chunks (tree origins may differ between the builders: compare traced rays),
+    unsupported worlds are rejected by the device path with the same messages, empty worlds take the host path."""
+    from blok_amd._ffi import BlokError
+    rng = np.random.default_rng(8)
+    cm = W.ChunkManager(128, 1.0)
+    xyz = rng.integers(-200, 180, size=(9000, 3)).astype(np.int32)
+    cm.set_voxels(xyz, rng.integers(1, 500, size=len(xyz)).astype(np.uint32))
+    cm.rebuild_dirty_chunks()
+    pw = cm.pack_chunks_to_gpu_svo()
+    rays = random_rays(380, 8000, 3)
+    rays["org"] -= 200
+    ref, ctr = O.Lattice(pw.nodes, pw.sub_chunks).trace(rays, threads=8)
+    tr = tracer_cls(64, 64).init()
+    st = tr.add_world(pw)
+    assert tr.built_on_device() and st.n_voxels == len(np.unique(xyz, axis=0)) and ctr["hits"] > 300
+    assert records_equal(tr.trace_rays(rays), ref).all()
+    tr.set_host_build(True)
+    tr.add_world(pw)
+    assert records_equal(tr.trace_rays(rays), ref).all()
+    tr.set_host_build(False)
+    bad = pw.nodes.copy()
+    root = int(pw.sub_chunks[0]["node_offset"] + pw.sub_chunks[0]["root_node_index"])
+    bad[root]["child_mask"] = 0
+    bad[root]["occupancy"] = 1.0
+    with pytest.raises(BlokError, match="leaf above voxel level"):
+        tr.add_world(W.PackedWorld(bad, pw.sub_chunks, pw.materials))
+    tr.add_world(W.ChunkManager(128, 1.0).pack_chunks_to_gpu_svo())
+    assert not tr.built_on_device()
+    small = W.ChunkManager(8, 1.0)                      # 8^3 chunks -> sub-chunks of one voxel: general host path
+    small.set_voxels(np.array([[1, 2, 3], [9, 2, 3]], dtype=np.int32), np.array([4, 5], dtype=np.uint32))
+    small.rebuild_dirty_chunks()
+    spw = small.pack_chunks_to_gpu_svo()
+    assert tr.add_world(spw).n_voxels == 2 and not tr.built_on_device()
+    r = np.zeros(1, dtype=O.RAY); r["org"] = (1.5, 10, 3.5); r["dir"] = (0, -1, 0); r["tmin"] = 0.001; r["tmax"] = 1e4
+    got = tr.trace_rays(r)
+    assert got[0]["hit"] == 1 and got[0]["material_id"] == 4 and tuple(got[0]["voxel"]) == (1, 2, 3)
+    tr.shutdown()
