@@ -285,7 +285,7 @@ int blok_hip_trace_primary_device(blok_hip_ctx* ctx, const blok_camera* cam, uin
     a.x0 = x0; a.y0 = y0; a.w = w; a.h = h;
     a.out = static_cast<blok_hit*>(out_hits_dev);
     a.out_rgba = static_cast<uint32_t*>(out_rgba_dev);
-    const uint32_t blocks = ((w + blok::kTileW - 1u) / blok::kTileW) * ((h + blok::kTileH - 1u) / blok::kTileH);
+    const uint32_t blocks = blok::rect_grid_blocks(w, h);
     return launch_timed(ctx, blok::RayMode::Rect, a, blocks, static_cast<hipStream_t>(hip_stream));
 }
 
@@ -399,7 +399,7 @@ int blok_hip_trace_paths_device(blok_hip_ctx* ctx, const blok_camera* cam, uint3
     p.normal_roughness = planes->normal_roughness; p.albedo_metallic = planes->albedo_metallic;
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     if (ctx->timing) BLOK_HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, stream));
-    blok::launch_paths(p, ((w + blok::kTileW - 1u) / blok::kTileW) * ((h + blok::kTileH - 1u) / blok::kTileH), stream);
+    blok::launch_paths(p, blok::rect_grid_blocks(w, h), stream);
     BLOK_HIP_TRY(ctx, hipGetLastError());
     if (ctx->timing) { BLOK_HIP_TRY(ctx, hipEventRecord(ctx->ev_end, stream)); ctx->timed = true; }
     return BLOK_OK;

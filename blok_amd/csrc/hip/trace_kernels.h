@@ -48,6 +48,29 @@ constexpr uint32_t kTileW = kBlock >= 128 ? 2u * kWaveW : kWaveW;   // pixels pe
 constexpr uint32_t kTileH = kBlock >= 256 ? 2u * kWaveH : kWaveH;   // pixels per block, y
 static_assert(kBlock == 64 || kBlock == 128 || kBlock == 256, "block = 1, 2 or 4 waves of 8x8 pixels");
 
+// Block -> tile mapping of the rectangle kernels.  Workgroups are dealt round-robin to the 8 XCDs (blocks b and
+// b + 8 share an XCD and its L2); BLOK_XCD_MAP chooses what that means on screen:
+//   0  row-major tiles (neighbouring tiles on different XCDs)
+//   1  each XCD gets one contiguous eighth of the row-major tile sequence
+//   2  as 1, and inside an XCD's share tiles are visited supertile by supertile (16x16 tiles, Morton order)
+#ifndef BLOK_XCD_MAP
+#define BLOK_XCD_MAP 0
+#endif
+constexpr uint32_t kSuper = 16u;          // tiles per supertile edge (mapping 2)
+
+// Number of workgroups to launch for a w x h rectangle under the mapping.
+inline uint32_t rect_grid_blocks(uint32_t w, uint32_t h) {
+    const uint32_t bx = (w + kTileW - 1u) / kTileW, by = (h + kTileH - 1u) / kTileH;
+#if BLOK_XCD_MAP == 0
+    return bx * by;
+#elif BLOK_XCD_MAP == 1
+    return (bx * by + 7u) / 8u * 8u;
+#else
+    const uint32_t sx = (bx + kSuper - 1u) / kSuper, sy = (by + kSuper - 1u) / kSuper;
+    return (sx * sy * kSuper * kSuper + 7u) / 8u * 8u;
+#endif
+}
+
 enum class RayMode : int { Rect = 0, Tiles = 1, Rays = 2 };
 
 struct TraceArgs {

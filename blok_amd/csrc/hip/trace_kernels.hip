@@ -9,6 +9,31 @@ namespace blok {
 
 namespace {
 
+// Tile (bx, by) of workgroup b for a rectangle of bx_count x by_count tiles; false if the workgroup has no tile.
+__device__ __forceinline__ bool block_to_tile(uint32_t b, uint32_t grid, uint32_t bx_count, uint32_t by_count,
+                                              uint32_t& bx, uint32_t& by) {
+#if BLOK_XCD_MAP == 0
+    (void)grid;
+    bx = b % bx_count; by = b / bx_count;
+    return by < by_count;
+#else
+    const uint32_t vb = (b & 7u) * (grid >> 3) + (b >> 3);        // XCD k owns virtual blocks [k*grid/8, (k+1)*grid/8)
+#if BLOK_XCD_MAP == 1
+    bx = vb % bx_count; by = vb / bx_count;
+    return by < by_count;
+#else
+    const uint32_t super_x = (bx_count + kSuper - 1u) / kSuper;
+    const uint32_t st = vb / (kSuper * kSuper), in = vb % (kSuper * kSuper);
+    // Morton order inside the supertile: even bits -> x, odd bits -> y
+    uint32_t mx = in & 0x55u, my = (in >> 1) & 0x55u;
+    mx = (mx | (mx >> 1)) & 0x33u; mx = (mx | (mx >> 2)) & 0x0Fu;
+    my = (my | (my >> 1)) & 0x33u; my = (my | (my >> 2)) & 0x0Fu;
+    bx = (st % super_x) * kSuper + mx; by = (st / super_x) * kSuper + my;
+    return bx < bx_count && by < by_count;
+#endif
+#endif
+}
+
 template <RayMode MODE>
 __global__ __launch_bounds__(kBlock) void trace_kernel(const TraceArgs A) {
     extern __shared__ uint4 lds_stack[];       // [levels-1][kBlock]
@@ -31,8 +56,9 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const TraceArgs A) {
         size_t out_index;
         bool inside;
         if constexpr (MODE == RayMode::Rect) {
-            const uint32_t bx_count = (A.w + kTileW - 1u) / kTileW;
-            const uint32_t bx = blockIdx.x % bx_count, by = blockIdx.x / bx_count;
+            const uint32_t bx_count = (A.w + kTileW - 1u) / kTileW, by_count = (A.h + kTileH - 1u) / kTileH;
+            uint32_t bx, by;
+            if (!block_to_tile(blockIdx.x, gridDim.x, bx_count, by_count, bx, by)) return;
             const uint32_t rx = bx * kTileW + lx, ry = by * kTileH + ly;
             inside = rx < A.w && ry < A.h;
             if (!inside) return;
@@ -63,8 +89,9 @@ __global__ __launch_bounds__(kBlock) void path_kernel(const PathArgs P) {
     const uint32_t wave = tid >> 6, lane = tid & 63u;
     const uint32_t lx = (wave & 1u) * kWaveW + (lane % kWaveW);
     const uint32_t ly = (wave >> 1) * kWaveH + (lane / kWaveW);
-    const uint32_t bx_count = (A.w + kTileW - 1u) / kTileW;
-    const uint32_t bx = blockIdx.x % bx_count, by = blockIdx.x / bx_count;
+    const uint32_t bx_count = (A.w + kTileW - 1u) / kTileW, by_count = (A.h + kTileH - 1u) / kTileH;
+    uint32_t bx, by;
+    if (!block_to_tile(blockIdx.x, gridDim.x, bx_count, by_count, bx, by)) return;
     const uint32_t rx = bx * kTileW + lx, ry = by * kTileH + ly;
     if (rx >= A.w || ry >= A.h) return;
     shade_pixel(P, A.x0 + rx, A.y0 + ry, static_cast<size_t>(ry) * A.w + rx, lds_stack + tid);

@@ -267,3 +267,30 @@ def test_device_build_odd_worlds(tracer_cls):
     got = tr.trace_rays(r)
     assert got[0]["hit"] == 1 and got[0]["material_id"] == 4 and tuple(got[0]["voxel"]) == (1, 2, 3)
     tr.shutdown()
+
+
+def test_config4_2048_svo_4k_tiles(tracer_cls):
+    """BASELINE.json configs[3] geometry: 2048^3 SVO (6 tree levels, 633 MB of reference nodes) at 4K, the
+    8-GPU tile partition rehearsed with virtual ranks on one device, oracle on a strided sample."""
+    import torch
+    cm, pw = make_scene_world(2048)
+    Wd, Ht = 3840, 2160
+    tr = tracer_cls(Wd, Ht).init()
+    st = tr.add_world(pw)
+    assert st.levels == 6 and tr.built_on_device() and st.n_ref_nodes == len(pw.nodes)
+    cam = W.scene_camera(2048, 0, Wd, Ht, SEED)
+    full = tr.draw_frame(cam)
+    stride = 8
+    ref, ctr = O.Lattice(pw.nodes, pw.sub_chunks).trace_primary(cam, Wd, Ht, stride=stride, threads=16)
+    assert ctr["hits"] > 20000
+    assert records_equal(full[::stride, ::stride].reshape(-1), ref).all()
+    n_ranks, tile = 8, 32
+    per = tr.tiles_for_rank(tile, 0, n_ranks)
+    gathered = torch.zeros((n_ranks * per * tile * tile, 4), dtype=torch.int32, device="cuda")
+    for r in range(n_ranks):
+        tr.draw_tiles_device(cam, tile, r, n_ranks, hits_ptr=gathered[r * per * tile * tile:].data_ptr())
+    out = torch.empty((Ht * Wd, 4), dtype=torch.int32, device="cuda")
+    tr.untile_device(gathered.data_ptr(), 16, tile, n_ranks, per, out.data_ptr())
+    torch.cuda.synchronize()
+    assert (out.cpu().numpy().view(np.uint8).reshape(-1, 16) == full.reshape(-1).view(np.uint8).reshape(-1, 16)).all()
+    tr.shutdown()
