@@ -65,6 +65,7 @@ HOST_SYMBOLS = {
     "blok_world_set_voxel": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.c_float]),
     "blok_world_set_voxels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "blok_world_get_voxel_material": (C.c_uint32, [C.c_void_p, C.POINTER(C.c_float)]),
+    "blok_world_apply_brush": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_float, C.c_float, C.c_int]),
     "blok_world_rebuild_dirty": (C.c_int, [C.c_void_p, C.c_int]),
     "blok_world_pack": (C.c_int, [C.c_void_p]),
     "blok_world_node_count": (C.c_size_t, [C.c_void_p]),
@@ -138,6 +139,8 @@ HIP_SYMBOLS = {
                                          C.c_void_p, C.c_void_p]),
     "blok_hip_trace_paths_device": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_uint32] * 7 + [C.POINTER(GBuffer), C.c_void_p]),
     "blok_hip_trace_paths": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_uint32] * 7 + [C.POINTER(GBuffer)]),
+    "blok_hip_tonemap_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
+    "blok_hip_tonemap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_int, C.c_void_p]),
     "blok_hip_trace_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "blok_hip_shade_rgba8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
                                        C.c_uint32, C.c_void_p]),
@@ -180,6 +183,12 @@ def host_lib() -> C.CDLL:
 def hip_lib() -> C.CDLL:
     global _hip
     if _hip is None:
+        # PyTorch ships its own libamdhip64; if this library pulled in /opt/rocm's copy first, torch would later
+        # bind to that one and report no device.  Loading torch first makes both share torch's runtime.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _hip = _load(HIP_LIB, HIP_SYMBOLS)
     return _hip
 

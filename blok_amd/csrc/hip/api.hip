@@ -430,6 +430,36 @@ int blok_hip_trace_paths(blok_hip_ctx* ctx, const blok_camera* cam, uint32_t x0,
     return BLOK_OK;
 }
 
+int blok_hip_tonemap_device(blok_hip_ctx* ctx, const float* hdr_dev, uint32_t n_pixels, float exposure,
+                            float saturation_boost, int tonemap_operator, void* out_rgba8_dev, void* hip_stream) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    if (!hdr_dev || !out_rgba8_dev) return set_error(ctx, BLOK_ERR_INVALID_ARG, "null tonemap buffer");
+    BLOK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    blok::TonemapArgs t{hdr_dev, static_cast<uint32_t*>(out_rgba8_dev), n_pixels, exposure, saturation_boost, tonemap_operator};
+    blok::launch_tonemap(t, static_cast<hipStream_t>(hip_stream));
+    BLOK_HIP_TRY(ctx, hipGetLastError());
+    return BLOK_OK;
+}
+
+int blok_hip_tonemap(blok_hip_ctx* ctx, const float* hdr_host, uint32_t n_pixels, float exposure, float saturation_boost,
+                     int tonemap_operator, uint32_t* out_rgba8_host) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    if (!hdr_host || !out_rgba8_host) return set_error(ctx, BLOK_ERR_INVALID_ARG, "null tonemap buffer");
+    if (!n_pixels) return BLOK_OK;
+    BLOK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    float* d_in = nullptr; uint32_t* d_out = nullptr;
+    BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d_in), static_cast<size_t>(n_pixels) * 16));
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_out), static_cast<size_t>(n_pixels) * 4);
+    int rc = BLOK_OK;
+    if (e == hipSuccess) e = hipMemcpy(d_in, hdr_host, static_cast<size_t>(n_pixels) * 16, hipMemcpyHostToDevice);
+    if (e == hipSuccess) rc = blok_hip_tonemap_device(ctx, d_in, n_pixels, exposure, saturation_boost, tonemap_operator, d_out, nullptr);
+    if (e == hipSuccess && rc == BLOK_OK) e = hipMemcpy(out_rgba8_host, d_out, static_cast<size_t>(n_pixels) * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d_in); if (d_out) (void)hipFree(d_out);
+    if (rc != BLOK_OK) return rc;
+    if (e != hipSuccess) return set_error(ctx, BLOK_ERR_HIP, std::string("tonemap: ") + hipGetErrorString(e));
+    return BLOK_OK;
+}
+
 int blok_hip_reset_accum(blok_hip_ctx* ctx) {
     if (!ctx) return BLOK_ERR_INVALID_ARG;
     return BLOK_OK;   // primary-hit frames carry no accumulation state

@@ -249,5 +249,67 @@ BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t in
     store4(P.albedo_metallic, index, final_albedo.x, final_albedo.y, final_albedo.z, first_metallic);    // :407
 }
 
+// ---------------------------------------------------------------------------------------------------
+// tonemap.comp (reference assets/shaders/tonemap.comp:17-143): exposure, Khronos PBR Neutral (or the soft-clip
+// "neutral" operator), post-tonemap saturation recovery, clamp, RGBA8.  Defaults of the reference:
+// exposure 1.0, saturationBoost 1.15, operator 1 (renderer_postprocess.hpp:110-113).
+struct TonemapArgs {
+    const float* hdr;        // float4 per pixel
+    uint32_t* ldr;           // RGBA8
+    uint32_t n;
+    float exposure, saturation_boost;
+    int op;                  // 0 neutral soft clip, 1 Khronos PBR Neutral
+};
+BLOK_DEV float vlength(V3 v) { return rn_sqrt(vdot(v, v)); }
+BLOK_DEV V3 khronos_pbr_neutral(V3 hdr) {                        // tonemap.comp:65-82
+    const float start = 0.8f - 0.04f;
+    const float desaturation = 0.15f;
+    const float x = fminf(hdr.x, fminf(hdr.y, hdr.z));
+    const float offset = x < 0.08f ? x - 6.25f * x * x : 0.04f;
+    hdr = v3(hdr.x - offset, hdr.y - offset, hdr.z - offset);
+    const float peak = fmaxf(hdr.x, fmaxf(hdr.y, hdr.z));
+    if (peak < start) return hdr;
+    const float d = 1.0f - start;
+    const float new_peak = 1.0f - d * d / (peak + d - start);
+    hdr = vscale(hdr, new_peak / peak);
+    const float g = 1.0f - 1.0f / (desaturation * (peak - new_peak) + 1.0f);
+    return vmix(hdr, v3(new_peak, new_peak, new_peak), g);
+}
+BLOK_DEV V3 neutral_tonemap(V3 hdr) {                            // tonemap.comp:85-95
+    const float peak = fmaxf(fmaxf(hdr.x, hdr.y), hdr.z);
+    if (peak <= 1.0f) return hdr;
+    const float compressed = 1.0f - expf(-(peak - 1.0f));
+    return vscale(hdr, (1.0f + compressed) / peak);
+}
+BLOK_DEV V3 saturation_recovery(V3 ldr, V3 hdr, float boost) {   // tonemap.comp:43-61
+    if (boost <= 1.0f) return ldr;
+    const float hdr_luma = luminance(hdr);
+    const float hdr_sat = hdr_luma > 0.0001f ? vlength(vsub(hdr, v3(hdr_luma, hdr_luma, hdr_luma))) / hdr_luma : 0.0f;
+    const float ldr_luma = luminance(ldr);
+    const float ldr_sat = ldr_luma > 0.0001f ? vlength(vsub(ldr, v3(ldr_luma, ldr_luma, ldr_luma))) / ldr_luma : 0.0f;
+    if (ldr_sat > 0.0001f && ldr_luma > 0.01f) {
+        const float ratio = fminf(hdr_sat / fmaxf(ldr_sat, 0.001f), 2.0f);
+        const float recovery = 1.0f * (1.0f - (boost - 1.0f)) + ratio * (boost - 1.0f);
+        return vmix(v3(ldr_luma, ldr_luma, ldr_luma), ldr, fminf(recovery, 1.5f));
+    }
+    return ldr;
+}
+BLOK_DEV uint32_t unorm8(float v) {                              // rgba8 imageStore: clamp, scale, round to nearest
+    const float c = fminf(fmaxf(v, 0.0f), 1.0f);
+    return static_cast<uint32_t>(c * 255.0f + 0.5f);
+}
+BLOK_DEV uint32_t tonemap_pixel(const TonemapArgs& T, uint32_t i) {   // tonemap.comp:97-143
+    V3 hdr = v3(T.hdr[4 * i], T.hdr[4 * i + 1], T.hdr[4 * i + 2]);
+    hdr = vscale(hdr, T.exposure);
+    const V3 original = hdr;
+    V3 ldr = T.op == 0 ? neutral_tonemap(hdr) : khronos_pbr_neutral(hdr);
+    if (T.saturation_boost > 1.0f) ldr = saturation_recovery(ldr, original, T.saturation_boost);
+    else if (T.saturation_boost < 1.0f && T.saturation_boost > 0.0f) {
+        const float luma = luminance(ldr);
+        ldr = vmix(v3(luma, luma, luma), ldr, T.saturation_boost);
+    }
+    return unorm8(ldr.x) | (unorm8(ldr.y) << 8) | (unorm8(ldr.z) << 16) | 0xFF000000u;
+}
+
 }  // namespace blok
 #endif

@@ -98,6 +98,8 @@ struct UntileArgs {
 };
 
 struct PathArgs;
+struct TonemapArgs;
+void launch_tonemap(const TonemapArgs& args, hipStream_t stream);
 void launch_paths(const PathArgs& args, uint32_t n_blocks, hipStream_t stream);
 void launch_trace(RayMode mode, const TraceArgs& args, uint32_t n_blocks, hipStream_t stream);
 void launch_untile(const UntileArgs& args, hipStream_t stream);

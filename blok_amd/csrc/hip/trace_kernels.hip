@@ -97,6 +97,11 @@ __global__ __launch_bounds__(kBlock) void path_kernel(const PathArgs P) {
     shade_pixel(P, A.x0 + rx, A.y0 + ry, static_cast<size_t>(ry) * A.w + rx, lds_stack + tid);
 }
 
+__global__ __launch_bounds__(256) void tonemap_kernel(const TonemapArgs T) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < T.n) T.ldr[i] = tonemap_pixel(T, i);
+}
+
 template <typename Elem>
 __global__ __launch_bounds__(256) void untile_kernel(const UntileArgs U) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -126,6 +131,10 @@ void launch_paths(const PathArgs& args, uint32_t n_blocks, hipStream_t stream) {
     const uint32_t levels = args.trace.levels;
     const size_t lds = static_cast<size_t>(levels > 1 ? levels - 1 : 1) * kBlock * sizeof(uint4);
     hipLaunchKernelGGL(path_kernel, dim3(n_blocks), dim3(kBlock), lds, stream, args);
+}
+
+void launch_tonemap(const TonemapArgs& args, hipStream_t stream) {
+    if (args.n) hipLaunchKernelGGL(tonemap_kernel, dim3((args.n + 255u) / 256u), dim3(256), 0, stream, args);
 }
 
 void launch_untile(const UntileArgs& args, hipStream_t stream) {

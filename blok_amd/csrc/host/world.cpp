@@ -314,6 +314,41 @@ uint32_t blok_world_get_voxel_material(const blok_world* cw, const float p[3]) {
     return it->material;
 }
 
+// reference blok/src/brush.cpp:13-63
+int blok_world_apply_brush(blok_world* w, const float center[3], float radius, float value, int mode) {
+    if (!w || !center || (mode != 0 && mode != 1)) return fail(w, "apply_brush: bad argument");
+    int32_t lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = static_cast<int32_t>(std::floor(center[a] - radius));
+        hi[a] = static_cast<int32_t>(std::floor(center[a] + radius)) + 1;        // brush.cpp:22
+    }
+    const int32_t C = static_cast<int32_t>(w->C);
+    for (int32_t gz = lo[2]; gz < hi[2]; ++gz)
+        for (int32_t gy = lo[1]; gy < hi[1]; ++gy)
+            for (int32_t gx = lo[0]; gx < hi[0]; ++gx) {
+                const int32_t cx = w->chunk_of(gx), cy = w->chunk_of(gy), cz = w->chunk_of(gz);
+                ChunkRec* ch = w->chunk_at(cx, cy, cz, true);                      // created even if nothing is written
+                const int32_t lx = gx - cx * C, ly = gy - cy * C, lz = gz - cz * C;
+                const float ox = static_cast<float>(cx * C) * w->voxel_size, oy = static_cast<float>(cy * C) * w->voxel_size,
+                            oz = static_cast<float>(cz * C) * w->voxel_size;
+                const float dx = (ox + (static_cast<float>(lx) + 0.5f * w->voxel_size)) - center[0];
+                const float dy = (oy + (static_cast<float>(ly) + 0.5f * w->voxel_size)) - center[1];
+                const float dz = (oz + (static_cast<float>(lz) + 0.5f * w->voxel_size)) - center[2];
+                if (std::sqrt(dx * dx + dy * dy + dz * dz) > radius) continue;
+                blok_world::settle(ch);
+                const uint32_t local = static_cast<uint32_t>(lx) + static_cast<uint32_t>(ly) * w->C + static_cast<uint32_t>(lz) * w->C * w->C;
+                auto it = std::lower_bound(ch->log.begin(), ch->log.end(), local,
+                                           [](const VoxelWrite& a, uint32_t key) { return a.local < key; });
+                const bool have = it != ch->log.end() && it->local == local;
+                const float d = have ? it->density : 0.0f;
+                const float nd = mode == 0 ? std::max(d, value) : std::min(d, value);
+                if (have) it->density = nd;                                        // in place: the log stays sorted
+                else ch->log.insert(it, VoxelWrite{local, 0u, 0u, nd});            // material id 0, like a fresh dense cell
+                ch->dirty = true;
+            }
+    return BLOK_OK;
+}
+
 int blok_world_rebuild_dirty(blok_world* w, int max_per_frame) {
     if (!w) return BLOK_ERR_INVALID_ARG;
     int rebuilt = 0;

@@ -159,6 +159,14 @@ class HipTracer:
         self._check(self._lib.blok_hip_trace_paths_device(self._ctx, _ffi.ptr(cam), x0, y0, w, h, spp, max_bounces,
                                                           frame_index, C.byref(g), C.c_void_p(stream)))
 
+    def tonemap(self, hdr: np.ndarray, exposure: float = 1.0, saturation_boost: float = 1.15, operator: int = 1) -> np.ndarray:
+        """tonemap.comp: (..., 4) float32 HDR -> (...) uint32 RGBA8 (reference defaults)."""
+        hdr = np.ascontiguousarray(hdr, dtype=np.float32)
+        out = np.zeros(hdr.shape[:-1], dtype=np.uint32)
+        self._check(self._lib.blok_hip_tonemap(self._ctx, _ffi.ptr(hdr), out.size, exposure, saturation_boost, operator,
+                                               _ffi.ptr(out)))
+        return out
+
     def shade_rgba8(self, cam: np.ndarray, rect=None) -> np.ndarray:
         x0, y0, w, h = rect if rect is not None else (0, 0, self.width, self.height)
         cam = np.ascontiguousarray(cam, dtype=CAMERA)

@@ -73,6 +73,11 @@ class ChunkManager:
         p = (C.c_float * 3)(*world_pos)
         return int(self._lib.blok_world_get_voxel_material(self._h, p))
 
+    def apply_brush(self, center, radius: float, value: float, mode: str = "add"):
+        """= applyBrush (reference blok/src/brush.cpp:13-63); mode "add" | "subtract"."""
+        c = (C.c_float * 3)(*center)
+        self._check(self._lib.blok_world_apply_brush(self._h, c, radius, value, {"add": 0, "subtract": 1}[mode]))
+
     def rebuild_dirty_chunks(self, max_per_frame: int = 1 << 30) -> int:
         return self._check(self._lib.blok_world_rebuild_dirty(self._h, max_per_frame))
 

@@ -232,6 +232,15 @@ int blok_hip_trace_paths(blok_hip_ctx* ctx, const blok_camera* cam,
                          uint32_t spp, uint32_t max_bounces, uint32_t frame_index,
                          const blok_gbuffer* planes_host);
 
+/* = the tonemap pass of the post-process chain (reference assets/shaders/tonemap.comp:97-143, dispatched at
+ * blok/src/renderer_postprocess.cpp:588-612): HDR float4 -> RGBA8.  Reference defaults: exposure 1.0,
+ * saturation_boost 1.15, tonemap_operator 1 = Khronos PBR Neutral (0 = soft clip)
+ * (reference blok/include/renderer_postprocess.hpp:110-113). */
+int blok_hip_tonemap_device(blok_hip_ctx* ctx, const float* hdr_rgba_dev, uint32_t n_pixels, float exposure,
+                            float saturation_boost, int tonemap_operator, void* out_rgba8_dev, void* hip_stream);
+int blok_hip_tonemap(blok_hip_ctx* ctx, const float* hdr_rgba_host, uint32_t n_pixels, float exposure,
+                     float saturation_boost, int tonemap_operator, uint32_t* out_rgba8_host);
+
 /* Explicit rays (secondary rays; edge-case tests). n rays in, n records out, host arrays. */
 int blok_hip_trace_rays(blok_hip_ctx* ctx, const blok_ray* rays_host, size_t n,
                         blok_hit* out_hits_host);

@@ -43,6 +43,12 @@ int blok_world_set_voxels(blok_world* w, const int32_t* xyz, const uint32_t* mat
 /* = ChunkManager::getVoxelMaterial (reference blok/src/chunk_manager.cpp:330-348). */
 uint32_t blok_world_get_voxel_material(const blok_world* w, const float world_pos[3]);
 
+/* = applyBrush(mgr, Brush{centerWS, radiusWS, value, mode}) (reference blok/src/brush.cpp:13-63,
+ * blok/include/brush.hpp:14-21): sphere edit of the density field — mode 0 ADD: d = max(d, value),
+ * mode 1 SUBTRACT: d = min(d, value); material ids are left as they are; every chunk the brush's bounding box
+ * touches is created and every chunk with a voxel inside the sphere is marked dirty. */
+int blok_world_apply_brush(blok_world* w, const float center[3], float radius, float value, int mode);
+
 /* = rebuildDirtyChunks(mgr, maxPerFrame) (reference blok/src/chunk_manager.cpp:121-140):
  *   clear + re-insert every density>0 voxel in z,y,x order (x fastest, :106-119) through
  *   SvoTree::insertVoxel (reference blok/src/svo.cpp:59-101).  Returns chunks rebuilt (>=0). */

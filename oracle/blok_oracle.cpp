@@ -255,6 +255,31 @@ struct World {
         return count;
     }
 
+    // applyBrush, brush.cpp:13-63 (mode 0 ADD, 1 SUBTRACT; brush.hpp:14-21)
+    void applyBrush(float cxw, float cyw, float czw, float radiusWS, float value, int mode) {
+        const int32_t gvMin[3] = {int(std::floor(cxw - radiusWS)), int(std::floor(cyw - radiusWS)), int(std::floor(czw - radiusWS))};
+        const int32_t gvMax[3] = {int(std::floor(cxw + radiusWS)) + 1, int(std::floor(cyw + radiusWS)) + 1, int(std::floor(czw + radiusWS)) + 1};
+        for (int gz = gvMin[2]; gz < gvMax[2]; gz++)
+        for (int gy = gvMin[1]; gy < gvMax[1]; gy++)
+        for (int gx = gvMin[0]; gx < gvMax[0]; gx++) {
+            const int32_t cx = toChunk(gx), cy = toChunk(gy), cz = toChunk(gz);
+            Chunk* ch = getOrCreate(cx, cy, cz);
+            const int32_t lx = gx - cx * int32_t(C), ly = gy - cy * int32_t(C), lz = gz - cz * int32_t(C);
+            if (lx < 0 || lx >= int(C) || ly < 0 || ly >= int(C) || lz < 0 || lz >= int(C)) continue;
+            // ch->svo.origin = chunk coordinate * C * voxelSize (chunk_manager.cpp:66-70)
+            const float ox = static_cast<float>(cx * int32_t(C)) * voxelSize, oy = static_cast<float>(cy * int32_t(C)) * voxelSize,
+                        oz = static_cast<float>(cz * int32_t(C)) * voxelSize;
+            const float vx = ox + (static_cast<float>(lx) + 0.5f * voxelSize), vy = oy + (static_cast<float>(ly) + 0.5f * voxelSize),
+                        vz = oz + (static_cast<float>(lz) + 0.5f * voxelSize);
+            const float dx = vx - cxw, dy = vy - cyw, dz = vz - czw;
+            const float dist = std::sqrt(dx * dx + dy * dy + dz * dz);           // glm::distance
+            if (dist > radiusWS) continue;
+            float& d = ch->density[size_t(lx) + size_t(ly) * C + size_t(lz) * C * C];
+            if (mode == 0) d = std::max(d, value); else d = std::min(d, value);
+            ch->dirty = true;
+        }
+    }
+
     static bool subChunkHasGeometry(const std::vector<SvoNode>& nodes, uint32_t subX, uint32_t subY,
                                     uint32_t subZ, uint32_t subDivisions) {     // :144-193
         if (nodes.empty()) return false;
@@ -617,6 +642,9 @@ void orc_world_set_voxels(void* w, const int32_t* xyz, const uint32_t* mats, siz
 }
 uint32_t orc_world_get_voxel_material(const void* w, float x, float y, float z) {
     return static_cast<const World*>(w)->getVoxelMaterial(x, y, z);
+}
+void orc_world_apply_brush(void* w, float x, float y, float z, float radius, float value, int mode) {
+    static_cast<World*>(w)->applyBrush(x, y, z, radius, value, mode);
 }
 int orc_world_rebuild(void* w, int maxPerFrame) { return static_cast<World*>(w)->rebuildDirtyChunks(maxPerFrame); }
 void orc_world_pack(void* w) { static_cast<World*>(w)->pack(); }
@@ -1083,6 +1111,62 @@ void orc_render_paths(const void* lattice, const void* nodes, const void* subs, 
 }  // extern "C"
 
 extern "C" {
+
+// tonemap.comp:17-143 (literal; push constants exposure / saturationBoost / tonemapOperator)
+namespace {
+inline float tmLuminance(Vec3 c) { return dot3(c, {0.2126f, 0.7152f, 0.0722f}); }
+inline float length3(Vec3 v) { return std::sqrt(dot3(v, v)); }
+Vec3 postTonemapSaturationBoost(Vec3 tonemapped, Vec3 originalHdr, float boost) {          // :43-61
+    if (boost <= 1.0f) return tonemapped;
+    const float hdrLuma = tmLuminance(originalHdr);
+    const float hdrSat = (hdrLuma > 0.0001f) ? length3(sub3(originalHdr, {hdrLuma, hdrLuma, hdrLuma})) / hdrLuma : 0.0f;
+    const float ldrLuma = tmLuminance(tonemapped);
+    const float ldrSat = (ldrLuma > 0.0001f) ? length3(sub3(tonemapped, {ldrLuma, ldrLuma, ldrLuma})) / ldrLuma : 0.0f;
+    if (ldrSat > 0.0001f && ldrLuma > 0.01f) {
+        const float satRatio = std::fmin(hdrSat / std::fmax(ldrSat, 0.001f), 2.0f);
+        const float recovery = 1.0f * (1.0f - (boost - 1.0f)) + satRatio * (boost - 1.0f);   // mix(1.0, satRatio, boost - 1.0)
+        return mix3({ldrLuma, ldrLuma, ldrLuma}, tonemapped, std::fmin(recovery, 1.5f));
+    }
+    return tonemapped;
+}
+Vec3 khronosPbrNeutral(Vec3 hdr) {                                                          // :65-82
+    const float startCompression = 0.8f - 0.04f;
+    const float desaturation = 0.15f;
+    const float x = std::fmin(hdr.x, std::fmin(hdr.y, hdr.z));
+    const float offset = x < 0.08f ? x - 6.25f * x * x : 0.04f;
+    hdr = {hdr.x - offset, hdr.y - offset, hdr.z - offset};
+    const float peak = std::fmax(hdr.x, std::fmax(hdr.y, hdr.z));
+    if (peak < startCompression) return hdr;
+    const float d = 1.0f - startCompression;
+    const float newPeak = 1.0f - d * d / (peak + d - startCompression);
+    hdr = scale3(hdr, newPeak / peak);
+    const float g = 1.0f - 1.0f / (desaturation * (peak - newPeak) + 1.0f);
+    return mix3(hdr, {newPeak, newPeak, newPeak}, g);
+}
+Vec3 neutralTonemap(Vec3 hdr) {                                                             // :85-95
+    const float peak = std::fmax(std::fmax(hdr.x, hdr.y), hdr.z);
+    if (peak <= 1.0f) return hdr;
+    const float compressed = 1.0f - std::exp(-(peak - 1.0f));
+    const float scale = (1.0f + compressed) / peak;
+    return scale3(hdr, scale);
+}
+}  // namespace
+
+extern "C" void orc_tonemap(const float* hdrRgba, uint32_t n, float exposure, float saturationBoost, int op, uint32_t* out) {
+    for (uint32_t i = 0; i < n; ++i) {                                                      // main(), :97-143
+        Vec3 hdr = {hdrRgba[4 * i], hdrRgba[4 * i + 1], hdrRgba[4 * i + 2]};
+        hdr = scale3(hdr, exposure);
+        const Vec3 hdrOriginal = hdr;
+        Vec3 ldr = op == 0 ? neutralTonemap(hdr) : khronosPbrNeutral(hdr);
+        if (saturationBoost > 1.0f) ldr = postTonemapSaturationBoost(ldr, hdrOriginal, saturationBoost);
+        else if (saturationBoost < 1.0f && saturationBoost > 0.0f) {
+            const float luma = tmLuminance(ldr);
+            ldr = mix3({luma, luma, luma}, ldr, saturationBoost);
+        }
+        auto unorm = [](float v) { return uint32_t(std::fmin(std::fmax(v, 0.0f), 1.0f) * 255.0f + 0.5f); };   // rgba8 store
+        out[i] = unorm(ldr.x) | (unorm(ldr.y) << 8) | (unorm(ldr.z) << 16) | 0xFF000000u;
+    }
+}
 
 // =============================================================================================
 // material.hpp:17-114, material.cpp, vox_loader.cpp:60-462 — materials and the MagicaVoxel importer.

@@ -94,6 +94,11 @@ void hh_trace_primary_events(const void* h, const blok_camera* cam, uint32_t wid
     g_seq = nullptr;
 }
 
+void hh_tonemap(const float* hdr, uint32_t n, float exposure, float saturation_boost, int op, uint32_t* out) {
+    TonemapArgs t{hdr, out, n, exposure, saturation_boost, op};
+    for (uint32_t i = 0; i < n; ++i) out[i] = tonemap_pixel(t, i);
+}
+
 // Per-ray iteration counts for a frame (row-major), plus the event totals [4][8].
 void hh_trace_primary_stats(const void* h, const blok_camera* cam, uint32_t width, uint32_t height, blok_hit* out,
                             uint32_t* iters_per_ray, uint64_t* totals) {

@@ -43,6 +43,7 @@ def lib() -> C.CDLL:
         L.orc_world_set_voxels.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         L.orc_world_get_voxel_material.restype = C.c_uint32
         L.orc_world_get_voxel_material.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float]
+        L.orc_world_apply_brush.argtypes = [C.c_void_p] + [C.c_float] * 5 + [C.c_int]
         L.orc_world_rebuild.restype = C.c_int
         L.orc_world_rebuild.argtypes = [C.c_void_p, C.c_int]
         L.orc_world_pack.argtypes = [C.c_void_p]
@@ -148,6 +149,9 @@ class OracleWorld:
     def get_voxel_material(self, p):
         return int(self.L.orc_world_get_voxel_material(self.h, p[0], p[1], p[2]))
 
+    def apply_brush(self, center, radius, value, mode="add"):
+        self.L.orc_world_apply_brush(self.h, center[0], center[1], center[2], radius, value, {"add": 0, "subtract": 1}[mode])
+
     def rebuild(self, max_per_frame=1 << 30):
         return self.L.orc_world_rebuild(self.h, max_per_frame)
 
@@ -227,6 +231,15 @@ def render_paths(lattice: "Lattice", materials, cam, width, height, spp=8, max_b
                            _p(planes["world_pos"]), _p(planes["normal_roughness"]), _p(planes["albedo_metallic"]),
                            _p(ctr), threads)
     return planes, ctr[0]
+
+
+def tonemap(hdr, exposure=1.0, saturation_boost=1.15, operator=1):
+    hdr = np.ascontiguousarray(hdr, dtype=np.float32)
+    out = np.zeros(hdr.shape[:-1], dtype=np.uint32)
+    L = lib()
+    L.orc_tonemap.argtypes = [C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_int, C.c_void_p]
+    L.orc_tonemap(_p(hdr), out.size, exposure, saturation_boost, operator, _p(out))
+    return out
 
 
 def trace_voxels_bruteforce(xyz, mats, rays):
