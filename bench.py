@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0xB10C0001)
     ap.add_argument("--cpu-stride", type=int, default=1, help="CPU baseline traces every stride-th pixel in x and y")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-paths", action="store_true", help="skip the 64-spp path-tracing side measurement")
     return ap.parse_args()
 
 
@@ -166,6 +167,22 @@ def main():
     sky = 0xFF000000 | (230 << 16) | (200 << 8) | 160
     lit_pixels = int((pipe.frame_rgba != (sky - (1 << 32))).sum().item()) if rank == 0 else 0
 
+    # side measurement (not the headline value): BASELINE.json configs[4], the reference's sample/bounce loop at
+    # 64 spp, 2 bounces, over the same world and frame — two frames, HIP events around the kernel
+    paths = None
+    if world_size == 1 and not args.no_paths:
+        color = torch.empty((H_ * W_, 4), dtype=torch.float32, device="cuda")
+        tracer.set_timing(True)
+        ms = []
+        for f in range(3):
+            tracer.trace_paths_device(cam, color.data_ptr(), spp=64, max_bounces=2, frame_index=f, stream=stream.cuda_stream)
+            torch.cuda.synchronize()
+            ms.append(tracer.last_kernel_ms())
+        tracer.set_timing(False)
+        paths = {"config": "3840x2160 x 64 spp, 2 bounces + sun shadow ray (raygen.rgen loop)", "ms_per_frame": float(np.mean(ms[1:])),
+                 "Gpaths_per_s": W_ * H_ * 64 / (float(np.mean(ms[1:])) * 1e-3) / 1e9}
+        del color
+
     if rank == 0:
         rays_per_step = W_ * H_
         value = rays_per_step * args.steps / elapsed / 1e6
@@ -181,7 +198,7 @@ def main():
                        "parallelism": "single GPU" if world_size == 1 else f"{args.tile}x{args.tile} screen tiles round-robin over {world_size} GPUs, RCCL gather of RGBA8 tiles to rank 0, 2-deep pipeline",
                        "hits_per_frame": hits, "framebuffer_pixels_hit": lit_pixels,
                        "outputs": "16-B first-hit records (kept on the tracing GPU) + RGBA8 framebuffer on rank 0",
-                       "device_ms_per_step": device_ms / args.steps},
+                       "device_ms_per_step": device_ms / args.steps, "also_measured_paths": paths},
         }
         alg = None
         if not args.no_cpu_baseline:

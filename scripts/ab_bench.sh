@@ -3,7 +3,7 @@
 cd "$GRAFT_REPO_ROOT"
 for rep in 1 2; do
   for lib in blok_amd/libblok_hip.so blok_amd/variants/*.so; do
-    BLOK_HIP_LIB=$PWD/$lib timeout -k 10 120 python bench.py --steps 100 --warmup 10 --no-cpu-baseline 2>/dev/null | python -c "
+    BLOK_HIP_LIB=$PWD/$lib timeout -k 10 120 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-paths 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.readlines()[-1]); print('$lib', 'rep$rep', round(d['value']), 'Mrays/s', round(d['ms_per_step'], 4), 'ms')"
   done
