@@ -255,6 +255,29 @@ int blok_hip_upload_dense(blok_hip_ctx* ctx, const uint32_t* ids, uint32_t nx, u
         return set_error(ctx, BLOK_ERR_INVALID_ARG, "bad dense grid arguments");
     BLOK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int32_t o[3] = {origin ? origin[0] : 0, origin ? origin[1] : 0, origin ? origin[2] : 0};
+    if (!ctx->force_host_build) {                      // device-side build straight from the grid (gpu_build.hip)
+        blok::GpuTree gpu;
+        std::string reason;
+        const blok::GpuBuildStatus st = blok::gpu_build_tree_dense(ids, nx, ny, nz, o, &gpu, &reason);
+        if (st == blok::GpuBuildStatus::Unsupported) return set_error(ctx, BLOK_ERR_UNSUPPORTED, reason);
+        if (st == blok::GpuBuildStatus::HipError) return set_error(ctx, BLOK_ERR_HIP, reason);
+        if (st == blok::GpuBuildStatus::OutOfMemory) return set_error(ctx, BLOK_ERR_OOM, reason);
+        if (st == blok::GpuBuildStatus::Ok) {
+            free_world(ctx);
+            ctx->d_nodes = gpu.d_nodes;
+            ctx->d_tree_materials = gpu.d_materials;
+            const int rc = install_materials(ctx, materials, n_materials);
+            if (rc != BLOK_OK) { free_world(ctx); return rc; }
+            ctx->stats.n_voxels = gpu.n_voxels;
+            ctx->stats.n_tree_nodes = gpu.n_nodes;
+            ctx->stats.tree_bytes = gpu.n_nodes * sizeof(blok::TreeNode) + gpu.n_voxels * sizeof(uint32_t);
+            ctx->stats.levels = gpu.levels;
+            for (int a = 0; a < 3; ++a) ctx->stats.origin[a] = gpu.origin[a];
+            ctx->has_world = true;
+            ctx->built_on_device = true;
+            return BLOK_OK;
+        }
+    }
     std::vector<blok::VoxelRec> voxels;
     for (uint32_t z = 0; z < nz; ++z)
         for (uint32_t y = 0; y < ny; ++y) {

@@ -26,5 +26,9 @@ enum class GpuBuildStatus { Ok, UseHostBuilder, Unsupported, HipError, OutOfMemo
 GpuBuildStatus gpu_build_tree(const blok_svo_node* nodes, size_t n_nodes, const blok_sub_chunk* subs, size_t n_subs,
                               GpuTree* out, std::string* why);
 
+// Same, from a dense id grid ids[x + y*nx + z*nx*ny] (0 = empty) whose voxel (0,0,0) sits at world `origin`.
+GpuBuildStatus gpu_build_tree_dense(const uint32_t* ids, uint32_t nx, uint32_t ny, uint32_t nz, const int32_t origin[3],
+                                    GpuTree* out, std::string* why);
+
 }  // namespace blok
 #endif

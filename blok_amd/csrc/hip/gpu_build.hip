@@ -170,6 +170,71 @@ struct DeviceBuffers {          // frees everything it still owns on scope exit
 
 inline uint32_t blocks_for(uint64_t n) { return static_cast<uint32_t>((n + 255u) / 256u); }
 
+// Common tail of the builders: compaction of the non-empty bricks, keys, radix sort, material offsets, material
+// ids, upper levels, final node array.  `launch_keys` / `launch_materials` enqueue the source-specific kernels.
+template <class KeyLauncher, class MaterialLauncher>
+GpuBuildStatus finish_from_masks(DeviceBuffers& mem, uint64_t total, const uint64_t* d_masks, uint32_t* d_flag, uint32_t* d_slot,
+                                 uint32_t levels, const int32_t lo[3], KeyLauncher launch_keys, MaterialLauncher launch_materials,
+                                 GpuTree* out, std::string* why) {
+    size_t temp_bytes = 0;
+    GB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, temp_bytes, d_flag, d_slot, static_cast<int>(total + 1)));
+    size_t scan_bytes = temp_bytes;
+    uint8_t* d_scratch;
+    GB_TRY(mem.alloc(&d_scratch, scan_bytes));
+    GB_TRY(hipcub::DeviceScan::ExclusiveSum(d_scratch, temp_bytes, d_flag, d_slot, static_cast<int>(total + 1)));
+    uint32_t n_bricks = 0;
+    GB_TRY(hipMemcpy(&n_bricks, d_slot + total, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (n_bricks == 0) return GpuBuildStatus::UseHostBuilder;
+
+    uint64_t *d_keys, *d_keys_sorted, *d_masks_sorted; uint32_t *d_src, *d_src_sorted, *d_counts, *d_mat_base;
+    GB_TRY(mem.alloc(&d_keys, n_bricks)); GB_TRY(mem.alloc(&d_keys_sorted, n_bricks));
+    GB_TRY(mem.alloc(&d_src, n_bricks)); GB_TRY(mem.alloc(&d_src_sorted, n_bricks));
+    GB_TRY(mem.alloc(&d_masks_sorted, n_bricks));
+    GB_TRY(mem.alloc(&d_counts, n_bricks + 1)); GB_TRY(mem.alloc(&d_mat_base, n_bricks + 1));
+    launch_keys(d_slot, d_keys, d_src);
+    GB_TRY(hipGetLastError());
+    const int key_bits = std::max(1, static_cast<int>(6 * (levels - 1)));
+    temp_bytes = 0;
+    GB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, d_keys, d_keys_sorted, d_src, d_src_sorted, static_cast<int>(n_bricks), 0, key_bits));
+    uint8_t* d_sort_scratch;
+    GB_TRY(mem.alloc(&d_sort_scratch, temp_bytes));
+    GB_TRY(hipcub::DeviceRadixSort::SortPairs(d_sort_scratch, temp_bytes, d_keys, d_keys_sorted, d_src, d_src_sorted, static_cast<int>(n_bricks), 0, key_bits));
+    hipLaunchKernelGGL(gather_mask_kernel, dim3(blocks_for(n_bricks)), dim3(256), 0, nullptr, d_masks, d_src_sorted, n_bricks, d_masks_sorted, d_counts);
+    GB_TRY(hipGetLastError());
+    GB_TRY(hipMemset(d_counts + n_bricks, 0, sizeof(uint32_t)));
+    temp_bytes = 0;
+    GB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, temp_bytes, d_counts, d_mat_base, static_cast<int>(n_bricks + 1)));
+    if (temp_bytes > scan_bytes) { GB_TRY(mem.alloc(&d_scratch, temp_bytes)); scan_bytes = temp_bytes; }
+    GB_TRY(hipcub::DeviceScan::ExclusiveSum(d_scratch, temp_bytes, d_counts, d_mat_base, static_cast<int>(n_bricks + 1)));
+    uint32_t n_voxels = 0;
+    GB_TRY(hipMemcpy(&n_voxels, d_mat_base + n_bricks, sizeof(uint32_t), hipMemcpyDeviceToHost));
+
+    uint32_t* d_materials;
+    GB_TRY(mem.alloc(&d_materials, n_voxels));
+    launch_materials(d_masks_sorted, d_src_sorted, d_mat_base, n_bricks, d_materials);
+    GB_TRY(hipGetLastError());
+
+    // the levels above the bricks, on the host, from the sorted keys
+    std::vector<uint64_t> keys(n_bricks);
+    GB_TRY(hipMemcpy(keys.data(), d_keys_sorted, n_bricks * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    std::vector<TreeNode> upper;
+    if (!build_upper_levels(keys, levels, upper)) return GpuBuildStatus::UseHostBuilder;    // duplicate bricks: general path
+    uint4* d_tree;
+    const size_t n_tree = upper.size() + n_bricks;
+    GB_TRY(mem.alloc(&d_tree, n_tree));
+    GB_TRY(hipMemcpy(d_tree, upper.data(), upper.size() * sizeof(TreeNode), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(brick_node_kernel, dim3(blocks_for(n_bricks)), dim3(256), 0, nullptr, d_masks_sorted, d_mat_base, n_bricks,
+                       d_tree + upper.size());
+    GB_TRY(hipGetLastError());
+    GB_TRY(hipDeviceSynchronize());
+
+    mem.release(d_tree); mem.release(d_materials);
+    out->d_nodes = d_tree; out->d_materials = d_materials;
+    out->n_nodes = n_tree; out->n_voxels = n_voxels; out->levels = levels;
+    for (int a = 0; a < 3; ++a) out->origin[a] = lo[a];
+    return GpuBuildStatus::Ok;
+}
+
 }  // namespace
 
 GpuBuildStatus gpu_build_tree(const blok_svo_node* nodes, size_t n_nodes, const blok_sub_chunk* subs, size_t n_subs,
@@ -232,70 +297,117 @@ GpuBuildStatus gpu_build_tree(const blok_svo_node* nodes, size_t n_nodes, const 
 
     hipLaunchKernelGGL(brick_mask_kernel, dim3(blocks_for(total)), dim3(256), 0, nullptr, c, d_masks, d_flag, d_error);
     GB_TRY(hipGetLastError());
-    // exclusive scan of the non-empty flags (one extra element = total count)
-    void* d_temp = nullptr; size_t temp_bytes = 0;
-    GB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, temp_bytes, d_flag, d_slot, static_cast<int>(total + 1)));
-    size_t scan_bytes = temp_bytes;
-    uint8_t* d_scratch;
-    GB_TRY(mem.alloc(&d_scratch, scan_bytes));
-    d_temp = d_scratch;
-    GB_TRY(hipcub::DeviceScan::ExclusiveSum(d_temp, temp_bytes, d_flag, d_slot, static_cast<int>(total + 1)));
-    uint32_t n_bricks = 0, error = 0;
-    GB_TRY(hipMemcpy(&n_bricks, d_slot + total, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    uint32_t error = 0;
     GB_TRY(hipMemcpy(&error, d_error, sizeof(uint32_t), hipMemcpyDeviceToHost));
     if (error & kErrLeafAboveVoxel) { *why = "filled leaf above voxel level (not produced by SvoTree::insertVoxel)"; return GpuBuildStatus::Unsupported; }
     if (error & kErrInteriorBelowVoxel) { *why = "interior node below voxel level"; return GpuBuildStatus::Unsupported; }
-    if (n_bricks == 0) return GpuBuildStatus::UseHostBuilder;
-
-    uint64_t *d_keys, *d_keys_sorted, *d_masks_sorted; uint32_t *d_src, *d_src_sorted, *d_counts, *d_mat_base;
-    GB_TRY(mem.alloc(&d_keys, n_bricks)); GB_TRY(mem.alloc(&d_keys_sorted, n_bricks));
-    GB_TRY(mem.alloc(&d_src, n_bricks)); GB_TRY(mem.alloc(&d_src_sorted, n_bricks));
-    GB_TRY(mem.alloc(&d_masks_sorted, n_bricks));
-    GB_TRY(mem.alloc(&d_counts, n_bricks + 1)); GB_TRY(mem.alloc(&d_mat_base, n_bricks + 1));
     KeyCtx k{}; for (int a = 0; a < 3; ++a) k.origin[a] = lo[a]; k.levels = levels;
-    hipLaunchKernelGGL(brick_key_kernel, dim3(blocks_for(total)), dim3(256), 0, nullptr, c, k, d_masks, d_slot, total, d_keys, d_src);
-    GB_TRY(hipGetLastError());
-    const int key_bits = std::max(1, static_cast<int>(6 * (levels - 1)));
-    temp_bytes = 0;
-    GB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, d_keys, d_keys_sorted, d_src, d_src_sorted, static_cast<int>(n_bricks), 0, key_bits));
-    uint8_t* d_sort_scratch;
-    GB_TRY(mem.alloc(&d_sort_scratch, temp_bytes));
-    GB_TRY(hipcub::DeviceRadixSort::SortPairs(d_sort_scratch, temp_bytes, d_keys, d_keys_sorted, d_src, d_src_sorted, static_cast<int>(n_bricks), 0, key_bits));
-    hipLaunchKernelGGL(gather_mask_kernel, dim3(blocks_for(n_bricks)), dim3(256), 0, nullptr, d_masks, d_src_sorted, n_bricks, d_masks_sorted, d_counts);
-    GB_TRY(hipGetLastError());
-    GB_TRY(hipMemset(d_counts + n_bricks, 0, sizeof(uint32_t)));
-    temp_bytes = 0;
-    GB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, temp_bytes, d_counts, d_mat_base, static_cast<int>(n_bricks + 1)));
-    if (temp_bytes > scan_bytes) { GB_TRY(mem.alloc(&d_scratch, temp_bytes)); scan_bytes = temp_bytes; }
-    GB_TRY(hipcub::DeviceScan::ExclusiveSum(d_scratch, temp_bytes, d_counts, d_mat_base, static_cast<int>(n_bricks + 1)));
-    uint32_t n_voxels = 0;
-    GB_TRY(hipMemcpy(&n_voxels, d_mat_base + n_bricks, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return finish_from_masks(mem, total, d_masks, d_flag, d_slot, levels, lo,
+        [&](const uint32_t* slot, uint64_t* keys, uint32_t* src) {
+            hipLaunchKernelGGL(brick_key_kernel, dim3(blocks_for(total)), dim3(256), 0, nullptr, c, k, d_masks, slot, total, keys, src);
+        },
+        [&](const uint64_t* masks_sorted, const uint32_t* src_sorted, const uint32_t* mat_base, uint32_t n_bricks, uint32_t* materials) {
+            hipLaunchKernelGGL(material_kernel, dim3(blocks_for(static_cast<uint64_t>(n_bricks) * 64u)), dim3(256), 0, nullptr,
+                               c, masks_sorted, src_sorted, mat_base, n_bricks, materials);
+        }, out, why);
+}
 
-    uint32_t* d_materials;
-    GB_TRY(mem.alloc(&d_materials, n_voxels));
-    hipLaunchKernelGGL(material_kernel, dim3(blocks_for(static_cast<uint64_t>(n_bricks) * 64u)), dim3(256), 0, nullptr,
-                       c, d_masks_sorted, d_src_sorted, d_mat_base, n_bricks, d_materials);
-    GB_TRY(hipGetLastError());
+// ---- dense id grid (BASELINE.json configs[0..1]; reference dense store chunk.hpp:35-36) --------------------------
+namespace {
 
-    // ---- the levels above the bricks, on the host, from the sorted keys
-    std::vector<uint64_t> keys(n_bricks);
-    GB_TRY(hipMemcpy(keys.data(), d_keys_sorted, n_bricks * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    std::vector<TreeNode> upper;
-    if (!build_upper_levels(keys, levels, upper)) return GpuBuildStatus::UseHostBuilder;    // duplicate bricks: general path
-    uint4* d_tree;
-    const size_t n_tree = upper.size() + n_bricks;
-    GB_TRY(mem.alloc(&d_tree, n_tree));
-    GB_TRY(hipMemcpy(d_tree, upper.data(), upper.size() * sizeof(TreeNode), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(brick_node_kernel, dim3(blocks_for(n_bricks)), dim3(256), 0, nullptr, d_masks_sorted, d_mat_base, n_bricks,
-                       d_tree + upper.size());
-    GB_TRY(hipGetLastError());
-    GB_TRY(hipDeviceSynchronize());
+struct DenseCtx {
+    const uint32_t* ids;          // ids[x + y*nx + z*nx*ny], 0 = empty
+    uint32_t nx, ny, nz;
+    uint32_t bx, by, bz;          // bricks per axis
+    uint32_t levels;
+};
 
-    mem.release(d_tree); mem.release(d_materials);
-    out->d_nodes = d_tree; out->d_materials = d_materials;
-    out->n_nodes = n_tree; out->n_voxels = n_voxels; out->levels = levels;
-    for (int a = 0; a < 3; ++a) out->origin[a] = lo[a];
-    return GpuBuildStatus::Ok;
+// One lane per brick: 16 rows of 4 consecutive ids; neighbouring lanes read neighbouring 16-byte groups of a row.
+__global__ __launch_bounds__(256) void dense_brick_kernel(const DenseCtx d, uint64_t total, uint64_t* masks, uint32_t* non_empty) {
+    const uint64_t tid = static_cast<uint64_t>(blockIdx.x) * 256u + threadIdx.x;
+    if (tid >= total) return;
+    const uint32_t b_x = static_cast<uint32_t>(tid % d.bx), b_y = static_cast<uint32_t>((tid / d.bx) % d.by), b_z = static_cast<uint32_t>(tid / (static_cast<uint64_t>(d.bx) * d.by));
+    uint64_t mask = 0;
+    for (uint32_t z = 0; z < 4u; ++z)
+        for (uint32_t y = 0; y < 4u; ++y) {
+            const uint32_t vy = b_y * 4u + y, vz = b_z * 4u + z;
+            if (vy >= d.ny || vz >= d.nz) continue;
+            const uint32_t* row = d.ids + (static_cast<size_t>(vz) * d.ny + vy) * d.nx + b_x * 4u;
+            for (uint32_t x = 0; x < 4u; ++x)
+                if (b_x * 4u + x < d.nx && row[x] != 0u) mask |= 1ull << (x | (y << 2) | (z << 4));
+        }
+    masks[tid] = mask;
+    non_empty[tid] = mask != 0ull;
+}
+
+__global__ __launch_bounds__(256) void dense_key_kernel(const DenseCtx d, const uint64_t* masks, const uint32_t* slot_of, uint64_t total,
+                                                        uint64_t* keys, uint32_t* src) {
+    const uint64_t tid = static_cast<uint64_t>(blockIdx.x) * 256u + threadIdx.x;
+    if (tid >= total || masks[tid] == 0ull) return;
+    const uint32_t x = static_cast<uint32_t>(tid % d.bx) * 4u, y = static_cast<uint32_t>((tid / d.bx) % d.by) * 4u,
+                   z = static_cast<uint32_t>(tid / (static_cast<uint64_t>(d.bx) * d.by)) * 4u;
+    uint64_t key = 0;
+    for (uint32_t l = 1; l < d.levels; ++l) {
+        const uint64_t digit = ((x >> (2 * l)) & 3u) | (((y >> (2 * l)) & 3u) << 2) | (((z >> (2 * l)) & 3u) << 4);
+        key |= digit << (6 * (l - 1));
+    }
+    const uint32_t slot = slot_of[tid];
+    keys[slot] = key;
+    src[slot] = static_cast<uint32_t>(tid);
+}
+
+__global__ __launch_bounds__(256) void dense_material_kernel(const DenseCtx d, const uint64_t* masks_sorted, const uint32_t* src_sorted,
+                                                             const uint32_t* mat_base, uint32_t n_bricks, uint32_t* materials) {
+    const uint64_t tid = static_cast<uint64_t>(blockIdx.x) * 256u + threadIdx.x;
+    const uint32_t i = static_cast<uint32_t>(tid >> 6), bit = static_cast<uint32_t>(tid & 63u);
+    if (i >= n_bricks) return;
+    const uint64_t mask = masks_sorted[i];
+    if (!((mask >> bit) & 1ull)) return;
+    const uint32_t g = src_sorted[i];
+    const uint32_t vx = (g % d.bx) * 4u + (bit & 3u), vy = ((g / d.bx) % d.by) * 4u + ((bit >> 2) & 3u), vz = (g / (d.bx * d.by)) * 4u + (bit >> 4);
+    materials[mat_base[i] + __popcll(mask & ((1ull << bit) - 1ull))] = d.ids[(static_cast<size_t>(vz) * d.ny + vy) * d.nx + vx];
+}
+
+}  // namespace
+
+GpuBuildStatus gpu_build_tree_dense(const uint32_t* ids, uint32_t nx, uint32_t ny, uint32_t nz, const int32_t origin[3],
+                                    GpuTree* out, std::string* why) {
+    *out = GpuTree{};
+    const uint64_t cells = static_cast<uint64_t>(nx) * ny * nz;
+    if (cells == 0) return GpuBuildStatus::UseHostBuilder;
+    for (int a = 0; a < 3; ++a) {
+        const int64_t hi = int64_t(origin[a]) + (a == 0 ? nx : a == 1 ? ny : nz);
+        if (origin[a] < -32768 || hi > 32768) { *why = "world voxel coordinates exceed int16 (hit records carry int16)"; return GpuBuildStatus::Unsupported; }
+    }
+    const uint32_t extent = std::max(nx, std::max(ny, nz));
+    uint32_t levels = 1;
+    while ((uint64_t(1) << (2 * levels)) < extent) ++levels;
+    if (levels > kMaxLevels) { *why = "world extent exceeds 4^7 voxels per axis"; return GpuBuildStatus::Unsupported; }
+    DenseCtx d{};
+    d.nx = nx; d.ny = ny; d.nz = nz; d.levels = levels;
+    d.bx = (nx + 3) / 4; d.by = (ny + 3) / 4; d.bz = (nz + 3) / 4;
+    const uint64_t total = static_cast<uint64_t>(d.bx) * d.by * d.bz;
+    if (total > 0x7FFFFFFFull) return GpuBuildStatus::UseHostBuilder;
+    DeviceBuffers mem;
+    uint32_t* d_ids; uint64_t* d_masks; uint32_t *d_flag, *d_slot;
+    GB_TRY(mem.alloc(&d_ids, cells));
+    GB_TRY(mem.alloc(&d_masks, total));
+    GB_TRY(mem.alloc(&d_flag, total + 1));
+    GB_TRY(mem.alloc(&d_slot, total + 1));
+    GB_TRY(hipMemcpy(d_ids, ids, cells * sizeof(uint32_t), hipMemcpyHostToDevice));
+    GB_TRY(hipMemset(d_flag + total, 0, sizeof(uint32_t)));
+    d.ids = d_ids;
+    hipLaunchKernelGGL(dense_brick_kernel, dim3(blocks_for(total)), dim3(256), 0, nullptr, d, total, d_masks, d_flag);
+    GB_TRY(hipGetLastError());
+    const int32_t lo[3] = {origin[0], origin[1], origin[2]};
+    return finish_from_masks(mem, total, d_masks, d_flag, d_slot, levels, lo,
+        [&](const uint32_t* slot, uint64_t* keys, uint32_t* src) {
+            hipLaunchKernelGGL(dense_key_kernel, dim3(blocks_for(total)), dim3(256), 0, nullptr, d, d_masks, slot, total, keys, src);
+        },
+        [&](const uint64_t* masks_sorted, const uint32_t* src_sorted, const uint32_t* mat_base, uint32_t n_bricks, uint32_t* materials) {
+            hipLaunchKernelGGL(dense_material_kernel, dim3(blocks_for(static_cast<uint64_t>(n_bricks) * 64u)), dim3(256), 0, nullptr,
+                               d, masks_sorted, src_sorted, mat_base, n_bricks, materials);
+        }, out, why);
 }
 
 }  // namespace blok

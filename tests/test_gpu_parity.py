@@ -294,3 +294,34 @@ def test_config4_2048_svo_4k_tiles(tracer_cls):
     torch.cuda.synchronize()
     assert (out.cpu().numpy().view(np.uint8).reshape(-1, 16) == full.reshape(-1).view(np.uint8).reshape(-1, 16)).all()
     tr.shutdown()
+
+
+def test_dense_upload_device_build(tracer_cls):
+    """blok_hip_upload_dense builds on the device straight from the id grid: ragged extents, negative origin,
+    same frames as the general host path; 256^3 timing printed."""
+    import time
+    rng = np.random.default_rng(12)
+    ids = np.where(rng.random((37, 22, 51)) < 0.03, rng.integers(1, 300, size=(37, 22, 51)), 0).astype(np.uint32)   # [z][y][x]
+    origin = (-20, 5, -9)
+    z, y, x = np.nonzero(ids)
+    cm = W.ChunkManager(128, 1.0)
+    cm.set_voxels(np.stack([x + origin[0], y + origin[1], z + origin[2]], 1), ids[z, y, x])
+    cm.rebuild_dirty_chunks()
+    pw = cm.pack_chunks_to_gpu_svo()
+    rays = random_rays(60, 6000, 2)
+    rays["org"] += np.array(origin, dtype=np.float32)
+    ref, ctr = O.Lattice(pw.nodes, pw.sub_chunks).trace(rays, threads=4)
+    tr = tracer_cls(64, 64).init()
+    st = tr.add_dense(ids, origin)
+    assert tr.built_on_device() and st.n_voxels == len(x) and list(st.origin) == list(origin) and ctr["hits"] > 300
+    assert records_equal(tr.trace_rays(rays), ref).all()
+    tr.set_host_build(True)
+    tr.add_dense(ids, origin)
+    assert not tr.built_on_device() and records_equal(tr.trace_rays(rays), ref).all()
+    tr.set_host_build(False)
+    big = W.scene_dense(256, SEED)
+    t0 = time.perf_counter(); tr.add_dense(big); t_dev = time.perf_counter() - t0
+    tr.set_host_build(True)
+    t0 = time.perf_counter(); tr.add_dense(big); t_host = time.perf_counter() - t0
+    print(f"dense 256^3 upload: device build {t_dev * 1e3:.1f} ms, host build {t_host * 1e3:.1f} ms")
+    tr.shutdown()
