@@ -1,9 +1,9 @@
 // Per-pixel sample / bounce loop on top of walk(): the reference's ray-generation shader
 // (assets/shaders/raygen.rgen:77-165 RNG, sampling, sky; :167-414 main) with hit.rchit / miss.rmiss /
 // shadow.rmiss folded in.  One lane = one pixel.  Operation order follows the shader statement by statement;
-// every float op is a single rounded op (no contraction), sqrt and divide are correctly rounded, and
-// sin / cos / pow come from the device math library (a few ulp from any other implementation — the tolerance
-// the parity tests state).  Compiles for the host under BLOK_TRACE_HOST_HARNESS like trace_core.h.
+// every float op is a single rounded op (no contraction), sqrt and divide are correctly rounded; sin / cos come
+// from the device math library and the shader's pow(x, 5 | 8 | 128) are done by multiplication (both a few ulp
+// from any other implementation — the tolerance the parity tests state).  Compiles for the host under BLOK_TRACE_HOST_HARNESS like trace_core.h.
 //
 // Deliberate, documented differences from the shader:
 //  - the primary ray is formed from the camera basis (cuda_tracer.cu:276-282) instead of invProj/invView
@@ -90,8 +90,15 @@ BLOK_DEV V3 sample_ggx(float ux, float uy, V3 n, float roughness) {    // :115-1
     tangent_frame(n, t, b);
     return vnormalize(vadd(vadd(vscale(t, h.x), vscale(b, h.y)), vscale(n, h.z)));
 }
+// pow(x, k) for the shader's integer exponents 5, 8, 128 by multiplication (<= 4 ulp from a correctly rounded
+// pow; GLSL's own pow is exp2(y*log2(x)) at driver precision).  Far inside the stated colour tolerance, and
+// ~10x fewer instructions than the library powf on a path where every miss sample evaluates two of them.
+BLOK_DEV float pow5(float x) { const float x2 = x * x; return x2 * x2 * x; }
+BLOK_DEV float pow8(float x) { const float x2 = x * x; const float x4 = x2 * x2; return x4 * x4; }
+BLOK_DEV float pow128(float x) { float y = pow8(x); y = y * y; y = y * y; y = y * y; return y * y; }
+
 BLOK_DEV V3 fresnel_schlick(float cos_theta, V3 f0) {                  // :132-134
-    const float w = powf(fmaxf(1.0f - cos_theta, 0.0f), 5.0f);
+    const float w = pow5(fmaxf(1.0f - cos_theta, 0.0f));
     return v3(f0.x + (1.0f - f0.x) * w, f0.y + (1.0f - f0.y) * w, f0.z + (1.0f - f0.z) * w);
 }
 BLOK_DEV V3 sun_direction() { return vnormalize(v3(0.5f, 0.8f, 0.3f)); }   // :142, :185
@@ -99,8 +106,8 @@ BLOK_DEV V3 sky_color(V3 dir) {                                         // :136-
     const float t = 0.5f * (dir.y + 1.0f);
     const V3 sky = vmix(v3(0.8f, 0.85f, 0.95f), v3(0.4f, 0.6f, 0.9f), t);
     const float sun_dot = fmaxf(vdot(dir, sun_direction()), 0.0f);
-    const V3 sun = vscale(vscale(v3(1.0f, 0.95f, 0.8f), powf(sun_dot, 128.0f)), 5.0f);
-    const V3 glow = vscale(vscale(v3(1.0f, 0.9f, 0.7f), powf(sun_dot, 8.0f)), 0.3f);
+    const V3 sun = vscale(vscale(v3(1.0f, 0.95f, 0.8f), pow128(sun_dot)), 5.0f);
+    const V3 glow = vscale(vscale(v3(1.0f, 0.9f, 0.7f), pow8(sun_dot)), 0.3f);
     return vadd(vadd(sky, sun), glow);
 }
 BLOK_DEV bool is_emissive(V3 e) { return vdot(e, v3(1.0f, 1.0f, 1.0f)) > 0.01f; }                // :158-160
@@ -113,6 +120,13 @@ BLOK_DEV void store4(float* plane, size_t i, float a, float b, float c, float d)
 }
 
 // raygen.rgen:167-414 for pixel (px, py) of the full frame; `index` is its slot in the output planes.
+//
+// The shader's nested loops (samples x bounces, each bounce a radiance trace and possibly a shadow trace) are
+// run as a state machine with ONE trace per iteration: a lane whose sample ended starts its next sample at once,
+// and a lane waiting for its shadow ray traces it in the same walk() call in which its neighbours trace radiance
+// rays.  Every lane still performs exactly the shader's sequence of operations for its pixel, so results do not
+// depend on what the other lanes do; what changes is that the wave runs max-over-lanes of the TOTAL number of
+// traces instead of the sum over samples of per-sample maxima, and that walk() exists once in the code.
 BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t index, uint4* stk) {
     const TraceArgs& A = P.trace;
     const blok_camera& cam = A.cam;
@@ -120,16 +134,24 @@ BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t in
     const V3 cam_f = v3(cam.fwd[0], cam.fwd[1], cam.fwd[2]);
     const V3 cam_r = v3(cam.right[0], cam.right[1], cam.right[2]);
     const V3 cam_u = v3(cam.up[0], cam.up[1], cam.up[2]);
-    V3 first_pos = v3(0, 0, 0), first_normal = v3(0, 0, 0), first_albedo = v3(0, 0, 0), first_emission = v3(0, 0, 0);
+    V3 first_pos = v3(0, 0, 0), first_normal = v3(0, 0, 0), first_albedo = v3(0, 0, 0), first_emission = v3(0, 0, 0);   // :173-181
     float first_roughness = 0.0f, first_metallic = 0.0f, first_depth = 0.0f;
     bool had_first_hit = false, first_was_emissive = false;
     V3 accumulated = v3(0, 0, 0);
     const V3 sun_dir = sun_direction();
     const V3 sun_radiance = v3(3.0f, 2.9f, 2.7f);
 
-    for (uint32_t s = 0u; s < P.spp; ++s) {                                                  // :188
-        uint32_t rng = init_rng(px, py, A.frame_w, P.frame_count, s);
-        float pcx, pcy;                                                                        // :193-199
+    // per-sample state
+    uint32_t s = 0u, bounce = 0u, rng = 0u;
+    V3 ray_org = cam_pos, ray_dir = cam_f, radiance = v3(0, 0, 0), throughput = v3(1, 1, 1);
+    // surface state kept across the shadow trace
+    bool shadow_phase = false;
+    V3 n = v3(0, 1, 0), albedo = v3(0, 0, 0), hit_pos = v3(0, 0, 0);
+    float roughness = 0.0f, metallic = 0.0f, n_dot_l = 0.0f;
+
+    auto begin_sample = [&]() {                                                              // :190-209
+        rng = init_rng(px, py, A.frame_w, P.frame_count, s);
+        float pcx, pcy;
         if (s == 0u) { pcx = static_cast<float>(px) + 0.5f; pcy = static_cast<float>(py) + 0.5f; }
         else {
             const float jx = random_float(rng) - 0.5f;
@@ -139,31 +161,62 @@ BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t in
         }
         const float u = (2.0f * (pcx / static_cast<float>(A.frame_w)) - 1.0f) * cam.tan_half_fov * cam.aspect;
         const float v = (1.0f - 2.0f * (pcy / static_cast<float>(A.frame_h))) * cam.tan_half_fov;
-        V3 ray_dir = vnormalize(vadd(vadd(cam_f, vscale(cam_r, u)), vscale(cam_u, v)));
-        V3 ray_org = cam_pos;
-        V3 radiance = v3(0, 0, 0), throughput = v3(1, 1, 1);
+        ray_dir = vnormalize(vadd(vadd(cam_f, vscale(cam_r, u)), vscale(cam_u, v)));
+        ray_org = cam_pos;
+        radiance = v3(0, 0, 0); throughput = v3(1, 1, 1);
+        bounce = 0u;
+    };
+    if (P.spp != 0u && P.max_bounces != 0u) begin_sample();
 
-        for (uint32_t bounce = 0u; bounce < P.max_bounces; ++bounce) {                        // :212
-            RayIn r;
+    while (s < P.spp && P.max_bounces != 0u) {
+        RayIn r;
+        if (shadow_phase) {
+            const V3 so = vadd(hit_pos, vscale(n, 0.001f));                                   // :284
+            r.ox = so.x; r.oy = so.y; r.oz = so.z;
+            r.dx = sun_dir.x; r.dy = sun_dir.y; r.dz = sun_dir.z;
+            r.tmin = 0.001f; r.tmax = 1000.0f;                                                // :294,:296
+        } else {
             r.ox = ray_org.x; r.oy = ray_org.y; r.oz = ray_org.z;
             r.dx = ray_dir.x; r.dy = ray_dir.y; r.dz = ray_dir.z;
             r.tmin = 0.001f; r.tmax = 10000.0f;                                               // :225,:227
-            const HitInfo hit = walk(A, r, stk);
-            if (!hit.found) {                                                                 // :232-235, miss.rmiss
-                radiance = vadd(radiance, vmul(throughput, sky_color(ray_dir)));
-                break;
+        }
+        const HitInfo hit = walk(A, r, stk);
+
+        bool end_sample = false, continue_path = false;
+        if (shadow_phase) {
+            shadow_phase = false;
+            if (!hit.found) {                                                                 // not shadowed, :300-325
+                const V3 diffuse = vscale(albedo, 1.0f - metallic);
+                radiance = vadd(radiance, vscale(vscale(vmul(vmul(throughput, diffuse), sun_radiance), n_dot_l), kInvPi));
+                if (roughness < 0.9f) {
+                    const V3 h = vnormalize(vsub(sun_dir, ray_dir));
+                    const float n_dot_h = fmaxf(vdot(n, h), 0.0f);
+                    const float v_dot_h = fmaxf(vdot(vneg(ray_dir), h), 0.0f);
+                    const float a = roughness * roughness;
+                    const float a2 = a * a;
+                    const float denom = n_dot_h * n_dot_h * (a2 - 1.0f) + 1.0f;
+                    const float d = a2 / (kPi * denom * denom);
+                    const V3 f0 = vmix(v3(0.04f, 0.04f, 0.04f), albedo, metallic);
+                    const V3 f = fresnel_schlick(v_dot_h, f0);
+                    radiance = vadd(radiance, vscale(vmul(vscale(vscale(vmul(throughput, f), d), 0.25f), sun_radiance), n_dot_l));
+                }
             }
-            const V3 hit_pos = vadd(ray_org, vscale(ray_dir, hit.t));                         // :238
+            continue_path = true;
+        } else if (!hit.found) {                                                              // :232-235, miss.rmiss
+            radiance = vadd(radiance, vmul(throughput, sky_color(ray_dir)));
+            end_sample = true;
+        } else {
+            hit_pos = vadd(ray_org, vscale(ray_dir, hit.t));                                  // :238
             // hit.rchit:58-75
             const uint32_t id = hit.material < 65535u ? hit.material : 65535u;
             const blok_material mat = A.mat_table[id < A.n_materials ? id : 0u];
-            V3 n = v3(hit.face == 0u ? 1.0f : (hit.face == 1u ? -1.0f : 0.0f),
-                      hit.face == 2u ? 1.0f : (hit.face == 3u ? -1.0f : 0.0f),
-                      hit.face == 4u ? 1.0f : (hit.face == 5u ? -1.0f : 0.0f));
-            const V3 albedo = v3(mat.albedo[0], mat.albedo[1], mat.albedo[2]);
+            n = v3(hit.face == 0u ? 1.0f : (hit.face == 1u ? -1.0f : 0.0f),
+                   hit.face == 2u ? 1.0f : (hit.face == 3u ? -1.0f : 0.0f),
+                   hit.face == 4u ? 1.0f : (hit.face == 5u ? -1.0f : 0.0f));
+            albedo = v3(mat.albedo[0], mat.albedo[1], mat.albedo[2]);
             const V3 emission = v3(mat.emission[0], mat.emission[1], mat.emission[2]);
-            const float metallic = static_cast<float>((mat.flags >> 24) & 0xFFu) / 255.0f;
-            const float roughness = fmaxf(static_cast<float>((mat.flags >> 16) & 0xFFu) / 255.0f, 0.04f);
+            metallic = static_cast<float>((mat.flags >> 24) & 0xFFu) / 255.0f;
+            roughness = fmaxf(static_cast<float>((mat.flags >> 16) & 0xFFu) / 255.0f, 0.04f);
             if (vdot(n, ray_dir) > 0.0f) n = vneg(n);                                         // :248-250
             if (bounce == 0u && s == 0u && !had_first_hit) {                                  // :253-263
                 had_first_hit = true;
@@ -173,66 +226,63 @@ BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t in
             }
             if (is_emissive(emission)) {                                                      // :265-277
                 radiance = vadd(radiance, vmul(throughput, emission));
-                if (luminance(emission) > 5.0f || bounce > 0u) break;
+                if (luminance(emission) > 5.0f || bounce > 0u) end_sample = true;
             }
-            const float n_dot_l = fmaxf(vdot(n, sun_dir), 0.0f);                              // :280
-            if (n_dot_l > 0.0f && bounce == 0u) {
-                const V3 so = vadd(hit_pos, vscale(n, 0.001f));
-                RayIn sr;
-                sr.ox = so.x; sr.oy = so.y; sr.oz = so.z;
-                sr.dx = sun_dir.x; sr.dy = sun_dir.y; sr.dz = sun_dir.z;
-                sr.tmin = 0.001f; sr.tmax = 1000.0f;                                          // :294,:296
-                const bool shadowed = walk(A, sr, stk).found;                                 // any accepted hit
-                if (!shadowed) {                                                              // :300-325
-                    const V3 diffuse = vscale(albedo, 1.0f - metallic);
-                    radiance = vadd(radiance, vscale(vscale(vmul(vmul(throughput, diffuse), sun_radiance), n_dot_l), kInvPi));
-                    if (roughness < 0.9f) {
-                        const V3 h = vnormalize(vsub(sun_dir, ray_dir));
-                        const float n_dot_h = fmaxf(vdot(n, h), 0.0f);
-                        const float v_dot_h = fmaxf(vdot(vneg(ray_dir), h), 0.0f);
-                        const float a = roughness * roughness;
-                        const float a2 = a * a;
-                        const float denom = n_dot_h * n_dot_h * (a2 - 1.0f) + 1.0f;
-                        const float d = a2 / (kPi * denom * denom);
-                        const V3 f0 = vmix(v3(0.04f, 0.04f, 0.04f), albedo, metallic);
-                        const V3 f = fresnel_schlick(v_dot_h, f0);
-                        radiance = vadd(radiance, vscale(vmul(vscale(vscale(vmul(throughput, f), d), 0.25f), sun_radiance), n_dot_l));
-                    }
-                }
+            if (!end_sample) {
+                n_dot_l = fmaxf(vdot(n, sun_dir), 0.0f);                                      // :280
+                if (n_dot_l > 0.0f && bounce == 0u) shadow_phase = true;                      // next trace: the shadow ray
+                else continue_path = true;
             }
+        }
+
+        if (continue_path) {
             if (bounce > 0u) {                                                                // :329-335
                 const float p = fminf(max3f(throughput), 0.95f);
-                if (random_float(rng) > p) break;
-                throughput = vdivs(throughput, p);
+                if (random_float(rng) > p) end_sample = true;
+                else throughput = vdivs(throughput, p);
             }
-            const float ux = random_float(rng);                                               // :338
-            const float uy = random_float(rng);
-            const V3 f0 = vmix(v3(0.04f, 0.04f, 0.04f), albedo, metallic);                    // :341-347
-            const V3 view = vneg(ray_dir);
-            const float n_dot_v = fmaxf(vdot(n, view), 0.001f);
-            const V3 f = fresnel_schlick(n_dot_v, f0);
-            float spec_w = (f.x + f.y + f.z) / 3.0f;
-            spec_w = spec_w * (1.0f - metallic) + 1.0f * metallic;
-            if (random_float(rng) < spec_w) {                                                 // :349-360
-                const V3 h = sample_ggx(ux, uy, n, fmaxf(roughness, 0.04f));
-                const V3 new_dir = vsub(ray_dir, vscale(h, 2.0f * vdot(h, ray_dir)));
-                if (vdot(new_dir, n) <= 0.0f) break;
-                const float h_dot_v = fmaxf(vdot(h, view), 0.0f);
-                const V3 fh = fresnel_schlick(h_dot_v, f0);
-                throughput = vmul(throughput, vdivs(fh, fmaxf(spec_w, 0.001f)));
-                ray_dir = new_dir;
-            } else {                                                                          // :361-367
-                const V3 new_dir = sample_cosine_hemisphere(ux, uy, n);
-                const V3 diffuse = vscale(albedo, 1.0f - metallic);
-                throughput = vmul(throughput, vdivs(diffuse, fmaxf(1.0f - spec_w, 0.001f)));
-                ray_dir = new_dir;
+            if (!end_sample) {
+                const float ux = random_float(rng);                                           // :338
+                const float uy = random_float(rng);
+                const V3 f0 = vmix(v3(0.04f, 0.04f, 0.04f), albedo, metallic);                // :341-347
+                const V3 view = vneg(ray_dir);
+                const float n_dot_v = fmaxf(vdot(n, view), 0.001f);
+                const V3 f = fresnel_schlick(n_dot_v, f0);
+                float spec_w = (f.x + f.y + f.z) / 3.0f;
+                spec_w = spec_w * (1.0f - metallic) + 1.0f * metallic;
+                if (random_float(rng) < spec_w) {                                             // :349-360
+                    const V3 h = sample_ggx(ux, uy, n, fmaxf(roughness, 0.04f));
+                    const V3 new_dir = vsub(ray_dir, vscale(h, 2.0f * vdot(h, ray_dir)));
+                    if (vdot(new_dir, n) <= 0.0f) end_sample = true;
+                    else {
+                        const float h_dot_v = fmaxf(vdot(h, view), 0.0f);
+                        const V3 fh = fresnel_schlick(h_dot_v, f0);
+                        throughput = vmul(throughput, vdivs(fh, fmaxf(spec_w, 0.001f)));
+                        ray_dir = new_dir;
+                    }
+                } else {                                                                      // :361-367
+                    const V3 new_dir = sample_cosine_hemisphere(ux, uy, n);
+                    const V3 diffuse = vscale(albedo, 1.0f - metallic);
+                    throughput = vmul(throughput, vdivs(diffuse, fmaxf(1.0f - spec_w, 0.001f)));
+                    ray_dir = new_dir;
+                }
+                if (!end_sample) {
+                    const float max_t = max3f(throughput);                                    // :370-373
+                    if (max_t > 10.0f) throughput = vscale(throughput, 10.0f / max_t);
+                    ray_org = vadd(hit_pos, vscale(n, 0.002f));                               // :376
+                    bounce += 1u;
+                    if (bounce >= P.max_bounces) end_sample = true;                           // loop bound, :212
+                }
             }
-            const float max_t = max3f(throughput);                                            // :370-373
-            if (max_t > 10.0f) throughput = vscale(throughput, 10.0f / max_t);
-            ray_org = vadd(hit_pos, vscale(n, 0.002f));                                       // :376
         }
-        accumulated = vadd(accumulated, radiance);                                            // :379
+
+        if (end_sample) {
+            accumulated = vadd(accumulated, radiance);                                        // :379
+            s += 1u;
+            if (s < P.spp) begin_sample();
+        }
     }
+
     V3 color = vdivs(accumulated, static_cast<float>(P.spp));                                 // :383
     const float max_val = max3f(color);                                                       // :386-389
     if (max_val > 100.0f) color = vscale(color, 100.0f / max_val);

@@ -126,6 +126,7 @@ struct HitInfo {
 // Walks one ray.  `stk` points at this lane's slot of the LDS node stack (stride kBlock entries between
 // levels; slot l-2 holds the node of level l on the current path).
 BLOK_DEV HitInfo walk(const TraceArgs& A, const RayIn& r, uint4* stk) {
+    BLOK_STAT(4, 0);                       // a walk begins
     HitInfo out;
     out.found = false; out.t = -1.0f; out.material = 0u; out.face = 0xFFu; out.vx = out.vy = out.vz = 0;
     const uint32_t L = A.levels;

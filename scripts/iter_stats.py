@@ -12,7 +12,7 @@ hk = H.HostKernel(pw.nodes, pw.sub_chunks)
 L = H.lib()
 L.hh_trace_primary_stats.argtypes = [C.c_void_p] * 2 + [C.c_uint32] * 2 + [C.c_void_p] * 3
 cam = W.scene_camera(n, pose, w, h)
-out = np.zeros(w * h, dtype=O.HIT); it = np.zeros(w * h, dtype=np.uint32); tot = np.zeros((4, 8), dtype=np.uint64)
+out = np.zeros(w * h, dtype=O.HIT); it = np.zeros(w * h, dtype=np.uint32); tot = np.zeros((5, 8), dtype=np.uint64)
 L.hh_trace_primary_stats(hk.h, C.c_void_p(cam.ctypes.data), w, h, C.c_void_p(out.ctypes.data), C.c_void_p(it.ctypes.data), C.c_void_p(tot.ctypes.data))
 it2 = it.reshape(h, w)
 print("rays", w * h, "hit frac", out['hit'].mean(), "iters/ray mean", it.mean(), "max", it.max(), "hit rays mean", it[out['hit'] == 1].mean(), "miss rays mean", it[out['hit'] == 0].mean())

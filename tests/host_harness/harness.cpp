@@ -3,11 +3,11 @@
 #define BLOK_TRACE_HOST_HARNESS 1
 #include <cstdint>
 // statistics build: events 0 iteration, 1 descend, 2 step, 3 ascend, per level
-static thread_local uint64_t g_stat[4][8];
+static thread_local uint64_t g_stat[5][8];
 static thread_local unsigned char* g_seq = nullptr;      // optional per-ray event log: 1 descend, 2 step (+level*4)
 static thread_local uint32_t g_seq_len = 0, g_seq_cap = 0;
 #define BLOK_STAT(event, level) do { ++g_stat[event][level]; \
-    if (g_seq && (event == 1 || event == 2) && g_seq_len < g_seq_cap) g_seq[g_seq_len++] = (unsigned char)(event | ((level) << 2)); } while (0)
+    if (g_seq && (event == 1 || event == 2 || event == 4) && g_seq_len < g_seq_cap) g_seq[g_seq_len++] = (unsigned char)(event | ((level) << 2)); } while (0)
 #include "trace_core.h"
 #include "path_core.h"
 #include "reference_world.h"
@@ -53,7 +53,7 @@ static TraceArgs make_args(const Harness* H) {
 void hh_trace_rays(const void* h, const blok_ray* rays, size_t n, blok_hit* out) {
     const Harness* H = static_cast<const Harness*>(h);
     TraceArgs a = make_args(H);
-    std::vector<uint4> stack(size_t(kMaxLevels) * kBlock);
+    std::vector<uint4> stack(size_t(kMaxLevels) * 2 * kBlock);
     for (size_t i = 0; i < n; ++i) {
         RayIn r{rays[i].org[0], rays[i].org[1], rays[i].org[2], rays[i].dir[0], rays[i].dir[1], rays[i].dir[2],
                 rays[i].tmin, rays[i].tmax};
@@ -72,7 +72,7 @@ void hh_render_paths(const void* h, const blok_camera* cam, const blok_material*
     p.trace.mat_table = materials; p.trace.n_materials = n_materials;
     p.spp = spp; p.max_bounces = max_bounces; p.frame_count = frame_index;
     p.color = color; p.world_pos = world_pos; p.normal_roughness = normal_roughness; p.albedo_metallic = albedo_metallic;
-    std::vector<uint4> stack(size_t(kMaxLevels) * kBlock);
+    std::vector<uint4> stack(size_t(kMaxLevels) * 2 * kBlock);
     for (uint32_t y = 0; y < height; ++y)
         for (uint32_t x = 0; x < width; ++x) shade_pixel(p, x, y, size_t(y) * width + x, stack.data());
 }
@@ -83,7 +83,7 @@ void hh_trace_primary_events(const void* h, const blok_camera* cam, uint32_t wid
     const Harness* H = static_cast<const Harness*>(h);
     TraceArgs a = make_args(H);
     a.cam = *cam; a.frame_w = width; a.frame_h = height;
-    std::vector<uint4> stack(size_t(kMaxLevels) * kBlock);
+    std::vector<uint4> stack(size_t(kMaxLevels) * 2 * kBlock);
     blok_hit tmp;
     for (uint32_t y = 0; y < hgt; ++y)
         for (uint32_t x = 0; x < w; ++x) {
@@ -99,13 +99,32 @@ void hh_tonemap(const float* hdr, uint32_t n, float exposure, float saturation_b
     for (uint32_t i = 0; i < n; ++i) out[i] = tonemap_pixel(t, i);
 }
 
+// Event log per PIXEL of the path loop (cap bytes each): 1 descend / 2 step events of every walk, a 3 before each walk.
+void hh_render_paths_events(const void* h, const blok_camera* cam, const blok_material* materials, uint32_t n_materials,
+                            uint32_t width, uint32_t height, uint32_t x0, uint32_t y0, uint32_t w, uint32_t hgt,
+                            uint32_t spp, uint32_t max_bounces, uint32_t cap, unsigned char* events) {
+    const Harness* H = static_cast<const Harness*>(h);
+    PathArgs p{};
+    p.trace = make_args(H);
+    p.trace.cam = *cam; p.trace.frame_w = width; p.trace.frame_h = height;
+    p.trace.mat_table = materials; p.trace.n_materials = n_materials;
+    p.spp = spp; p.max_bounces = max_bounces; p.frame_count = 1;
+    std::vector<uint4> stack(size_t(kMaxLevels) * 2 * kBlock);
+    for (uint32_t y = 0; y < hgt; ++y)
+        for (uint32_t x = 0; x < w; ++x) {
+            g_seq = events + (size_t(y) * w + x) * cap; g_seq_len = 0; g_seq_cap = cap;
+            shade_pixel(p, x0 + x, y0 + y, 0, stack.data());
+        }
+    g_seq = nullptr;
+}
+
 // Per-ray iteration counts for a frame (row-major), plus the event totals [4][8].
 void hh_trace_primary_stats(const void* h, const blok_camera* cam, uint32_t width, uint32_t height, blok_hit* out,
                             uint32_t* iters_per_ray, uint64_t* totals) {
     const Harness* H = static_cast<const Harness*>(h);
     TraceArgs a = make_args(H);
     a.cam = *cam; a.frame_w = width; a.frame_h = height;
-    std::vector<uint4> stack(size_t(kMaxLevels) * kBlock);
+    std::vector<uint4> stack(size_t(kMaxLevels) * 2 * kBlock);
     std::memset(g_stat, 0, sizeof(g_stat));
     for (uint32_t y = 0; y < height; ++y)
         for (uint32_t x = 0; x < width; ++x) {
@@ -124,7 +143,7 @@ void hh_trace_primary(const void* h, const blok_camera* cam, uint32_t width, uin
     const Harness* H = static_cast<const Harness*>(h);
     TraceArgs a = make_args(H);
     a.cam = *cam; a.frame_w = width; a.frame_h = height;
-    std::vector<uint4> stack(size_t(kMaxLevels) * kBlock);
+    std::vector<uint4> stack(size_t(kMaxLevels) * 2 * kBlock);
     for (uint32_t y = 0; y < height; ++y)
         for (uint32_t x = 0; x < width; ++x) {
             const RayIn r = primary_ray(a, x, y);

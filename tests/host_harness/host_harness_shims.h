@@ -15,5 +15,6 @@ inline int __ffs(int v) { return __builtin_ffs(v); }
 inline int __popc(uint32_t v) { return __builtin_popcount(v); }
 inline uint32_t __clz(uint32_t v) { return v ? static_cast<uint32_t>(__builtin_clz(v)) : 32u; }
 inline uint32_t __float_as_uint(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+inline float __uint_as_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 using std::fabs;
 #endif
