@@ -33,8 +33,8 @@ HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--n", type=int, default=1024, help="world edge in voxels")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--tile", type=int, default=32)
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0xB10C0001)
     ap.add_argument("--cpu-stride", type=int, default=1, help="CPU baseline traces every stride-th pixel in x and y")
+    ap.add_argument("--frames-in-flight", type=int, default=2, help="pipeline depth (reference: MAX_FRAMES_IN_FLIGHT = 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-paths", action="store_true", help="skip the 64-spp path-tracing side measurement")
     return ap.parse_args()
@@ -120,8 +121,7 @@ def main():
 
     from blok_amd.multi_gpu import FramePipeline, HipBackend
     stream = torch.cuda.current_stream()
-    pipe = FramePipeline(HipBackend(tracer, cam), W_, H_, rank, world_size, dist, tile=args.tile,
-                         stream_handle=lambda: stream.cuda_stream)
+    pipe = FramePipeline(HipBackend(tracer, cam), W_, H_, rank, world_size, dist, tile=args.tile, depth=args.frames_in_flight)
 
     def fence():
         if dist is not None:
@@ -132,17 +132,21 @@ def main():
         pipe.step()
     pipe.flush()
     fence()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # HIP events on the streams the kernels are launched on: one at the head of slot 0's stream, one at the tail of
+    # every slot's stream; the device time of the region is the longest head->tail span
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in pipe.streams]
     t0 = time.perf_counter()
-    ev0.record(stream)
+    ev0.record(pipe.streams[0])
     for _ in range(args.steps):
         pipe.step()
-    pipe.flush()                                 # the last frame's gather + un-permute are inside the timed region
-    ev1.record(stream)
+    pipe.flush()                                 # every frame's trace, gather and un-permute are inside the timed region
+    for e, st in zip(ev1, pipe.streams):
+        e.record(st)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     fence()
-    device_ms = ev0.elapsed_time(ev1)          # HIP events on the launch stream, whole timed region
+    device_ms = max(ev0.elapsed_time(e) for e in ev1)
     if dist is not None:
         t = torch.tensor([elapsed, device_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -153,7 +157,7 @@ def main():
     kernel_ms = []
     for _ in range(min(args.steps, 20)):
         if world_size == 1:
-            pipe.backend.trace_full(pipe.hits, pipe.frame_rgba, stream.cuda_stream)
+            pipe.backend.trace_full(pipe.hits, pipe._frame[0], stream.cuda_stream)
         else:
             pipe.backend.trace_tiles(args.tile, rank, world_size, pipe.hits, pipe.rgba[0], stream.cuda_stream)
         torch.cuda.synchronize()
@@ -195,10 +199,11 @@ def main():
                                    f"{stats.n_voxels} voxels, {stats.n_ref_nodes} reference SvoNodes, "
                                    f"{stats.n_sub_chunks} sub-chunks), {W_}x{H_} primary rays, camera pose "
                                    f"{'ABC'[args.pose]}, first-hit records 16 B/ray",
-                       "parallelism": "single GPU" if world_size == 1 else f"{args.tile}x{args.tile} screen tiles round-robin over {world_size} GPUs, RCCL gather of RGBA8 tiles to rank 0, 2-deep pipeline",
+                       "parallelism": f"single GPU, {args.frames_in_flight} frames in flight on alternating HIP streams" if world_size == 1 else f"{args.tile}x{args.tile} screen tiles round-robin over {world_size} GPUs, RCCL gather of RGBA8 tiles to rank 0, {args.frames_in_flight} frames in flight",
                        "hits_per_frame": hits, "framebuffer_pixels_hit": lit_pixels,
                        "outputs": "16-B first-hit records (kept on the tracing GPU) + RGBA8 framebuffer on rank 0",
-                       "device_ms_per_step": device_ms / args.steps, "also_measured_paths": paths},
+                       "frames_in_flight": args.frames_in_flight, "device_ms_per_step": device_ms / args.steps,
+                       "also_measured_paths": paths},
         }
         alg = None
         if not args.no_cpu_baseline:
@@ -208,14 +213,17 @@ def main():
                 _, alg = cpu_baseline(packed, cam, W_, H_, 4, min_seconds=0.0)
         rays_per_launch = rays_per_step / world_size
         if alg is not None:
-            achieved = alg["bytes_per_ray"] * rays_per_launch / (kernel_ms_avg * 1e-3) / 1e9
+            # one launch per step and rank: average launch duration over the timed region (HIP events, frames in
+            # flight overlap) = device time / steps; the duration of a launch running alone is reported beside it
+            launch_ms = device_ms / args.steps
+            achieved = alg["bytes_per_ray"] * rays_per_launch / (launch_ms * 1e-3) / 1e9
             traffic = None
             pmc = ROOT / "profiles" / "pmc_traffic.json"
             if pmc.exists() and world_size == 1 and (args.n, W_, H_, args.pose) == (1024, 3840, 2160, 0):
                 traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                               "kernel": "trace_kernel", "kernel_ms": kernel_ms_avg,
+                               "kernel": "trace_kernel", "kernel_ms": launch_ms, "kernel_ms_alone": kernel_ms_avg,
                                "algorithmic_bytes_per_ray": alg["bytes_per_ray"],
                                "rays_per_launch": rays_per_launch,
                                "sub_chunks_per_ray": alg["sub_chunks_per_ray"], "nodes_per_ray": alg["nodes_per_ray"],

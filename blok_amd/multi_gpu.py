@@ -1,21 +1,26 @@
 """Frame pipeline: one frame per step on 1..N GPUs of one node (one process per GPU).
 
-No reference counterpart — blok is single-GPU.  The frame is cut into screen tiles dealt
-round-robin to the ranks (blok_amd/tiles.py); the world is replicated; every rank traces its own tiles into
-first-hit records (kept on the rank) and RGBA8 pixels; ONE collective per frame — a gather of the RGBA8 tile
-buffers to rank 0 over RCCL/xGMI — assembles the framebuffer, which rank 0 un-permutes.
+No reference counterpart for the multi-GPU part — blok is single-GPU; the frames-in-flight
+part mirrors the reference's MAX_FRAMES_IN_FLIGHT = 2 frame loop (reference blok/src/renderer_draw.cpp:93-95,335).
 
-Why RGBA8 and a gather-to-root: xGMI is point to point (7 links per GPU, each far below HBM speed), so the
-frame time at N = 8 is bounded by bytes per link, not by the kernel: 16-byte hit records would put 16.6 MB on
-every link per 4K frame (~0.2 ms, longer than the whole 1-GPU frame), RGBA8 4.1 MB; a gather uses each peer's own
-link to the root in parallel where an all-gather would move 7x the bytes.
+Multi-GPU: the frame is cut into screen tiles dealt round-robin to the ranks (blok_amd/tiles.py); the world is
+replicated; every rank traces its own tiles into first-hit records (kept on the rank) and RGBA8 pixels; ONE
+collective per frame — a gather of the RGBA8 tile buffers to rank 0 over RCCL/xGMI — assembles the framebuffer,
+which rank 0 un-permutes.  Why RGBA8 and a gather-to-root: xGMI is point to point (7 links per GPU, each far below
+HBM speed), so the frame time at N = 8 is bounded by bytes per link, not by the kernel: 16-byte hit records would
+put 16.6 MB on every link per 4K frame (~0.2 ms, longer than half the whole 1-GPU frame), RGBA8 4.1 MB; a gather
+uses each peer's own link to the root in parallel where an all-gather would move 7x the bytes.
 
-The pipeline is software-pipelined two deep: the gather of frame k (RCCL's own stream) runs under the trace of
-frame k+1 (compute stream); a slot is rewritten only after its gather has been waited for.
+Frames in flight: `depth` slots, each with its own HIP stream and buffers.  A trace kernel ends with a long tail
+(waves holding grazing rays run up to ~80 us while the rest of the chip drains — a 480x270 frame costs 85 us
+against 360 us for 64x the rays), so consecutive frames go to alternating streams and the next frame's waves fill
+the slots the previous frame's tail leaves idle; with N ranks the gather of frame k (RCCL's stream) also runs
+under the trace of frame k+1.  A slot is reused only after its previous frame was retired.
 """
 from __future__ import annotations
 
-from typing import List, Optional
+import contextlib
+from typing import List
 
 
 class HipBackend:
@@ -41,52 +46,71 @@ class HipBackend:
 
 class FramePipeline:
     def __init__(self, backend, width: int, height: int, rank: int = 0, world_size: int = 1, dist=None,
-                 tile: int = 32, device="cuda", depth: int = 2, stream_handle=lambda: 0):
+                 tile: int = 32, device="cuda", depth: int = 2):
         import torch
         self.torch = torch
         self.backend, self.width, self.height = backend, width, height
         self.rank, self.world_size, self.dist, self.tile, self.depth = rank, world_size, dist, tile, depth
-        self.stream_handle = stream_handle
+        self.on_gpu = str(device).startswith("cuda")
+        self.streams = [torch.cuda.Stream() for _ in range(depth)] if self.on_gpu else [None] * depth
         self.frames_submitted = 0
         self.frames_done = 0
-        self.in_flight: List[tuple] = []          # (slot, work)
+        self.in_flight: List[tuple] = []          # (slot, work or None)
         n_px = width * height
-        self.frame_rgba = torch.empty(n_px, dtype=torch.int32, device=device) if rank == 0 else None
+        # the newest completed frame: frame_rgba (rank 0) and hits (this rank's pixels) point at its slot
+        self.frame_rgba = None
+        self.hits = None
         if world_size == 1:
-            self.hits = torch.empty((n_px, 4), dtype=torch.int32, device=device)
+            self._hits = [torch.empty((n_px, 4), dtype=torch.int32, device=device) for _ in range(depth)]
+            self._frame = [torch.empty(n_px, dtype=torch.int32, device=device) for _ in range(depth)]
             return
         self.per_rank = backend.tiles_for_rank(tile, 0, world_size)          # rank 0 owns the most tiles
         n_tile_px = self.per_rank * tile * tile
-        self.hits = torch.empty((n_tile_px, 4), dtype=torch.int32, device=device)     # this rank's tiles only
+        self._hits = [torch.empty((n_tile_px, 4), dtype=torch.int32, device=device) for _ in range(depth)]
         self.rgba = [torch.empty(n_tile_px, dtype=torch.int32, device=device) for _ in range(depth)]
-        self.gathered = ([torch.empty((world_size, n_tile_px), dtype=torch.int32, device=device) for _ in range(depth)]
-                         if rank == 0 else None)
+        if rank == 0:
+            self.gathered = [torch.empty((world_size, n_tile_px), dtype=torch.int32, device=device) for _ in range(depth)]
+            self._frame = [torch.empty(n_px, dtype=torch.int32, device=device) for _ in range(depth)]
 
-    # one frame: enqueue the trace, start its gather, retire the previous frame
+    def _on(self, slot):
+        return self.torch.cuda.stream(self.streams[slot]) if self.on_gpu else contextlib.nullcontext()
+
+    def _handle(self, slot):
+        return self.streams[slot].cuda_stream if self.on_gpu else 0
+
+    # one frame: enqueue its trace on the slot's stream, start its gather, retire frames beyond the depth
     def step(self):
-        stream = self.stream_handle()
-        if self.world_size == 1:
-            self.backend.trace_full(self.hits, self.frame_rgba, stream)
-            self.frames_submitted += 1
-            self.frames_done += 1
-            return
-        slot = self.frames_submitted % self.depth
-        self.backend.trace_tiles(self.tile, self.rank, self.world_size, self.hits, self.rgba[slot], stream)
-        gather_list = [self.gathered[slot][r] for r in range(self.world_size)] if self.rank == 0 else None
-        work = self.dist.gather(self.rgba[slot], gather_list=gather_list, dst=0, async_op=True)
-        self.in_flight.append((slot, work))
-        self.frames_submitted += 1
         while len(self.in_flight) >= self.depth:
             self._retire()
+        slot = self.frames_submitted % self.depth
+        with self._on(slot):
+            if self.world_size == 1:
+                self.backend.trace_full(self._hits[slot], self._frame[slot], self._handle(slot))
+                work = None
+            else:
+                self.backend.trace_tiles(self.tile, self.rank, self.world_size, self._hits[slot], self.rgba[slot],
+                                         self._handle(slot))
+                gather_list = [self.gathered[slot][r] for r in range(self.world_size)] if self.rank == 0 else None
+                work = self.dist.gather(self.rgba[slot], gather_list=gather_list, dst=0, async_op=True)
+        self.in_flight.append((slot, work))
+        self.frames_submitted += 1
 
     def _retire(self):
         slot, work = self.in_flight.pop(0)
-        work.wait()                                # compute stream (or host, on gloo) waits for that gather only
+        with self._on(slot):
+            if work is not None:
+                work.wait()                        # the slot's stream (or the host, on gloo) waits for that gather only
+                if self.rank == 0:
+                    self.backend.untile(self.gathered[slot], 4, self.tile, self.world_size, self.per_rank,
+                                        self._frame[slot], self._handle(slot))
+        self.hits = self._hits[slot]
         if self.rank == 0:
-            self.backend.untile(self.gathered[slot], 4, self.tile, self.world_size, self.per_rank,
-                                self.frame_rgba, self.stream_handle())
+            self.frame_rgba = self._frame[slot]
         self.frames_done += 1
 
     def flush(self):
         while self.in_flight:
             self._retire()
+        if self.on_gpu:
+            for s in self.streams:
+                s.synchronize()

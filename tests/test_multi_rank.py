@@ -120,13 +120,18 @@ def _pipeline_worker(rank, world_size, port, out_dir):
     pipe = FramePipeline(_FakeBackend(width, height, frames), width, height, rank, world_size, dist, tile=tile,
                          device="cpu", depth=2)
     seen = []
-    for k in range(5):
-        pipe.step()
+
+    def collect():
         if rank == 0 and pipe.frames_done > len(seen):        # frame (frames_done - 1) is complete on the root
             seen.append(pipe.frame_rgba.numpy().reshape(height, width).copy())
+    for k in range(5):
+        pipe.step()
+        collect()
+    while pipe.in_flight:
+        pipe._retire()
+        collect()
     pipe.flush()
     if rank == 0:
-        seen.append(pipe.frame_rgba.numpy().reshape(height, width).copy())
         ok = len(seen) == 5 and all((a == b).all() for a, b in zip(seen, frames))
     else:
         ok = pipe.frames_done == 5
