@@ -1,6 +1,7 @@
 // C ABI of the gfx950 backend (include/blok_hip.h).  Owns device memory; every HIP call is checked.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -29,6 +30,13 @@ struct blok_hip_ctx {
     // scratch frame for the host-output entry points
     blok_hit* d_frame = nullptr;
     size_t frame_capacity = 0;
+    // progressive accumulation (CudaTracer::m_dAccum / m_frameIndex / m_prevCam, reference cuda_tracer.hpp:51-55)
+    float* d_accum = nullptr;
+    float* d_color = nullptr;
+    size_t accum_pixels = 0;
+    uint32_t accum_frames = 0;
+    blok_camera prev_cam{};
+    bool has_prev_cam = false;
     // timing
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool timing = false, timed = false;
@@ -167,7 +175,7 @@ int blok_hip_create(blok_hip_ctx** out_ctx, int device_ordinal, uint32_t width, 
 int blok_hip_resize(blok_hip_ctx* ctx, uint32_t width, uint32_t height) {
     if (!ctx) return BLOK_ERR_INVALID_ARG;
     if (!width || !height) return set_error(ctx, BLOK_ERR_INVALID_ARG, "zero-sized frame");
-    ctx->width = width; ctx->height = height;
+    ctx->width = width; ctx->height = height;     // the accumulation buffer is re-created on the next progressive frame
     return BLOK_OK;
 }
 
@@ -176,6 +184,8 @@ void blok_hip_destroy(blok_hip_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     free_world(ctx);
     if (ctx->d_frame) (void)hipFree(ctx->d_frame);
+    if (ctx->d_accum) (void)hipFree(ctx->d_accum);
+    if (ctx->d_color) (void)hipFree(ctx->d_color);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
     delete ctx;
@@ -483,9 +493,67 @@ int blok_hip_tonemap(blok_hip_ctx* ctx, const float* hdr_host, uint32_t n_pixels
     return BLOK_OK;
 }
 
-int blok_hip_reset_accum(blok_hip_ctx* ctx) {
+int blok_hip_reset_accum(blok_hip_ctx* ctx) {                      // reference cuda_tracer.cu:450-454
     if (!ctx) return BLOK_ERR_INVALID_ARG;
-    return BLOK_OK;   // primary-hit frames carry no accumulation state
+    ctx->accum_frames = 0;
+    if (!ctx->d_accum) return BLOK_OK;
+    BLOK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    BLOK_HIP_TRY(ctx, hipMemset(ctx->d_accum, 0, ctx->accum_pixels * 4 * sizeof(float)));
+    return BLOK_OK;
+}
+
+namespace {
+// reference cuda_tracer.cu:456-472: any basis component, position or fov moving by more than 1e-5
+bool camera_changed(const blok_hip_ctx* ctx, const blok_camera& c) {
+    if (!ctx->has_prev_cam) return true;
+    const float* a = reinterpret_cast<const float*>(&c);
+    const float* b = reinterpret_cast<const float*>(&ctx->prev_cam);
+    for (size_t i = 0; i < sizeof(blok_camera) / sizeof(float); ++i)
+        if (std::fabs(a[i] - b[i]) > 1e-5f) return true;
+    return false;
+}
+}  // namespace
+
+int blok_hip_draw_frame_accumulate(blok_hip_ctx* ctx, const blok_camera* cam, uint32_t spp_per_frame, uint32_t max_bounces,
+                                   uint32_t* out_rgba8_host, uint32_t* out_frames_accumulated) {
+    int rc = check_trace(ctx, cam);
+    if (rc != BLOK_OK) return rc;
+    if (!spp_per_frame || !max_bounces) return set_error(ctx, BLOK_ERR_INVALID_ARG, "spp and bounces must be positive");
+    const size_t n = static_cast<size_t>(ctx->width) * ctx->height;
+    if (ctx->accum_pixels != n) {                                      // first use or resize: (re)allocate and clear
+        if (ctx->d_accum) (void)hipFree(ctx->d_accum);
+        if (ctx->d_color) (void)hipFree(ctx->d_color);
+        ctx->d_accum = ctx->d_color = nullptr; ctx->accum_pixels = 0;
+        BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_accum), n * 4 * sizeof(float)));
+        BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_color), n * 4 * sizeof(float)));
+        ctx->accum_pixels = n;
+        ctx->has_prev_cam = false;
+    }
+    if (camera_changed(ctx, *cam)) { rc = blok_hip_reset_accum(ctx); if (rc != BLOK_OK) return rc; }      // cuda_tracer.cu:485
+    ctx->prev_cam = *cam; ctx->has_prev_cam = true;                                                         // :486
+    const blok_gbuffer planes{ctx->d_color, nullptr, nullptr, nullptr};
+    rc = blok_hip_trace_paths_device(ctx, cam, 0, 0, ctx->width, ctx->height, spp_per_frame, max_bounces, ctx->accum_frames,
+                                     &planes, nullptr);
+    if (rc != BLOK_OK) return rc;
+    rc = ensure_frame(ctx, (n + 3) / 4);
+    if (rc != BLOK_OK) return rc;
+    blok::AccumArgs a{ctx->d_color, ctx->d_accum, out_rgba8_host ? reinterpret_cast<uint32_t*>(ctx->d_frame) : nullptr,
+                      static_cast<uint32_t>(n)};
+    blok::launch_accumulate(a, nullptr);
+    BLOK_HIP_TRY(ctx, hipGetLastError());
+    ctx->accum_frames += 1;                                                                                  // ++m_frameIndex
+    if (out_frames_accumulated) *out_frames_accumulated = ctx->accum_frames;
+    if (out_rgba8_host) BLOK_HIP_TRY(ctx, hipMemcpy(out_rgba8_host, ctx->d_frame, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    else BLOK_HIP_TRY(ctx, hipDeviceSynchronize());
+    return BLOK_OK;
+}
+
+int blok_hip_accum_download(blok_hip_ctx* ctx, float* out_rgba32f_host) {
+    if (!ctx || !out_rgba32f_host) return BLOK_ERR_INVALID_ARG;
+    if (!ctx->d_accum) return set_error(ctx, BLOK_ERR_INVALID_ARG, "no accumulation buffer yet");
+    BLOK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    BLOK_HIP_TRY(ctx, hipMemcpy(out_rgba32f_host, ctx->d_accum, ctx->accum_pixels * 4 * sizeof(float), hipMemcpyDeviceToHost));
+    return BLOK_OK;
 }
 
 int blok_hip_set_timing(blok_hip_ctx* ctx, int enabled) {

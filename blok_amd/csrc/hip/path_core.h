@@ -361,5 +361,34 @@ BLOK_DEV uint32_t tonemap_pixel(const TonemapArgs& T, uint32_t i) {   // tonemap
     return unorm8(ldr.x) | (unorm8(ldr.y) << 8) | (unorm8(ldr.z) << 16) | 0xFF000000u;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Progressive accumulation + display transform of the reference's compute backend
+// (blok/src/cuda_tracer.cu:372-386 accumulate, :209-216 ACES fit, :95-99 gamma 2.2 to 8 bits).
+struct AccumArgs {
+    const float* color;      // this frame's average radiance, float4 per pixel
+    float* accum;            // xyz running sum, w frames accumulated
+    uint32_t* rgba;          // may be null
+    uint32_t n;
+};
+BLOK_DEV float aces_channel(float x) {                            // cuda_tracer.cu:209-216
+    const float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
+    return fminf(fmaxf((x * (a * x + b)) / (x * (c * x + d) + e), 0.0f), 1.0f);
+}
+BLOK_DEV uint32_t to_srgb8(float x) {                             // cuda_tracer.cu:95-99
+    x = fminf(fmaxf(x, 0.0f), 1.0f);
+    const float g = powf(x, 1.0f / 2.2f);
+    return static_cast<uint32_t>(g * 255.0f + 0.5f) & 0xFFu;
+}
+BLOK_DEV void accumulate_pixel(const AccumArgs& T, uint32_t i) {  // cuda_tracer.cu:372-386
+    float sx = T.accum[4 * i], sy = T.accum[4 * i + 1], sz = T.accum[4 * i + 2], spp = T.accum[4 * i + 3];
+    sx = sx + T.color[4 * i]; sy = sy + T.color[4 * i + 1]; sz = sz + T.color[4 * i + 2];
+    spp += 1.0f;
+    T.accum[4 * i] = sx; T.accum[4 * i + 1] = sy; T.accum[4 * i + 2] = sz; T.accum[4 * i + 3] = spp;
+    if (!T.rgba) return;
+    const float inv = 1.0f / spp;
+    T.rgba[i] = to_srgb8(aces_channel(sx * inv)) | (to_srgb8(aces_channel(sy * inv)) << 8) |
+                (to_srgb8(aces_channel(sz * inv)) << 16) | 0xFF000000u;
+}
+
 }  // namespace blok
 #endif

@@ -99,6 +99,8 @@ struct UntileArgs {
 
 struct PathArgs;
 struct TonemapArgs;
+struct AccumArgs;
+void launch_accumulate(const AccumArgs& args, hipStream_t stream);
 void launch_tonemap(const TonemapArgs& args, hipStream_t stream);
 void launch_paths(const PathArgs& args, uint32_t n_blocks, hipStream_t stream);
 void launch_trace(RayMode mode, const TraceArgs& args, uint32_t n_blocks, hipStream_t stream);

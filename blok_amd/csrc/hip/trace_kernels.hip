@@ -102,6 +102,11 @@ __global__ __launch_bounds__(256) void tonemap_kernel(const TonemapArgs T) {
     if (i < T.n) T.ldr[i] = tonemap_pixel(T, i);
 }
 
+__global__ __launch_bounds__(256) void accumulate_kernel(const AccumArgs T) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < T.n) accumulate_pixel(T, i);
+}
+
 template <typename Elem>
 __global__ __launch_bounds__(256) void untile_kernel(const UntileArgs U) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -135,6 +140,10 @@ void launch_paths(const PathArgs& args, uint32_t n_blocks, hipStream_t stream) {
 
 void launch_tonemap(const TonemapArgs& args, hipStream_t stream) {
     if (args.n) hipLaunchKernelGGL(tonemap_kernel, dim3((args.n + 255u) / 256u), dim3(256), 0, stream, args);
+}
+
+void launch_accumulate(const AccumArgs& args, hipStream_t stream) {
+    if (args.n) hipLaunchKernelGGL(accumulate_kernel, dim3((args.n + 255u) / 256u), dim3(256), 0, stream, args);
 }
 
 void launch_untile(const UntileArgs& args, hipStream_t stream) {

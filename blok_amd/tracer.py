@@ -159,6 +159,20 @@ class HipTracer:
         self._check(self._lib.blok_hip_trace_paths_device(self._ctx, _ffi.ptr(cam), x0, y0, w, h, spp, max_bounces,
                                                           frame_index, C.byref(g), C.c_void_p(stream)))
 
+    def draw_frame_accumulate(self, cam: np.ndarray, spp_per_frame: int = 1, max_bounces: int = 2):
+        """Progressive frame of the compute backend (CudaTracer::drawFrame): returns (RGBA8 (h, w) uint32, frames accumulated)."""
+        cam = np.ascontiguousarray(cam, dtype=CAMERA)
+        out = np.zeros((self.height, self.width), dtype=np.uint32)
+        frames = C.c_uint32()
+        self._check(self._lib.blok_hip_draw_frame_accumulate(self._ctx, _ffi.ptr(cam), spp_per_frame, max_bounces,
+                                                             _ffi.ptr(out), C.byref(frames)))
+        return out, frames.value
+
+    def accum_download(self) -> np.ndarray:
+        out = np.zeros((self.height, self.width, 4), dtype=np.float32)
+        self._check(self._lib.blok_hip_accum_download(self._ctx, _ffi.ptr(out)))
+        return out
+
     def tonemap(self, hdr: np.ndarray, exposure: float = 1.0, saturation_boost: float = 1.15, operator: int = 1) -> np.ndarray:
         """tonemap.comp: (..., 4) float32 HDR -> (...) uint32 RGBA8 (reference defaults)."""
         hdr = np.ascontiguousarray(hdr, dtype=np.float32)

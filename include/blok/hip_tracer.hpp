@@ -187,6 +187,17 @@ public:
         return m_pixels;
     }
 
+    // = CudaTracer::drawFrame in its progressive mode (reference cuda_tracer.cu:484-555): path-traced samples added to the
+    // accumulation buffer, which is cleared when the camera moved; returns the ACES + gamma 2.2 RGBA8 running average
+    const std::vector<uint32_t>& drawFrameProgressive(Camera& cam, uint32_t sppPerFrame = 1, uint32_t maxBounces = 2) {
+        const blok_camera c = cam.basis(m_width, m_height);
+        m_pixels.resize(static_cast<size_t>(m_width) * m_height);
+        check(blok_hip_draw_frame_accumulate(m_ctx, &c, sppPerFrame, maxBounces, m_pixels.data(), &m_frameIndex));
+        cam.cameraChanged = false;
+        return m_pixels;
+    }
+    uint32_t framesAccumulated() const { return m_frameIndex; }
+
     const std::vector<blok_hit>& hits() const { return m_hits; }     // output accessor (getGLTex analogue)
     unsigned int width() const { return m_width; }
     unsigned int height() const { return m_height; }

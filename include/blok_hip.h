@@ -251,6 +251,16 @@ int blok_hip_shade_rgba8(blok_hip_ctx* ctx, const blok_camera* cam,
                          uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
                          uint32_t* out_rgba8_host);
 
+/* = CudaTracer::drawFrame in the compute backend's progressive mode (reference blok/src/cuda_tracer.cu:484-555 with the
+ * kernel's accumulate / ACES / gamma tail, :372-386, :209-216, :95-99): traces spp_per_frame samples per pixel of the
+ * reference's sample/bounce loop with the RNG frame index = frames accumulated so far, adds the frame's average to the
+ * accumulation buffer (xyz running sum, w = frames), clears that buffer first when any camera component moved by more
+ * than 1e-5 (camChanged, :456-472) and writes the ACES-tonemapped, gamma-2.2 RGBA8 image of the running average to
+ * out_rgba8_host (may be NULL).  Blocking. */
+int blok_hip_draw_frame_accumulate(blok_hip_ctx* ctx, const blok_camera* cam, uint32_t spp_per_frame, uint32_t max_bounces,
+                                   uint32_t* out_rgba8_host, uint32_t* out_frames_accumulated);
+/* The accumulation buffer: width*height float4 (xyz sum, w frames). */
+int blok_hip_accum_download(blok_hip_ctx* ctx, float* out_rgba32f_host);
 /* = CudaTracer::resetAccum (reference blok/src/cuda_tracer.cu:450-454). */
 int blok_hip_reset_accum(blok_hip_ctx* ctx);
 

@@ -1112,6 +1112,27 @@ void orc_render_paths(const void* lattice, const void* nodes, const void* subs, 
 
 extern "C" {
 
+// cuda_tracer.cu:372-386 (progressive accumulation), :209-216 (ACES fit), :95-99 (gamma 2.2 to 8 bits)
+extern "C" void orc_accumulate(float* accum, const float* color, uint32_t n, uint32_t* pixels) {
+    auto toSRGB8 = [](float x) {
+        x = std::fmin(std::fmax(x, 0.0f), 1.0f);
+        const float g = std::pow(x, 1.0f / 2.2f);
+        return uint32_t((unsigned char)(g * 255.0f + 0.5f));
+    };
+    auto aces = [](float x) {
+        const float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
+        return std::fmin(std::fmax((x * (a * x + b)) / (x * (c * x + d) + e), 0.f), 1.f);
+    };
+    for (uint32_t idx = 0; idx < n; ++idx) {
+        float sumx = accum[4 * idx], sumy = accum[4 * idx + 1], sumz = accum[4 * idx + 2], spp = accum[4 * idx + 3];
+        sumx = sumx + color[4 * idx]; sumy = sumy + color[4 * idx + 1]; sumz = sumz + color[4 * idx + 2];
+        spp += 1.f;
+        accum[4 * idx] = sumx; accum[4 * idx + 1] = sumy; accum[4 * idx + 2] = sumz; accum[4 * idx + 3] = spp;
+        const float inv = 1.0f / spp;
+        if (pixels) pixels[idx] = toSRGB8(aces(sumx * inv)) | (toSRGB8(aces(sumy * inv)) << 8) | (toSRGB8(aces(sumz * inv)) << 16) | 0xFF000000u;
+    }
+}
+
 // tonemap.comp:17-143 (literal; push constants exposure / saturationBoost / tonemapOperator)
 namespace {
 inline float tmLuminance(Vec3 c) { return dot3(c, {0.2126f, 0.7152f, 0.0722f}); }

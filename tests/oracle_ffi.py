@@ -233,6 +233,16 @@ def render_paths(lattice: "Lattice", materials, cam, width, height, spp=8, max_b
     return planes, ctr[0]
 
 
+def accumulate(accum, color):
+    """In place: accum += color (w += 1); returns the ACES + gamma RGBA8 image of the running average."""
+    n = accum.size // 4
+    out = np.zeros(accum.shape[:-1], dtype=np.uint32)
+    L = lib()
+    L.orc_accumulate.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.orc_accumulate(_p(accum), _p(np.ascontiguousarray(color, dtype=np.float32)), n, _p(out))
+    return out
+
+
 def tonemap(hdr, exposure=1.0, saturation_boost=1.15, operator=1):
     hdr = np.ascontiguousarray(hdr, dtype=np.float32)
     out = np.zeros(hdr.shape[:-1], dtype=np.uint32)
