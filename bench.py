@@ -46,6 +46,7 @@ def parse():
                     help="pipeline depth; 0 = 2 for N <= 2, 3 for N <= 4, else 4 (reference: MAX_FRAMES_IN_FLIGHT = 2). "
                          "Measured on one GPU with a rank's tile share (scripts/tile_depth_test.py): an 8-rank share is "
                          "40 us of work under a kernel that lasts 114 us alone, and needs 4 frames in flight to hide it")
+    ap.add_argument("--beam", type=int, default=32, help="beam pre-pass tile in pixels (0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-paths", action="store_true", help="skip the 64-spp path-tracing side measurement")
     return ap.parse_args()
@@ -121,6 +122,7 @@ def main():
     cam = W.scene_camera(args.n, args.pose, W_, H_, args.seed)
     tracer = HipTracer(W_, H_, device=device_index).init()
     stats = tracer.add_world(packed)                      # world resident in HBM from here on
+    tracer.set_beam(args.beam)
 
     if args.frames_in_flight <= 0:
         args.frames_in_flight = 2 if world_size <= 2 else (3 if world_size <= 4 else 4)
@@ -207,7 +209,7 @@ def main():
                        "parallelism": f"single GPU, {args.frames_in_flight} frames in flight on alternating HIP streams" if world_size == 1 else f"{args.tile}x{args.tile} screen tiles round-robin over {world_size} GPUs, RCCL gather of RGBA8 tiles to rank 0, {args.frames_in_flight} frames in flight",
                        "hits_per_frame": hits, "framebuffer_pixels_hit": lit_pixels,
                        "outputs": "16-B first-hit records (kept on the tracing GPU) + RGBA8 framebuffer on rank 0",
-                       "frames_in_flight": args.frames_in_flight, "device_ms_per_step": device_ms / args.steps,
+                       "frames_in_flight": args.frames_in_flight, "device_ms_per_step": device_ms / args.steps, "kernel_ms_alone": kernel_ms_avg, "beam_tile": args.beam,
                        "also_measured_paths": paths},
         }
         alg = None
@@ -228,7 +230,7 @@ def main():
                 traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                               "kernel": "trace_kernel", "kernel_ms": launch_ms, "kernel_ms_alone": kernel_ms_avg,
+                               "kernel": "trace_kernel", "kernel_ms": launch_ms, "kernel_ms_alone": kernel_ms_avg, "beam_tile": args.beam,
                                "algorithmic_bytes_per_ray": alg["bytes_per_ray"],
                                "rays_per_launch": rays_per_launch,
                                "sub_chunks_per_ray": alg["sub_chunks_per_ray"], "nodes_per_ray": alg["nodes_per_ray"],

@@ -2,6 +2,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <unordered_map>
+#include <utility>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -37,6 +39,10 @@ struct blok_hip_ctx {
     uint32_t accum_frames = 0;
     blok_camera prev_cam{};
     bool has_prev_cam = false;
+    // beam pre-pass (beam.h): start parameters per beam tile, one buffer per stream (launches on one stream are
+    // ordered, frames in flight on different streams must not share)
+    uint32_t beam_tile = 32;
+    std::unordered_map<hipStream_t, std::pair<float*, size_t>> beam_buffers;
     // timing
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool timing = false, timed = false;
@@ -120,8 +126,33 @@ blok::TraceArgs base_args(const blok_hip_ctx* ctx, const blok_camera* cam) {
     return a;
 }
 
-int launch_timed(blok_hip_ctx* ctx, blok::RayMode mode, const blok::TraceArgs& args, uint32_t blocks, hipStream_t stream) {
+// The stream's beam buffer, grown to n floats.
+int beam_buffer(blok_hip_ctx* ctx, hipStream_t stream, size_t n, float** out) {
+    auto& slot = ctx->beam_buffers[stream];
+    if (slot.second < n) {
+        if (slot.first) { BLOK_HIP_TRY(ctx, hipStreamSynchronize(stream)); (void)hipFree(slot.first); }
+        slot = {nullptr, 0};
+        BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&slot.first), n * sizeof(float)));
+        slot.second = n;
+    }
+    *out = slot.first;
+    return BLOK_OK;
+}
+
+// Rect / Tiles launches run the beam pre-pass first, on the same stream (tiles_of_rank: Tiles only).
+int launch_timed(blok_hip_ctx* ctx, blok::RayMode mode, blok::TraceArgs args, uint32_t blocks, hipStream_t stream,
+                 uint32_t tiles_of_rank = 0) {
+    uint32_t n_beams = 0;
+    if (mode != blok::RayMode::Rays && ctx->beam_tile && blocks) {
+        args.beam_tile = ctx->beam_tile;
+        if (mode == blok::RayMode::Tiles && args.tile % args.beam_tile) args.beam_tile = 16;   // tiles are multiples of 16
+        args.beam_bx = (args.w + args.beam_tile - 1u) / args.beam_tile;
+        n_beams = blok::beam_tiles(mode, args, tiles_of_rank);
+        const int rc = beam_buffer(ctx, stream, n_beams, &args.beam);
+        if (rc != BLOK_OK) return rc;
+    }
     if (ctx->timing) BLOK_HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, stream));
+    if (n_beams) blok::launch_beam(mode, args, n_beams, stream);
     blok::launch_trace(mode, args, blocks, stream);
     BLOK_HIP_TRY(ctx, hipGetLastError());
     if (ctx->timing) { BLOK_HIP_TRY(ctx, hipEventRecord(ctx->ev_end, stream)); ctx->timed = true; }
@@ -184,6 +215,7 @@ void blok_hip_destroy(blok_hip_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     free_world(ctx);
     if (ctx->d_frame) (void)hipFree(ctx->d_frame);
+    for (auto& kv : ctx->beam_buffers) if (kv.second.first) (void)hipFree(kv.second.first);
     if (ctx->d_accum) (void)hipFree(ctx->d_accum);
     if (ctx->d_color) (void)hipFree(ctx->d_color);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
@@ -357,7 +389,7 @@ int blok_hip_trace_tiles_device(blok_hip_ctx* ctx, const blok_camera* cam, uint3
     a.out_rgba = static_cast<uint32_t*>(out_rgba_dev);
     const uint32_t mine = blok_hip_tiles_for_rank(ctx->width, ctx->height, tile, rank, n_ranks);
     const uint32_t blocks = mine * (tile / blok::kTileW) * (tile / blok::kTileH);
-    return launch_timed(ctx, blok::RayMode::Tiles, a, blocks, static_cast<hipStream_t>(hip_stream));
+    return launch_timed(ctx, blok::RayMode::Tiles, a, blocks, static_cast<hipStream_t>(hip_stream), mine);
 }
 
 int blok_hip_untile_device(blok_hip_ctx* ctx, const void* gathered_dev, uint32_t elem_bytes, uint32_t tile,
@@ -521,7 +553,8 @@ int blok_hip_draw_frame_accumulate(blok_hip_ctx* ctx, const blok_camera* cam, ui
     if (!spp_per_frame || !max_bounces) return set_error(ctx, BLOK_ERR_INVALID_ARG, "spp and bounces must be positive");
     const size_t n = static_cast<size_t>(ctx->width) * ctx->height;
     if (ctx->accum_pixels != n) {                                      // first use or resize: (re)allocate and clear
-        if (ctx->d_accum) (void)hipFree(ctx->d_accum);
+        for (auto& kv : ctx->beam_buffers) if (kv.second.first) (void)hipFree(kv.second.first);
+    if (ctx->d_accum) (void)hipFree(ctx->d_accum);
         if (ctx->d_color) (void)hipFree(ctx->d_color);
         ctx->d_accum = ctx->d_color = nullptr; ctx->accum_pixels = 0;
         BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_accum), n * 4 * sizeof(float)));
@@ -553,6 +586,14 @@ int blok_hip_accum_download(blok_hip_ctx* ctx, float* out_rgba32f_host) {
     if (!ctx->d_accum) return set_error(ctx, BLOK_ERR_INVALID_ARG, "no accumulation buffer yet");
     BLOK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     BLOK_HIP_TRY(ctx, hipMemcpy(out_rgba32f_host, ctx->d_accum, ctx->accum_pixels * 4 * sizeof(float), hipMemcpyDeviceToHost));
+    return BLOK_OK;
+}
+
+int blok_hip_set_beam(blok_hip_ctx* ctx, uint32_t beam_tile_pixels) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    if (beam_tile_pixels != 0 && beam_tile_pixels != 8 && beam_tile_pixels != 16 && beam_tile_pixels != 32 && beam_tile_pixels != 64)
+        return set_error(ctx, BLOK_ERR_INVALID_ARG, "beam tile must be 0 (off), 8, 16, 32 or 64 pixels");
+    ctx->beam_tile = beam_tile_pixels;
     return BLOK_OK;
 }
 

@@ -1,0 +1,139 @@
+// Beam pre-pass: a conservative start parameter for all primary rays of a tile of pixels (32x32 by default).
+//
+// No reference counterpart: the reference lets Vulkan RT hardware cull sub-chunk boxes per ray
+// (reference blok/src/renderer_raytracing.cpp:15-254).  Here one wave walks the 64-tree ONCE for the whole
+// tile, cooperatively — lane i tests child i of the current node against the tile's frustum — and finds a
+// lower bound t0 on the parameter of any filled voxel any ray of the tile can report (beam_kernel, a few
+// thousand waves per 4K frame).  The per-ray walk then runs with tmin' = max(tmin, t0).  That cannot change a record: a voxel is reported iff
+// max(entry, tmin) < min(exit, tmax) with t = max(entry, tmin) (trace_kernels.h), and raising tmin to a value
+// below every reportable voxel's entry leaves both the set of reported voxels and their t untouched.  If no
+// cell of the tree meets the frustum, all 64 rays miss and no walk runs.
+//
+// Conservative by construction, not by tuning:
+//   * the frustum is the tile's pixel rectangle grown by one pixel on every side (covers the pixel centres, the
+//     path kernel's sub-pixel jitter and the |d_a| < 1e-6 direction clamp of the walk) and each side plane is
+//     pushed outward by kBeamSlack voxels (covers float rounding of the plane tests, ~1e-3 at 16384^3);
+//   * a cell is culled only if its farthest corner is strictly behind a side plane (NaNs never cull);
+//   * the bound is the smallest depth, along the tile's central direction c, of the nearest corner of any
+//     surviving non-empty cell: for a unit direction d and a point p = o + t d of that cell,
+//     t = (p - o).c / (d.c) >= (p - o).c because d.c <= 1; it is then reduced by kBeamSlack and 1e-4 relative
+//     (|d| = 1 within float rounding).
+#ifndef BLOK_BEAM_H
+#define BLOK_BEAM_H
+
+#include "trace_kernels.h"
+
+namespace blok {
+
+#ifndef BLOK_BEAM_STOP_LEVEL
+#define BLOK_BEAM_STOP_LEVEL 2      // finest cells examined = children of a node of this level (2: 4^3 bricks, 1: voxels)
+#endif
+constexpr float kBeamSlack = 0.05f;
+constexpr float kBeamNone = 3.0e38f;   // "no cell of the tree meets the frustum"
+
+struct BeamVec { float x, y, z; };
+
+// un-normalised direction through continuous pixel coordinates (px, py); 1 ulp reciprocals are fine here, the
+// one-pixel margin is eight orders of magnitude larger
+__device__ __forceinline__ BeamVec beam_dir(const blok_camera& c, float px, float py, float inv_w, float inv_h) {
+    const float u = (2.0f * (px * inv_w) - 1.0f) * c.tan_half_fov * c.aspect;
+    const float v = (1.0f - 2.0f * (py * inv_h)) * c.tan_half_fov;
+    return {__builtin_fmaf(c.up[0], v, __builtin_fmaf(c.right[0], u, c.fwd[0])), __builtin_fmaf(c.up[1], v, __builtin_fmaf(c.right[1], u, c.fwd[1])),
+            __builtin_fmaf(c.up[2], v, __builtin_fmaf(c.right[2], u, c.fwd[2]))};
+}
+__device__ __forceinline__ float beam_dot(BeamVec n, float x, float y, float z) { return __builtin_fmaf(n.x, x, __builtin_fmaf(n.y, y, n.z * z)); }
+__device__ __forceinline__ BeamVec beam_unit(BeamVec a) {
+    const float k = __builtin_amdgcn_rsqf(beam_dot(a, a.x, a.y, a.z));
+    return {a.x * k, a.y * k, a.z * k};
+}
+__device__ __forceinline__ uint32_t beam_uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float beam_lane(float v, uint32_t lane) { return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), lane)); }
+__device__ __forceinline__ BeamVec beam_lane(BeamVec v, uint32_t lane) { return {beam_lane(v.x, lane), beam_lane(v.y, lane), beam_lane(v.z, lane)}; }
+
+// Pixel rectangle [px_lo, px_hi] x [py_lo, py_hi] in continuous pixel coordinates of the frame (pixel x covers
+// [x, x+1]).  Must be called by all 64 lanes of the wave.  Returns kBeamNone or a start parameter >= 0.
+__device__ __forceinline__ float beam_start(const TraceArgs& A, float px_lo, float py_lo, float px_hi, float py_hi, uint32_t lane) {
+    const float inv_w = __builtin_amdgcn_rcpf(static_cast<float>(A.frame_w)), inv_h = __builtin_amdgcn_rcpf(static_cast<float>(A.frame_h));
+    const BeamVec mid = beam_unit(beam_dir(A.cam, 0.5f * (px_lo + px_hi), 0.5f * (py_lo + py_hi), inv_w, inv_h));
+    // lane k < 4 builds side plane k through corners k and k+1 of the grown rectangle (corner i: x high for i = 1, 2;
+    // y high for i = 2, 3), oriented towards the central direction; the four planes are then read back wave-wide
+    const uint32_t k0 = lane & 3u, k1 = (lane + 1u) & 3u;
+    const BeamVec p = beam_dir(A.cam, (k0 == 1u || k0 == 2u) ? px_hi + 1.0f : px_lo - 1.0f, k0 >= 2u ? py_hi + 1.0f : py_lo - 1.0f, inv_w, inv_h);
+    const BeamVec q = beam_dir(A.cam, (k1 == 1u || k1 == 2u) ? px_hi + 1.0f : px_lo - 1.0f, k1 >= 2u ? py_hi + 1.0f : py_lo - 1.0f, inv_w, inv_h);
+    BeamVec side = beam_unit({p.y * q.z - p.z * q.y, p.z * q.x - p.x * q.z, p.x * q.y - p.y * q.x});
+    if (beam_dot(side, mid.x, mid.y, mid.z) < 0.0f) side = {-side.x, -side.y, -side.z};
+    const BeamVec n0 = beam_lane(side, 0), n1 = beam_lane(side, 1), n2 = beam_lane(side, 2), n3 = beam_lane(side, 3);
+
+    // lanes are children in front-to-back order for the central direction: mirrored child index
+    const uint32_t mirror = beam_uniform((mid.x < 0.0f ? 0x03u : 0u) | (mid.y < 0.0f ? 0x0Cu : 0u) | (mid.z < 0.0f ? 0x30u : 0u));
+    const uint32_t child = lane ^ mirror;
+    const float cx = static_cast<float>(child & 3u), cy = static_cast<float>((child >> 2) & 3u), cz = static_cast<float>(child >> 4);
+    // per lane: plane value of the child's far (side planes) / near (depth) corner, in units of the child size
+    auto far_corner = [&](BeamVec n) { return beam_dot(n, cx + (n.x > 0.0f ? 1.0f : 0.0f), cy + (n.y > 0.0f ? 1.0f : 0.0f), cz + (n.z > 0.0f ? 1.0f : 0.0f)); };
+    const float b0 = far_corner(n0), b1 = far_corner(n1), b2 = far_corner(n2), b3 = far_corner(n3);
+    const float b4 = beam_dot(mid, cx + (mid.x < 0.0f ? 1.0f : 0.0f), cy + (mid.y < 0.0f ? 1.0f : 0.0f), cz + (mid.z < 0.0f ? 1.0f : 0.0f));
+    const bool child_hi = child >= 32u;
+    const uint32_t child_bit = 1u << (child & 31u);
+
+    const uint32_t root_level = A.levels;
+    uint32_t level = root_level, node = 0;
+    int mx = 0, my = 0, mz = 0;                        // min corner of `node`, tree coordinates
+    float best = kBeamNone;
+    uint32_t stk_node = 0, stk_lo = 0, stk_hi = 0;     // lane l holds the entry of level l
+    bool fresh = true;
+    uint64_t cand = 0;
+    for (;;) {
+        const uint4 rec = A.nodes[node];
+        const uint32_t mlo = beam_uniform(rec.x), mhi = beam_uniform(rec.y), base = beam_uniform(rec.z);
+        const uint32_t shift = 2u * (level - 1u);
+        const float s = static_cast<float>(1u << shift);
+        const float rx = static_cast<float>(A.origin[0] + mx) - A.cam.pos[0];
+        const float ry = static_cast<float>(A.origin[1] + my) - A.cam.pos[1];
+        const float rz = static_cast<float>(A.origin[2] + mz) - A.cam.pos[2];
+        const float depth = __builtin_fmaf(s, b4, beam_dot(mid, rx, ry, rz));         // lower bound of the child's depth
+        const bool nearer = !(depth >= best);
+        if (fresh) {
+            const bool outside = (__builtin_fmaf(s, b0, beam_dot(n0, rx, ry, rz)) < -kBeamSlack) | (__builtin_fmaf(s, b1, beam_dot(n1, rx, ry, rz)) < -kBeamSlack) |
+                                 (__builtin_fmaf(s, b2, beam_dot(n2, rx, ry, rz)) < -kBeamSlack) | (__builtin_fmaf(s, b3, beam_dot(n3, rx, ry, rz)) < -kBeamSlack);
+            const bool filled = ((child_hi ? mhi : mlo) & child_bit) != 0u;
+            cand = __ballot(filled && !outside && nearer);
+            if (level <= BLOK_BEAM_STOP_LEVEL) {
+                while (cand) {
+                    const uint32_t j = static_cast<uint32_t>(__builtin_ctzll(cand));
+                    const float dj = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(depth), j));
+                    best = dj >= 0.0f ? fminf(best, dj) : 0.0f;        // negative or NaN: start at the ray origin
+                    cand &= cand - 1u;
+                    cand &= __ballot(!(depth >= best));
+                }
+            }
+        } else {
+            cand &= __ballot(nearer);
+        }
+        if (cand == 0u) {
+            if (level == root_level) break;
+            ++level;
+            node = __builtin_amdgcn_readlane(stk_node, level);
+            cand = static_cast<uint64_t>(__builtin_amdgcn_readlane(stk_lo, level)) |
+                   (static_cast<uint64_t>(__builtin_amdgcn_readlane(stk_hi, level)) << 32);
+            const int keep = ~((1 << (2u * level)) - 1);
+            mx &= keep; my &= keep; mz &= keep;
+            fresh = false;
+            continue;
+        }
+        const uint32_t j = static_cast<uint32_t>(__builtin_ctzll(cand));
+        cand &= cand - 1u;
+        if (lane == level) { stk_node = node; stk_lo = static_cast<uint32_t>(cand); stk_hi = static_cast<uint32_t>(cand >> 32); }
+        const uint32_t cj = j ^ mirror;
+        const uint32_t below_lo = cj < 32u ? (mlo & ((1u << cj) - 1u)) : mlo;
+        const uint32_t below_hi = cj < 32u ? 0u : (mhi & ((1u << (cj & 31u)) - 1u));
+        node = base + __builtin_popcount(below_lo) + __builtin_popcount(below_hi);
+        mx += static_cast<int>(cj & 3u) << shift; my += static_cast<int>((cj >> 2) & 3u) << shift; mz += static_cast<int>(cj >> 4) << shift;
+        --level;
+        fresh = true;
+    }
+    if (best >= kBeamNone) return kBeamNone;
+    return fmaxf(best * (1.0f - 1.0e-4f) - 2.0f * kBeamSlack, 0.0f);
+}
+
+}  // namespace blok
+#endif

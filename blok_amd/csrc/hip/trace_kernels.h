@@ -89,6 +89,10 @@ struct TraceArgs {
     const blok_material* mat_table;
     uint32_t n_materials;
     float tmin, tmax;
+    // beam pre-pass (beam.h): one conservative start parameter per beam_tile x beam_tile pixels, written by
+    // beam_kernel and read by the Rect / Tiles trace kernels of the same stream; null = no pre-pass
+    float* beam;
+    uint32_t beam_tile, beam_bx;           // beam_bx: beam tiles per row of the rectangle (Rect)
 };
 
 struct UntileArgs {
@@ -104,6 +108,9 @@ void launch_accumulate(const AccumArgs& args, hipStream_t stream);
 void launch_tonemap(const TonemapArgs& args, hipStream_t stream);
 void launch_paths(const PathArgs& args, uint32_t n_blocks, hipStream_t stream);
 void launch_trace(RayMode mode, const TraceArgs& args, uint32_t n_blocks, hipStream_t stream);
+// Number of beam tiles of a launch (= floats of TraceArgs::beam) and the pre-pass itself; Rect and Tiles only.
+uint32_t beam_tiles(RayMode mode, const TraceArgs& args, uint32_t tiles_of_rank);
+void launch_beam(RayMode mode, const TraceArgs& args, uint32_t n_beam_tiles, hipStream_t stream);
 void launch_untile(const UntileArgs& args, hipStream_t stream);
 
 }  // namespace blok

@@ -4,6 +4,7 @@
 #include "trace_kernels.h"
 #include "trace_core.h"
 #include "path_core.h"
+#include "beam.h"
 
 namespace blok {
 
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const TraceArgs A) {
         const uint32_t wave = tid >> 6, lane = tid & 63u;
         const uint32_t lx = (wave & 1u) * kWaveW + (lane % kWaveW);
         const uint32_t ly = (wave >> 1) * kWaveH + (lane / kWaveW);
-        uint32_t x, y;
+        uint32_t x, y, beam_index = 0;             // beam_index: this wave's entry of A.beam (wave-uniform)
         size_t out_index;
         bool inside;
         if constexpr (MODE == RayMode::Rect) {
@@ -61,9 +62,9 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const TraceArgs A) {
             if (!block_to_tile(blockIdx.x, gridDim.x, bx_count, by_count, bx, by)) return;
             const uint32_t rx = bx * kTileW + lx, ry = by * kTileH + ly;
             inside = rx < A.w && ry < A.h;
-            if (!inside) return;
             x = A.x0 + rx; y = A.y0 + ry;
             out_index = static_cast<size_t>(ry) * A.w + rx;
+            if (A.beam) beam_index = ((ry - lane / kWaveW) / A.beam_tile) * A.beam_bx + (rx - lane % kWaveW) / A.beam_tile;
         } else {
             const uint32_t per_side = A.tile / kTileW;                  // blocks per tile row
             const uint32_t per_tile = per_side * (A.tile / kTileH);
@@ -73,12 +74,51 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const TraceArgs A) {
             const uint32_t ix = (sub % per_side) * kTileW + lx, iy = (sub / per_side) * kTileH + ly;
             x = tx * A.tile + ix; y = ty * A.tile + iy;
             out_index = static_cast<size_t>(local_tile) * A.tile * A.tile + static_cast<size_t>(iy) * A.tile + ix;
-            inside = global_tile < A.tiles_total && x < A.frame_w && y < A.frame_h;
-            if (!inside) { write_miss(Sink{A.out ? A.out + out_index : nullptr, A.out_rgba ? A.out_rgba + out_index : nullptr}); return; }
+            inside = x < A.frame_w && y < A.frame_h;
+            if (A.beam) {
+                const uint32_t beams_per_side = A.tile / A.beam_tile;
+                beam_index = (local_tile * beams_per_side + (iy - lane / kWaveW) / A.beam_tile) * beams_per_side + (ix - lane % kWaveW) / A.beam_tile;
+            }
+            if (global_tile >= A.tiles_total) {                        // whole workgroup: padding tile of the last round
+                write_miss(Sink{A.out ? A.out + out_index : nullptr, A.out_rgba ? A.out_rgba + out_index : nullptr});
+                return;
+            }
         }
-        const RayIn r = primary_ray(A, x, y);
-        trace_one(A, r, stk, Sink{A.out ? A.out + out_index : nullptr, A.out_rgba ? A.out_rgba + out_index : nullptr});
+        const Sink sink{A.out ? A.out + out_index : nullptr, A.out_rgba ? A.out_rgba + out_index : nullptr};
+        if (!inside) {
+            if constexpr (MODE == RayMode::Tiles) write_miss(sink);     // the tile buffer is dense
+            return;
+        }
+        RayIn r = primary_ray(A, x, y);
+        if (A.beam) {                                                   // start parameter of this wave's beam tile (beam.h)
+            const float t0 = A.beam[__builtin_amdgcn_readfirstlane(beam_index)];
+            if (t0 >= kBeamNone) { write_miss(sink); return; }
+            r.tmin = fmaxf(r.tmin, t0);
+        }
+        trace_one(A, r, stk, sink);
     }
+}
+
+// One wave per beam tile: TraceArgs::beam[tile] = conservative start parameter of the tile's rays, or kBeamNone.
+template <RayMode MODE>
+__global__ __launch_bounds__(64) void beam_kernel(const TraceArgs A, const uint32_t n_beam_tiles) {
+    const uint32_t b = blockIdx.x, lane = threadIdx.x;
+    if (b >= n_beam_tiles) return;
+    const uint32_t B = A.beam_tile;
+    uint32_t px, py, px_end, py_end;                                   // frame pixels [px, px_end) x [py, py_end)
+    if constexpr (MODE == RayMode::Rect) {
+        px = A.x0 + (b % A.beam_bx) * B; py = A.y0 + (b / A.beam_bx) * B;
+        px_end = min(px + B, A.x0 + A.w); py_end = min(py + B, A.y0 + A.h);
+    } else {
+        const uint32_t per_side = A.tile / B, per_tile = per_side * per_side;
+        const uint32_t local_tile = b / per_tile, sub = b % per_tile;
+        const uint32_t global_tile = A.rank + local_tile * A.n_ranks;
+        if (global_tile >= A.tiles_total) { if (lane == 0) A.beam[b] = kBeamNone; return; }
+        px = (global_tile % A.tiles_x) * A.tile + (sub % per_side) * B; py = (global_tile / A.tiles_x) * A.tile + (sub / per_side) * B;
+        px_end = px + B; py_end = py + B;
+    }
+    const float t0 = beam_start(A, static_cast<float>(px), static_cast<float>(py), static_cast<float>(px_end), static_cast<float>(py_end), lane);
+    if (lane == 0) A.beam[b] = t0;
 }
 
 // raygen.rgen main(): one lane per pixel of the rectangle, same 16x16 / 8x8 pixel mapping as the trace kernel.
@@ -129,6 +169,17 @@ void launch_trace(RayMode mode, const TraceArgs& args, uint32_t n_blocks, hipStr
         case RayMode::Tiles: hipLaunchKernelGGL(trace_kernel<RayMode::Tiles>, dim3(n_blocks), dim3(kBlock), lds, stream, args); break;
         case RayMode::Rays:  hipLaunchKernelGGL(trace_kernel<RayMode::Rays>,  dim3(n_blocks), dim3(kBlock), lds, stream, args); break;
     }
+}
+
+uint32_t beam_tiles(RayMode mode, const TraceArgs& a, uint32_t tiles_of_rank) {
+    if (mode == RayMode::Rect) return ((a.w + a.beam_tile - 1u) / a.beam_tile) * ((a.h + a.beam_tile - 1u) / a.beam_tile);
+    return tiles_of_rank * (a.tile / a.beam_tile) * (a.tile / a.beam_tile);
+}
+
+void launch_beam(RayMode mode, const TraceArgs& args, uint32_t n_beam_tiles, hipStream_t stream) {
+    if (n_beam_tiles == 0 || mode == RayMode::Rays) return;
+    if (mode == RayMode::Rect) hipLaunchKernelGGL(beam_kernel<RayMode::Rect>, dim3(n_beam_tiles), dim3(64), 0, stream, args, n_beam_tiles);
+    else hipLaunchKernelGGL(beam_kernel<RayMode::Tiles>, dim3(n_beam_tiles), dim3(64), 0, stream, args, n_beam_tiles);
 }
 
 void launch_paths(const PathArgs& args, uint32_t n_blocks, hipStream_t stream) {

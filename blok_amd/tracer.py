@@ -54,6 +54,10 @@ class HipTracer:
         self._check(self._lib.blok_hip_resize(self._ctx, width, height))
         self.width, self.height = int(width), int(height)
 
+    def set_beam(self, beam_tile_pixels: int):
+        """Beam pre-pass granularity of the frame kernels in pixels (0 = off, default 32); never changes a result."""
+        self._check(self._lib.blok_hip_set_beam(self._ctx, beam_tile_pixels))
+
     def reset_accum(self):
         self._check(self._lib.blok_hip_reset_accum(self._ctx))
 

@@ -268,6 +268,11 @@ int blok_hip_reset_accum(blok_hip_ctx* ctx);
  * launch stream around the kernel only (valid after that stream has been synchronised). */
 int blok_hip_last_kernel_ms(blok_hip_ctx* ctx, float* out_ms);
 
+/* Beam pre-pass of the frame kernels (no reference counterpart; the reference culls per ray in Vulkan RT hardware,
+ * blok/src/renderer_raytracing.cpp:15-254): before a rectangle / tile launch, one wave per beam_tile_pixels^2 pixels finds a
+ * conservative start parameter for that tile's rays, and tiles whose frustum meets no voxel are written as misses without
+ * a walk.  Results are identical with and without it (tests/test_gpu_parity.py).  0 turns it off; default 32. */
+int blok_hip_set_beam(blok_hip_ctx* ctx, uint32_t beam_tile_pixels);
 /* Enable/disable the per-launch HIP event pair (default off: nothing but the kernel is
  * enqueued by the *_device entries). */
 int blok_hip_set_timing(blok_hip_ctx* ctx, int enabled);

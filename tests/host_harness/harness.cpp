@@ -37,6 +37,12 @@ void* hh_build(const blok_svo_node* nodes, size_t n_nodes, const blok_sub_chunk*
     return h;
 }
 void hh_free(void* h) { delete static_cast<Harness*>(h); }
+const void* hh_tree_nodes(const void* h, size_t* count, int32_t* origin) {
+    const Harness* H = static_cast<const Harness*>(h);
+    *count = H->nodes.size();
+    for (int i = 0; i < 3; ++i) origin[i] = H->tree.origin[i];
+    return H->nodes.data();
+}
 uint32_t hh_levels(const void* h) { return static_cast<const Harness*>(h)->tree.levels; }
 uint64_t hh_voxels(const void* h) { return static_cast<const Harness*>(h)->tree.n_voxels; }
 
@@ -116,6 +122,27 @@ void hh_render_paths_events(const void* h, const blok_camera* cam, const blok_ma
             shade_pixel(p, x0 + x, y0 + y, 0, stack.data());
         }
     g_seq = nullptr;
+}
+
+// Per-ray iteration counts for a rectangle of a frame with an optional per-pixel start parameter (beam experiments).
+void hh_trace_rect_stats(const void* h, const blok_camera* cam, uint32_t width, uint32_t height, uint32_t x0, uint32_t y0,
+                         uint32_t w, uint32_t hgt, const float* tstart, blok_hit* out, uint32_t* iters_per_ray) {
+    const Harness* H = static_cast<const Harness*>(h);
+    TraceArgs a = make_args(H);
+    a.cam = *cam; a.frame_w = width; a.frame_h = height;
+    std::vector<uint4> stack(size_t(kMaxLevels) * 2 * kBlock);
+    std::memset(g_stat, 0, sizeof(g_stat));
+    for (uint32_t y = 0; y < hgt; ++y)
+        for (uint32_t x = 0; x < w; ++x) {
+            uint64_t before = 0;
+            for (int l = 0; l < 8; ++l) before += g_stat[0][l];
+            RayIn r = primary_ray(a, x0 + x, y0 + y);
+            if (tstart && tstart[size_t(y) * w + x] > r.tmin) r.tmin = tstart[size_t(y) * w + x];
+            trace_one(a, r, stack.data(), Sink{out + size_t(y) * w + x, nullptr});
+            uint64_t after = 0;
+            for (int l = 0; l < 8; ++l) after += g_stat[0][l];
+            iters_per_ray[size_t(y) * w + x] = uint32_t(after - before);
+        }
 }
 
 // Per-ray iteration counts for a frame (row-major), plus the event totals [4][8].

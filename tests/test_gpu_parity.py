@@ -154,6 +154,61 @@ def test_config3_1024_svo_4k(tracer_cls, scene1024):
     tr.shutdown()
 
 
+def test_beam_prepass_never_changes_a_record(tracer_cls, scene64, scene1024):
+    """The beam pre-pass (blok_amd/csrc/hip/beam.h) only raises the walk's start parameter to a conservative bound and
+    writes whole tiles as misses when their frustum meets no voxel: frames with every beam tile size — full frame, odd
+    rectangles and rank tiles, camera outside / inside / grazing the world — equal the frames without it, bit for bit."""
+    import torch
+    cm, pw = scene1024
+    Wd, Ht = 3840, 2160
+    tr = tracer_cls(Wd, Ht).init()
+    tr.add_world(pw)
+    cams = [W.scene_camera(1024, pose, Wd, Ht, SEED) for pose in (0, 1, 2)]
+    inside = W.scene_camera(1024, 0, Wd, Ht, SEED).copy()
+    inside["pos"][0] = (512.3, 300.7, 512.9)           # inside the terrain shell's bounding volume, looking along the pose
+    cams.append(inside)
+    for cam in cams:
+        tr.set_beam(0)
+        plain = tr.draw_frame(cam)
+        rect = (1001, 703, 333, 211)
+        plain_rect = tr.draw_frame(cam, rect)
+        for beam in (8, 16, 32, 64):
+            tr.set_beam(beam)
+            assert records_equal(tr.draw_frame(cam).reshape(-1), plain.reshape(-1)).all(), beam
+            assert records_equal(tr.draw_frame(cam, rect).reshape(-1), plain_rect.reshape(-1)).all(), beam
+    cam = cams[1]
+    tr.set_beam(0)
+    plain = tr.draw_frame(cam)
+    for beam, tile, n_ranks in [(32, 32, 8), (32, 48, 3), (16, 64, 2), (64, 64, 5)]:
+        tr.set_beam(beam)
+        per = tr.tiles_for_rank(tile, 0, n_ranks)
+        gathered = torch.zeros((n_ranks * per * tile * tile, 4), dtype=torch.int32, device="cuda")
+        for r in range(n_ranks):
+            tr.draw_tiles_device(cam, tile, r, n_ranks, hits_ptr=gathered[r * per * tile * tile:].data_ptr())
+        out = torch.empty((Ht * Wd, 4), dtype=torch.int32, device="cuda")
+        tr.untile_device(gathered.data_ptr(), 16, tile, n_ranks, per, out.data_ptr())
+        torch.cuda.synchronize()
+        assert (out.cpu().numpy().view(np.uint8).reshape(-1, 16) == plain.reshape(-1).view(np.uint8).reshape(-1, 16)).all(), (beam, tile)
+    tr.shutdown()
+    # small world, small odd frame, many camera positions incl. inside filled voxels and far outside
+    cm, pw = scene64
+    tr = tracer_cls(203, 117).init()
+    tr.add_world(pw)
+    rng = np.random.default_rng(7)
+    for k in range(24):
+        cam = W.scene_camera(64, k % 3, 203, 117, SEED).copy()
+        if k >= 3:
+            cam["pos"][0] = rng.uniform(-40, 104, 3).astype(np.float32)
+        tr.set_beam(0)
+        plain = tr.draw_frame(cam)
+        for beam in (8, 32):
+            tr.set_beam(beam)
+            assert records_equal(tr.draw_frame(cam).reshape(-1), plain.reshape(-1)).all(), (k, beam)
+    with pytest.raises(Exception):
+        tr.set_beam(12)
+    tr.shutdown()
+
+
 def test_world_edge_cases(tracer_cls):
     """Empty world, single voxel, negative coordinates, material ids above 65535, replace-world, errors."""
     from blok_amd._ffi import BlokError
