@@ -26,7 +26,7 @@
 namespace blok {
 
 #ifndef BLOK_BEAM_STOP_LEVEL
-#define BLOK_BEAM_STOP_LEVEL 2      // finest cells examined = children of a node of this level (2: 4^3 bricks, 1: voxels)
+#define BLOK_BEAM_STOP_LEVEL 1      // finest cells examined = children of a node of this level (1: voxels, 2: 4^3 bricks)
 #endif
 constexpr float kBeamSlack = 0.05f;
 constexpr float kBeamNone = 3.0e38f;   // "no cell of the tree meets the frustum"

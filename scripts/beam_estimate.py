@@ -17,7 +17,7 @@ L = H.lib()
 L.hh_trace_rect_stats.argtypes = [C.c_void_p] * 2 + [C.c_uint32] * 6 + [C.c_void_p] * 3
 cam = W.scene_camera(n, pose, W_, H_)
 plain = beam = 0; waves = sky_waves = 0
-for y0 in range(0, H_ - B + 1, 216):
+for y0 in [int(a) for a in (sys.argv[5].split(",") if len(sys.argv) > 5 else range(0, H_ - B + 1, 216))]:
     w, h = W_, B
     out = np.zeros(w * h, dtype=O.HIT); it = np.zeros(w * h, dtype=np.uint32)
     L.hh_trace_rect_stats(hk.h, C.c_void_p(cam.ctypes.data), W_, H_, 0, y0, w, h, None, C.c_void_p(out.ctypes.data), C.c_void_p(it.ctypes.data))
@@ -32,3 +32,10 @@ for y0 in range(0, H_ - B + 1, 216):
     sky = np.repeat(np.repeat(~np.isfinite(tmin_tile)[None, :], h // 8, axis=0), B // 8, axis=1)
     plain += a.sum(); beam += b[~sky].sum(); waves += a.size; sky_waves += sky.sum()
 print(f"pose {pose} beam tile {B}: wave-iterations plain {plain} ({plain / waves:.1f}/wave), with beam start {beam} ({beam / waves:.1f}/wave); sky waves {sky_waves / waves:.2f}")
+# per-level event totals of the last band with the beam start (g_stat of the harness): iter / descend / step / ascend
+tot = np.zeros((5, 8), dtype=np.uint64)
+L.hh_stat_totals.argtypes = [C.c_void_p]
+L.hh_stat_totals(C.c_void_p(tot.ctypes.data))
+rays_hit_tiles = (~sky).sum() * 64
+for e, name in enumerate(["iter", "descend", "step", "ascend"]):
+    print(name, "per ray of the band by level", np.round(tot[e] / (w * h), 2))

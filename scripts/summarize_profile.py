@@ -34,7 +34,7 @@ for f in sorted(src.glob("pmc*/**/*counter_collection.csv")):
         pmc[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
 summary = {}
 for kernel, counters in pmc.items():
-    if "trace_kernel" not in kernel:
+    if "trace_kernel" not in kernel and "beam_kernel" not in kernel:
         continue
     summary[kernel] = {c: {"mean": sum(v) / len(v), "n": len(v)} for c, v in counters.items()}
     d = durations.get(kernel)

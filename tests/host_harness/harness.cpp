@@ -145,6 +145,8 @@ void hh_trace_rect_stats(const void* h, const blok_camera* cam, uint32_t width, 
         }
 }
 
+void hh_stat_totals(uint64_t* totals) { std::memcpy(totals, g_stat, sizeof(g_stat)); }
+
 // Per-ray iteration counts for a frame (row-major), plus the event totals [4][8].
 void hh_trace_primary_stats(const void* h, const blok_camera* cam, uint32_t width, uint32_t height, blok_hit* out,
                             uint32_t* iters_per_ray, uint64_t* totals) {
