@@ -230,7 +230,8 @@ def main():
                 traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                               "kernel": "trace_kernel", "kernel_ms": launch_ms, "kernel_ms_alone": kernel_ms_avg, "beam_tile": args.beam,
+                               "kernel": "trace_kernel (+ its beam_kernel pre-pass when --beam > 0): one launch pair per frame",
+                               "kernel_ms": launch_ms, "kernel_ms_alone": kernel_ms_avg, "beam_tile": args.beam,
                                "algorithmic_bytes_per_ray": alg["bytes_per_ray"],
                                "rays_per_launch": rays_per_launch,
                                "sub_chunks_per_ray": alg["sub_chunks_per_ray"], "nodes_per_ray": alg["nodes_per_ray"],
