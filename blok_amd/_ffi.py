@@ -148,6 +148,13 @@ HIP_SYMBOLS = {
     "blok_hip_accum_download": (C.c_int, [C.c_void_p, C.c_void_p]),
     "blok_hip_reset_accum": (C.c_int, [C.c_void_p]),
     "blok_hip_set_beam": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "blok_hip_volume_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float]),
+    "blok_hip_volume_destroy": (C.c_int, [C.c_void_p]),
+    "blok_hip_volume_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "blok_hip_volume_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "blok_hip_volume_set_voxels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "blok_hip_volume_apply_brush": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_float, C.c_float, C.c_int]),
+    "blok_hip_volume_rebuild": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "blok_hip_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "blok_hip_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "blok_hip_abi_version": (C.c_uint32, []),

@@ -316,28 +316,36 @@ GpuBuildStatus gpu_build_tree(const blok_svo_node* nodes, size_t n_nodes, const 
 namespace {
 
 struct DenseCtx {
-    const uint32_t* ids;          // ids[x + y*nx + z*nx*ny], 0 = empty
+    const uint32_t* ids;          // ids[x + y*nx + z*nx*ny]; filled iff != 0 when there is no density array
+    const float* density;         // null, or: filled iff density > 0 (chunk_manager.cpp:121) and ids are material ids
     uint32_t nx, ny, nz;
     uint32_t bx, by, bz;          // bricks per axis
     uint32_t levels;
+    uint32_t rx0, ry0, rz0, rbx, rby, rbz;   // brick sub-range handled by dense_brick_kernel (whole grid: 0,0,0,bx,by,bz)
 };
+
+__device__ __forceinline__ bool dense_filled(const DenseCtx& d, size_t i) {
+    return d.density ? d.density[i] > 0.0f : d.ids[i] != 0u;
+}
 
 // One lane per brick: 16 rows of 4 consecutive ids; neighbouring lanes read neighbouring 16-byte groups of a row.
 __global__ __launch_bounds__(256) void dense_brick_kernel(const DenseCtx d, uint64_t total, uint64_t* masks, uint32_t* non_empty) {
     const uint64_t tid = static_cast<uint64_t>(blockIdx.x) * 256u + threadIdx.x;
-    if (tid >= total) return;
-    const uint32_t b_x = static_cast<uint32_t>(tid % d.bx), b_y = static_cast<uint32_t>((tid / d.bx) % d.by), b_z = static_cast<uint32_t>(tid / (static_cast<uint64_t>(d.bx) * d.by));
+    if (tid >= total) return;                                                  // total = rbx * rby * rbz
+    const uint32_t b_x = d.rx0 + static_cast<uint32_t>(tid % d.rbx), b_y = d.ry0 + static_cast<uint32_t>((tid / d.rbx) % d.rby),
+                   b_z = d.rz0 + static_cast<uint32_t>(tid / (static_cast<uint64_t>(d.rbx) * d.rby));
     uint64_t mask = 0;
     for (uint32_t z = 0; z < 4u; ++z)
         for (uint32_t y = 0; y < 4u; ++y) {
             const uint32_t vy = b_y * 4u + y, vz = b_z * 4u + z;
             if (vy >= d.ny || vz >= d.nz) continue;
-            const uint32_t* row = d.ids + (static_cast<size_t>(vz) * d.ny + vy) * d.nx + b_x * 4u;
+            const size_t row = (static_cast<size_t>(vz) * d.ny + vy) * d.nx + b_x * 4u;
             for (uint32_t x = 0; x < 4u; ++x)
-                if (b_x * 4u + x < d.nx && row[x] != 0u) mask |= 1ull << (x | (y << 2) | (z << 4));
+                if (b_x * 4u + x < d.nx && dense_filled(d, row + x)) mask |= 1ull << (x | (y << 2) | (z << 4));
         }
-    masks[tid] = mask;
-    non_empty[tid] = mask != 0ull;
+    const size_t g = b_x + (static_cast<size_t>(b_z) * d.by + b_y) * d.bx;
+    masks[g] = mask;
+    non_empty[g] = mask != 0ull;
 }
 
 __global__ __launch_bounds__(256) void dense_key_kernel(const DenseCtx d, const uint64_t* masks, const uint32_t* slot_of, uint64_t total,
@@ -386,6 +394,7 @@ GpuBuildStatus gpu_build_tree_dense(const uint32_t* ids, uint32_t nx, uint32_t n
     DenseCtx d{};
     d.nx = nx; d.ny = ny; d.nz = nz; d.levels = levels;
     d.bx = (nx + 3) / 4; d.by = (ny + 3) / 4; d.bz = (nz + 3) / 4;
+    d.rbx = d.bx; d.rby = d.by; d.rbz = d.bz;
     const uint64_t total = static_cast<uint64_t>(d.bx) * d.by * d.bz;
     if (total > 0x7FFFFFFFull) return GpuBuildStatus::UseHostBuilder;
     DeviceBuffers mem;
@@ -403,6 +412,194 @@ GpuBuildStatus gpu_build_tree_dense(const uint32_t* ids, uint32_t nx, uint32_t n
     return finish_from_masks(mem, total, d_masks, d_flag, d_slot, levels, lo,
         [&](const uint32_t* slot, uint64_t* keys, uint32_t* src) {
             hipLaunchKernelGGL(dense_key_kernel, dim3(blocks_for(total)), dim3(256), 0, nullptr, d, d_masks, slot, total, keys, src);
+        },
+        [&](const uint64_t* masks_sorted, const uint32_t* src_sorted, const uint32_t* mat_base, uint32_t n_bricks, uint32_t* materials) {
+            hipLaunchKernelGGL(dense_material_kernel, dim3(blocks_for(static_cast<uint64_t>(n_bricks) * 64u)), dim3(256), 0, nullptr,
+                               d, masks_sorted, src_sorted, mat_base, n_bricks, materials);
+        }, out, why);
+}
+
+// ---- device-resident dense store (gpu_build.h: GpuVolume) ------------------------------------------------------------
+namespace {
+
+DenseCtx volume_ctx(const GpuVolume& v) {
+    DenseCtx d{};
+    d.ids = v.d_ids; d.density = v.d_density;
+    d.nx = v.nx; d.ny = v.ny; d.nz = v.nz; d.bx = v.nbx; d.by = v.nby; d.bz = v.nbz; d.levels = v.levels;
+    d.rbx = v.nbx; d.rby = v.nby; d.rbz = v.nbz;
+    return d;
+}
+
+// Recomputes the masks of the bricks that contain voxels [lo, hi) (box-local voxel coordinates).
+GpuBuildStatus volume_refresh(GpuVolume* v, const uint32_t lo[3], const uint32_t hi[3], std::string* why) {
+    DenseCtx d = volume_ctx(*v);
+    d.rx0 = lo[0] / 4u; d.ry0 = lo[1] / 4u; d.rz0 = lo[2] / 4u;
+    d.rbx = (hi[0] + 3u) / 4u - d.rx0; d.rby = (hi[1] + 3u) / 4u - d.ry0; d.rbz = (hi[2] + 3u) / 4u - d.rz0;
+    const uint64_t total = static_cast<uint64_t>(d.rbx) * d.rby * d.rbz;
+    if (!total) return GpuBuildStatus::Ok;
+    hipLaunchKernelGGL(dense_brick_kernel, dim3(blocks_for(total)), dim3(256), 0, nullptr, d, total, v->d_masks, v->d_flag);
+    GB_TRY(hipGetLastError());
+    return GpuBuildStatus::Ok;
+}
+
+struct VoxelEdit { uint32_t index; uint32_t material; float density; };
+
+__global__ __launch_bounds__(256) void volume_set_kernel(float* density, uint32_t* ids, const VoxelEdit* edits, uint32_t n) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const VoxelEdit e = edits[i];                   // indices are unique (the host keeps the last write per voxel)
+    density[e.index] = e.density;
+    ids[e.index] = e.material;
+}
+
+struct BrushCtx {
+    float* density;
+    uint32_t nx, ny, nz;
+    int32_t origin[3];
+    int32_t lo[3];               // gvMin (world voxels), brush.cpp:20-21
+    uint32_t ex, ey, ez;         // gvMax - gvMin
+    int32_t chunk;
+    float voxel_size, cx, cy, cz, radius, value;
+    int mode;
+};
+
+__device__ __forceinline__ int32_t chunk_of(int32_t g, int32_t c) { return g >= 0 ? g / c : (g - c + 1) / c; }   // chunk_manager.cpp:41-47
+
+// One lane per voxel of the brush's bounding box; float ops in the reference's order (brush.cpp:36-50), no contraction.
+__global__ __launch_bounds__(256) void volume_brush_kernel(const BrushCtx b) {
+    const uint64_t tid = static_cast<uint64_t>(blockIdx.x) * 256u + threadIdx.x;
+    if (tid >= static_cast<uint64_t>(b.ex) * b.ey * b.ez) return;
+    const int32_t gx = b.lo[0] + static_cast<int32_t>(tid % b.ex), gy = b.lo[1] + static_cast<int32_t>((tid / b.ex) % b.ey),
+                  gz = b.lo[2] + static_cast<int32_t>(tid / (static_cast<uint64_t>(b.ex) * b.ey));
+    const int32_t ccx = chunk_of(gx, b.chunk), ccy = chunk_of(gy, b.chunk), ccz = chunk_of(gz, b.chunk);
+    const int32_t lx = gx - ccx * b.chunk, ly = gy - ccy * b.chunk, lz = gz - ccz * b.chunk;
+    const float ox = static_cast<float>(ccx * b.chunk) * b.voxel_size, oy = static_cast<float>(ccy * b.chunk) * b.voxel_size,
+                oz = static_cast<float>(ccz * b.chunk) * b.voxel_size;
+    const float half = 0.5f * b.voxel_size;
+    const float vx = ox + (static_cast<float>(lx) + half), vy = oy + (static_cast<float>(ly) + half), vz = oz + (static_cast<float>(lz) + half);
+    const float dx = vx - b.cx, dy = vy - b.cy, dz = vz - b.cz;
+    const float dist = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);
+    if (dist > b.radius) return;
+    const size_t i = static_cast<size_t>(gx - b.origin[0]) + (static_cast<size_t>(gz - b.origin[2]) * b.ny + static_cast<size_t>(gy - b.origin[1])) * b.nx;
+    const float d = b.density[i];
+    b.density[i] = b.mode == 0 ? (d < b.value ? b.value : d) : (b.value < d ? b.value : d);     // std::max / std::min, brush.cpp:52-57
+}
+
+}  // namespace
+
+GpuBuildStatus gpu_volume_create(const int32_t origin[3], uint32_t nx, uint32_t ny, uint32_t nz, uint32_t chunk, float voxel_size,
+                                 GpuVolume* out, std::string* why) {
+    *out = GpuVolume{};
+    if (!nx || !ny || !nz || !chunk || !(voxel_size == 1.0f)) { *why = "volume: empty box, zero chunk size or voxel size other than 1"; return GpuBuildStatus::Unsupported; }
+    for (int a = 0; a < 3; ++a) {
+        const int64_t hi = int64_t(origin[a]) + (a == 0 ? nx : a == 1 ? ny : nz);
+        if (origin[a] < -32768 || hi > 32768) { *why = "world voxel coordinates exceed int16 (hit records carry int16)"; return GpuBuildStatus::Unsupported; }
+    }
+    const uint32_t extent = std::max(nx, std::max(ny, nz));
+    uint32_t levels = 1;
+    while ((uint64_t(1) << (2 * levels)) < extent) ++levels;
+    if (levels > kMaxLevels) { *why = "world extent exceeds 4^7 voxels per axis"; return GpuBuildStatus::Unsupported; }
+    GpuVolume v;
+    v.nx = nx; v.ny = ny; v.nz = nz; v.nbx = (nx + 3) / 4; v.nby = (ny + 3) / 4; v.nbz = (nz + 3) / 4; v.levels = levels;
+    for (int a = 0; a < 3; ++a) v.origin[a] = origin[a];
+    v.chunk = chunk; v.voxel_size = voxel_size;
+    if (v.bricks() > 0x7FFFFFFFull) { *why = "volume: more than 2^31 bricks"; return GpuBuildStatus::Unsupported; }
+    DeviceBuffers mem;
+    GB_TRY(mem.alloc(&v.d_density, v.cells())); GB_TRY(mem.alloc(&v.d_ids, v.cells()));
+    GB_TRY(mem.alloc(&v.d_masks, v.bricks())); GB_TRY(mem.alloc(&v.d_flag, v.bricks() + 1)); GB_TRY(mem.alloc(&v.d_slot, v.bricks() + 1));
+    GB_TRY(hipMemset(v.d_density, 0, v.cells() * sizeof(float))); GB_TRY(hipMemset(v.d_ids, 0, v.cells() * sizeof(uint32_t)));
+    GB_TRY(hipMemset(v.d_masks, 0, v.bricks() * sizeof(uint64_t))); GB_TRY(hipMemset(v.d_flag, 0, (v.bricks() + 1) * sizeof(uint32_t)));
+    GB_TRY(hipDeviceSynchronize());
+    for (void* p : {static_cast<void*>(v.d_density), static_cast<void*>(v.d_ids), static_cast<void*>(v.d_masks), static_cast<void*>(v.d_flag), static_cast<void*>(v.d_slot)}) mem.release(p);
+    *out = v;
+    return GpuBuildStatus::Ok;
+}
+
+void gpu_volume_destroy(GpuVolume* v) {
+    if (!v) return;
+    for (void* p : {static_cast<void*>(v->d_density), static_cast<void*>(v->d_ids), static_cast<void*>(v->d_masks), static_cast<void*>(v->d_flag), static_cast<void*>(v->d_slot)})
+        if (p) (void)hipFree(p);
+    *v = GpuVolume{};
+}
+
+GpuBuildStatus gpu_volume_upload(GpuVolume* v, const float* density, const uint32_t* ids, std::string* why) {
+    if (density) GB_TRY(hipMemcpy(v->d_density, density, v->cells() * sizeof(float), hipMemcpyHostToDevice));
+    else GB_TRY(hipMemset(v->d_density, 0, v->cells() * sizeof(float)));
+    if (ids) GB_TRY(hipMemcpy(v->d_ids, ids, v->cells() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    else GB_TRY(hipMemset(v->d_ids, 0, v->cells() * sizeof(uint32_t)));
+    const uint32_t lo[3] = {0, 0, 0}, hi[3] = {v->nx, v->ny, v->nz};
+    return volume_refresh(v, lo, hi, why);
+}
+
+GpuBuildStatus gpu_volume_download(const GpuVolume* v, float* density, uint32_t* ids, std::string* why) {
+    if (density) GB_TRY(hipMemcpy(density, v->d_density, v->cells() * sizeof(float), hipMemcpyDeviceToHost));
+    if (ids) GB_TRY(hipMemcpy(ids, v->d_ids, v->cells() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return GpuBuildStatus::Ok;
+}
+
+GpuBuildStatus gpu_volume_set_voxels(GpuVolume* v, const int32_t* xyz, const uint32_t* material, const float* density, size_t n,
+                                     std::string* why) {
+    if (!n) return GpuBuildStatus::Ok;
+    std::vector<VoxelEdit> edits(n);
+    uint32_t lo[3] = {v->nx, v->ny, v->nz}, hi[3] = {0, 0, 0};
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t l[3];
+        for (int a = 0; a < 3; ++a) {
+            const int64_t c = int64_t(xyz[3 * i + a]) - v->origin[a];
+            if (c < 0 || c >= int64_t(a == 0 ? v->nx : a == 1 ? v->ny : v->nz)) { *why = "set_voxels: voxel outside the resident volume"; return GpuBuildStatus::Unsupported; }
+            l[a] = static_cast<uint32_t>(c);
+            lo[a] = std::min(lo[a], l[a]); hi[a] = std::max(hi[a], l[a] + 1u);
+        }
+        edits[i] = VoxelEdit{static_cast<uint32_t>(l[0] + (static_cast<size_t>(l[2]) * v->ny + l[1]) * v->nx), material ? material[i] : 0u,
+                             density ? density[i] : 1.0f};
+    }
+    if (v->cells() > 0xFFFFFFFFull) { *why = "set_voxels: volume larger than 2^32 cells"; return GpuBuildStatus::Unsupported; }
+    // sequential semantics: the last write of a voxel wins
+    std::stable_sort(edits.begin(), edits.end(), [](const VoxelEdit& a, const VoxelEdit& b) { return a.index < b.index; });
+    size_t m = 0;
+    for (size_t i = 0; i < n; ++i) { if (i + 1 < n && edits[i + 1].index == edits[i].index) continue; edits[m++] = edits[i]; }
+    DeviceBuffers mem;
+    VoxelEdit* d_edits;
+    GB_TRY(mem.alloc(&d_edits, m));
+    GB_TRY(hipMemcpy(d_edits, edits.data(), m * sizeof(VoxelEdit), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(volume_set_kernel, dim3(blocks_for(m)), dim3(256), 0, nullptr, v->d_density, v->d_ids, d_edits, static_cast<uint32_t>(m));
+    GB_TRY(hipGetLastError());
+    const GpuBuildStatus st = volume_refresh(v, lo, hi, why);
+    GB_TRY(hipDeviceSynchronize());
+    return st;
+}
+
+GpuBuildStatus gpu_volume_brush(GpuVolume* v, const float center[3], float radius, float value, int mode, std::string* why) {
+    BrushCtx b{};
+    b.density = v->d_density; b.nx = v->nx; b.ny = v->ny; b.nz = v->nz;
+    uint32_t lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) {
+        b.origin[a] = v->origin[a];
+        const int32_t gmin = static_cast<int32_t>(std::floor(center[a] - radius));               // brush.cpp:20
+        const int32_t gmax = static_cast<int32_t>(std::floor(center[a] + radius)) + 1;           // brush.cpp:21-22
+        const int64_t dim = a == 0 ? v->nx : a == 1 ? v->ny : v->nz;
+        if (gmin < v->origin[a] || gmax > v->origin[a] + dim) { *why = "brush: bounding box leaves the resident volume"; return GpuBuildStatus::Unsupported; }
+        b.lo[a] = gmin;
+        lo[a] = static_cast<uint32_t>(gmin - v->origin[a]); hi[a] = static_cast<uint32_t>(gmax - v->origin[a]);
+    }
+    b.ex = hi[0] - lo[0]; b.ey = hi[1] - lo[1]; b.ez = hi[2] - lo[2];
+    b.chunk = static_cast<int32_t>(v->chunk); b.voxel_size = v->voxel_size;
+    b.cx = center[0]; b.cy = center[1]; b.cz = center[2]; b.radius = radius; b.value = value; b.mode = mode;
+    const uint64_t total = static_cast<uint64_t>(b.ex) * b.ey * b.ez;
+    if (!total) return GpuBuildStatus::Ok;
+    hipLaunchKernelGGL(volume_brush_kernel, dim3(blocks_for(total)), dim3(256), 0, nullptr, b);
+    GB_TRY(hipGetLastError());
+    return volume_refresh(v, lo, hi, why);
+}
+
+GpuBuildStatus gpu_volume_build(GpuVolume* v, GpuTree* out, std::string* why) {
+    *out = GpuTree{};
+    const DenseCtx d = volume_ctx(*v);
+    const uint64_t total = v->bricks();
+    DeviceBuffers mem;
+    return finish_from_masks(mem, total, v->d_masks, v->d_flag, v->d_slot, v->levels, v->origin,
+        [&](const uint32_t* slot, uint64_t* keys, uint32_t* src) {
+            hipLaunchKernelGGL(dense_key_kernel, dim3(blocks_for(total)), dim3(256), 0, nullptr, d, v->d_masks, slot, total, keys, src);
         },
         [&](const uint64_t* masks_sorted, const uint32_t* src_sorted, const uint32_t* mat_base, uint32_t n_bricks, uint32_t* materials) {
             hipLaunchKernelGGL(dense_material_kernel, dim3(blocks_for(static_cast<uint64_t>(n_bricks) * 64u)), dim3(256), 0, nullptr,

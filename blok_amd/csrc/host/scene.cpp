@@ -162,7 +162,7 @@ int blok_scene_generate(blok_world* w, uint32_t n, uint32_t seed, uint64_t* out_
 }
 
 int blok_scene_generate_dense(uint32_t n, uint32_t seed, uint32_t* ids, uint64_t* out_n_voxels) {
-    if (!ids || n < 16 || n > 512 || (n & (n - 1))) return BLOK_ERR_INVALID_ARG;
+    if (!ids || n < 16 || n > 1024 || (n & (n - 1))) return BLOK_ERR_INVALID_ARG;     // 1024^3 ids = 4 GiB
     const size_t total = static_cast<size_t>(n) * n * n;
     std::fill(ids, ids + total, 0u);
     generate(n, seed, [&](int32_t x, int32_t y, int32_t z, uint32_t m) {

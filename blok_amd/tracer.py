@@ -54,6 +54,45 @@ class HipTracer:
         self._check(self._lib.blok_hip_resize(self._ctx, width, height))
         self.width, self.height = int(width), int(height)
 
+    # -- device-resident dense store: edits and rebuilds without leaving HBM ----------------
+    def volume_create(self, origin, shape_xyz, chunk_size: int = 128, voxel_size: float = 1.0):
+        o = (C.c_int32 * 3)(*[int(v) for v in origin])
+        self._check(self._lib.blok_hip_volume_create(self._ctx, o, int(shape_xyz[0]), int(shape_xyz[1]), int(shape_xyz[2]),
+                                                     int(chunk_size), float(voxel_size)))
+        self._volume_shape = (int(shape_xyz[2]), int(shape_xyz[1]), int(shape_xyz[0]))        # arrays are [z][y][x]
+
+    def volume_destroy(self):
+        self._check(self._lib.blok_hip_volume_destroy(self._ctx))
+
+    def volume_upload(self, density=None, material_ids=None):
+        d = None if density is None else np.ascontiguousarray(density, dtype=np.float32)
+        m = None if material_ids is None else np.ascontiguousarray(material_ids, dtype=np.uint32)
+        for a in (d, m):
+            assert a is None or a.shape == self._volume_shape, "arrays are [z][y][x] over the whole box"
+        self._check(self._lib.blok_hip_volume_upload(self._ctx, None if d is None else _ffi.ptr(d), None if m is None else _ffi.ptr(m)))
+
+    def volume_download(self):
+        d = np.zeros(self._volume_shape, dtype=np.float32)
+        m = np.zeros(self._volume_shape, dtype=np.uint32)
+        self._check(self._lib.blok_hip_volume_download(self._ctx, _ffi.ptr(d), _ffi.ptr(m)))
+        return d, m
+
+    def volume_set_voxels(self, xyz, material_ids=None, density=None):
+        xyz = np.ascontiguousarray(xyz, dtype=np.int32).reshape(-1, 3)
+        m = None if material_ids is None else np.ascontiguousarray(material_ids, dtype=np.uint32)
+        d = None if density is None else np.ascontiguousarray(density, dtype=np.float32)
+        self._check(self._lib.blok_hip_volume_set_voxels(self._ctx, _ffi.ptr(xyz), None if m is None else _ffi.ptr(m),
+                                                         None if d is None else _ffi.ptr(d), len(xyz)))
+
+    def volume_apply_brush(self, center, radius: float, value: float, mode: int):
+        c = (C.c_float * 3)(*[float(v) for v in center])
+        self._check(self._lib.blok_hip_volume_apply_brush(self._ctx, c, float(radius), float(value), int(mode)))
+
+    def volume_rebuild(self, materials=None) -> WorldStats:
+        mats = np.zeros(0, dtype=MATERIAL) if materials is None else np.ascontiguousarray(materials, dtype=MATERIAL)
+        self._check(self._lib.blok_hip_volume_rebuild(self._ctx, _ffi.ptr(mats) if len(mats) else None, len(mats)))
+        return self.world_stats()
+
     def set_beam(self, beam_tile_pixels: int):
         """Beam pre-pass granularity of the frame kernels in pixels (0 = off, default 32); never changes a result."""
         self._check(self._lib.blok_hip_set_beam(self._ctx, beam_tile_pixels))

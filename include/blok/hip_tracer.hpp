@@ -105,6 +105,18 @@ private:
     blok_world* w_ = nullptr;
 };
 
+// = blok::Brush / applyBrush (reference blok/include/brush.hpp:14-21, blok/src/brush.cpp:13-63)
+struct Brush {
+    float centerWS[3];
+    float radiusWS;
+    float value;
+    enum Mode { ADD, SUBTRACT } mode;
+};
+inline void applyBrush(ChunkManager& mgr, const Brush& brush) {
+    if (blok_world_apply_brush(mgr.handle(), brush.centerWS, brush.radiusWS, brush.value, brush.mode == Brush::ADD ? 0 : 1) != BLOK_OK)
+        throw std::runtime_error(std::string("applyBrush: ") + blok_world_last_error(mgr.handle()));
+}
+
 // = blok::MaterialLibrary (reference blok/include/material.hpp:116-163), RAII over the C ABI.
 class MaterialLibrary {
 public:
@@ -197,6 +209,20 @@ public:
         return m_pixels;
     }
     uint32_t framesAccumulated() const { return m_frameIndex; }
+
+    // ---- device-resident dense store (blok_hip_volume_*): ChunkManager's edit API for one box of the world, with the
+    // arrays, the edits and the rebuild in HBM.  rebuildVolume() = rebuildDirtyChunks + packChunksToGpuSvo + updateWorld.
+    void createVolume(const int32_t origin[3], uint32_t nx, uint32_t ny, uint32_t nz, uint32_t chunkSize = 128, float voxelSize = 1.0f) {
+        check(blok_hip_volume_create(m_ctx, origin, nx, ny, nz, chunkSize, voxelSize));
+    }
+    void uploadVolume(const float* density, const uint32_t* materialIds) { check(blok_hip_volume_upload(m_ctx, density, materialIds)); }
+    void setVoxelMaterial(const int32_t voxel[3], uint32_t materialId, float density = 1.0f) {
+        check(blok_hip_volume_set_voxels(m_ctx, voxel, &materialId, &density, 1));
+    }
+    void applyBrush(const Brush& brush) {
+        check(blok_hip_volume_apply_brush(m_ctx, brush.centerWS, brush.radiusWS, brush.value, brush.mode == Brush::ADD ? 0 : 1));
+    }
+    void rebuildVolume(const std::vector<blok_material>& materials) { check(blok_hip_volume_rebuild(m_ctx, materials.data(), materials.size())); }
 
     const std::vector<blok_hit>& hits() const { return m_hits; }     // output accessor (getGLTex analogue)
     unsigned int width() const { return m_width; }

@@ -268,6 +268,31 @@ int blok_hip_reset_accum(blok_hip_ctx* ctx);
  * launch stream around the kernel only (valid after that stream has been synchronised). */
 int blok_hip_last_kernel_ms(blok_hip_ctx* ctx, float* out_ms);
 
+/* ---- device-resident dense voxel store (edits and the rebuild they trigger, on the GPU) ----
+ * The reference keeps Chunk::density / Chunk::materialIds on the host (blok/src/chunk.hpp:33-42), edits them with
+ * setVoxelMaterial (chunk_manager.cpp:316-328) and applyBrush (brush.cpp:13-63), rebuilds dirty chunks' SVOs on the CPU
+ * (chunk_manager.cpp:106-140), repacks (:213-314) and re-uploads (renderer_upload.cpp:237-312).  Here one box of the world
+ * [origin, origin + (nx, ny, nz)) lives in HBM with the same two arrays (x fastest, then y, then z), edits are kernels
+ * with the reference's float arithmetic, and blok_hip_volume_rebuild derives the traversal structure on the device from
+ * "density > 0" (chunk_manager.cpp:121) and installs it as the context's world.  voxel_size must be 1; chunk_size is
+ * ChunkManager's chunk edge (the brush computes voxel centres per chunk).  Edits outside the box are refused
+ * (BLOK_ERR_UNSUPPORTED, nothing written).  All calls are blocking. */
+int blok_hip_volume_create(blok_hip_ctx* ctx, const int32_t origin[3], uint32_t nx, uint32_t ny, uint32_t nz,
+                           uint32_t chunk_size, float voxel_size);
+int blok_hip_volume_destroy(blok_hip_ctx* ctx);
+/* Whole-box upload / download of the two arrays; a null pointer uploads zeros / skips the download. */
+int blok_hip_volume_upload(blok_hip_ctx* ctx, const float* density, const uint32_t* material_ids);
+int blok_hip_volume_download(blok_hip_ctx* ctx, float* density, uint32_t* material_ids);
+/* = ChunkManager::setVoxelMaterial for n world voxels xyz[3*i..], in order (a later entry of the same voxel wins);
+ * material_ids null = 0, density null = 1. */
+int blok_hip_volume_set_voxels(blok_hip_ctx* ctx, const int32_t* xyz, const uint32_t* material_ids, const float* density, size_t n);
+/* = applyBrush (brush.cpp:13-63): mode 0 ADD density = max(density, value), 1 SUBTRACT density = min(density, value),
+ * inside the sphere around `center` (world units), voxel centres as the reference computes them. */
+int blok_hip_volume_apply_brush(blok_hip_ctx* ctx, const float center[3], float radius, float value, int mode);
+/* = rebuildDirtyChunks + packChunksToGpuSvo + Renderer::updateWorld for the box: installs the world made of the voxels with
+ * density > 0 and their material ids, with the given material table. */
+int blok_hip_volume_rebuild(blok_hip_ctx* ctx, const blok_material* materials, size_t n_materials);
+
 /* Beam pre-pass of the frame kernels (no reference counterpart; the reference culls per ray in Vulkan RT hardware,
  * blok/src/renderer_raytracing.cpp:15-254): before a rectangle / tile launch, one wave per beam_tile_pixels^2 pixels finds a
  * conservative start parameter for that tile's rays, and tiles whose frustum meets no voxel are written as misses without

@@ -144,7 +144,7 @@ int blok_camera_look_at(const float pos[3], const float target[3], float fov_deg
  * materialId in [1,255].  Writes into `w` (chunk size as created), then the caller
  * rebuilds and packs.  Not reference behaviour — benchmark input synthesis. */
 int blok_scene_generate(blok_world* w, uint32_t n, uint32_t seed, uint64_t* out_n_voxels);
-/* Same voxel set as a dense id grid ids[x + y*n + z*n*n] (0 = empty); n <= 512. */
+/* Same voxel set as a dense id grid ids[x + y*n + z*n*n] (0 = empty); n <= 1024 (4 GiB of ids). */
 int blok_scene_generate_dense(uint32_t n, uint32_t seed, uint32_t* ids, uint64_t* out_n_voxels);
 /* 256 hashed diffuse materials (roughness 0.5, metallic 0: reference material.cpp:102-106). */
 int blok_scene_materials(uint32_t seed, blok_material* out256);

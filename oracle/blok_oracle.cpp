@@ -662,6 +662,15 @@ int orc_world_chunk_info(const void* w, size_t i, int32_t coord[3], uint64_t* nN
     *nNodes = it->second->svo.nodes.size();
     return 0;
 }
+// test accessor: the dense arrays of chunk i (chunk.hpp:35-36), [x + y*C + z*C*C]
+int orc_world_chunk_dense(const void* w, size_t i, const float** density, const uint32_t** ids) {
+    const World* W = static_cast<const World*>(w);
+    if (i >= W->chunks.size()) return -1;
+    auto it = W->chunks.begin();
+    std::advance(it, i);
+    *density = it->second->density.data(); *ids = it->second->materialIds.data();
+    return 0;
+}
 const void* orc_world_chunk_nodes(const void* w, size_t i) {
     const World* W = static_cast<const World*>(w);
     if (i >= W->chunks.size()) return nullptr;

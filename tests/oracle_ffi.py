@@ -173,6 +173,15 @@ class OracleWorld:
     def find_leaf(self, i, x, y, z):
         return int(self.L.orc_world_find_leaf(self.h, i, x, y, z))
 
+    def chunk_dense(self, i, chunk_size=128):
+        """(density, material ids) of chunk i as [z][y][x] arrays (copies)."""
+        d, m = C.c_void_p(), C.c_void_p()
+        self.L.orc_world_chunk_dense.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+        assert self.L.orc_world_chunk_dense(self.h, i, C.byref(d), C.byref(m)) == 0
+        n = chunk_size ** 3
+        shape = (chunk_size,) * 3
+        return (_copy(d.value, n, np.dtype("<f4")).reshape(shape), _copy(m.value, n, np.dtype("<u4")).reshape(shape))
+
 
 def primary_rays(cam: np.ndarray, width, height, x0=0, y0=0, w=None, h=None, stride=1) -> np.ndarray:
     w = width if w is None else w

@@ -63,3 +63,79 @@ def test_edited_world_on_gpu():
         before = got
         cm.apply_brush((40.0, 25.0, 30.0), 8.0, 0.0, "subtract")
     tr.shutdown()
+
+
+@pytest.mark.gpu
+def test_device_resident_volume_edits_and_rebuild():
+    """N3 on the GPU: the dense store lives in HBM (blok_hip_volume_*), setVoxelMaterial / applyBrush are kernels with
+    the reference's arithmetic and the rebuild derives the traversal structure on the device.  After the same edits
+    as the oracle's ChunkManager: the dense arrays are bit-identical to the oracle's chunks, and frames of the rebuilt
+    world equal frames of the oracle's packed records uploaded the ordinary way."""
+    from blok_amd.tracer import HipTracer
+    from blok_amd._ffi import BlokError
+    _, ow, edits = edited_worlds()
+    C_ = 128
+    w, h = 320, 240
+    mats = W.scene_materials(SEED)
+    vol = HipTracer(w, h).init()
+    box_origin, box_shape = (-C_, 0, 0), (3 * C_, C_, C_)               # chunks (-1..1, 0, 0): everything the edits touch
+    vol.volume_create(box_origin, box_shape, C_, 1.0)
+    ids = W.scene_dense(64, SEED)
+    z, y, x = np.nonzero(ids)
+    xyz = np.stack([x, y, z], 1).astype(np.int32)
+    vol.volume_set_voxels(xyz, ids[z, y, x], np.ones(len(xyz), dtype=np.float32))
+    # later entries of the same voxel win, like sequential setVoxelMaterial calls
+    vol.volume_set_voxels([[5, 5, 5], [5, 5, 5]], [7, 9], [1.0, 0.25])
+    d, m = vol.volume_download()
+    assert d[5, 5, 5 + C_] == np.float32(0.25) and m[5, 5, 5 + C_] == 9      # arrays are [z][y][x - origin x]
+    vol.volume_set_voxels([[5, 5, 5]], [int(ids[5, 5, 5])], [1.0 if ids[5, 5, 5] else 0.0])
+    for c, r, v, mode in edits:
+        vol.volume_apply_brush(c, r, v, {"add": 0, "subtract": 1}[mode])
+    # 1. dense arrays == the oracle's chunks, bit for bit (signs of zero and negative densities included)
+    d, m = vol.volume_download()
+    seen = 0
+    for i in range(ow.n_chunks()):
+        (cx, cy, cz), _ = ow.chunk(i)
+        od, om = ow.chunk_dense(i, C_)
+        x0 = cx * C_ - box_origin[0]
+        assert cy == 0 and cz == 0 and 0 <= x0 < box_shape[0]
+        assert d[:, :, x0:x0 + C_].tobytes() == od.tobytes(), (cx, cy, cz)
+        filled = od > 0
+        assert np.array_equal(m[:, :, x0:x0 + C_][filled], om[filled])
+        seen += 1
+    assert seen == ow.n_chunks() >= 3
+    # 2. frames of the device-rebuilt world == frames of the oracle's records through the ordinary upload
+    st = vol.volume_rebuild(mats)
+    assert vol.built_on_device()
+    ow.rebuild()
+    on, osub = ow.pack()
+    ref_tr = HipTracer(w, h).init()
+    ref_st = ref_tr.add_world(W.PackedWorld(on, osub, mats))
+    assert st.n_voxels == ref_st.n_voxels == int((np.concatenate([ow.chunk_dense(i, C_)[0].ravel() for i in range(ow.n_chunks())]) > 0).sum())
+    lat = O.Lattice(on, osub)
+    for eye, at in [((70.0, 60.0, -20.0), (30.0, 20.0, 30.0)), ((-30.0, 30.0, 40.0), (20.0, 20.0, 20.0)), ((150.0, 50.0, 60.0), (120.0, 30.0, 10.0))]:
+        cam = W.camera_look_at(eye, at, 60.0, w, h)
+        got = vol.draw_frame(cam).reshape(-1)
+        assert records_equal(got, ref_tr.draw_frame(cam).reshape(-1)).all()
+        ref, ctr = lat.trace(O.primary_rays(cam, w, h), threads=8)
+        assert ctr["hits"] > 1000 and records_equal(got, ref).all()
+    # 3. a further edit + rebuild changes the picture; edits leaving the box are refused and write nothing
+    cam = W.camera_look_at((70.0, 60.0, -20.0), (30.0, 20.0, 30.0), 60.0, w, h)
+    before = vol.draw_frame(cam).reshape(-1)
+    vol.volume_apply_brush((40.0, 25.0, 30.0), 8.0, 0.0, 1)
+    vol.volume_rebuild(mats)
+    ow.apply_brush((40.0, 25.0, 30.0), 8.0, 0.0, "subtract"); ow.rebuild()
+    on, osub = ow.pack()
+    ref, _ = O.Lattice(on, osub).trace(O.primary_rays(cam, w, h), threads=8)
+    after = vol.draw_frame(cam).reshape(-1)
+    assert records_equal(after, ref).all() and (~records_equal(after, before)).sum() > 100
+    d0, _ = vol.volume_download()
+    with pytest.raises(BlokError):
+        vol.volume_apply_brush((60.0, 125.0, 30.0), 6.0, 1.0, 0)        # reaches y = 131 > 128
+    with pytest.raises(BlokError):
+        vol.volume_set_voxels([[0, -1, 0]])
+    assert vol.volume_download()[0].tobytes() == d0.tobytes()
+    # 4. an emptied volume is an empty world
+    vol.volume_upload(None, None)
+    assert vol.volume_rebuild(mats).n_voxels == 0 and (vol.draw_frame(cam)["hit"] == 0).all()
+    vol.shutdown(); ref_tr.shutdown()
