@@ -49,6 +49,14 @@ class GBuffer(C.Structure):
                 ("albedo_metallic", C.c_void_p)]
 
 
+class DenoiseSettings(C.Structure):
+    """= blok_denoise_settings (Denoiser::Settings, reference blok/include/renderer_denoising.hpp:49-66)."""
+    _fields_ = [("temporal_alpha", C.c_float), ("moment_alpha", C.c_float), ("variance_clip_gamma", C.c_float),
+                ("depth_threshold", C.c_float), ("normal_threshold", C.c_float), ("phi_color", C.c_float),
+                ("phi_normal", C.c_float), ("phi_depth", C.c_float), ("atrous_iterations", C.c_int32),
+                ("variance_boost", C.c_float), ("min_history_length", C.c_int32)]
+
+
 class WorldStats(C.Structure):
     _fields_ = [("n_voxels", C.c_uint64), ("n_ref_nodes", C.c_uint64), ("n_sub_chunks", C.c_uint64),
                 ("n_tree_nodes", C.c_uint64), ("tree_bytes", C.c_uint64), ("levels", C.c_uint32),
@@ -148,6 +156,13 @@ HIP_SYMBOLS = {
     "blok_hip_accum_download": (C.c_int, [C.c_void_p, C.c_void_p]),
     "blok_hip_reset_accum": (C.c_int, [C.c_void_p]),
     "blok_hip_set_beam": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "blok_denoise_settings_default": (None, [C.c_void_p]),
+    "blok_hip_denoise_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.c_void_p,
+                                          C.c_void_p, C.c_void_p]),
+    "blok_hip_denoise_state": (C.c_int, [C.c_void_p] * 6),
+    "blok_hip_taa_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "blok_hip_sharpen_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
+    "blok_hip_post_reset": (C.c_int, [C.c_void_p]),
     "blok_hip_volume_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float]),
     "blok_hip_volume_destroy": (C.c_int, [C.c_void_p]),
     "blok_hip_volume_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -12,7 +12,7 @@ INCLUDE = ROOT / "include"
 
 HOST_SRC = [PKG / "csrc/host/world.cpp", PKG / "csrc/host/scene.cpp", PKG / "csrc/host/vox.cpp"]
 HIP_SRC = [PKG / "csrc/hip/api.hip", PKG / "csrc/hip/trace_kernels.hip", PKG / "csrc/hip/gpu_build.hip",
-           PKG / "csrc/hip/tree_build.cpp"]
+           PKG / "csrc/hip/post_kernels.hip", PKG / "csrc/hip/tree_build.cpp"]
 HIP_HDR = sorted((PKG / "csrc/hip").glob("*.h")) + [INCLUDE / "blok_hip.h", INCLUDE / "blok_world.h"]
 
 

@@ -12,6 +12,9 @@
 
 #include "blok_hip.h"
 #include "gpu_build.h"
+#include <hip/hip_fp16.h>
+#include "post_kernels.h"
+#include "post_core.h"
 #include "reference_world.h"
 #include "trace_kernels.h"
 #include "path_args.h"
@@ -39,6 +42,17 @@ struct blok_hip_ctx {
     uint32_t accum_frames = 0;
     blok_camera prev_cam{};
     bool has_prev_cam = false;
+    // image-space chain (post_core.h): history ping-pong [2] and per-frame planes, all width x height
+    struct Post {
+        size_t pixels = 0;
+        float *hist_color[2] = {nullptr, nullptr}, *moments[2] = {nullptr, nullptr}, *world_pos[2] = {nullptr, nullptr};
+        uint16_t *hist_len[2] = {nullptr, nullptr}, *normals[2] = {nullptr, nullptr};
+        uint16_t* motion = nullptr;          // half2
+        float *variance = nullptr, *ping = nullptr, *pong = nullptr, *taa_hist[2] = {nullptr, nullptr};
+        float* widen = nullptr;              // scratch for state downloads
+        int cur = 0, taa_cur = 0;
+        bool has_motion = false, taa_has_history = false;
+    } post;
     // device-resident dense store (gpu_build.h: GpuVolume)
     blok::GpuVolume volume;
     bool has_volume = false;
@@ -68,6 +82,17 @@ int set_error(blok_hip_ctx* ctx, int status, const std::string& msg) {
             return set_error(ctx, e_ == hipErrorOutOfMemory ? BLOK_ERR_OOM : BLOK_ERR_HIP,         \
                              std::string(#call) + ": " + hipGetErrorString(e_));                   \
     } while (0)
+
+void free_post(blok_hip_ctx* ctx) {
+    auto& P = ctx->post;
+    for (int k = 0; k < 2; ++k)
+        for (void* p : {static_cast<void*>(P.hist_color[k]), static_cast<void*>(P.moments[k]), static_cast<void*>(P.world_pos[k]),
+                        static_cast<void*>(P.hist_len[k]), static_cast<void*>(P.normals[k]), static_cast<void*>(P.taa_hist[k])})
+            if (p) (void)hipFree(p);
+    for (void* p : {static_cast<void*>(P.motion), static_cast<void*>(P.variance), static_cast<void*>(P.ping), static_cast<void*>(P.pong), static_cast<void*>(P.widen)})
+        if (p) (void)hipFree(p);
+    P = blok_hip_ctx::Post{};
+}
 
 void free_world(blok_hip_ctx* ctx) {
     if (ctx->d_nodes) (void)hipFree(ctx->d_nodes);
@@ -218,6 +243,7 @@ void blok_hip_destroy(blok_hip_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     free_world(ctx);
     if (ctx->d_frame) (void)hipFree(ctx->d_frame);
+    free_post(ctx);
     if (ctx->has_volume) blok::gpu_volume_destroy(&ctx->volume);
     for (auto& kv : ctx->beam_buffers) if (kv.second.first) (void)hipFree(kv.second.first);
     if (ctx->d_accum) (void)hipFree(ctx->d_accum);
@@ -557,7 +583,8 @@ int blok_hip_draw_frame_accumulate(blok_hip_ctx* ctx, const blok_camera* cam, ui
     if (!spp_per_frame || !max_bounces) return set_error(ctx, BLOK_ERR_INVALID_ARG, "spp and bounces must be positive");
     const size_t n = static_cast<size_t>(ctx->width) * ctx->height;
     if (ctx->accum_pixels != n) {                                      // first use or resize: (re)allocate and clear
-        if (ctx->has_volume) blok::gpu_volume_destroy(&ctx->volume);
+        free_post(ctx);
+    if (ctx->has_volume) blok::gpu_volume_destroy(&ctx->volume);
     for (auto& kv : ctx->beam_buffers) if (kv.second.first) (void)hipFree(kv.second.first);
     if (ctx->d_accum) (void)hipFree(ctx->d_accum);
         if (ctx->d_color) (void)hipFree(ctx->d_color);
@@ -591,6 +618,181 @@ int blok_hip_accum_download(blok_hip_ctx* ctx, float* out_rgba32f_host) {
     if (!ctx->d_accum) return set_error(ctx, BLOK_ERR_INVALID_ARG, "no accumulation buffer yet");
     BLOK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     BLOK_HIP_TRY(ctx, hipMemcpy(out_rgba32f_host, ctx->d_accum, ctx->accum_pixels * 4 * sizeof(float), hipMemcpyDeviceToHost));
+    return BLOK_OK;
+}
+
+// ---- image-space chain ------------------------------------------------------------------------------------------------
+namespace {
+int post_alloc_bytes(blok_hip_ctx* ctx, void** p, size_t bytes) {
+    BLOK_HIP_TRY(ctx, hipMalloc(p, bytes));
+    BLOK_HIP_TRY(ctx, hipMemset(*p, 0, bytes));
+    return BLOK_OK;
+}
+#define post_alloc(ctx, pp, count) post_alloc_bytes((ctx), reinterpret_cast<void**>(pp), (count) * sizeof(**(pp)))
+int ensure_post(blok_hip_ctx* ctx) {
+    const size_t n = static_cast<size_t>(ctx->width) * ctx->height;
+    auto& P = ctx->post;
+    if (P.pixels == n) return BLOK_OK;
+    free_post(ctx);
+    int rc = BLOK_OK;
+    for (int k = 0; k < 2 && rc == BLOK_OK; ++k) {
+        rc = post_alloc(ctx, &P.hist_color[k], 4 * n);
+        if (rc == BLOK_OK) rc = post_alloc(ctx, &P.moments[k], 2 * n);
+        if (rc == BLOK_OK) rc = post_alloc(ctx, &P.world_pos[k], 4 * n);
+        if (rc == BLOK_OK) rc = post_alloc(ctx, &P.hist_len[k], n);
+        if (rc == BLOK_OK) rc = post_alloc(ctx, &P.normals[k], 4 * n);
+        if (rc == BLOK_OK) rc = post_alloc(ctx, &P.taa_hist[k], 4 * n);
+    }
+    if (rc == BLOK_OK) rc = post_alloc(ctx, &P.motion, 2 * n);
+    if (rc == BLOK_OK) rc = post_alloc(ctx, &P.variance, n);
+    if (rc == BLOK_OK) rc = post_alloc(ctx, &P.ping, 4 * n);
+    if (rc == BLOK_OK) rc = post_alloc(ctx, &P.pong, 4 * n);
+    if (rc == BLOK_OK) rc = post_alloc(ctx, &P.widen, 2 * n);
+    if (rc != BLOK_OK) { free_post(ctx); return rc; }
+    P.pixels = n;
+    return BLOK_OK;
+}
+blok::DenoiseSettings to_settings(const blok_denoise_settings& s) {
+    blok::DenoiseSettings d;
+    d.temporal_alpha = s.temporal_alpha; d.moment_alpha = s.moment_alpha; d.variance_clip_gamma = s.variance_clip_gamma;
+    d.depth_threshold = s.depth_threshold; d.normal_threshold = s.normal_threshold;
+    d.phi_color = s.phi_color; d.phi_normal = s.phi_normal; d.phi_depth = s.phi_depth;
+    d.atrous_iterations = s.atrous_iterations; d.variance_boost = s.variance_boost; d.min_history_length = s.min_history_length;
+    return d;
+}
+}  // namespace
+
+void blok_denoise_settings_default(blok_denoise_settings* s) {       // renderer_denoising.hpp:49-66
+    if (!s) return;
+    s->temporal_alpha = 0.05f; s->moment_alpha = 0.2f; s->variance_clip_gamma = 1.5f;
+    s->depth_threshold = 0.1f; s->normal_threshold = 0.95f;
+    s->phi_color = 0.5f; s->phi_normal = 128.0f; s->phi_depth = 0.1f;
+    s->atrous_iterations = 4; s->variance_boost = 1.5f; s->min_history_length = 4;
+}
+
+int blok_hip_denoise_device(blok_hip_ctx* ctx, const blok_gbuffer* planes, const float* motion_dev, const float prev_view_proj[16],
+                            uint32_t frame_count, const blok_denoise_settings* settings, float* out_color_dev, void* hip_stream) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    if (!planes || !planes->color || !planes->world_pos || !planes->normal_roughness || !prev_view_proj || !out_color_dev)
+        return set_error(ctx, BLOK_ERR_INVALID_ARG, "denoise: colour, world position and normal planes, prevViewProj and an output are required");
+    blok_denoise_settings def;
+    blok_denoise_settings_default(&def);
+    const blok_denoise_settings& S = settings ? *settings : def;
+    if (S.atrous_iterations < 0 || S.atrous_iterations > 5) return set_error(ctx, BLOK_ERR_INVALID_ARG, "denoise: 0..5 a-trous iterations");
+    BLOK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_post(ctx);
+    if (rc != BLOK_OK) return rc;
+    auto& P = ctx->post;
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    const int cur = P.cur, prev = cur ^ 1;
+    blok::PostFrame f{};
+    f.w = ctx->width; f.h = ctx->height; f.frame_count = frame_count; f.s = to_settings(S);
+    for (int k = 0; k < 16; ++k) f.prev_view_proj[k] = prev_view_proj[k];
+
+    blok::TemporalArgs t{};
+    t.f = f;
+    t.color = planes->color; t.world_pos = planes->world_pos; t.normal_roughness = planes->normal_roughness; t.motion_in = motion_dev;
+    t.prev_color = P.hist_color[prev]; t.prev_moments = P.moments[prev]; t.prev_world_pos = P.world_pos[prev];
+    t.prev_hist_len = P.hist_len[prev]; t.prev_normals = P.normals[prev];
+    t.out_color = P.hist_color[cur]; t.out_moments = P.moments[cur]; t.hist_world_pos = P.world_pos[cur];
+    t.out_hist_len = P.hist_len[cur]; t.hist_normals = P.normals[cur]; t.motion = P.motion;
+    blok::launch_temporal(t, stream);
+
+    blok::VarianceArgs v{};
+    v.f = f;
+    v.color = P.hist_color[cur]; v.moments = P.moments[cur]; v.world_pos = P.world_pos[cur];
+    v.hist_len = P.hist_len[cur]; v.normals = P.normals[cur]; v.variance = P.variance;
+    blok::launch_variance(v, stream);
+
+    // iteration 0 reads the temporal output; then ping <-> pong (renderer_denoising.cpp:520-536); the last one writes the caller's plane
+    const float* in = P.hist_color[cur];
+    for (int it = 0; it < S.atrous_iterations; ++it) {
+        blok::AtrousArgs a{};
+        a.w = f.w; a.h = f.h; a.step = 1 << it; a.phi_color = S.phi_color; a.phi_depth = S.phi_depth;
+        a.color = in; a.variance = P.variance; a.world_pos = P.world_pos[cur]; a.normals = P.normals[cur];
+        a.out = it == S.atrous_iterations - 1 ? out_color_dev : ((it & 1) ? P.pong : P.ping);
+        blok::launch_atrous(a, stream);
+        in = a.out;
+    }
+    if (S.atrous_iterations == 0)
+        BLOK_HIP_TRY(ctx, hipMemcpyAsync(out_color_dev, P.hist_color[cur], P.pixels * 4 * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    BLOK_HIP_TRY(ctx, hipGetLastError());
+    P.cur = prev;                                          // swapHistoryBuffers
+    P.has_motion = true;
+    return BLOK_OK;
+}
+
+int blok_hip_denoise_state(blok_hip_ctx* ctx, float* history_color, float* moments, float* history_length, float* variance, float* motion) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    auto& P = ctx->post;
+    if (!P.pixels || !P.has_motion) return set_error(ctx, BLOK_ERR_INVALID_ARG, "no denoised frame yet");
+    BLOK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    BLOK_HIP_TRY(ctx, hipDeviceSynchronize());
+    const int last = P.cur ^ 1;                            // the slot the last frame wrote
+    const size_t n = P.pixels;
+    if (history_color) BLOK_HIP_TRY(ctx, hipMemcpy(history_color, P.hist_color[last], 4 * n * sizeof(float), hipMemcpyDeviceToHost));
+    if (moments) BLOK_HIP_TRY(ctx, hipMemcpy(moments, P.moments[last], 2 * n * sizeof(float), hipMemcpyDeviceToHost));
+    if (variance) BLOK_HIP_TRY(ctx, hipMemcpy(variance, P.variance, n * sizeof(float), hipMemcpyDeviceToHost));
+    if (history_length) {
+        blok::launch_widen(P.hist_len[last], P.widen, n, nullptr);
+        BLOK_HIP_TRY(ctx, hipMemcpy(history_length, P.widen, n * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    if (motion) {
+        blok::launch_widen(P.motion, P.widen, 2 * n, nullptr);
+        BLOK_HIP_TRY(ctx, hipMemcpy(motion, P.widen, 2 * n * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    return BLOK_OK;
+}
+
+namespace {
+__global__ __launch_bounds__(256) void narrow_motion_kernel(const float* src, uint16_t* dst, size_t n) {
+    const size_t i = static_cast<size_t>(blockIdx.x) * 256u + threadIdx.x;
+    if (i < n) dst[i] = __half_as_ushort(__float2half_rn(src[i]));
+}
+}  // namespace
+
+int blok_hip_taa_device(blok_hip_ctx* ctx, const float* color_dev, const float* motion_dev, float feedback_min, float feedback_max,
+                        uint32_t frame_count, float* out_color_dev, void* hip_stream) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    if (!color_dev || !out_color_dev) return set_error(ctx, BLOK_ERR_INVALID_ARG, "taa: null plane");
+    BLOK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_post(ctx);
+    if (rc != BLOK_OK) return rc;
+    auto& P = ctx->post;
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    if (motion_dev) {
+        const size_t n = 2 * P.pixels;
+        hipLaunchKernelGGL(narrow_motion_kernel, dim3(static_cast<uint32_t>((n + 255) / 256)), dim3(256), 0, stream, motion_dev, P.motion, n);
+        P.has_motion = true;
+    } else if (!P.has_motion) {
+        return set_error(ctx, BLOK_ERR_INVALID_ARG, "taa: no motion vectors (pass a plane or denoise a frame first)");
+    }
+    blok::TaaArgs a{};
+    a.w = ctx->width; a.h = ctx->height; a.frame_count = frame_count; a.feedback_min = feedback_min; a.feedback_max = feedback_max;
+    a.color = color_dev; a.history = P.taa_hist[P.taa_cur ^ 1]; a.motion = P.motion;
+    a.out = out_color_dev; a.out_history = P.taa_hist[P.taa_cur];
+    blok::launch_taa(a, stream);
+    BLOK_HIP_TRY(ctx, hipGetLastError());
+    P.taa_cur ^= 1;
+    return BLOK_OK;
+}
+
+int blok_hip_sharpen_device(blok_hip_ctx* ctx, const uint32_t* rgba8_dev, float strength, uint32_t* out_rgba8_dev, void* hip_stream) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    if (!rgba8_dev || !out_rgba8_dev || rgba8_dev == out_rgba8_dev) return set_error(ctx, BLOK_ERR_INVALID_ARG, "sharpen: two distinct planes are required");
+    BLOK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    blok::SharpenArgs a{};
+    a.w = ctx->width; a.h = ctx->height; a.strength = strength; a.in = rgba8_dev; a.out = out_rgba8_dev;
+    blok::launch_sharpen(a, static_cast<hipStream_t>(hip_stream));
+    BLOK_HIP_TRY(ctx, hipGetLastError());
+    return BLOK_OK;
+}
+
+int blok_hip_post_reset(blok_hip_ctx* ctx) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    free_post(ctx);
     return BLOK_OK;
 }
 

@@ -93,6 +93,40 @@ class HipTracer:
         self._check(self._lib.blok_hip_volume_rebuild(self._ctx, _ffi.ptr(mats) if len(mats) else None, len(mats)))
         return self.world_stats()
 
+    # -- image-space chain: denoiser, TAA, sharpen on device planes ----------------------------
+    def denoise_settings(self) -> "_ffi.DenoiseSettings":
+        s = _ffi.DenoiseSettings()
+        self._lib.blok_denoise_settings_default(C.byref(s))
+        return s
+
+    def denoise_device(self, color_ptr: int, world_pos_ptr: int, normal_roughness_ptr: int, prev_view_proj, frame_count: int,
+                       out_color_ptr: int, motion_ptr: int = 0, settings=None, stream: int = 0):
+        """Denoiser::denoise for one frame over float4 device planes (as trace_paths_device writes them)."""
+        planes = _ffi.GBuffer(color_ptr, world_pos_ptr, normal_roughness_ptr, 0)
+        m = (C.c_float * 16)(*[float(v) for v in np.asarray(prev_view_proj, dtype=np.float32).reshape(-1)])
+        self._check(self._lib.blok_hip_denoise_device(self._ctx, C.byref(planes), motion_ptr or None, m, int(frame_count),
+                                                      C.byref(settings) if settings is not None else None, out_color_ptr,
+                                                      stream or None))
+
+    def denoise_state(self):
+        """Host copies of (history colour, moments, history length, variance, motion vectors) after the last frame."""
+        h, w = self.height, self.width
+        out = (np.zeros((h, w, 4), np.float32), np.zeros((h, w, 2), np.float32), np.zeros((h, w), np.float32),
+               np.zeros((h, w), np.float32), np.zeros((h, w, 2), np.float32))
+        self._check(self._lib.blok_hip_denoise_state(self._ctx, *[_ffi.ptr(a) for a in out]))
+        return out
+
+    def taa_device(self, color_ptr: int, out_color_ptr: int, frame_count: int, feedback_min: float = 0.93, feedback_max: float = 0.98,
+                   motion_ptr: int = 0, stream: int = 0):
+        self._check(self._lib.blok_hip_taa_device(self._ctx, color_ptr, motion_ptr or None, feedback_min, feedback_max,
+                                                  int(frame_count), out_color_ptr, stream or None))
+
+    def sharpen_device(self, rgba8_ptr: int, out_rgba8_ptr: int, strength: float = 0.5, stream: int = 0):
+        self._check(self._lib.blok_hip_sharpen_device(self._ctx, rgba8_ptr, strength, out_rgba8_ptr, stream or None))
+
+    def post_reset(self):
+        self._check(self._lib.blok_hip_post_reset(self._ctx))
+
     def set_beam(self, beam_tile_pixels: int):
         """Beam pre-pass granularity of the frame kernels in pixels (0 = off, default 32); never changes a result."""
         self._check(self._lib.blok_hip_set_beam(self._ctx, beam_tile_pixels))
@@ -223,6 +257,11 @@ class HipTracer:
         self._check(self._lib.blok_hip_tonemap(self._ctx, _ffi.ptr(hdr), out.size, exposure, saturation_boost, operator,
                                                _ffi.ptr(out)))
         return out
+
+    def tonemap_device(self, hdr_ptr: int, out_rgba8_ptr: int, n_pixels: int = 0, exposure: float = 1.0, saturation_boost: float = 1.15,
+                       operator: int = 1, stream: int = 0):
+        self._check(self._lib.blok_hip_tonemap_device(self._ctx, hdr_ptr, n_pixels or self.width * self.height, exposure,
+                                                      saturation_boost, operator, out_rgba8_ptr, stream or None))
 
     def shade_rgba8(self, cam: np.ndarray, rect=None) -> np.ndarray:
         x0, y0, w, h = rect if rect is not None else (0, 0, self.width, self.height)

@@ -152,3 +152,19 @@ def camera_look_at(pos, target, fov_deg, width, height) -> np.ndarray:
     if rc != 0:
         raise BlokError(rc, "blok_camera_look_at")
     return cam
+
+
+def view_proj_from_camera(cam: np.ndarray) -> np.ndarray:
+    """Column-major 4x4 (GLM layout) M with uv = ndc.xy * 0.5 + 0.5, ndc = (M @ [p, 1]).xyz / w, mapping a world point to
+    the screen position of the camera basis' own primary-ray mapping (pixel x + 0.5 = u * width, y + 0.5 = v * height):
+    what FrameUBO::prevViewProj is to the reference's shaders (temporal_reproject.comp:108-113), for callers that hold a
+    camera basis instead of view / projection matrices."""
+    c = np.asarray(cam).reshape(-1)[0]
+    pos, fwd, right, up = (np.asarray(c[k], dtype=np.float64) for k in ("pos", "fwd", "right", "up"))
+    t, a = float(c["tan_half_fov"]), float(c["aspect"])
+    rows = np.zeros((4, 4), dtype=np.float64)
+    rows[0, :3] = right / (t * a); rows[0, 3] = -np.dot(right, pos) / (t * a)
+    rows[1, :3] = -up / t;         rows[1, 3] = np.dot(up, pos) / t
+    rows[2, :3] = fwd;             rows[2, 3] = -np.dot(fwd, pos)
+    rows[3, :3] = fwd;             rows[3, 3] = -np.dot(fwd, pos)
+    return np.ascontiguousarray(rows.T.astype(np.float32)).reshape(-1)       # column-major: M[c * 4 + r]

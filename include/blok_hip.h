@@ -268,6 +268,42 @@ int blok_hip_reset_accum(blok_hip_ctx* ctx);
  * launch stream around the kernel only (valid after that stream has been synchronised). */
 int blok_hip_last_kernel_ms(blok_hip_ctx* ctx, float* out_ms);
 
+/* ---- image-space chain behind the path tracer -----------------------------------------------
+ * Denoiser (temporal accumulation -> variance -> a-trous iterations), TAA resolve and sharpen as HIP kernels; the tonemap
+ * pass between TAA and sharpen is blok_hip_tonemap_device.  Reference: assets/shaders/temporal_reproject.comp, variance.comp,
+ * atrous.comp, taa.comp, sharpen.comp; orchestration blok/src/renderer_denoising.cpp:714-776, renderer_postprocess.cpp:505-556.
+ * All planes are full-frame (ctx width x height), row-major, in device memory; calls enqueue on hip_stream and return. */
+typedef struct blok_denoise_settings {       /* = Denoiser::Settings, blok/include/renderer_denoising.hpp:49-66 */
+    float temporal_alpha, moment_alpha, variance_clip_gamma;
+    float depth_threshold, normal_threshold;
+    float phi_color, phi_normal, phi_depth;
+    int32_t atrous_iterations;               /* <= 5 (DenoiserPipeline::MAX_ATROUS_ITERATIONS) */
+    float variance_boost;
+    int32_t min_history_length;
+} blok_denoise_settings;
+void blok_denoise_settings_default(blok_denoise_settings* out);
+/* = Denoiser::denoise + copyCurrentGeometryToHistory + swapHistoryBuffers (renderer_denoising.cpp:714-776, 833-866, 690-697)
+ * for one frame.  planes: float4 planes as blok_hip_trace_paths_device writes them (color, world_pos, normal_roughness;
+ * albedo_metallic unused).  motion_dev: float2 per pixel, or NULL = the motion vectors of raygen.rgen:150-155,409-413 computed
+ * from world_pos and prev_view_proj (column-major 4x4, = FrameUBO::prevViewProj).  frame_count = FrameUBO::frameCount
+ * (0: no history is read).  settings NULL = defaults.  out_color_dev: float4 per pixel = Denoiser::getOutputImage(). */
+int blok_hip_denoise_device(blok_hip_ctx* ctx, const blok_gbuffer* planes_dev, const float* motion_dev,
+                            const float prev_view_proj[16], uint32_t frame_count, const blok_denoise_settings* settings,
+                            float* out_color_dev, void* hip_stream);
+/* Host copies of the denoiser's state after the last blok_hip_denoise_device (blocking; NULL pointers are skipped):
+ * history colour float4, moments float2, history length float, variance float, motion vectors float2 (per pixel). */
+int blok_hip_denoise_state(blok_hip_ctx* ctx, float* history_color, float* moments, float* history_length,
+                           float* variance, float* motion);
+/* = PostProcess TAA pass (taa.comp; renderer_postprocess.cpp:526-534,558-589): color_dev float4 in, out_color_dev float4 out;
+ * the TAA history is kept by the context.  motion_dev: float2 per pixel or NULL = the motion vectors of the last
+ * blok_hip_denoise_device call.  Defaults of the reference: feedback_min 0.93, feedback_max 0.98. */
+int blok_hip_taa_device(blok_hip_ctx* ctx, const float* color_dev, const float* motion_dev, float feedback_min,
+                        float feedback_max, uint32_t frame_count, float* out_color_dev, void* hip_stream);
+/* = PostProcess sharpen pass (sharpen.comp; renderer_postprocess.cpp:548-555,619-642): RGBA8 in, RGBA8 out; default strength 0.5. */
+int blok_hip_sharpen_device(blok_hip_ctx* ctx, const uint32_t* rgba8_dev, float strength, uint32_t* out_rgba8_dev, void* hip_stream);
+/* Forget the denoiser and TAA histories (swapchain recreate: Denoiser::resize / PostProcess::resize). */
+int blok_hip_post_reset(blok_hip_ctx* ctx);
+
 /* ---- device-resident dense voxel store (edits and the rebuild they trigger, on the GPU) ----
  * The reference keeps Chunk::density / Chunk::materialIds on the host (blok/src/chunk.hpp:33-42), edits them with
  * setVoxelMaterial (chunk_manager.cpp:316-328) and applyBrush (brush.cpp:13-63), rebuilds dirty chunks' SVOs on the CPU

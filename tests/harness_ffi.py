@@ -17,7 +17,7 @@ HIT = np.dtype([("t", "<f4"), ("material_id", "<u4"), ("voxel", "<i2", 3), ("fac
 def build(sanitize: bool = False) -> Path:
     out = SRC / ("libhost_harness_asan.so" if sanitize else "libhost_harness.so")
     deps = [SRC / "harness.cpp", SRC / "host_harness_shims.h", ROOT / "blok_amd/csrc/hip/trace_core.h",
-            ROOT / "blok_amd/csrc/hip/path_core.h",
+            ROOT / "blok_amd/csrc/hip/path_core.h", ROOT / "blok_amd/csrc/hip/post_core.h",
             ROOT / "blok_amd/csrc/hip/trace_kernels.h", ROOT / "blok_amd/csrc/hip/tree_build.cpp",
             ROOT / "blok_amd/csrc/hip/tree.h"]
     if out.exists() and all(d.stat().st_mtime <= out.stat().st_mtime for d in deps):

@@ -10,6 +10,7 @@ static thread_local uint32_t g_seq_len = 0, g_seq_cap = 0;
     if (g_seq && (event == 1 || event == 2 || event == 4) && g_seq_len < g_seq_cap) g_seq[g_seq_len++] = (unsigned char)(event | ((level) << 2)); } while (0)
 #include "trace_core.h"
 #include "path_core.h"
+#include "post_core.h"
 #include "reference_world.h"
 
 #include <vector>
@@ -179,5 +180,85 @@ void hh_trace_primary(const void* h, const blok_camera* cam, uint32_t width, uin
             trace_one(a, r, stack.data(), Sink{out + size_t(y) * width + x, nullptr});
         }
 }
+
+
+// ---- image-space chain (post_core.h) on the CPU: the same ping-pong as blok_amd/csrc/hip/api.hip's denoiser -------------
+struct HostPost {
+    uint32_t w, h;
+    std::vector<float> hist_color[2], moments[2], world_pos[2], variance, ping, pong, taa_hist[2];
+    std::vector<uint16_t> hist_len[2], normals[2], motion;
+    int cur = 0, taa_cur = 0;
+};
+void* hh_post_new(uint32_t w, uint32_t h) {
+    auto* P = new HostPost();
+    P->w = w; P->h = h;
+    const size_t n = size_t(w) * h;
+    for (int k = 0; k < 2; ++k) {
+        P->hist_color[k].assign(4 * n, 0.f); P->moments[k].assign(2 * n, 0.f); P->world_pos[k].assign(4 * n, 0.f);
+        P->hist_len[k].assign(n, 0); P->normals[k].assign(4 * n, 0); P->taa_hist[k].assign(4 * n, 0.f);
+    }
+    P->variance.assign(n, 0.f); P->ping.assign(4 * n, 0.f); P->pong.assign(4 * n, 0.f); P->motion.assign(2 * n, 0);
+    return P;
+}
+void hh_post_free(void* p) { delete static_cast<HostPost*>(p); }
+struct hh_settings { float temporal_alpha, moment_alpha, variance_clip_gamma, depth_threshold, normal_threshold, phi_color, phi_normal, phi_depth;
+                     int atrous_iterations; float variance_boost; int min_history_length; };
+void hh_post_denoise(void* p, const float* color, const float* world_pos, const float* normal_roughness, const float* motion_in,
+                     const float* prev_view_proj, uint32_t frame_count, const hh_settings* S, float* out_color) {
+    HostPost& P = *static_cast<HostPost*>(p);
+    const int cur = P.cur, prev = cur ^ 1;
+    PostFrame f{};
+    f.w = P.w; f.h = P.h; f.frame_count = frame_count;
+    std::memcpy(&f.s, S, sizeof(DenoiseSettings));
+    static_assert(sizeof(DenoiseSettings) == sizeof(hh_settings), "settings layout");
+    for (int k = 0; k < 16; ++k) f.prev_view_proj[k] = prev_view_proj[k];
+    TemporalArgs t{};
+    t.f = f; t.color = color; t.world_pos = world_pos; t.normal_roughness = normal_roughness; t.motion_in = motion_in;
+    t.prev_color = P.hist_color[prev].data(); t.prev_moments = P.moments[prev].data(); t.prev_world_pos = P.world_pos[prev].data();
+    t.prev_hist_len = P.hist_len[prev].data(); t.prev_normals = P.normals[prev].data();
+    t.out_color = P.hist_color[cur].data(); t.out_moments = P.moments[cur].data(); t.hist_world_pos = P.world_pos[cur].data();
+    t.out_hist_len = P.hist_len[cur].data(); t.hist_normals = P.normals[cur].data(); t.motion = P.motion.data();
+    for (uint32_t y = 0; y < P.h; ++y) for (uint32_t x = 0; x < P.w; ++x) temporal_pixel(t, int(x), int(y));
+    VarianceArgs v{};
+    v.f = f; v.color = P.hist_color[cur].data(); v.moments = P.moments[cur].data(); v.world_pos = P.world_pos[cur].data();
+    v.hist_len = P.hist_len[cur].data(); v.normals = P.normals[cur].data(); v.variance = P.variance.data();
+    for (uint32_t y = 0; y < P.h; ++y) for (uint32_t x = 0; x < P.w; ++x) variance_pixel(v, int(x), int(y));
+    const float* in = P.hist_color[cur].data();
+    for (int it = 0; it < S->atrous_iterations; ++it) {
+        AtrousArgs a{};
+        a.w = P.w; a.h = P.h; a.step = 1 << it; a.phi_color = S->phi_color; a.phi_depth = S->phi_depth;
+        a.color = in; a.variance = P.variance.data(); a.world_pos = P.world_pos[cur].data(); a.normals = P.normals[cur].data();
+        a.out = it == S->atrous_iterations - 1 ? out_color : ((it & 1) ? P.pong.data() : P.ping.data());
+        for (uint32_t y = 0; y < P.h; ++y) for (uint32_t x = 0; x < P.w; ++x) atrous_pixel(a, int(x), int(y));
+        in = a.out;
+    }
+    if (S->atrous_iterations == 0) std::memcpy(out_color, P.hist_color[cur].data(), P.hist_color[cur].size() * sizeof(float));
+    P.cur = prev;
+}
+void hh_post_state(const void* p, float* history_color, float* moments, float* history_length, float* variance, float* motion) {
+    const HostPost& P = *static_cast<const HostPost*>(p);
+    const int last = P.cur ^ 1;
+    const size_t n = size_t(P.w) * P.h;
+    std::memcpy(history_color, P.hist_color[last].data(), 4 * n * sizeof(float));
+    std::memcpy(moments, P.moments[last].data(), 2 * n * sizeof(float));
+    std::memcpy(variance, P.variance.data(), n * sizeof(float));
+    for (size_t i = 0; i < n; ++i) history_length[i] = h2f(P.hist_len[last][i]);
+    for (size_t i = 0; i < 2 * n; ++i) motion[i] = h2f(P.motion[i]);
+}
+void hh_post_taa(void* p, const float* color, const float* motion_in, float feedback_min, float feedback_max, uint32_t frame_count, float* out) {
+    HostPost& P = *static_cast<HostPost*>(p);
+    if (motion_in) for (size_t i = 0; i < P.motion.size(); ++i) P.motion[i] = f2h(motion_in[i]);
+    TaaArgs a{};
+    a.w = P.w; a.h = P.h; a.frame_count = frame_count; a.feedback_min = feedback_min; a.feedback_max = feedback_max;
+    a.color = color; a.history = P.taa_hist[P.taa_cur ^ 1].data(); a.motion = P.motion.data(); a.out = out; a.out_history = P.taa_hist[P.taa_cur].data();
+    for (uint32_t y = 0; y < P.h; ++y) for (uint32_t x = 0; x < P.w; ++x) taa_pixel(a, int(x), int(y));
+    P.taa_cur ^= 1;
+}
+void hh_post_sharpen(const uint32_t* in, uint32_t w, uint32_t h, float strength, uint32_t* out) {
+    SharpenArgs a{w, h, strength, in, out};
+    for (uint32_t y = 0; y < h; ++y) for (uint32_t x = 0; x < w; ++x) sharpen_pixel(a, int(x), int(y));
+}
+float hh_q16(float x) { return q16(x); }
+uint16_t hh_f2h(float x) { return f2h(x); }
 
 }

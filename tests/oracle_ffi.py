@@ -340,3 +340,80 @@ def default_palette():
     out = np.zeros(256, dtype=np.uint32)
     lib().orc_default_palette(_p(out))
     return out
+
+
+# ---------------------------------------------------------------- image-space chain (oracle/blok_oracle_post.cpp)
+class OrcDenoiseSettings(C.Structure):
+    _fields_ = [("temporalAlpha", C.c_float), ("momentAlpha", C.c_float), ("varianceClipGamma", C.c_float),
+                ("depthThreshold", C.c_float), ("normalThreshold", C.c_float), ("phiColor", C.c_float), ("phiNormal", C.c_float),
+                ("phiDepth", C.c_float), ("atrousIterations", C.c_int), ("varianceBoost", C.c_float), ("minHistoryLength", C.c_int)]
+
+    @classmethod
+    def default(cls):                                         # renderer_denoising.hpp:49-66
+        return cls(0.05, 0.2, 1.5, 0.1, 0.95, 0.5, 128.0, 0.1, 4, 1.5, 4)
+
+
+def q16(x):
+    L = lib()
+    L.orc_q16.restype = C.c_float; L.orc_q16.argtypes = [C.c_float]
+    return L.orc_q16(float(x))
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class OracleDenoiser:
+    """Denoiser::denoise + copyCurrentGeometryToHistory + swapHistoryBuffers over the oracle's pass functions
+    (renderer_denoising.cpp:714-776, 833-866, 690-697), and PostProcess's TAA history (renderer_postprocess.cpp:526-534)."""
+
+    def __init__(self, w, h, settings=None):
+        self.w, self.h = w, h
+        self.S = settings or OrcDenoiseSettings.default()
+        z = lambda c: np.zeros((h, w, c), np.float32) if c > 1 else np.zeros((h, w), np.float32)
+        self.prev = dict(color=z(4), moments=z(2), hist_len=z(1), world_pos=z(4), normals=z(4))
+        self.taa_hist = z(4)
+        self.variance = z(1); self.motion = z(2)
+
+    def denoise(self, color, world_pos, normal_roughness, prev_view_proj, frame_count, motion=None):
+        L, w, h = lib(), self.w, self.h
+        color, world_pos, normal_roughness = _f32(color), _f32(world_pos), _f32(normal_roughness)
+        M = _f32(prev_view_proj).reshape(-1)
+        if motion is None:
+            motion = np.zeros((h, w, 2), np.float32)
+            L.orc_motion_vectors(_p(world_pos), w, h, _p(M), _p(motion))
+        self.motion = _f32(motion)
+        out_c, out_m, out_l = np.zeros((h, w, 4), np.float32), np.zeros((h, w, 2), np.float32), np.zeros((h, w), np.float32)
+        P = self.prev
+        L.orc_temporal(_p(color), _p(world_pos), _p(normal_roughness), _p(self.motion), _p(P["color"]), _p(P["moments"]),
+                       _p(P["hist_len"]), _p(P["world_pos"]), _p(P["normals"]), w, h, C.c_uint32(frame_count), _p(M),
+                       C.byref(self.S), _p(out_c), _p(out_m), _p(out_l))
+        var = np.zeros((h, w), np.float32)
+        L.orc_variance(_p(out_c), _p(out_m), _p(out_l), _p(world_pos), _p(normal_roughness), w, h, C.byref(self.S), _p(var))
+        cur = out_c
+        for it in range(self.S.atrousIterations):
+            nxt = np.zeros((h, w, 4), np.float32)
+            L.orc_atrous(_p(cur), _p(var), _p(world_pos), _p(normal_roughness), w, h, 1 << it, C.c_float(self.S.phiColor),
+                         C.c_float(self.S.phiNormal), C.c_float(self.S.phiDepth), _p(nxt))
+            cur = nxt
+        self.prev = dict(color=out_c, moments=out_m, hist_len=out_l, world_pos=world_pos.copy(), normals=normal_roughness.copy())
+        self.variance = var
+        return cur
+
+    def taa(self, color, frame_count, feedback_min=0.93, feedback_max=0.98, motion=None):
+        L, w, h = lib(), self.w, self.h
+        color = _f32(color)
+        motion = self.motion if motion is None else _f32(motion)
+        out, hist = np.zeros((h, w, 4), np.float32), np.zeros((h, w, 4), np.float32)
+        L.orc_taa(_p(color), _p(self.taa_hist), _p(motion), w, h, C.c_uint32(frame_count), C.c_float(feedback_min),
+                  C.c_float(feedback_max), _p(out), _p(hist))
+        self.taa_hist = hist
+        return out
+
+
+def sharpen(rgba8, strength=0.5):
+    rgba8 = np.ascontiguousarray(rgba8, dtype=np.uint32)
+    h, w = rgba8.shape
+    out = np.zeros((h, w), np.uint32)
+    lib().orc_sharpen(_p(rgba8), w, h, C.c_float(strength), _p(out))
+    return out

@@ -1,0 +1,298 @@
+"""the image-space chain behind the path tracer — temporal accumulation, variance, a-trous,
+TAA, sharpen (reference assets/shaders/temporal_reproject.comp, variance.comp, atrous.comp, taa.comp, sharpen.comp).
+
+The reference holds no fixture for these shaders and they cannot run here, so the oracle (oracle/blok_oracle_post.cpp)
+is a literal restatement pinned only by the hand-computed cases below ("parity unpinned" in its header).  The product
+(blok_amd/csrc/hip/post_core.h) is checked against it twice: compiled for the CPU it must agree bit for bit over a
+multi-frame sequence with camera motion; on the GPU it may differ through expf in variance.comp's depth weight
+(a few ulp, which can flip that shader's `weight > 0.01` test on isolated pixels), so the GPU test requires
+|delta| <= 1e-5 + 1e-4 |ref| on >= 99.9 % of the pixels of every plane and at most 1 LSB in the final RGBA8 image
+on those pixels."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from blok_amd import world as W
+from tests import harness_ffi as H
+from tests import oracle_ffi as O
+from tests.conftest import SEED
+
+Wd, Ht = 96, 64
+
+
+# ------------------------------------------------------------------------------------------------ helpers
+class HarnessPost:
+    """The product's per-pixel bodies compiled for the CPU, with the product's ping-pong (tests/host_harness)."""
+
+    def __init__(self, w, h, settings=None):
+        self.L, self.w, self.h = H.lib(), w, h
+        self.L.hh_post_new.restype = C.c_void_p
+        self.L.hh_post_denoise.argtypes = [C.c_void_p] * 6 + [C.c_uint32, C.c_void_p, C.c_void_p]
+        self.L.hh_post_state.argtypes = [C.c_void_p] * 6
+        self.L.hh_post_taa.argtypes = [C.c_void_p] * 3 + [C.c_float, C.c_float, C.c_uint32, C.c_void_p]
+        self.L.hh_post_free.argtypes = [C.c_void_p]
+        self.p = C.c_void_p(self.L.hh_post_new(w, h))
+        self.S = settings or O.OrcDenoiseSettings.default()
+
+    def __del__(self):
+        self.L.hh_post_free(self.p)
+
+    def denoise(self, color, world_pos, normals, prev_view_proj, frame_count, motion=None):
+        out = np.zeros((self.h, self.w, 4), np.float32)
+        a = [np.ascontiguousarray(x, dtype=np.float32) for x in (color, world_pos, normals)]
+        M = np.ascontiguousarray(prev_view_proj, dtype=np.float32)
+        m = None if motion is None else np.ascontiguousarray(motion, dtype=np.float32)
+        self.L.hh_post_denoise(self.p, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, None if m is None else m.ctypes.data,
+                               M.ctypes.data, frame_count, C.byref(self.S), out.ctypes.data)
+        return out
+
+    def state(self):
+        h, w = self.h, self.w
+        out = (np.zeros((h, w, 4), np.float32), np.zeros((h, w, 2), np.float32), np.zeros((h, w), np.float32),
+               np.zeros((h, w), np.float32), np.zeros((h, w, 2), np.float32))
+        self.L.hh_post_state(self.p, *[a.ctypes.data for a in out])
+        return out
+
+    def taa(self, color, frame_count, fmin=0.93, fmax=0.98):
+        out = np.zeros((self.h, self.w, 4), np.float32)
+        c = np.ascontiguousarray(color, dtype=np.float32)
+        self.L.hh_post_taa(self.p, c.ctypes.data, None, fmin, fmax, frame_count, out.ctypes.data)
+        return out
+
+
+def harness_sharpen(rgba8, strength=0.5):
+    L = H.lib()
+    L.hh_post_sharpen.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_void_p]
+    rgba8 = np.ascontiguousarray(rgba8, dtype=np.uint32)
+    out = np.zeros_like(rgba8)
+    L.hh_post_sharpen(rgba8.ctypes.data, rgba8.shape[1], rgba8.shape[0], strength, out.ctypes.data)
+    return out
+
+
+def camera_path(n_frames):
+    """A slow dolly + pan around the 64^3 scene: consecutive frames overlap, so history is reused but reprojected."""
+    cams = []
+    for k in range(n_frames):
+        eye = (96.0 + 0.25 * k, 60.0 + 0.05 * k, -30.0 + 0.1 * k)
+        cams.append(W.camera_look_at(eye, (32.0 + 0.05 * k, 24.0, 32.0), 60.0, Wd, Ht))
+    return cams
+
+
+@pytest.fixture(scope="module")
+def gbuffer_frames():
+    """Noisy 1-spp path-traced frames of the 64^3 scene from the oracle's raygen.rgen restatement."""
+    cm = W.ChunkManager(128, 1.0)
+    cm.generate_scene(64, SEED)
+    cm.rebuild_dirty_chunks()
+    mats = W.scene_materials(SEED)
+    pw = cm.pack_chunks_to_gpu_svo(mats)
+    lat = O.Lattice(pw.nodes, pw.sub_chunks)
+    frames = []
+    cams = camera_path(5)
+    for k, cam in enumerate(cams):
+        planes, _ = O.render_paths(lat, mats, cam, Wd, Ht, spp=1, max_bounces=2, frame_index=k, threads=8)
+        prev = W.view_proj_from_camera(cams[max(k - 1, 0)])
+        frames.append((planes, prev))
+    return frames, pw, mats, cams
+
+
+# ------------------------------------------------------------------------------------------------ binary16
+def test_binary16_rounding_matches_numpy():
+    rng = np.random.default_rng(3)
+    xs = np.concatenate([rng.normal(0, 1, 2000), rng.normal(0, 1e-6, 500), rng.uniform(-7e4, 7e4, 500),
+                         [0.0, -0.0, 1.0, -1.0, 65504.0, 65519.9, 65520.0, 1e-8, 2.0 ** -25, 2.0 ** -24, 3 * 2.0 ** -26, 6.1e-5, 6.2e-5,
+                          0.1, 1.0009765625, 1.00048828125, 1.00146484375, 64.0, 0.95]]).astype(np.float32)
+    ref = xs.astype(np.float16).astype(np.float32)
+    L = H.lib()
+    L.hh_q16.restype = C.c_float; L.hh_q16.argtypes = [C.c_float]
+    L.hh_f2h.restype = C.c_uint16; L.hh_f2h.argtypes = [C.c_float]
+    for x, r in zip(xs, ref):
+        assert np.float32(O.q16(x)).tobytes() == r.tobytes(), x
+        assert np.float32(L.hh_q16(x)).tobytes() == r.tobytes(), x
+        assert L.hh_f2h(x) == np.float16(x).view(np.uint16), x
+
+
+# ------------------------------------------------------------------------------------------------ hand-computed cases
+def flat_gbuffer(color, depth=50.0, normal=(0.0, 1.0, 0.0)):
+    c = np.zeros((Ht, Wd, 4), np.float32); c[..., :3] = color; c[..., 3] = 1
+    wp = np.zeros((Ht, Wd, 4), np.float32)
+    ys, xs = np.mgrid[0:Ht, 0:Wd]
+    wp[..., 0] = xs * 0.1; wp[..., 1] = 0.0; wp[..., 2] = ys * 0.1; wp[..., 3] = depth
+    nr = np.zeros((Ht, Wd, 4), np.float32); nr[..., :3] = normal; nr[..., 3] = 0.5
+    return c, wp, nr
+
+
+@pytest.mark.parametrize("impl", ["oracle", "product_on_cpu"])
+def test_known_answers(impl):
+    make = (lambda: O.OracleDenoiser(Wd, Ht)) if impl == "oracle" else (lambda: HarnessPost(Wd, Ht))
+    ident = np.eye(4, dtype=np.float32).reshape(-1)
+    # frame 0 has no history: temporal output = clamp(colour, 0, 100), moments = (lum, lum^2), history length 1;
+    # on a flat surface of constant colour every filter is the identity
+    col = np.array([0.2, 0.5, 150.0], np.float32)
+    c, wp, nr = flat_gbuffer(col)
+    d = make()
+    out = d.denoise(c, wp, nr, ident, 0)
+    clamped = np.minimum(col, np.float32(100.0))
+    # (the a-trous normalisation sum(c w) / sum(w) reproduces c to rounding only)
+    assert np.allclose(out[..., :3], np.broadcast_to(clamped, (Ht, Wd, 3)), rtol=2e-6, atol=0) and (out[..., 3] == 1).all()
+    lum = (np.float32(0.2126) * col[0] + np.float32(0.7152) * col[1]) + np.float32(0.0722) * col[2]
+    if impl == "product_on_cpu":
+        hist, mom, hl, var, mot = d.state()
+    else:
+        hist, mom, hl, var, mot = d.prev["color"], d.prev["moments"], d.prev["hist_len"], d.variance, d.motion
+    assert np.array_equal(hist[..., :3], np.broadcast_to(clamped, (Ht, Wd, 3)))
+    assert (mom[..., 0] == lum).all() and (mom[..., 1] == min(lum * lum, np.float32(10000.0))).all()
+    assert (hl == 1).all()
+    # variance: temporal weight 0 at history 1, spatial variance 0 on a constant plane, boost 1.5..1 -> floor 1e-4
+    assert (var == np.float32(0.0001)).all()
+    # sky pixels (depth > 9000) pass through the a-trous filter untouched and are never sampled
+    c, wp, nr = flat_gbuffer(np.array([0.3, 0.3, 0.3], np.float32))
+    rng = np.random.default_rng(0)
+    c[..., :3] = rng.uniform(0, 1, (Ht, Wd, 3)).astype(np.float32)
+    wp[: Ht // 2, :, 3] = 10000.0
+    out = make().denoise(c, wp, nr, ident, 0)
+    assert np.array_equal(out[: Ht // 2, :, :3], c[: Ht // 2, :, :3])
+    assert not np.array_equal(out[Ht // 2 + 8:, :, :3], c[Ht // 2 + 8:, :, :3])       # the surface half is filtered
+    assert (out[Ht // 2 + 8:, :, :3].std() < c[Ht // 2 + 8:, :, :3].std())
+    # surfaces facing different ways do not mix: a vertical normal discontinuity keeps a hard colour edge
+    c, wp, nr = flat_gbuffer(np.array([1.0, 0.0, 0.0], np.float32))
+    c[:, Wd // 2:, :3] = (0.0, 0.0, 1.0); nr[:, Wd // 2:, :3] = (1.0, 0.0, 0.0)
+    out = make().denoise(c, wp, nr, ident, 0)
+    assert np.allclose(out[..., :3], c[..., :3], rtol=2e-6, atol=0) and (out[:, : Wd // 2, 2] == 0).all() and (out[:, Wd // 2:, 0] == 0).all()
+
+
+def test_sharpen_and_taa_formulas():
+    # sharpen: constant image is a fixed point; an isolated texel follows e + (e - blur) * 1.5
+    img = np.full((Ht, Wd), 0xFF808080, np.uint32)
+    assert np.array_equal(O.sharpen(img), img) and np.array_equal(harness_sharpen(img), img)
+    img[10, 10] = 0xFFFFFFFF
+    out = O.sharpen(img)
+    e, nb = np.float32(1.0), np.float32(128 / 255)
+    blur = ((nb + nb + nb + nb) * np.float32(1) + (nb + nb + nb + nb) * np.float32(2) + np.float32(4) * e) / np.float32(16)
+    centre = min(max(e + (e - blur) * np.float32(1.5), 0), 1)
+    assert out[10, 10] & 0xFF == int(centre * np.float32(255) + np.float32(0.5))
+    blur_n = (((nb + nb) + nb + nb) + ((nb + nb) + nb + e) * np.float32(2) + np.float32(4) * nb) / np.float32(16)   # a 4-neighbour
+    assert out[10, 11] & 0xFF == int(min(max(nb + (nb - blur_n) * np.float32(1.5), 0), 1) * np.float32(255) + np.float32(0.5))
+    assert np.array_equal(harness_sharpen(img), out)
+    # TAA with frameCount 0: feedback 0 -> output = current + 0.1 (current - neighbourhood mean), history = current
+    rng = np.random.default_rng(1)
+    c = np.zeros((Ht, Wd, 4), np.float32); c[..., :3] = rng.uniform(0, 2, (Ht, Wd, 3)); c[..., 3] = 0.25
+    o = O.OracleDenoiser(Wd, Ht)
+    out = o.taa(c, 0, motion=np.zeros((Ht, Wd, 2), np.float32))
+    assert np.array_equal(o.taa_hist[..., :3], c[..., :3]) and (out[..., 3] == 0.25).all()
+    pad = np.pad(c[..., :3].astype(np.float64), ((1, 1), (1, 1), (0, 0)), mode="edge")
+    mean = sum(pad[1 + dy:Ht + 1 + dy, 1 + dx:Wd + 1 + dx] for dy in (-1, 0, 1) for dx in (-1, 0, 1)) / 9.0
+    assert np.abs(out[..., :3] - (c[..., :3] + 0.1 * (c[..., :3] - mean))).max() < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ sequences
+def test_product_on_cpu_equals_oracle_over_a_sequence(gbuffer_frames):
+    frames, _, _, _ = gbuffer_frames
+    o, p = O.OracleDenoiser(Wd, Ht), HarnessPost(Wd, Ht)
+    reused = []
+    for k, (planes, prev_vp) in enumerate(frames):
+        a = o.denoise(planes["color"], planes["world_pos"], planes["normal_roughness"], prev_vp, k)
+        b = p.denoise(planes["color"], planes["world_pos"], planes["normal_roughness"], prev_vp, k)
+        assert a.tobytes() == b.tobytes(), f"denoised frame {k}"
+        hist, mom, hl, var, mot = p.state()
+        assert hist.tobytes() == o.prev["color"].tobytes() and mom.tobytes() == o.prev["moments"].tobytes()
+        assert hl.tobytes() == o.prev["hist_len"].tobytes() and var.tobytes() == o.variance.tobytes()
+        q = np.vectorize(O.q16)(o.motion).astype(np.float32)
+        assert mot.tobytes() == q.tobytes()
+        ta, tb = o.taa(a, k), p.taa(b, k)
+        assert ta.tobytes() == tb.tobytes(), f"taa frame {k}"
+        ldr = O.tonemap(ta)
+        assert np.array_equal(O.sharpen(ldr.reshape(Ht, Wd)), harness_sharpen(ldr.reshape(Ht, Wd)))
+        surface = planes["world_pos"][..., 3] < 9000
+        reused.append((hl[surface] > 1).mean())
+        if k:
+            assert (np.abs(mot[surface]).max() > 1e-3)                    # the camera moves: real reprojection
+    # history is accepted on most surface pixels and grows by one per frame (the sky plane sits 10000 units away, so
+    # the slightest rotation moves it by more than the 2-unit world-position tolerance: it never accumulates)
+    assert reused[0] == 0 and reused[-1] > 0.5, reused
+    assert hl.max() == len(frames)
+    # the chain does what it is for: the denoised sequence is less noisy than its input
+    noisy, surface = frames[-1][0]["color"][..., :3], frames[-1][0]["world_pos"][..., 3] < 9000
+    lap = lambda im: np.abs(im[1:-1, 1:-1] - 0.25 * (im[:-2, 1:-1] + im[2:, 1:-1] + im[1:-1, :-2] + im[1:-1, 2:]))[surface[1:-1, 1:-1]].mean()
+    assert lap(a[..., :3]) < 0.8 * lap(noisy)            # (at 96x64 most of the remaining variation is voxel-face detail)
+
+
+def test_explicit_motion_plane_and_settings(gbuffer_frames):
+    """A caller-provided motion plane replaces the computed one; non-default settings and 0 / 5 iterations."""
+    frames, _, _, _ = gbuffer_frames
+    for iters in (0, 1, 5):
+        S = O.OrcDenoiseSettings.default()
+        S.atrousIterations = iters; S.temporalAlpha = 0.2; S.phiColor = 1.5; S.minHistoryLength = 8; S.varianceClipGamma = 0.75
+        o, p = O.OracleDenoiser(Wd, Ht, S), HarnessPost(Wd, Ht, S)
+        rng = np.random.default_rng(iters)
+        for k, (planes, prev_vp) in enumerate(frames[:3]):
+            motion = rng.normal(0, 0.01, (Ht, Wd, 2)).astype(np.float32)
+            a = o.denoise(planes["color"], planes["world_pos"], planes["normal_roughness"], prev_vp, k, motion=motion)
+            b = p.denoise(planes["color"], planes["world_pos"], planes["normal_roughness"], prev_vp, k, motion=motion)
+            assert a.tobytes() == b.tobytes(), (iters, k)
+
+
+def test_view_proj_from_camera_inverts_the_primary_ray_mapping():
+    cam = camera_path(3)[2]
+    M = W.view_proj_from_camera(cam).reshape(4, 4).T.astype(np.float64)          # rows
+    rays = O.primary_rays(cam, Wd, Ht)
+    for (x, y) in [(0, 0), (Wd - 1, Ht - 1), (17, 40), (Wd // 2, Ht // 2)]:
+        r = rays[y * Wd + x]
+        p = np.append(np.asarray(r["org"], np.float64) + 37.5 * np.asarray(r["dir"], np.float64), 1.0)
+        clip = M @ p
+        u, v = clip[0] / clip[3] * 0.5 + 0.5, clip[1] / clip[3] * 0.5 + 0.5
+        assert abs(u * Wd - (x + 0.5)) < 1e-3 and abs(v * Ht - (y + 0.5)) < 1e-3
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_gpu_chain_matches_oracle(gbuffer_frames):
+    """Path kernel -> denoiser -> TAA -> tonemap -> sharpen on the device, against the oracle chain fed with the same
+    (device-produced) G-buffer planes."""
+    import torch
+    from blok_amd.tracer import HipTracer
+    _, pw, mats, cams = gbuffer_frames
+    tr = HipTracer(Wd, Ht).init()
+    tr.add_world(pw)
+    o = O.OracleDenoiser(Wd, Ht)
+    n = Wd * Ht
+    planes = {k: torch.zeros((n, 4), dtype=torch.float32, device="cuda") for k in ("color", "world_pos", "normal_roughness", "albedo_metallic")}
+    den = torch.zeros((n, 4), dtype=torch.float32, device="cuda"); taa = torch.zeros_like(den)
+    ldr = torch.zeros(n, dtype=torch.int32, device="cuda"); sharp = torch.zeros_like(ldr)
+
+    def close(got, ref, what):
+        ok = np.abs(got - ref) <= 1e-5 + 1e-4 * np.abs(ref)
+        ok = ok.reshape(Ht, Wd, -1).all(axis=2)
+        assert ok.mean() >= 0.999, (what, ok.mean())
+        return ok
+
+    for k, cam in enumerate(cams):
+        tr.trace_paths_device(cam, planes["color"].data_ptr(), spp=1, max_bounces=2, frame_index=k,
+                              world_pos_ptr=planes["world_pos"].data_ptr(), normal_roughness_ptr=planes["normal_roughness"].data_ptr(),
+                              albedo_metallic_ptr=planes["albedo_metallic"].data_ptr())
+        prev_vp = W.view_proj_from_camera(cams[max(k - 1, 0)])
+        tr.denoise_device(planes["color"].data_ptr(), planes["world_pos"].data_ptr(), planes["normal_roughness"].data_ptr(), prev_vp, k, den.data_ptr())
+        tr.taa_device(den.data_ptr(), taa.data_ptr(), k)
+        tr.tonemap_device(taa.data_ptr(), ldr.data_ptr())
+        tr.sharpen_device(ldr.data_ptr(), sharp.data_ptr())
+        torch.cuda.synchronize()
+        host = {name: t.cpu().numpy().reshape(Ht, Wd, 4) for name, t in planes.items()}
+        ref_den = o.denoise(host["color"], host["world_pos"], host["normal_roughness"], prev_vp, k)
+        ok = close(den.cpu().numpy().reshape(Ht, Wd, 4), ref_den, f"denoised {k}")
+        hist, mom, hl, var, mot = tr.denoise_state()
+        close(hist, o.prev["color"], f"history {k}"); close(mom, o.prev["moments"], f"moments {k}")
+        assert (hl == o.prev["hist_len"]).mean() >= 0.999
+        close(var[..., None], o.variance[..., None], f"variance {k}")
+        assert np.array_equal(mot, np.vectorize(O.q16)(o.motion).astype(np.float32))
+        ref_taa = o.taa(ref_den, k)
+        ok &= close(taa.cpu().numpy().reshape(Ht, Wd, 4), ref_taa, f"taa {k}")
+        ref_sharp = O.sharpen(O.tonemap(ref_taa).reshape(Ht, Wd))
+        got_sharp = sharp.cpu().numpy().view(np.uint32).reshape(Ht, Wd)
+        d = np.abs(got_sharp.view(np.uint8).reshape(Ht, Wd, 4).astype(int) - ref_sharp.view(np.uint8).reshape(Ht, Wd, 4).astype(int))
+        inner = ok.copy()                                                   # a differing neighbour reaches into the 3x3 sharpen footprint
+        inner[1:-1, 1:-1] = ok[1:-1, 1:-1] & ok[:-2, 1:-1] & ok[2:, 1:-1] & ok[1:-1, :-2] & ok[1:-1, 2:] & ok[:-2, :-2] & ok[2:, 2:] & ok[:-2, 2:] & ok[2:, :-2]
+        assert (d[inner] <= 1).all(), d[inner].max()
+    assert (hl[host["world_pos"][..., 3] < 9000] > 1).mean() > 0.5
+    tr.post_reset()
+    tr.shutdown()
