@@ -46,7 +46,8 @@ struct blok_hip_ctx {
     struct Post {
         size_t pixels = 0;
         float *hist_color[2] = {nullptr, nullptr}, *moments[2] = {nullptr, nullptr}, *world_pos[2] = {nullptr, nullptr};
-        uint16_t *hist_len[2] = {nullptr, nullptr}, *normals[2] = {nullptr, nullptr};
+        uint16_t* hist_len[2] = {nullptr, nullptr};
+        float* unit_normals[2] = {nullptr, nullptr};   // float4: normalize(binary16 normal)
         uint16_t* motion = nullptr;          // half2
         float *variance = nullptr, *ping = nullptr, *pong = nullptr, *taa_hist[2] = {nullptr, nullptr};
         float* widen = nullptr;              // scratch for state downloads
@@ -87,7 +88,7 @@ void free_post(blok_hip_ctx* ctx) {
     auto& P = ctx->post;
     for (int k = 0; k < 2; ++k)
         for (void* p : {static_cast<void*>(P.hist_color[k]), static_cast<void*>(P.moments[k]), static_cast<void*>(P.world_pos[k]),
-                        static_cast<void*>(P.hist_len[k]), static_cast<void*>(P.normals[k]), static_cast<void*>(P.taa_hist[k])})
+                        static_cast<void*>(P.hist_len[k]), static_cast<void*>(P.unit_normals[k]), static_cast<void*>(P.taa_hist[k])})
             if (p) (void)hipFree(p);
     for (void* p : {static_cast<void*>(P.motion), static_cast<void*>(P.variance), static_cast<void*>(P.ping), static_cast<void*>(P.pong), static_cast<void*>(P.widen)})
         if (p) (void)hipFree(p);
@@ -640,7 +641,7 @@ int ensure_post(blok_hip_ctx* ctx) {
         if (rc == BLOK_OK) rc = post_alloc(ctx, &P.moments[k], 2 * n);
         if (rc == BLOK_OK) rc = post_alloc(ctx, &P.world_pos[k], 4 * n);
         if (rc == BLOK_OK) rc = post_alloc(ctx, &P.hist_len[k], n);
-        if (rc == BLOK_OK) rc = post_alloc(ctx, &P.normals[k], 4 * n);
+        if (rc == BLOK_OK) rc = post_alloc(ctx, &P.unit_normals[k], 4 * n);
         if (rc == BLOK_OK) rc = post_alloc(ctx, &P.taa_hist[k], 4 * n);
     }
     if (rc == BLOK_OK) rc = post_alloc(ctx, &P.motion, 2 * n);
@@ -693,15 +694,15 @@ int blok_hip_denoise_device(blok_hip_ctx* ctx, const blok_gbuffer* planes, const
     t.f = f;
     t.color = planes->color; t.world_pos = planes->world_pos; t.normal_roughness = planes->normal_roughness; t.motion_in = motion_dev;
     t.prev_color = P.hist_color[prev]; t.prev_moments = P.moments[prev]; t.prev_world_pos = P.world_pos[prev];
-    t.prev_hist_len = P.hist_len[prev]; t.prev_normals = P.normals[prev];
+    t.prev_hist_len = P.hist_len[prev]; t.prev_unit_normals = P.unit_normals[prev];
     t.out_color = P.hist_color[cur]; t.out_moments = P.moments[cur]; t.hist_world_pos = P.world_pos[cur];
-    t.out_hist_len = P.hist_len[cur]; t.hist_normals = P.normals[cur]; t.motion = P.motion;
+    t.out_hist_len = P.hist_len[cur]; t.unit_normals = P.unit_normals[cur]; t.motion = P.motion;
     blok::launch_temporal(t, stream);
 
     blok::VarianceArgs v{};
     v.f = f;
     v.color = P.hist_color[cur]; v.moments = P.moments[cur]; v.world_pos = P.world_pos[cur];
-    v.hist_len = P.hist_len[cur]; v.normals = P.normals[cur]; v.variance = P.variance;
+    v.hist_len = P.hist_len[cur]; v.unit_normals = P.unit_normals[cur]; v.variance = P.variance;
     blok::launch_variance(v, stream);
 
     // iteration 0 reads the temporal output; then ping <-> pong (renderer_denoising.cpp:520-536); the last one writes the caller's plane
@@ -709,7 +710,7 @@ int blok_hip_denoise_device(blok_hip_ctx* ctx, const blok_gbuffer* planes, const
     for (int it = 0; it < S.atrous_iterations; ++it) {
         blok::AtrousArgs a{};
         a.w = f.w; a.h = f.h; a.step = 1 << it; a.phi_color = S.phi_color; a.phi_depth = S.phi_depth;
-        a.color = in; a.variance = P.variance; a.world_pos = P.world_pos[cur]; a.normals = P.normals[cur];
+        a.color = in; a.variance = P.variance; a.world_pos = P.world_pos[cur]; a.unit_normals = P.unit_normals[cur];
         a.out = it == S.atrous_iterations - 1 ? out_color_dev : ((it & 1) ? P.pong : P.ping);
         blok::launch_atrous(a, stream);
         in = a.out;

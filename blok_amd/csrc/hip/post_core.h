@@ -7,12 +7,14 @@
 // plus the motion vectors the ray-generation shader writes for them (raygen.rgen:150-155, 409-413), computed here
 // from the first-hit position plane instead of inside the path kernel.
 //
-// HBM layout (the work is HBM-bound: 60-140 algorithmic bytes per pixel and pass): the planes the reference keeps in
-// 16-bit float images are stored as binary16 here too — normals + roughness as half4 (8 B instead of the path kernel's
-// 16), history length as half, motion vectors as half2 — so the reader sees exactly the values the reference's
-// images would hold and the passes after the first move half the bytes for those planes.  The temporal pass does the
-// narrowing, the copy of the current geometry into the history slot (Denoiser::copyCurrentGeometryToHistory,
-// renderer_denoising.cpp:833-866) and the motion vectors in the same sweep.
+// HBM layout (60-150 algorithmic bytes per pixel and pass): history length and motion vectors, which the reference keeps in
+// 16-bit float images, are stored as binary16 here too (half, half2), so a reader sees exactly the values the reference's
+// images would hold.  Normals are different: every later use of the rgba16f normal image is normalize(xyz) (variance.comp:113,
+// atrous.comp:172,191, temporal_reproject.comp:248 for the previous frame), 25 times per pixel and a-trous iteration, so the
+// temporal pass narrows the path kernel's normal to binary16, normalises it ONCE and stores that unit normal as a float4
+// plane (same values, none of the divides and square roots downstream).
+// The temporal pass also copies the current geometry into the history slot (Denoiser::copyCurrentGeometryToHistory,
+// renderer_denoising.cpp:833-866) and produces the motion vectors, in the same sweep.
 //
 // Arithmetic conventions (where GLSL leaves them open) are the ones oracle/blok_oracle_post.cpp states; every float
 // op is a single rounded binary32 op in the shader's order, so that on the CPU (tests/host_harness) this file and the
@@ -76,10 +78,14 @@ struct PostFrame {                 // what every pass of one frame shares
 BLOK_DEV int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 BLOK_DEV float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
 BLOK_DEV float mixf(float a, float b, float t) { return a * (1.0f - t) + b * t; }
-BLOK_DEV V3 load3(const float* plane, size_t i) { return v3(plane[4 * i], plane[4 * i + 1], plane[4 * i + 2]); }
+// float4 planes are read and written as one 16-byte access per pixel (planes are 16-byte aligned: hipMalloc / torch / numpy)
+struct alignas(16) F4 { float x, y, z, w; };
+BLOK_DEV F4 load4(const float* plane, size_t i) { return reinterpret_cast<const F4*>(plane)[i]; }
+BLOK_DEV V3 xyz(F4 v) { return v3(v.x, v.y, v.z); }
+BLOK_DEV V3 load3(const float* plane, size_t i) { return xyz(load4(plane, i)); }
 BLOK_DEV V3 load3h(const uint16_t* plane, size_t i) { return v3(h2f(plane[4 * i]), h2f(plane[4 * i + 1]), h2f(plane[4 * i + 2])); }
-BLOK_DEV V3 load3q(const float* plane, size_t i) { return v3(q16(plane[4 * i]), q16(plane[4 * i + 1]), q16(plane[4 * i + 2])); }
-BLOK_DEV void store4(float* plane, size_t i, V3 c, float a) { plane[4 * i] = c.x; plane[4 * i + 1] = c.y; plane[4 * i + 2] = c.z; plane[4 * i + 3] = a; }
+BLOK_DEV V3 load3q(const float* plane, size_t i) { const F4 v = load4(plane, i); return v3(q16(v.x), q16(v.y), q16(v.z)); }
+BLOK_DEV void store4(float* plane, size_t i, V3 c, float a) { F4 v; v.x = c.x; v.y = c.y; v.z = c.z; v.w = a; reinterpret_cast<F4*>(plane)[i] = v; }
 BLOK_DEV V3 vmin3(V3 a, V3 b) { return v3(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z)); }
 BLOK_DEV V3 vmax3(V3 a, V3 b) { return v3(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z)); }
 BLOK_DEV V3 vsplat(float s) { return v3(s, s, s); }
@@ -114,24 +120,26 @@ struct TemporalArgs {
     const float *color, *world_pos, *normal_roughness;      // this frame, float4 planes from the path kernel
     const float* motion_in;                                 // float2 per pixel or null (then computed from world_pos)
     const float *prev_color, *prev_moments, *prev_world_pos; // history of the previous frame
-    const uint16_t *prev_hist_len, *prev_normals;           // half, half4
-    float *out_color, *out_moments, *hist_world_pos;        // history of this frame
-    uint16_t *out_hist_len, *hist_normals, *motion;         // half, half4 (narrowed normal_roughness), half2
+    const uint16_t* prev_hist_len;                          // half
+    const float* prev_unit_normals;                         // float4: normalize(binary16 normal) of the previous frame
+    float *out_color, *out_moments, *hist_world_pos, *unit_normals;   // history of this frame
+    uint16_t *out_hist_len, *motion;                        // half, half2
 };
 
 BLOK_DEV void temporal_pixel(const TemporalArgs& T, int cx, int cy) {
     const int w = static_cast<int>(T.f.w), h = static_cast<int>(T.f.h);
     const size_t i = static_cast<size_t>(cy) * w + cx;
     const V3 current = load3(T.color, i);
-    const V3 world = load3(T.world_pos, i);
-    const float depth = T.world_pos[4 * i + 3];
+    const F4 wp = load4(T.world_pos, i);
+    const V3 world = xyz(wp);
+    const float depth = wp.w;
     const float cu = (static_cast<float>(cx) + 0.5f) / static_cast<float>(w), cv = (static_cast<float>(cy) + 0.5f) / static_cast<float>(h);
 
-    // geometry of this frame into the history slot, normals narrowed to binary16
-    const uint16_t nx = f2h(T.normal_roughness[4 * i]), ny = f2h(T.normal_roughness[4 * i + 1]), nz = f2h(T.normal_roughness[4 * i + 2]);
-    T.hist_normals[4 * i] = nx; T.hist_normals[4 * i + 1] = ny; T.hist_normals[4 * i + 2] = nz; T.hist_normals[4 * i + 3] = f2h(T.normal_roughness[4 * i + 3]);
+    // geometry of this frame into the history slot; the unit normal of the binary16-narrowed normal, once for all passes
+    const F4 nr = load4(T.normal_roughness, i);
+    const V3 normal = vnormalize(v3(q16(nr.x), q16(nr.y), q16(nr.z)));
+    store4(T.unit_normals, i, normal, q16(nr.w));
     store4(T.hist_world_pos, i, world, depth);
-    const V3 normal = vnormalize(v3(h2f(nx), h2f(ny), h2f(nz)));
 
     // motion vector (raygen.rgen:409-413), held as half2
     float mu = 0.0f, mv = 0.0f;
@@ -153,11 +161,11 @@ BLOK_DEV void temporal_pixel(const TemporalArgs& T, int cx, int cy) {
         const V3 history = bilinear3(T.prev_color, w, h, pu, pv);
         const int px = clampi(static_cast<int>(pu * static_cast<float>(w)), 0, w - 1), py = clampi(static_cast<int>(pv * static_cast<float>(h)), 0, h - 1);
         const size_t p = static_cast<size_t>(py) * w + px;
-        const float prev_depth = T.prev_world_pos[4 * p + 3];
-        const V3 prev_normal = vnormalize(load3h(T.prev_normals, p));
-        const bool depth_ok = fabsf(depth - prev_depth) < T.f.s.depth_threshold * depth + 0.5f;         // :252-255
+        const F4 pwp = load4(T.prev_world_pos, p);
+        const V3 prev_normal = load3(T.prev_unit_normals, p);
+        const bool depth_ok = fabsf(depth - pwp.w) < T.f.s.depth_threshold * depth + 0.5f;              // :252-255
         const bool normal_ok = vdot(normal, prev_normal) > T.f.s.normal_threshold;                       // :258-259
-        const bool pos_ok = vlength(vsub(world, load3(T.prev_world_pos, p))) < 2.0f;                     // :262-264
+        const bool pos_ok = vlength(vsub(world, xyz(pwp))) < 2.0f;                                       // :262-264
         if (depth_ok && normal_ok && pos_ok) {
             // neighbourhood statistics in YCoCg over the 3x3 pixels on the same surface (:120-193)
             V3 s1 = vsplat(0.0f), s2 = vsplat(0.0f), lo = vsplat(1e10f), hi = vsplat(-1e10f);
@@ -214,7 +222,8 @@ BLOK_DEV void temporal_pixel(const TemporalArgs& T, int cx, int cy) {
 struct VarianceArgs {
     PostFrame f;
     const float *color, *moments, *world_pos;    // temporal output colour + moments, geometry
-    const uint16_t *hist_len, *normals;          // half, half4
+    const uint16_t* hist_len;                    // half
+    const float* unit_normals;                   // float4
     float* variance;
 };
 
@@ -224,20 +233,34 @@ BLOK_DEV void variance_pixel(const VarianceArgs& A, int cx, int cy) {
     const float m1 = A.moments[2 * i], m2 = A.moments[2 * i + 1];
     const float history = h2f(A.hist_len[i]);
     const float depth = A.world_pos[4 * i + 3];
-    const V3 normal = vnormalize(load3h(A.normals, i));
+    const V3 normal = load3(A.unit_normals, i);
     const float temporal_var = fmaxf(m2 - m1 * m1, 0.0f);
-    float a1 = 0.0f, a2 = 0.0f, wsum = 0.0f;                                              // computeSpatialVariance :57-99
-    for (int dy = -1; dy <= 1; ++dy)
-        for (int dx = -1; dx <= 1; ++dx) {
-            const size_t s = static_cast<size_t>(clampi(cy + dy, 0, h - 1)) * w + clampi(cx + dx, 0, w - 1);
-            const float dd = fabsf(depth - A.world_pos[4 * s + 3]);
-            const float nd = vdot(normal, vnormalize(load3h(A.normals, s)));
-            const float wgt = expf(-dd * dd / (0.5f * 0.5f)) * (nd > 0.9f ? 1.0f : 0.0f);
-            if (wgt > 0.01f) {
-                const float l = lum709(load3(A.color, s));
-                a1 += l * wgt; a2 += l * l * wgt; wsum += wgt;
-            }
+    // computeSpatialVariance :57-99.  Memory-level parallelism: the nine taps' three planes are fetched before any of them is
+    // used (the shader's conditional colour fetch becomes an unconditional one whose value is only accumulated under the
+    // shader's condition), otherwise every tap is a dependent round trip to L2 / HBM
+    float tap_depth[9]; V3 tap_normal[9], tap_color[9];
+#if defined(__clang__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 9; ++k) {
+        const size_t s = static_cast<size_t>(clampi(cy + k / 3 - 1, 0, h - 1)) * w + clampi(cx + k % 3 - 1, 0, w - 1);
+        tap_depth[k] = A.world_pos[4 * s + 3];
+        tap_normal[k] = load3(A.unit_normals, s);
+        tap_color[k] = load3(A.color, s);
+    }
+    float a1 = 0.0f, a2 = 0.0f, wsum = 0.0f;
+#if defined(__clang__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 9; ++k) {
+        const float dd = fabsf(depth - tap_depth[k]);
+        const float nd = vdot(normal, tap_normal[k]);
+        const float wgt = expf(-dd * dd / (0.5f * 0.5f)) * (nd > 0.9f ? 1.0f : 0.0f);
+        if (wgt > 0.01f) {
+            const float l = lum709(tap_color[k]);
+            a1 += l * wgt; a2 += l * l * wgt; wsum += wgt;
         }
+    }
     float spatial_var = 0.0f;
     if (wsum > 0.0f) { const float mean = a1 / wsum; spatial_var = fmaxf(a2 / wsum - mean * mean, 0.0f); }
     const float min_len = static_cast<float>(A.f.s.min_history_length > 4 ? A.f.s.min_history_length : 4);
@@ -253,8 +276,7 @@ struct AtrousArgs {
     uint32_t w, h;
     int step;
     float phi_color, phi_depth;
-    const float *color, *variance, *world_pos;
-    const uint16_t* normals;
+    const float *color, *variance, *world_pos, *unit_normals;
     float* out;
 };
 
@@ -262,10 +284,11 @@ BLOK_DEV void atrous_pixel(const AtrousArgs& A, int cx, int cy) {
     const int w = static_cast<int>(A.w), h = static_cast<int>(A.h);
     const size_t i = static_cast<size_t>(cy) * w + cx;
     const V3 centre = load3(A.color, i);
-    const float depth = A.world_pos[4 * i + 3];
+    const F4 cwp = load4(A.world_pos, i);
+    const float depth = cwp.w;
     if (depth > 9000.0f) { store4(A.out, i, centre, 1.0f); return; }                        // sky, :174-177
-    const V3 pos = load3(A.world_pos, i);
-    const V3 normal = vnormalize(load3h(A.normals, i));
+    const V3 pos = xyz(cwp);
+    const V3 normal = load3(A.unit_normals, i);
     const float var = A.variance[i];
     // per-pixel constants of the weight functions
     const float sigma_c = 0.01f + A.phi_color * rn_sqrt(fmaxf(var, 0.0f));                  // :97-99
@@ -274,27 +297,46 @@ BLOK_DEV void atrous_pixel(const AtrousArgs& A, int cx, int cy) {
     const float denom_d = sigma_d * sigma_d + 1e-6f;
     V3 sum = vsplat(0.0f);
     float wsum = 0.0f;
-    for (int k = 0; k < 25; ++k) {
-        const int ox = k % 5 - 2, oy = k / 5 - 2;
-        const size_t s = static_cast<size_t>(clampi(cy + oy * A.step, 0, h - 1)) * w + clampi(cx + ox * A.step, 0, w - 1);
-        const float sdepth = A.world_pos[4 * s + 3];
-        if (sdepth > 9000.0f) continue;
-        const V3 sc = load3(A.color, s);
-        const float kx = ox == 0 ? 1.0f : ((ox == 1 || ox == -1) ? 2.0f / 3.0f : 1.0f / 6.0f);
+    // 25 taps, row by row: the five taps' three planes are fetched together, then weighted (no early exits between the
+    // loads; a tap the shader skips — sky sample :194-196, weight < 0.001 :207-209 — is simply not accumulated)
+#if defined(__clang__)
+#pragma unroll 1
+#endif
+    for (int row = 0; row < 5; ++row) {          // one row in flight: unrolling the rows too needs 255 VGPRs (one wave per SIMD)
+        const int oy = row - 2;
+        const size_t base = static_cast<size_t>(clampi(cy + oy * A.step, 0, h - 1)) * w;
+        V3 tc[5], tn[5]; F4 tp[5];
+#if defined(__clang__)
+#pragma unroll
+#endif
+        for (int col = 0; col < 5; ++col) {
+            const size_t s = base + clampi(cx + (col - 2) * A.step, 0, w - 1);
+            tc[col] = load3(A.color, s); tp[col] = load4(A.world_pos, s); tn[col] = load3(A.unit_normals, s);
+        }
         const float ky = oy == 0 ? 1.0f : ((oy == 1 || oy == -1) ? 2.0f / 3.0f : 1.0f / 6.0f);
-        const V3 diff = vsub(centre, sc);
-        const float wc = 1.0f / (1.0f + vdot(diff, diff) / denom_c);                        // fastExp, :78-80, :101
-        const float nd = fmaxf(vdot(normal, vnormalize(load3h(A.normals, s))), 0.0f);      // :105-122
-        float wn = 0.0f;
-        if (!(nd < 0.9f)) { const float t = (nd - 0.9f) / (1.0f - 0.9f); wn = t * t; }
-        const float dd = fabsf(depth - sdepth);                                             // :125-152
-        const float plane = fabsf(vdot(vsub(load3(A.world_pos, s), pos), normal));
-        const float dist = fmaxf(dd * 0.1f, plane);
-        const float wd = dist > sigma_d * 2.0f ? 0.0f : 1.0f / (1.0f + dist * dist / denom_d);
-        const float wgt = kx * ky * wc * wn * wd;
-        if (wgt < 0.001f) continue;
-        sum = vadd(sum, vscale(sc, wgt));
-        wsum += wgt;
+#if defined(__clang__)
+#pragma unroll
+#endif
+        for (int col = 0; col < 5; ++col) {
+            const int ox = col - 2;
+            const V3 sc = tc[col];
+            const float sdepth = tp[col].w;
+            const float kx = ox == 0 ? 1.0f : ((ox == 1 || ox == -1) ? 2.0f / 3.0f : 1.0f / 6.0f);
+            const V3 diff = vsub(centre, sc);
+            const float wc = 1.0f / (1.0f + vdot(diff, diff) / denom_c);                    // fastExp, :78-80, :101
+            const float nd = fmaxf(vdot(normal, tn[col]), 0.0f);                            // :105-122
+            const float t = (nd - 0.9f) / (1.0f - 0.9f);
+            const float wn = nd < 0.9f ? 0.0f : t * t;
+            const float dd = fabsf(depth - sdepth);                                         // :125-152
+            const float plane = fabsf(vdot(vsub(xyz(tp[col]), pos), normal));
+            const float dist = fmaxf(dd * 0.1f, plane);
+            const float wd = dist > sigma_d * 2.0f ? 0.0f : 1.0f / (1.0f + dist * dist / denom_d);
+            const float wgt = kx * ky * wc * wn * wd;
+            if (!(sdepth > 9000.0f) && !(wgt < 0.001f)) {
+                sum = vadd(sum, vscale(sc, wgt));
+                wsum += wgt;
+            }
+        }
     }
     const V3 res = wsum > 0.01f ? vdivs(sum, wsum) : centre;
     store4(A.out, i, vmax3(res, vsplat(0.0f)), 1.0f);
@@ -313,7 +355,8 @@ BLOK_DEV void taa_pixel(const TaaArgs& A, int px, int py) {
     const int w = static_cast<int>(A.w), h = static_cast<int>(A.h);
     const size_t i = static_cast<size_t>(py) * w + px;
     const float u = (static_cast<float>(px) + 0.5f) / static_cast<float>(w), v = (static_cast<float>(py) + 0.5f) / static_cast<float>(h);
-    const V3 current = load3(A.color, i);
+    const F4 cur4 = load4(A.color, i);
+    const V3 current = xyz(cur4);
     const float mx = h2f(A.motion[2 * i]), my = h2f(A.motion[2 * i + 1]);
     const float pu = u - mx, pv = v - my;
     const bool valid = pu >= 0.0f && pu <= 1.0f && pv >= 0.0f && pv <= 1.0f;
@@ -340,7 +383,7 @@ BLOK_DEV void taa_pixel(const TaaArgs& A, int px, int py) {
     feedback *= 1.0f - clampf(vlength(vsub(clipped_y, hy)) * 2.0f, 0.0f, 0.5f);
     const V3 result = vmix(current, clipped, feedback);
     const V3 sharpened = vadd(current, vscale(vsub(current, from_ycocg(mean)), 0.1f));
-    store4(A.out, i, vmix(sharpened, clipped, feedback), A.color[4 * i + 3]);
+    store4(A.out, i, vmix(sharpened, clipped, feedback), cur4.w);
     store4(A.out_history, i, result, 1.0f);
 }
 
@@ -351,14 +394,17 @@ struct SharpenArgs {
     const uint32_t* in;      // rgba8
     uint32_t* out;
 };
-BLOK_DEV V3 unpack_rgb8(uint32_t p) { return v3(static_cast<float>(p & 0xFFu) / 255.0f, static_cast<float>((p >> 8) & 0xFFu) / 255.0f, static_cast<float>((p >> 16) & 0xFFu) / 255.0f); }
-BLOK_DEV void sharpen_pixel(const SharpenArgs& A, int x, int y) {
+// unorm8 -> float is n / 255 correctly rounded: 27 IEEE divides per pixel if done in place, so the 256 quotients come from a
+// table (LDS on the device, filled with one divide per lane of the workgroup)
+BLOK_DEV float unorm8_to_float(uint32_t n) { return static_cast<float>(n) / 255.0f; }
+BLOK_DEV V3 unpack_rgb8(const float* lut, uint32_t p) { return v3(lut[p & 0xFFu], lut[(p >> 8) & 0xFFu], lut[(p >> 16) & 0xFFu]); }
+BLOK_DEV void sharpen_pixel(const SharpenArgs& A, int x, int y, const float* lut) {
     const int w = static_cast<int>(A.w), h = static_cast<int>(A.h);
     const int xl = clampi(x - 1, 0, w - 1), xr = clampi(x + 1, 0, w - 1);
     const size_t r0 = static_cast<size_t>(clampi(y - 1, 0, h - 1)) * w, r1 = static_cast<size_t>(y) * w, r2 = static_cast<size_t>(clampi(y + 1, 0, h - 1)) * w;
-    const V3 a = unpack_rgb8(A.in[r0 + xl]), b = unpack_rgb8(A.in[r0 + x]), c = unpack_rgb8(A.in[r0 + xr]);
-    const V3 d = unpack_rgb8(A.in[r1 + xl]), e = unpack_rgb8(A.in[r1 + x]), f = unpack_rgb8(A.in[r1 + xr]);
-    const V3 g = unpack_rgb8(A.in[r2 + xl]), hh = unpack_rgb8(A.in[r2 + x]), k = unpack_rgb8(A.in[r2 + xr]);
+    const V3 a = unpack_rgb8(lut, A.in[r0 + xl]), b = unpack_rgb8(lut, A.in[r0 + x]), c = unpack_rgb8(lut, A.in[r0 + xr]);
+    const V3 d = unpack_rgb8(lut, A.in[r1 + xl]), e = unpack_rgb8(lut, A.in[r1 + x]), f = unpack_rgb8(lut, A.in[r1 + xr]);
+    const V3 g = unpack_rgb8(lut, A.in[r2 + xl]), hh = unpack_rgb8(lut, A.in[r2 + x]), k = unpack_rgb8(lut, A.in[r2 + xr]);
     const V3 corners = vscale(vadd(vadd(vadd(a, c), g), k), 1.0f), cross = vscale(vadd(vadd(vadd(b, d), f), hh), 2.0f);
     const V3 blur = vdivs(vadd(vadd(corners, cross), vscale(e, 4.0f)), 16.0f);
     const V3 res = vadd(e, vscale(vsub(e, blur), A.strength * 3.0f));

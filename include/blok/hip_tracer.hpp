@@ -224,6 +224,19 @@ public:
     }
     void rebuildVolume(const std::vector<blok_material>& materials) { check(blok_hip_volume_rebuild(m_ctx, materials.data(), materials.size())); }
 
+    // ---- image-space chain (Denoiser::denoise, PostProcess::process) over device planes; see include/blok_hip.h
+    void denoise(const blok_gbuffer& planesDev, const float prevViewProj[16], uint32_t frameCount, float* outColorDev,
+                 const blok_denoise_settings* settings = nullptr, const float* motionDev = nullptr, void* stream = nullptr) {
+        check(blok_hip_denoise_device(m_ctx, &planesDev, motionDev, prevViewProj, frameCount, settings, outColorDev, stream));
+    }
+    void taa(const float* colorDev, float* outColorDev, uint32_t frameCount, float feedbackMin = 0.93f, float feedbackMax = 0.98f,
+             const float* motionDev = nullptr, void* stream = nullptr) {
+        check(blok_hip_taa_device(m_ctx, colorDev, motionDev, feedbackMin, feedbackMax, frameCount, outColorDev, stream));
+    }
+    void sharpen(const uint32_t* rgba8Dev, uint32_t* outRgba8Dev, float strength = 0.5f, void* stream = nullptr) {
+        check(blok_hip_sharpen_device(m_ctx, rgba8Dev, strength, outRgba8Dev, stream));
+    }
+
     const std::vector<blok_hit>& hits() const { return m_hits; }     // output accessor (getGLTex analogue)
     unsigned int width() const { return m_width; }
     unsigned int height() const { return m_height; }

@@ -41,7 +41,9 @@ for k, cam in enumerate(cams):
         for name, i in zip(rows, range(5)):
             rows[name].append(e[i].elapsed_time(e[i + 1]))
 # algorithmic bytes per pixel (read + write, each plane once per pass): see DESIGN.md
-alg = {"denoise (temporal + variance + 4 a-trous)": (16 + 16 + 16 + 16 + 16 + 8 + 8 + 2) + (16 + 8 + 2 + 16 + 8 + 4) + (16 + 8 + 2 + 16 + 8 + 4) + 4 * (16 + 4 + 16 + 8 + 16),
+# temporal: colour, position, normal in (48) + history colour, position, unit normal, moments, length in (74) + colour, moments,
+#           length, position, unit normal, motion out (62); variance: 16 + 8 + 2 + 16 + 16 in, 4 out; a-trous: 16 + 4 + 16 + 16 in, 16 out
+alg = {"denoise (temporal + variance + 4 a-trous)": (48 + 74 + 62) + 62 + 4 * 68,
        "taa": 16 + 16 + 4 + 32, "tonemap": 16 + 4, "sharpen": 4 + 4}
 hl = tr.denoise_state()[2]
 print(f"4K ({Wd}x{Ht}), 1024^3 world, history length > 1 on {(hl > 1).mean() * 100:.0f} % of the pixels")

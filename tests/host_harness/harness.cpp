@@ -185,8 +185,8 @@ void hh_trace_primary(const void* h, const blok_camera* cam, uint32_t width, uin
 // ---- image-space chain (post_core.h) on the CPU: the same ping-pong as blok_amd/csrc/hip/api.hip's denoiser -------------
 struct HostPost {
     uint32_t w, h;
-    std::vector<float> hist_color[2], moments[2], world_pos[2], variance, ping, pong, taa_hist[2];
-    std::vector<uint16_t> hist_len[2], normals[2], motion;
+    std::vector<float> hist_color[2], moments[2], world_pos[2], unit_normals[2], variance, ping, pong, taa_hist[2];
+    std::vector<uint16_t> hist_len[2], motion;
     int cur = 0, taa_cur = 0;
 };
 void* hh_post_new(uint32_t w, uint32_t h) {
@@ -195,7 +195,7 @@ void* hh_post_new(uint32_t w, uint32_t h) {
     const size_t n = size_t(w) * h;
     for (int k = 0; k < 2; ++k) {
         P->hist_color[k].assign(4 * n, 0.f); P->moments[k].assign(2 * n, 0.f); P->world_pos[k].assign(4 * n, 0.f);
-        P->hist_len[k].assign(n, 0); P->normals[k].assign(4 * n, 0); P->taa_hist[k].assign(4 * n, 0.f);
+        P->hist_len[k].assign(n, 0); P->unit_normals[k].assign(4 * n, 0.f); P->taa_hist[k].assign(4 * n, 0.f);
     }
     P->variance.assign(n, 0.f); P->ping.assign(4 * n, 0.f); P->pong.assign(4 * n, 0.f); P->motion.assign(2 * n, 0);
     return P;
@@ -215,19 +215,19 @@ void hh_post_denoise(void* p, const float* color, const float* world_pos, const 
     TemporalArgs t{};
     t.f = f; t.color = color; t.world_pos = world_pos; t.normal_roughness = normal_roughness; t.motion_in = motion_in;
     t.prev_color = P.hist_color[prev].data(); t.prev_moments = P.moments[prev].data(); t.prev_world_pos = P.world_pos[prev].data();
-    t.prev_hist_len = P.hist_len[prev].data(); t.prev_normals = P.normals[prev].data();
+    t.prev_hist_len = P.hist_len[prev].data(); t.prev_unit_normals = P.unit_normals[prev].data();
     t.out_color = P.hist_color[cur].data(); t.out_moments = P.moments[cur].data(); t.hist_world_pos = P.world_pos[cur].data();
-    t.out_hist_len = P.hist_len[cur].data(); t.hist_normals = P.normals[cur].data(); t.motion = P.motion.data();
+    t.out_hist_len = P.hist_len[cur].data(); t.unit_normals = P.unit_normals[cur].data(); t.motion = P.motion.data();
     for (uint32_t y = 0; y < P.h; ++y) for (uint32_t x = 0; x < P.w; ++x) temporal_pixel(t, int(x), int(y));
     VarianceArgs v{};
     v.f = f; v.color = P.hist_color[cur].data(); v.moments = P.moments[cur].data(); v.world_pos = P.world_pos[cur].data();
-    v.hist_len = P.hist_len[cur].data(); v.normals = P.normals[cur].data(); v.variance = P.variance.data();
+    v.hist_len = P.hist_len[cur].data(); v.unit_normals = P.unit_normals[cur].data(); v.variance = P.variance.data();
     for (uint32_t y = 0; y < P.h; ++y) for (uint32_t x = 0; x < P.w; ++x) variance_pixel(v, int(x), int(y));
     const float* in = P.hist_color[cur].data();
     for (int it = 0; it < S->atrous_iterations; ++it) {
         AtrousArgs a{};
         a.w = P.w; a.h = P.h; a.step = 1 << it; a.phi_color = S->phi_color; a.phi_depth = S->phi_depth;
-        a.color = in; a.variance = P.variance.data(); a.world_pos = P.world_pos[cur].data(); a.normals = P.normals[cur].data();
+        a.color = in; a.variance = P.variance.data(); a.world_pos = P.world_pos[cur].data(); a.unit_normals = P.unit_normals[cur].data();
         a.out = it == S->atrous_iterations - 1 ? out_color : ((it & 1) ? P.pong.data() : P.ping.data());
         for (uint32_t y = 0; y < P.h; ++y) for (uint32_t x = 0; x < P.w; ++x) atrous_pixel(a, int(x), int(y));
         in = a.out;
@@ -256,7 +256,9 @@ void hh_post_taa(void* p, const float* color, const float* motion_in, float feed
 }
 void hh_post_sharpen(const uint32_t* in, uint32_t w, uint32_t h, float strength, uint32_t* out) {
     SharpenArgs a{w, h, strength, in, out};
-    for (uint32_t y = 0; y < h; ++y) for (uint32_t x = 0; x < w; ++x) sharpen_pixel(a, int(x), int(y));
+    float lut[256];
+    for (uint32_t t = 0; t < 256; ++t) lut[t] = unorm8_to_float(t);
+    for (uint32_t y = 0; y < h; ++y) for (uint32_t x = 0; x < w; ++x) sharpen_pixel(a, int(x), int(y), lut);
 }
 float hh_q16(float x) { return q16(x); }
 uint16_t hh_f2h(float x) { return f2h(x); }
