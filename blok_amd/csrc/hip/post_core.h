@@ -16,9 +16,13 @@
 // The temporal pass also copies the current geometry into the history slot (Denoiser::copyCurrentGeometryToHistory,
 // renderer_denoising.cpp:833-866) and produces the motion vectors, in the same sweep.
 //
-// Arithmetic conventions (where GLSL leaves them open) are the ones oracle/blok_oracle_post.cpp states; every float
-// op is a single rounded binary32 op in the shader's order, so that on the CPU (tests/host_harness) this file and the
-// oracle agree bit for bit, and on the GPU they differ only through expf in variance.comp's depth weight.
+// Arithmetic conventions where GLSL leaves them open (the CPU checker in the test suite states the same ones):
+//   dot(a,b) = (a.x*b.x + a.y*b.y) + a.z*b.z; no fused multiply-add; length = sqrt(dot); normalize(v) = v / length(v);
+//   mix(a,b,t) = a*(1-t) + b*t; 16-bit float images hold round-to-nearest-even binary16 values; rgba8 stores
+//   floor(clamp(x,0,1)*255 + 0.5); a linear sampler (clamp to edge) is an exact binary32 bilinear blend of the four texels
+//   around uv*size - 0.5, and sampling at a texel centre returns that texel (atrous.comp, sharpen.comp).
+// Every float op is a single rounded binary32 op in the shader's order, so compiled for the CPU (tests/host_harness) this
+// file reproduces the checker bit for bit; on the GPU only expf in variance.comp's depth weight can differ (by ulps).
 #ifndef BLOK_POST_CORE_H
 #define BLOK_POST_CORE_H
 
