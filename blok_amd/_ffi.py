@@ -163,6 +163,8 @@ HIP_SYMBOLS = {
     "blok_hip_taa_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_uint32, C.c_void_p, C.c_void_p]),
     "blok_hip_sharpen_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     "blok_hip_post_reset": (C.c_int, [C.c_void_p]),
+    "blok_camera_view_proj": (None, [C.c_void_p, C.POINTER(C.c_float)]),
+    "blok_hip_draw_frame_rt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]),
     "blok_hip_volume_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float]),
     "blok_hip_volume_destroy": (C.c_int, [C.c_void_p]),
     "blok_hip_volume_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -53,6 +53,11 @@ struct blok_hip_ctx {
         float* widen = nullptr;              // scratch for state downloads
         int cur = 0, taa_cur = 0;
         bool has_motion = false, taa_has_history = false;
+        // blok_hip_draw_frame_rt: the frame's own planes and its camera history
+        float *rt_planes[4] = {nullptr, nullptr, nullptr, nullptr}, *rt_denoised = nullptr, *rt_resolved = nullptr;
+        uint32_t *rt_ldr = nullptr, *rt_final = nullptr;
+        uint32_t rt_frame = 0;
+        blok_camera rt_prev_cam{};
     } post;
     // device-resident dense store (gpu_build.h: GpuVolume)
     blok::GpuVolume volume;
@@ -90,7 +95,9 @@ void free_post(blok_hip_ctx* ctx) {
         for (void* p : {static_cast<void*>(P.hist_color[k]), static_cast<void*>(P.moments[k]), static_cast<void*>(P.world_pos[k]),
                         static_cast<void*>(P.hist_len[k]), static_cast<void*>(P.unit_normals[k]), static_cast<void*>(P.taa_hist[k])})
             if (p) (void)hipFree(p);
-    for (void* p : {static_cast<void*>(P.motion), static_cast<void*>(P.variance), static_cast<void*>(P.ping), static_cast<void*>(P.pong), static_cast<void*>(P.widen)})
+    for (void* p : {static_cast<void*>(P.motion), static_cast<void*>(P.variance), static_cast<void*>(P.ping), static_cast<void*>(P.pong), static_cast<void*>(P.widen),
+                    static_cast<void*>(P.rt_planes[0]), static_cast<void*>(P.rt_planes[1]), static_cast<void*>(P.rt_planes[2]), static_cast<void*>(P.rt_planes[3]),
+                    static_cast<void*>(P.rt_denoised), static_cast<void*>(P.rt_resolved), static_cast<void*>(P.rt_ldr), static_cast<void*>(P.rt_final)})
         if (p) (void)hipFree(p);
     P = blok_hip_ctx::Post{};
 }
@@ -786,6 +793,60 @@ int blok_hip_sharpen_device(blok_hip_ctx* ctx, const uint32_t* rgba8_dev, float 
     a.w = ctx->width; a.h = ctx->height; a.strength = strength; a.in = rgba8_dev; a.out = out_rgba8_dev;
     blok::launch_sharpen(a, static_cast<hipStream_t>(hip_stream));
     BLOK_HIP_TRY(ctx, hipGetLastError());
+    return BLOK_OK;
+}
+
+namespace {
+// Column-major prevViewProj of a camera basis: uv = ndc.xy * 0.5 + 0.5 reproduces the basis' own pixel mapping
+// (x + 0.5 = u * width, y + 0.5 = v * height), the role FrameUBO::prevViewProj plays for the reference's shaders.
+void view_proj_of(const blok_camera& c, float M[16]) {
+    const double ta = double(c.tan_half_fov) * double(c.aspect), t = double(c.tan_half_fov);
+    double rows[4][4] = {};
+    for (int a = 0; a < 3; ++a) {
+        rows[0][a] = double(c.right[a]) / ta; rows[0][3] -= double(c.right[a]) * double(c.pos[a]) / ta;
+        rows[1][a] = -double(c.up[a]) / t;    rows[1][3] += double(c.up[a]) * double(c.pos[a]) / t;
+        rows[2][a] = double(c.fwd[a]);        rows[2][3] -= double(c.fwd[a]) * double(c.pos[a]);
+    }
+    for (int a = 0; a < 4; ++a) rows[3][a] = rows[2][a];
+    for (int col = 0; col < 4; ++col) for (int r = 0; r < 4; ++r) M[col * 4 + r] = static_cast<float>(rows[r][col]);
+}
+}  // namespace
+
+void blok_camera_view_proj(const blok_camera* cam, float out_view_proj[16]) { if (cam && out_view_proj) view_proj_of(*cam, out_view_proj); }
+
+int blok_hip_draw_frame_rt(blok_hip_ctx* ctx, const blok_camera* cam, uint32_t spp, uint32_t max_bounces,
+                           const blok_denoise_settings* settings, uint32_t* out_rgba8_host, uint32_t* out_frame_count) {
+    int rc = check_trace(ctx, cam);
+    if (rc != BLOK_OK) return rc;
+    if (!spp || !max_bounces) return set_error(ctx, BLOK_ERR_INVALID_ARG, "spp and bounces must be positive");
+    rc = ensure_post(ctx);
+    if (rc != BLOK_OK) return rc;
+    auto& P = ctx->post;
+    const size_t n = P.pixels;
+    if (!P.rt_final) {
+        for (int k = 0; k < 4 && rc == BLOK_OK; ++k) rc = post_alloc(ctx, &P.rt_planes[k], 4 * n);
+        if (rc == BLOK_OK) rc = post_alloc(ctx, &P.rt_denoised, 4 * n);
+        if (rc == BLOK_OK) rc = post_alloc(ctx, &P.rt_resolved, 4 * n);
+        if (rc == BLOK_OK) rc = post_alloc(ctx, &P.rt_ldr, n);
+        if (rc == BLOK_OK) rc = post_alloc(ctx, &P.rt_final, n);
+        if (rc != BLOK_OK) { free_post(ctx); return rc; }
+        P.rt_frame = 0;
+    }
+    const uint32_t frame = P.rt_frame;
+    float prev_vp[16];
+    view_proj_of(frame ? P.rt_prev_cam : *cam, prev_vp);            // Denoiser::updatePreviousFrameData: last frame's matrices
+    const blok_gbuffer planes{P.rt_planes[0], P.rt_planes[1], P.rt_planes[2], P.rt_planes[3]};
+    rc = blok_hip_trace_paths_device(ctx, cam, 0, 0, ctx->width, ctx->height, spp, max_bounces, frame, &planes, nullptr);
+    if (rc == BLOK_OK) rc = blok_hip_denoise_device(ctx, &planes, nullptr, prev_vp, frame, settings, P.rt_denoised, nullptr);
+    if (rc == BLOK_OK) rc = blok_hip_taa_device(ctx, P.rt_denoised, nullptr, 0.93f, 0.98f, frame, P.rt_resolved, nullptr);       // renderer_postprocess.hpp:104-106
+    if (rc == BLOK_OK) rc = blok_hip_tonemap_device(ctx, P.rt_resolved, static_cast<uint32_t>(n), 1.0f, 1.15f, 1, P.rt_ldr, nullptr);   // :110-113
+    if (rc == BLOK_OK) rc = blok_hip_sharpen_device(ctx, P.rt_ldr, 0.5f, P.rt_final, nullptr);                                     // :117-118
+    if (rc != BLOK_OK) return rc;
+    P.rt_prev_cam = *cam;
+    P.rt_frame = frame + 1;
+    if (out_frame_count) *out_frame_count = P.rt_frame;
+    if (out_rgba8_host) BLOK_HIP_TRY(ctx, hipMemcpy(out_rgba8_host, P.rt_final, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    else BLOK_HIP_TRY(ctx, hipDeviceSynchronize());
     return BLOK_OK;
 }
 

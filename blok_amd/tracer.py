@@ -124,6 +124,22 @@ class HipTracer:
     def sharpen_device(self, rgba8_ptr: int, out_rgba8_ptr: int, strength: float = 0.5, stream: int = 0):
         self._check(self._lib.blok_hip_sharpen_device(self._ctx, rgba8_ptr, strength, out_rgba8_ptr, stream or None))
 
+    def draw_frame_rt(self, cam: np.ndarray, spp: int = 8, max_bounces: int = 2, settings=None):
+        """Renderer::drawFrame's ray-tracing path in one call: path trace -> denoise -> TAA -> tonemap -> sharpen.
+        Returns (RGBA8 (h, w) uint32, frames rendered so far)."""
+        cam = np.ascontiguousarray(cam, dtype=CAMERA)
+        out = np.zeros((self.height, self.width), dtype=np.uint32)
+        frames = C.c_uint32()
+        self._check(self._lib.blok_hip_draw_frame_rt(self._ctx, _ffi.ptr(cam), spp, max_bounces,
+                                                     C.byref(settings) if settings is not None else None, _ffi.ptr(out), C.byref(frames)))
+        return out, frames.value
+
+    def camera_view_proj(self, cam: np.ndarray) -> np.ndarray:
+        cam = np.ascontiguousarray(cam, dtype=CAMERA)
+        m = (C.c_float * 16)()
+        self._lib.blok_camera_view_proj(_ffi.ptr(cam), m)
+        return np.array(m, dtype=np.float32)
+
     def post_reset(self):
         self._check(self._lib.blok_hip_post_reset(self._ctx))
 

@@ -233,6 +233,14 @@ public:
              const float* motionDev = nullptr, void* stream = nullptr) {
         check(blok_hip_taa_device(m_ctx, colorDev, motionDev, feedbackMin, feedbackMax, frameCount, outColorDev, stream));
     }
+    // = Renderer::drawFrame's ray-tracing path: trace, denoise, TAA, tonemap, sharpen with the reference's default settings
+    const std::vector<uint32_t>& drawFrameRT(Camera& cam, uint32_t sampleCount = 8, uint32_t maxBounces = 2) {
+        const blok_camera c = cam.basis(m_width, m_height);
+        m_pixels.resize(static_cast<size_t>(m_width) * m_height);
+        check(blok_hip_draw_frame_rt(m_ctx, &c, sampleCount, maxBounces, nullptr, m_pixels.data(), &m_frameIndex));
+        cam.cameraChanged = false;
+        return m_pixels;
+    }
     void sharpen(const uint32_t* rgba8Dev, uint32_t* outRgba8Dev, float strength = 0.5f, void* stream = nullptr) {
         check(blok_hip_sharpen_device(m_ctx, rgba8Dev, strength, outRgba8Dev, stream));
     }

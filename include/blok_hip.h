@@ -301,6 +301,18 @@ int blok_hip_taa_device(blok_hip_ctx* ctx, const float* color_dev, const float* 
                         float feedback_max, uint32_t frame_count, float* out_color_dev, void* hip_stream);
 /* = PostProcess sharpen pass (sharpen.comp; renderer_postprocess.cpp:548-555,619-642): RGBA8 in, RGBA8 out; default strength 0.5. */
 int blok_hip_sharpen_device(blok_hip_ctx* ctx, const uint32_t* rgba8_dev, float strength, uint32_t* out_rgba8_dev, void* hip_stream);
+/* Column-major (GLM layout) view-projection of a camera basis, such that ndc.xy * 0.5 + 0.5 of (M * vec4(p, 1)) is the screen
+ * position of world point p under the basis' own primary-ray mapping: what FrameUBO::prevViewProj is to the reference's
+ * shaders (temporal_reproject.comp:108-113), for callers that keep camera bases instead of matrices. */
+void blok_camera_view_proj(const blok_camera* cam, float out_view_proj[16]);
+/* = Renderer::drawFrame's ray-tracing path (reference blok/src/renderer_draw.cpp: trace -> Denoiser::denoise -> PostProcess::process):
+ * one frame of the sample/bounce loop (spp samples, the reference forces 8; max_bounces, the reference's MAX_BOUNCES is 2) into
+ * planes owned by the context, then denoiser, TAA (feedback 0.93..0.98), tonemap (Khronos PBR neutral, exposure 1, saturation
+ * 1.15) and sharpen (0.5) with the reference's default settings; the previous frame's camera supplies prevViewProj and the frame
+ * counter (RNG frame index, FrameUBO::frameCount) advances by one per call; blok_hip_post_reset restarts it.  Blocking.
+ * out_rgba8_host: width*height RGBA8, may be NULL. */
+int blok_hip_draw_frame_rt(blok_hip_ctx* ctx, const blok_camera* cam, uint32_t spp, uint32_t max_bounces,
+                           const blok_denoise_settings* settings, uint32_t* out_rgba8_host, uint32_t* out_frame_count);
 /* Forget the denoiser and TAA histories (swapchain recreate: Denoiser::resize / PostProcess::resize). */
 int blok_hip_post_reset(blok_hip_ctx* ctx);
 

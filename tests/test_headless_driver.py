@@ -28,3 +28,19 @@ def test_driver_renders_a_frame(tmp_path):
     assert data.startswith(b"P6\n320 200\n255\n") and len(data) == len(b"P6\n320 200\n255\n") + 320 * 200 * 3
     body = data[len(b"P6\n320 200\n255\n"):]
     assert len(set(body[i:i + 3] for i in range(0, len(body), 3))) > 20      # terrain colours, not a flat image
+
+
+@pytest.mark.gpu
+def test_driver_full_ray_tracing_path(tmp_path):
+    """--rt: the C++ mirror's drawFrameRT (path trace -> denoise -> TAA -> tonemap -> sharpen) over several moving frames."""
+    exe = b.build_tools()
+    out = tmp_path / "rt.ppm"
+    proc = subprocess.run([str(exe), "--n", "64", "--size", "320x200", "--frames", "4", "--rt", "--spp", "2", "--out", str(out)],
+                          capture_output=True, text=True, timeout=300)
+    assert proc.returncode == 0, proc.stderr
+    assert "frame 3:" in proc.stdout and "denoise" in proc.stdout
+    data = out.read_bytes()
+    head = b"P6\n320 200\n255\n"
+    assert data.startswith(head) and len(data) == len(head) + 320 * 200 * 3
+    body = data[len(head):]
+    assert len(set(body[i:i + 3] for i in range(0, len(body), 3))) > 200     # shaded, filtered colours

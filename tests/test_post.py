@@ -245,7 +245,48 @@ def test_view_proj_from_camera_inverts_the_primary_ray_mapping():
         assert abs(u * Wd - (x + 0.5)) < 1e-3 and abs(v * Ht - (y + 0.5)) < 1e-3
 
 
+def test_c_abi_view_proj_matches_the_python_helper():
+    from blok_amd import _ffi
+    L = _ffi.hip_lib()
+    for cam in camera_path(4):
+        m = (C.c_float * 16)()
+        L.blok_camera_view_proj(_ffi.ptr(np.ascontiguousarray(cam)), m)
+        assert np.allclose(np.array(m, dtype=np.float32), W.view_proj_from_camera(cam), rtol=1e-6, atol=1e-6)
+
+
 # ------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_draw_frame_rt_is_the_composition_of_the_passes(gbuffer_frames):
+    """blok_hip_draw_frame_rt == trace_paths -> denoise -> taa -> tonemap -> sharpen with the reference's defaults, frame
+    counter and previous camera kept by the context."""
+    import torch
+    from blok_amd.tracer import HipTracer
+    _, pw, mats, cams = gbuffer_frames
+    one, many = HipTracer(Wd, Ht).init(), HipTracer(Wd, Ht).init()
+    one.add_world(pw); many.add_world(pw)
+    n = Wd * Ht
+    P = {k: torch.zeros((n, 4), dtype=torch.float32, device="cuda") for k in ("color", "world_pos", "normal_roughness", "albedo_metallic")}
+    den = torch.zeros((n, 4), dtype=torch.float32, device="cuda"); taa = torch.zeros_like(den)
+    ldr = torch.zeros(n, dtype=torch.int32, device="cuda"); sharp = torch.zeros_like(ldr)
+    for k, cam in enumerate(cams[:4]):
+        got, frames = one.draw_frame_rt(cam, spp=2)
+        assert frames == k + 1
+        many.trace_paths_device(cam, P["color"].data_ptr(), spp=2, max_bounces=2, frame_index=k, world_pos_ptr=P["world_pos"].data_ptr(),
+                                normal_roughness_ptr=P["normal_roughness"].data_ptr(), albedo_metallic_ptr=P["albedo_metallic"].data_ptr())
+        many.denoise_device(P["color"].data_ptr(), P["world_pos"].data_ptr(), P["normal_roughness"].data_ptr(),
+                            many.camera_view_proj(cams[max(k - 1, 0)]), k, den.data_ptr())
+        many.taa_device(den.data_ptr(), taa.data_ptr(), k)
+        many.tonemap_device(taa.data_ptr(), ldr.data_ptr())
+        many.sharpen_device(ldr.data_ptr(), sharp.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(got.reshape(-1), sharp.cpu().numpy().view(np.uint32))
+    one.post_reset()
+    _, frames = one.draw_frame_rt(cams[0], spp=1)
+    assert frames == 1
+    one.shutdown(); many.shutdown()
+
+
+
 @pytest.mark.gpu
 def test_gpu_chain_matches_oracle(gbuffer_frames):
     """Path kernel -> denoiser -> TAA -> tonemap -> sharpen on the device, against the oracle chain fed with the same

@@ -1,7 +1,8 @@
 // Headless driver shaped like the reference's App (reference blok/src/app.cpp:65-192) with the backend
 // switch extended by GraphicsApi::HIP: build a world through ChunkManager, rebuildDirtyChunks,
 // packChunksToGpuSvo, addWorld, then a frame loop of drawFrame; writes the last frame as a PPM.
-//   blok_headless [--n 256 | --vox model.vox] [--size 1280x720] [--pose 0|1|2] [--frames 10] [--out frame.ppm]
+//   blok_headless [--n 256 | --vox model.vox] [--size 1280x720] [--pose 0|1|2] [--frames 10] [--out frame.ppm] [--rt [--spp 8]]
+//   --rt: every frame goes through the reference's full ray-tracing path (path trace, denoise, TAA, tonemap, sharpen)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -18,6 +19,8 @@ struct Options {
     uint32_t n = 256, width = 1280, height = 720, frames = 10;     // reference window: 1280x720, app.cpp:95
     int pose = 0;
     std::string out = "frame.ppm";
+    bool rt = false;                      // full ray-tracing path per frame instead of first-hit frames
+    uint32_t spp = 8;                     // samples per pixel and frame in --rt mode (the reference forces 8)
     std::string vox;                      // optional .vox model instead of the synthetic scene (app.cpp:105-113)
 };
 
@@ -71,14 +74,16 @@ private:
         for (uint32_t f = 0; f < m_opt.frames; ++f) {
             const auto t0 = clock::now();
             m_tracer->beginFrame();
-            m_tracer->drawFrame(m_camera);
+            if (m_opt.rt) m_tracer->drawFrameRT(m_camera, m_opt.spp);
+            else m_tracer->drawFrame(m_camera);
             m_tracer->endFrame();
             const double ms = std::chrono::duration<double, std::milli>(clock::now() - t0).count();
-            std::cout << "frame " << f << ": " << ms << " ms (incl. device->host copy of "
-                      << m_tracer->hits().size() * sizeof(blok_hit) / 1e6 << " MB)\n";
-            m_camera.processKeyboard('W', 0.016f);
+            if (m_opt.rt) std::cout << "frame " << f << ": " << ms << " ms (path trace " << m_opt.spp << " spp, denoise, TAA, tonemap, sharpen; incl. device->host copy)\n";
+            else std::cout << "frame " << f << ": " << ms << " ms (incl. device->host copy of "
+                           << m_tracer->hits().size() * sizeof(blok_hit) / 1e6 << " MB)\n";
+            if (f + 1 < m_opt.frames || !m_opt.rt) m_camera.processKeyboard('W', 0.016f);
         }
-        const auto& px = m_tracer->drawFrameRgba8(m_camera);
+        const auto& px = m_opt.rt ? m_tracer->drawFrameRT(m_camera, m_opt.spp) : m_tracer->drawFrameRgba8(m_camera);
         std::ofstream ppm(m_opt.out, std::ios::binary);
         ppm << "P6\n" << m_opt.width << " " << m_opt.height << "\n255\n";
         for (uint32_t p : px) { const char rgb[3] = {char(p & 255), char((p >> 8) & 255), char((p >> 16) & 255)}; ppm.write(rgb, 3); }
@@ -107,6 +112,8 @@ int main(int argc, char** argv) {
         else if (!std::strcmp(argv[i], "--frames")) opt.frames = std::strtoul(next(), nullptr, 10);
         else if (!std::strcmp(argv[i], "--out")) opt.out = next();
         else if (!std::strcmp(argv[i], "--vox")) opt.vox = next();
+        else if (!std::strcmp(argv[i], "--rt")) opt.rt = true;
+        else if (!std::strcmp(argv[i], "--spp")) opt.spp = std::strtoul(next(), nullptr, 10);
         else { std::fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
     }
     try {
