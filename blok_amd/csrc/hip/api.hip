@@ -175,18 +175,22 @@ int beam_buffer(blok_hip_ctx* ctx, hipStream_t stream, size_t n, float** out) {
     return BLOK_OK;
 }
 
+// Fills the beam fields of a Rect / Tiles launch and returns the number of beam tiles (0 = pre-pass off).
+int prepare_beam(blok_hip_ctx* ctx, blok::RayMode mode, blok::TraceArgs& args, hipStream_t stream, uint32_t tiles_of_rank, uint32_t* n_beams) {
+    *n_beams = 0;
+    if (mode == blok::RayMode::Rays || !ctx->beam_tile) return BLOK_OK;
+    args.beam_tile = ctx->beam_tile;
+    if (mode == blok::RayMode::Tiles && args.tile % args.beam_tile) args.beam_tile = 16;   // tiles are multiples of 16
+    args.beam_bx = (args.w + args.beam_tile - 1u) / args.beam_tile;
+    *n_beams = blok::beam_tiles(mode, args, tiles_of_rank);
+    return beam_buffer(ctx, stream, *n_beams, &args.beam);
+}
+
 // Rect / Tiles launches run the beam pre-pass first, on the same stream (tiles_of_rank: Tiles only).
 int launch_timed(blok_hip_ctx* ctx, blok::RayMode mode, blok::TraceArgs args, uint32_t blocks, hipStream_t stream,
                  uint32_t tiles_of_rank = 0) {
     uint32_t n_beams = 0;
-    if (mode != blok::RayMode::Rays && ctx->beam_tile && blocks) {
-        args.beam_tile = ctx->beam_tile;
-        if (mode == blok::RayMode::Tiles && args.tile % args.beam_tile) args.beam_tile = 16;   // tiles are multiples of 16
-        args.beam_bx = (args.w + args.beam_tile - 1u) / args.beam_tile;
-        n_beams = blok::beam_tiles(mode, args, tiles_of_rank);
-        const int rc = beam_buffer(ctx, stream, n_beams, &args.beam);
-        if (rc != BLOK_OK) return rc;
-    }
+    if (blocks) { const int rc = prepare_beam(ctx, mode, args, stream, tiles_of_rank, &n_beams); if (rc != BLOK_OK) return rc; }
     if (ctx->timing) BLOK_HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, stream));
     if (n_beams) blok::launch_beam(mode, args, n_beams, stream);
     blok::launch_trace(mode, args, blocks, stream);
@@ -501,7 +505,11 @@ int blok_hip_trace_paths_device(blok_hip_ctx* ctx, const blok_camera* cam, uint3
     p.color = planes->color; p.world_pos = planes->world_pos;
     p.normal_roughness = planes->normal_roughness; p.albedo_metallic = planes->albedo_metallic;
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    uint32_t n_beams = 0;                                   // the primary rays of every sample start behind the beam pre-pass
+    rc = prepare_beam(ctx, blok::RayMode::Rect, p.trace, stream, 0, &n_beams);
+    if (rc != BLOK_OK) return rc;
     if (ctx->timing) BLOK_HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, stream));
+    if (n_beams) blok::launch_beam(blok::RayMode::Rect, p.trace, n_beams, stream);
     blok::launch_paths(p, blok::rect_grid_blocks(w, h), stream);
     BLOK_HIP_TRY(ctx, hipGetLastError());
     if (ctx->timing) { BLOK_HIP_TRY(ctx, hipEventRecord(ctx->ev_end, stream)); ctx->timed = true; }
@@ -591,10 +599,7 @@ int blok_hip_draw_frame_accumulate(blok_hip_ctx* ctx, const blok_camera* cam, ui
     if (!spp_per_frame || !max_bounces) return set_error(ctx, BLOK_ERR_INVALID_ARG, "spp and bounces must be positive");
     const size_t n = static_cast<size_t>(ctx->width) * ctx->height;
     if (ctx->accum_pixels != n) {                                      // first use or resize: (re)allocate and clear
-        free_post(ctx);
-    if (ctx->has_volume) blok::gpu_volume_destroy(&ctx->volume);
-    for (auto& kv : ctx->beam_buffers) if (kv.second.first) (void)hipFree(kv.second.first);
-    if (ctx->d_accum) (void)hipFree(ctx->d_accum);
+        if (ctx->d_accum) (void)hipFree(ctx->d_accum);
         if (ctx->d_color) (void)hipFree(ctx->d_color);
         ctx->d_accum = ctx->d_color = nullptr; ctx->accum_pixels = 0;
         BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_accum), n * 4 * sizeof(float)));

@@ -29,7 +29,6 @@ namespace blok {
 #define BLOK_BEAM_STOP_LEVEL 1      // finest cells examined = children of a node of this level (1: voxels, 2: 4^3 bricks)
 #endif
 constexpr float kBeamSlack = 0.05f;
-constexpr float kBeamNone = 3.0e38f;   // "no cell of the tree meets the frustum"
 
 struct BeamVec { float x, y, z; };
 

@@ -127,7 +127,9 @@ BLOK_DEV void store4(float* plane, size_t i, float a, float b, float c, float d)
 // rays.  Every lane still performs exactly the shader's sequence of operations for its pixel, so results do not
 // depend on what the other lanes do; what changes is that the wave runs max-over-lanes of the TOTAL number of
 // traces instead of the sum over samples of per-sample maxima, and that walk() exists once in the code.
-BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t index, uint4* stk) {
+// t0: conservative start parameter of this pixel's primary rays from the beam pre-pass (beam.h), kBeamNone = they all
+// miss, 0 = none computed; it covers the sub-pixel jitter (+-0.25 pixel, the beam's frustum is grown by a whole pixel).
+BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t index, uint4* stk, float t0 = 0.0f) {
     const TraceArgs& A = P.trace;
     const blok_camera& cam = A.cam;
     const V3 cam_pos = v3(cam.pos[0], cam.pos[1], cam.pos[2]);
@@ -179,6 +181,10 @@ BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t in
             r.ox = ray_org.x; r.oy = ray_org.y; r.oz = ray_org.z;
             r.dx = ray_dir.x; r.dy = ray_dir.y; r.dz = ray_dir.z;
             r.tmin = 0.001f; r.tmax = 10000.0f;                                               // :225,:227
+        }
+        if (!shadow_phase && bounce == 0u && t0 > 0.0f) {         // primary ray behind the beam pre-pass (one walk call site)
+            r.tmin = fmaxf(r.tmin, t0);
+            if (t0 >= kBeamNone) r.tmax = 0.0f;                   // the tile's frustum meets no voxel: empty interval, immediate miss
         }
         const HitInfo hit = walk(A, r, stk);
 

@@ -73,6 +73,8 @@ inline uint32_t rect_grid_blocks(uint32_t w, uint32_t h) {
 
 enum class RayMode : int { Rect = 0, Tiles = 1, Rays = 2 };
 
+constexpr float kBeamNone = 3.0e38f;   // beam pre-pass result: "no cell of the tree meets the tile's frustum" (beam.h)
+
 struct TraceArgs {
     const uint4*    nodes;
     const uint32_t* materials;

@@ -134,7 +134,9 @@ __global__ __launch_bounds__(kBlock) void path_kernel(const PathArgs P) {
     if (!block_to_tile(blockIdx.x, gridDim.x, bx_count, by_count, bx, by)) return;
     const uint32_t rx = bx * kTileW + lx, ry = by * kTileH + ly;
     if (rx >= A.w || ry >= A.h) return;
-    shade_pixel(P, A.x0 + rx, A.y0 + ry, static_cast<size_t>(ry) * A.w + rx, lds_stack + tid);
+    float t0 = 0.0f;
+    if (A.beam) t0 = A.beam[__builtin_amdgcn_readfirstlane(((ry - lane / kWaveW) / A.beam_tile) * A.beam_bx + (rx - lane % kWaveW) / A.beam_tile)];
+    shade_pixel(P, A.x0 + rx, A.y0 + ry, static_cast<size_t>(ry) * A.w + rx, lds_stack + tid, t0);
 }
 
 __global__ __launch_bounds__(256) void tonemap_kernel(const TonemapArgs T) {

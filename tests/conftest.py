@@ -94,3 +94,20 @@ def random_rays(n: int, count: int, seed: int):
     rays["tmin"] = 0.001
     rays["tmax"] = 10000.0
     return rays
+
+
+@pytest.fixture(autouse=True)
+def no_hip_error_left_behind(request):
+    """After every GPU test: no HIP runtime call may have failed silently (a stale error would surface in an unrelated
+    later launch check).  Found a double free this way."""
+    yield
+    if request.node.get_closest_marker("gpu") is None:
+        return
+    import ctypes
+    libs = [line.split()[-1] for line in open("/proc/self/maps") if "libamdhip64" in line]
+    if not libs:
+        return
+    hip = ctypes.CDLL(libs[0])
+    hip.hipGetErrorString.restype = ctypes.c_char_p
+    err = hip.hipGetLastError()
+    assert err == 0, f"a HIP call failed silently during this test: {hip.hipGetErrorString(err).decode()}"

@@ -137,3 +137,39 @@ def test_gpu_paths_1024_4k_sample_and_tonemapped_lsb():
     lsb = np.abs(tonemap8(got["color"]) - tonemap8(ref["color"])).max(axis=2)
     assert (lsb <= 1).mean() >= 0.995
     tr.shutdown()
+
+
+@pytest.mark.gpu
+def test_beam_prepass_does_not_change_path_traced_frames(world64):
+    """The primary rays of every sample start behind the beam pre-pass (sub-pixel jitter lies inside its grown frustum):
+    all four planes are bit-identical with and without it, on the small world (odd frame size, several poses incl. a
+    camera inside the volume) and on a 4K rectangle of the 1024^3 world."""
+    from blok_amd.tracer import HipTracer
+    from tests.conftest import make_scene_world
+    pw, mats, _ = world64
+    tr = HipTracer(203, 117).init()
+    tr.add_world(pw)
+    cams = [W.scene_camera(64, pose, 203, 117, SEED) for pose in (0, 1, 2)]
+    inside = cams[0].copy(); inside["pos"][0] = (30.5, 40.2, 33.1); cams.append(inside)
+    for cam in cams:
+        tr.set_beam(0)
+        plain = tr.trace_paths(cam, spp=6, max_bounces=3, frame_index=2)
+        for beam in (8, 32):
+            tr.set_beam(beam)
+            got = tr.trace_paths(cam, spp=6, max_bounces=3, frame_index=2)
+            for k in plain:
+                assert got[k].tobytes() == plain[k].tobytes(), (k, beam)
+    tr.shutdown()
+    cm, pw = make_scene_world(1024)
+    tr = HipTracer(3840, 2160).init()
+    tr.add_world(pw)
+    rect = (1400, 800, 640, 320)
+    for pose in (0, 1):
+        cam = W.scene_camera(1024, pose, 3840, 2160, SEED)
+        tr.set_beam(0)
+        plain = tr.trace_paths(cam, spp=4, max_bounces=2, frame_index=1, rect=rect)
+        tr.set_beam(32)
+        got = tr.trace_paths(cam, spp=4, max_bounces=2, frame_index=1, rect=rect)
+        for k in plain:
+            assert got[k].tobytes() == plain[k].tobytes(), (k, pose)
+    tr.shutdown()
