@@ -62,6 +62,10 @@ struct blok_hip_ctx {
     // device-resident dense store (gpu_build.h: GpuVolume)
     blok::GpuVolume volume;
     bool has_volume = false;
+    // "last occluder" map of the shadow rays (beam.h: prism_far), rebuilt with every world
+    float* d_sun_map = nullptr;
+    bool sun_map_enabled = true, has_sun_map = false;
+    blok::SunMapArgs sun{};
     // beam pre-pass (beam.h): start parameters per beam tile, one buffer per stream (launches on one stream are
     // ordered, frames in flight on different streams must not share)
     uint32_t beam_tile = 32;
@@ -106,6 +110,8 @@ void free_world(blok_hip_ctx* ctx) {
     if (ctx->d_nodes) (void)hipFree(ctx->d_nodes);
     if (ctx->d_tree_materials) (void)hipFree(ctx->d_tree_materials);
     if (ctx->d_materials) (void)hipFree(ctx->d_materials);
+    if (ctx->d_sun_map) (void)hipFree(ctx->d_sun_map);
+    ctx->d_sun_map = nullptr; ctx->has_sun_map = false;
     ctx->d_nodes = nullptr; ctx->d_tree_materials = nullptr; ctx->d_materials = nullptr;
     ctx->n_materials = 0; ctx->has_world = false; ctx->built_on_device = false; ctx->stats = blok_world_stats{};
 }
@@ -117,6 +123,8 @@ int install_materials(blok_hip_ctx* ctx, const blok_material* materials, size_t 
     ctx->n_materials = n_materials;
     return BLOK_OK;
 }
+
+int rebuild_sun_map(blok_hip_ctx* ctx);
 
 int install_tree(blok_hip_ctx* ctx, const blok::HostTree& tree, const blok_material* materials, size_t n_materials) {
     free_world(ctx);
@@ -136,6 +144,48 @@ int install_tree(blok_hip_ctx* ctx, const blok::HostTree& tree, const blok_mater
     ctx->stats.levels = tree.levels;
     for (int a = 0; a < 3; ++a) ctx->stats.origin[a] = tree.origin[a];
     ctx->has_world = true;
+    return rebuild_sun_map(ctx);
+}
+
+// Rebuilds the shadow rays' last-occluder map for the installed world (one wave per texel of the plane perpendicular to the
+// sun; texel = 4 voxels, coarser for worlds wider than 2048 voxels so that the map stays <= 512 x 512).
+int rebuild_sun_map(blok_hip_ctx* ctx) {
+    if (ctx->d_sun_map) { (void)hipDeviceSynchronize(); (void)hipFree(ctx->d_sun_map); ctx->d_sun_map = nullptr; }
+    ctx->has_sun_map = false;
+    if (!ctx->has_world || ctx->stats.levels == 0 || ctx->stats.n_voxels == 0) return BLOK_OK;
+    blok::SunMapArgs& m = ctx->sun;
+    m = blok::SunMapArgs{};
+    m.trace.nodes = ctx->d_nodes; m.trace.materials = ctx->d_tree_materials;
+    for (int a = 0; a < 3; ++a) m.trace.origin[a] = ctx->stats.origin[a];
+    m.trace.levels = ctx->stats.levels;
+    // the shader's sun: normalize(vec3(0.5, 0.8, 0.3)) (raygen.rgen:142,185) with path_core.h's operation order
+    const float sx = 0.5f, sy = 0.8f, sz = 0.3f;
+    const float len = std::sqrt(sx * sx + sy * sy + sz * sz);
+    m.s[0] = sx / len; m.s[1] = sy / len; m.s[2] = sz / len;
+    // u = normalize(s x Y), v = s x u: any orthonormal complement serves
+    const double s[3] = {m.s[0], m.s[1], m.s[2]};
+    double u[3] = {-s[2], 0.0, s[0]};
+    const double ul = std::sqrt(u[0] * u[0] + u[2] * u[2]);
+    for (double& c : u) c /= ul;
+    const double v[3] = {s[1] * u[2] - s[2] * u[1], s[2] * u[0] - s[0] * u[2], s[0] * u[1] - s[1] * u[0]};
+    for (int a = 0; a < 3; ++a) { m.u[a] = static_cast<float>(u[a]); m.v[a] = static_cast<float>(v[a]); }
+    const double W = std::ldexp(1.0, 2 * static_cast<int>(ctx->stats.levels));          // the tree's cube edge
+    double lo[2] = {1e30, 1e30}, hi[2] = {-1e30, -1e30};
+    for (int c = 0; c < 8; ++c) {
+        const double p[3] = {ctx->stats.origin[0] + ((c & 1) ? W : 0.0), ctx->stats.origin[1] + ((c & 2) ? W : 0.0), ctx->stats.origin[2] + ((c & 4) ? W : 0.0)};
+        const double pu = m.u[0] * p[0] + m.u[1] * p[1] + m.u[2] * p[2], pv = m.v[0] * p[0] + m.v[1] * p[1] + m.v[2] * p[2];
+        lo[0] = std::min(lo[0], pu); hi[0] = std::max(hi[0], pu); lo[1] = std::min(lo[1], pv); hi[1] = std::max(hi[1], pv);
+    }
+    const double extent = std::max(hi[0] - lo[0], hi[1] - lo[1]);
+    m.texel = static_cast<float>(std::max(4.0, std::ceil(extent / 512.0)));
+    m.u0 = static_cast<float>(std::floor(lo[0]) - m.texel); m.v0 = static_cast<float>(std::floor(lo[1]) - m.texel);
+    m.nu = static_cast<uint32_t>(std::ceil((hi[0] - m.u0) / m.texel)) + 1u; m.nv = static_cast<uint32_t>(std::ceil((hi[1] - m.v0) / m.texel)) + 1u;
+    BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_sun_map), static_cast<size_t>(m.nu) * m.nv * sizeof(float)));
+    m.map = ctx->d_sun_map;
+    blok::launch_sun_map(m, nullptr);
+    BLOK_HIP_TRY(ctx, hipGetLastError());
+    BLOK_HIP_TRY(ctx, hipDeviceSynchronize());
+    ctx->has_sun_map = true;
     return BLOK_OK;
 }
 
@@ -295,7 +345,7 @@ int blok_hip_upload_world(blok_hip_ctx* ctx, const blok_svo_node* nodes, size_t 
             ctx->stats.n_sub_chunks = n_sub_chunks;
             ctx->has_world = true;
             ctx->built_on_device = true;
-            return BLOK_OK;
+            return rebuild_sun_map(ctx);
         }
     }
     std::vector<blok::VoxelRec> voxels;
@@ -359,7 +409,7 @@ int blok_hip_upload_dense(blok_hip_ctx* ctx, const uint32_t* ids, uint32_t nx, u
             for (int a = 0; a < 3; ++a) ctx->stats.origin[a] = gpu.origin[a];
             ctx->has_world = true;
             ctx->built_on_device = true;
-            return BLOK_OK;
+            return rebuild_sun_map(ctx);
         }
     }
     std::vector<blok::VoxelRec> voxels;
@@ -504,6 +554,12 @@ int blok_hip_trace_paths_device(blok_hip_ctx* ctx, const blok_camera* cam, uint3
     p.spp = spp; p.max_bounces = max_bounces; p.frame_count = frame_index;
     p.color = planes->color; p.world_pos = planes->world_pos;
     p.normal_roughness = planes->normal_roughness; p.albedo_metallic = planes->albedo_metallic;
+    if (ctx->sun_map_enabled && ctx->has_sun_map) {         // shadow rays stop at the last occluder of their column
+        const blok::SunMapArgs& m = ctx->sun;
+        p.sun_map = ctx->d_sun_map;
+        for (int a = 0; a < 3; ++a) { p.sun_u[a] = m.u[a]; p.sun_v[a] = m.v[a]; }
+        p.sun_u0 = m.u0; p.sun_v0 = m.v0; p.sun_inv_texel = 1.0f / m.texel; p.sun_nu = m.nu; p.sun_nv = m.nv;
+    }
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     uint32_t n_beams = 0;                                   // the primary rays of every sample start behind the beam pre-pass
     rc = prepare_beam(ctx, blok::RayMode::Rect, p.trace, stream, 0, &n_beams);
@@ -960,6 +1016,12 @@ int blok_hip_volume_rebuild(blok_hip_ctx* ctx, const blok_material* materials, s
     for (int a = 0; a < 3; ++a) ctx->stats.origin[a] = gpu.origin[a];
     ctx->has_world = true;
     ctx->built_on_device = true;
+    return rebuild_sun_map(ctx);
+}
+
+int blok_hip_set_sun_map(blok_hip_ctx* ctx, int enabled) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    ctx->sun_map_enabled = enabled != 0;
     return BLOK_OK;
 }
 

@@ -49,20 +49,13 @@ __device__ __forceinline__ uint32_t beam_uniform(uint32_t v) { return __builtin_
 __device__ __forceinline__ float beam_lane(float v, uint32_t lane) { return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), lane)); }
 __device__ __forceinline__ BeamVec beam_lane(BeamVec v, uint32_t lane) { return {beam_lane(v.x, lane), beam_lane(v.y, lane), beam_lane(v.z, lane)}; }
 
-// Pixel rectangle [px_lo, px_hi] x [py_lo, py_hi] in continuous pixel coordinates of the frame (pixel x covers
-// [x, x+1]).  Must be called by all 64 lanes of the wave.  Returns kBeamNone or a start parameter >= 0.
-__device__ __forceinline__ float beam_start(const TraceArgs& A, float px_lo, float py_lo, float px_hi, float py_hi, uint32_t lane) {
-    const float inv_w = __builtin_amdgcn_rcpf(static_cast<float>(A.frame_w)), inv_h = __builtin_amdgcn_rcpf(static_cast<float>(A.frame_h));
-    const BeamVec mid = beam_unit(beam_dir(A.cam, 0.5f * (px_lo + px_hi), 0.5f * (py_lo + py_hi), inv_w, inv_h));
-    // lane k < 4 builds side plane k through corners k and k+1 of the grown rectangle (corner i: x high for i = 1, 2;
-    // y high for i = 2, 3), oriented towards the central direction; the four planes are then read back wave-wide
-    const uint32_t k0 = lane & 3u, k1 = (lane + 1u) & 3u;
-    const BeamVec p = beam_dir(A.cam, (k0 == 1u || k0 == 2u) ? px_hi + 1.0f : px_lo - 1.0f, k0 >= 2u ? py_hi + 1.0f : py_lo - 1.0f, inv_w, inv_h);
-    const BeamVec q = beam_dir(A.cam, (k1 == 1u || k1 == 2u) ? px_hi + 1.0f : px_lo - 1.0f, k1 >= 2u ? py_hi + 1.0f : py_lo - 1.0f, inv_w, inv_h);
-    BeamVec side = beam_unit({p.y * q.z - p.z * q.y, p.z * q.x - p.x * q.z, p.x * q.y - p.y * q.x});
-    if (beam_dot(side, mid.x, mid.y, mid.z) < 0.0f) side = {-side.x, -side.y, -side.z};
-    const BeamVec n0 = beam_lane(side, 0), n1 = beam_lane(side, 1), n2 = beam_lane(side, 2), n3 = beam_lane(side, 3);
-
+// The cooperative depth-first search both pre-passes share.  The region is the intersection of four half-spaces
+// n_k . (p - ref) + c_k >= 0 (each pushed out by kBeamSlack; a cell is culled only if its farthest corner is strictly
+// behind one); the result is the smallest value, over the filled voxels that meet the region, of mid . (nearest corner - ref),
+// or kBeamNone.  Must be called by all 64 lanes of the wave.
+template <bool kClampAtZero>
+__device__ __forceinline__ float beam_search(const TraceArgs& A, BeamVec ref, BeamVec n0, BeamVec n1, BeamVec n2, BeamVec n3,
+                                             float c0, float c1, float c2, float c3, BeamVec mid, uint32_t lane) {
     // lanes are children in front-to-back order for the central direction: mirrored child index
     const uint32_t mirror = beam_uniform((mid.x < 0.0f ? 0x03u : 0u) | (mid.y < 0.0f ? 0x0Cu : 0u) | (mid.z < 0.0f ? 0x30u : 0u));
     const uint32_t child = lane ^ mirror;
@@ -86,21 +79,22 @@ __device__ __forceinline__ float beam_start(const TraceArgs& A, float px_lo, flo
         const uint32_t mlo = beam_uniform(rec.x), mhi = beam_uniform(rec.y), base = beam_uniform(rec.z);
         const uint32_t shift = 2u * (level - 1u);
         const float s = static_cast<float>(1u << shift);
-        const float rx = static_cast<float>(A.origin[0] + mx) - A.cam.pos[0];
-        const float ry = static_cast<float>(A.origin[1] + my) - A.cam.pos[1];
-        const float rz = static_cast<float>(A.origin[2] + mz) - A.cam.pos[2];
+        const float rx = static_cast<float>(A.origin[0] + mx) - ref.x;
+        const float ry = static_cast<float>(A.origin[1] + my) - ref.y;
+        const float rz = static_cast<float>(A.origin[2] + mz) - ref.z;
         const float depth = __builtin_fmaf(s, b4, beam_dot(mid, rx, ry, rz));         // lower bound of the child's depth
         const bool nearer = !(depth >= best);
         if (fresh) {
-            const bool outside = (__builtin_fmaf(s, b0, beam_dot(n0, rx, ry, rz)) < -kBeamSlack) | (__builtin_fmaf(s, b1, beam_dot(n1, rx, ry, rz)) < -kBeamSlack) |
-                                 (__builtin_fmaf(s, b2, beam_dot(n2, rx, ry, rz)) < -kBeamSlack) | (__builtin_fmaf(s, b3, beam_dot(n3, rx, ry, rz)) < -kBeamSlack);
+            const bool outside = (__builtin_fmaf(s, b0, beam_dot(n0, rx, ry, rz)) + c0 < -kBeamSlack) | (__builtin_fmaf(s, b1, beam_dot(n1, rx, ry, rz)) + c1 < -kBeamSlack) |
+                                 (__builtin_fmaf(s, b2, beam_dot(n2, rx, ry, rz)) + c2 < -kBeamSlack) | (__builtin_fmaf(s, b3, beam_dot(n3, rx, ry, rz)) + c3 < -kBeamSlack);
             const bool filled = ((child_hi ? mhi : mlo) & child_bit) != 0u;
             cand = __ballot(filled && !outside && nearer);
             if (level <= BLOK_BEAM_STOP_LEVEL) {
                 while (cand) {
                     const uint32_t j = static_cast<uint32_t>(__builtin_ctzll(cand));
                     const float dj = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(depth), j));
-                    best = dj >= 0.0f ? fminf(best, dj) : 0.0f;        // negative or NaN: start at the ray origin
+                    if (kClampAtZero) best = dj >= 0.0f ? fminf(best, dj) : 0.0f;      // negative or NaN: start at the ray origin
+                    else best = dj == dj ? fminf(best, dj) : -kBeamNone;               // NaN: the most conservative answer
                     cand &= cand - 1u;
                     cand &= __ballot(!(depth >= best));
                 }
@@ -130,8 +124,40 @@ __device__ __forceinline__ float beam_start(const TraceArgs& A, float px_lo, flo
         --level;
         fresh = true;
     }
+    return best;
+}
+
+// Pixel rectangle [px_lo, px_hi] x [py_lo, py_hi] in continuous pixel coordinates of the frame (pixel x covers
+// [x, x+1]).  Must be called by all 64 lanes of the wave.  Returns kBeamNone or a start parameter >= 0.
+__device__ __forceinline__ float beam_start(const TraceArgs& A, float px_lo, float py_lo, float px_hi, float py_hi, uint32_t lane) {
+    const float inv_w = __builtin_amdgcn_rcpf(static_cast<float>(A.frame_w)), inv_h = __builtin_amdgcn_rcpf(static_cast<float>(A.frame_h));
+    const BeamVec mid = beam_unit(beam_dir(A.cam, 0.5f * (px_lo + px_hi), 0.5f * (py_lo + py_hi), inv_w, inv_h));
+    // lane k < 4 builds side plane k through corners k and k+1 of the grown rectangle (corner i: x high for i = 1, 2;
+    // y high for i = 2, 3), oriented towards the central direction; the four planes are then read back wave-wide
+    const uint32_t k0 = lane & 3u, k1 = (lane + 1u) & 3u;
+    const BeamVec p = beam_dir(A.cam, (k0 == 1u || k0 == 2u) ? px_hi + 1.0f : px_lo - 1.0f, k0 >= 2u ? py_hi + 1.0f : py_lo - 1.0f, inv_w, inv_h);
+    const BeamVec q = beam_dir(A.cam, (k1 == 1u || k1 == 2u) ? px_hi + 1.0f : px_lo - 1.0f, k1 >= 2u ? py_hi + 1.0f : py_lo - 1.0f, inv_w, inv_h);
+    BeamVec side = beam_unit({p.y * q.z - p.z * q.y, p.z * q.x - p.x * q.z, p.x * q.y - p.y * q.x});
+    if (beam_dot(side, mid.x, mid.y, mid.z) < 0.0f) side = {-side.x, -side.y, -side.z};
+    const BeamVec n0 = beam_lane(side, 0), n1 = beam_lane(side, 1), n2 = beam_lane(side, 2), n3 = beam_lane(side, 3);
+
+    const float best = beam_search<true>(A, {A.cam.pos[0], A.cam.pos[1], A.cam.pos[2]}, n0, n1, n2, n3, 0.0f, 0.0f, 0.0f, 0.0f, mid, lane);
     if (best >= kBeamNone) return kBeamNone;
     return fmaxf(best * (1.0f - 1.0e-4f) - 2.0f * kBeamSlack, 0.0f);
+}
+
+// ---- "last occluder" map for the shadow rays of the path kernel ------------------------------------------------------
+// All shadow rays share one direction (the shader's constant sun, raygen.rgen:142,185), so "the farthest point along the
+// sun direction at which any voxel exists" is a function of the two coordinates perpendicular to it.  One wave per texel
+// of that plane searches the prism {u_lo <= u.p <= u_hi, v_lo <= v.p <= v_hi} (grown by kBeamSlack) for the largest s-depth
+// of a filled voxel's far corner.  A shadow ray starting at o then needs tmax' = D(texel of o) - s.o (+ margin) only: every
+// voxel it can report is entered before that parameter, so lowering tmax changes no "any hit" answer (trace_kernels.h: a
+// voxel is reported iff max(entry, tmin) < min(exit, tmax)); rays above the last occluder skip the walk altogether.
+struct SunFrame { BeamVec u, v, s; };      // orthonormal; s = the sun direction of path_core.h
+__device__ __forceinline__ float prism_far(const TraceArgs& A, const SunFrame& F, float u_lo, float u_hi, float v_lo, float v_hi, uint32_t lane) {
+    const BeamVec nu = {-F.u.x, -F.u.y, -F.u.z}, nv = {-F.v.x, -F.v.y, -F.v.z}, back = {-F.s.x, -F.s.y, -F.s.z};
+    const float best = beam_search<false>(A, {0.0f, 0.0f, 0.0f}, F.u, nu, F.v, nv, -u_lo, u_hi, -v_lo, v_hi, back, lane);
+    return best >= kBeamNone ? -kBeamNone : -best;          // = max over voxels of s . (far corner)
 }
 
 }  // namespace blok

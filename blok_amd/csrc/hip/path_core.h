@@ -30,6 +30,12 @@ struct PathArgs {
     float* world_pos;
     float* normal_roughness;
     float* albedo_metallic;
+    // "last occluder" map for the shadow rays (beam.h: prism_far): per texel of the plane perpendicular to the sun, the largest
+    // sun-direction depth at which any voxel exists; null = none.  Texel (iu, iv) covers u0 + iu*texel <= u.p < u0 + (iu+1)*texel.
+    const float* sun_map;
+    float sun_u[3], sun_v[3];
+    float sun_u0, sun_v0, sun_inv_texel;
+    uint32_t sun_nu, sun_nv;
 };
 
 struct V3 { float x, y, z; };
@@ -177,6 +183,18 @@ BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t in
             r.ox = so.x; r.oy = so.y; r.oz = so.z;
             r.dx = sun_dir.x; r.dy = sun_dir.y; r.dz = sun_dir.z;
             r.tmin = 0.001f; r.tmax = 1000.0f;                                                // :294,:296
+            if (P.sun_map) {
+                // beyond the last occluder of this ray's column nothing can be hit: cap tmax there (an empty interval = an
+                // immediate miss); the "any hit" answer is unchanged, see beam.h
+                const float fu = (vdot(v3(P.sun_u[0], P.sun_u[1], P.sun_u[2]), so) - P.sun_u0) * P.sun_inv_texel;
+                const float fv = (vdot(v3(P.sun_v[0], P.sun_v[1], P.sun_v[2]), so) - P.sun_v0) * P.sun_inv_texel;
+                if (fu >= 0.0f && fv >= 0.0f && fu < static_cast<float>(P.sun_nu) && fv < static_cast<float>(P.sun_nv)) {
+                    const float last = P.sun_map[static_cast<uint32_t>(fv) * P.sun_nu + static_cast<uint32_t>(fu)];
+                    const float t_last = last - vdot(sun_dir, so);
+                    const float cap = t_last + 0.05f + 1.0e-4f * fabsf(t_last);
+                    r.tmax = cap > r.tmin ? fminf(r.tmax, cap) : 0.0f;
+                }
+            }
         } else {
             r.ox = ray_org.x; r.oy = ray_org.y; r.oz = ray_org.z;
             r.dx = ray_dir.x; r.dy = ray_dir.y; r.dz = ray_dir.z;

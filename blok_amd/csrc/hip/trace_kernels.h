@@ -103,6 +103,15 @@ struct UntileArgs {
     uint32_t frame_w, frame_h, tile, n_ranks, tiles_per_rank_max, tiles_x, elem_bytes;
 };
 
+struct SunMapArgs {                        // beam.h: prism_far, one wave per texel
+    TraceArgs trace;
+    float u[3], v[3], s[3];
+    float u0, v0, texel;
+    uint32_t nu, nv;
+    float* map;
+};
+void launch_sun_map(const SunMapArgs& args, hipStream_t stream);
+
 struct PathArgs;
 struct TonemapArgs;
 struct AccumArgs;

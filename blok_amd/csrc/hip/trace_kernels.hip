@@ -121,6 +121,15 @@ __global__ __launch_bounds__(64) void beam_kernel(const TraceArgs A, const uint3
     if (lane == 0) A.beam[b] = t0;
 }
 
+__global__ __launch_bounds__(64) void sun_map_kernel(const SunMapArgs a) {
+    const uint32_t b = blockIdx.x, lane = threadIdx.x;
+    if (b >= a.nu * a.nv) return;
+    const SunFrame f{{a.u[0], a.u[1], a.u[2]}, {a.v[0], a.v[1], a.v[2]}, {a.s[0], a.s[1], a.s[2]}};
+    const float u_lo = a.u0 + static_cast<float>(b % a.nu) * a.texel, v_lo = a.v0 + static_cast<float>(b / a.nu) * a.texel;
+    const float last = prism_far(a.trace, f, u_lo, u_lo + a.texel, v_lo, v_lo + a.texel, lane);
+    if (lane == 0) a.map[b] = last;
+}
+
 // raygen.rgen main(): one lane per pixel of the rectangle, same 16x16 / 8x8 pixel mapping as the trace kernel.
 __global__ __launch_bounds__(kBlock) void path_kernel(const PathArgs P) {
     extern __shared__ uint4 lds_stack[];
@@ -182,6 +191,11 @@ void launch_beam(RayMode mode, const TraceArgs& args, uint32_t n_beam_tiles, hip
     if (n_beam_tiles == 0 || mode == RayMode::Rays) return;
     if (mode == RayMode::Rect) hipLaunchKernelGGL(beam_kernel<RayMode::Rect>, dim3(n_beam_tiles), dim3(64), 0, stream, args, n_beam_tiles);
     else hipLaunchKernelGGL(beam_kernel<RayMode::Tiles>, dim3(n_beam_tiles), dim3(64), 0, stream, args, n_beam_tiles);
+}
+
+void launch_sun_map(const SunMapArgs& args, hipStream_t stream) {
+    const uint32_t n = args.nu * args.nv;
+    if (n) hipLaunchKernelGGL(sun_map_kernel, dim3(n), dim3(64), 0, stream, args);
 }
 
 void launch_paths(const PathArgs& args, uint32_t n_blocks, hipStream_t stream) {

@@ -143,6 +143,10 @@ class HipTracer:
     def post_reset(self):
         self._check(self._lib.blok_hip_post_reset(self._ctx))
 
+    def set_sun_map(self, enabled: bool):
+        """Shadow rays stop at the last occluder of their sun-direction column (never changes a result); default on."""
+        self._check(self._lib.blok_hip_set_sun_map(self._ctx, int(bool(enabled))))
+
     def set_beam(self, beam_tile_pixels: int):
         """Beam pre-pass granularity of the frame kernels in pixels (0 = off, default 32); never changes a result."""
         self._check(self._lib.blok_hip_set_beam(self._ctx, beam_tile_pixels))

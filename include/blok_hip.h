@@ -341,6 +341,11 @@ int blok_hip_volume_apply_brush(blok_hip_ctx* ctx, const float center[3], float 
  * density > 0 and their material ids, with the given material table. */
 int blok_hip_volume_rebuild(blok_hip_ctx* ctx, const blok_material* materials, size_t n_materials);
 
+/* "Last occluder" map of the path kernel's shadow rays (no reference counterpart): all shadow rays share the shader's constant sun
+ * direction (raygen.rgen:142,185), so with every world the backend records, per 4-voxel texel of the plane perpendicular to
+ * it, how far along that direction voxels exist at all; a shadow ray's tmax is capped there (rays above the last occluder skip
+ * their walk).  Results are identical with and without it (tests/test_paths.py).  Default on. */
+int blok_hip_set_sun_map(blok_hip_ctx* ctx, int enabled);
 /* Beam pre-pass of the frame kernels (no reference counterpart; the reference culls per ray in Vulkan RT hardware,
  * blok/src/renderer_raytracing.cpp:15-254): before a rectangle / tile launch, one wave per beam_tile_pixels^2 pixels finds a
  * conservative start parameter for that tile's rays, and tiles whose frustum meets no voxel are written as misses without

@@ -173,3 +173,50 @@ def test_beam_prepass_does_not_change_path_traced_frames(world64):
         for k in plain:
             assert got[k].tobytes() == plain[k].tobytes(), (k, pose)
     tr.shutdown()
+
+
+@pytest.mark.gpu
+def test_sun_map_does_not_change_path_traced_frames(world64):
+    """Shadow rays are capped at the last occluder of their sun-direction column: every plane is bit-identical with the
+    map on and off — small world with odd frame and several poses, a world edited after upload (the map is rebuilt with
+    the world), and a 4K rectangle of the 1024^3 world."""
+    from blok_amd.tracer import HipTracer
+    from tests.conftest import make_scene_world
+    pw, mats, _ = world64
+    tr = HipTracer(203, 117).init()
+    tr.add_world(pw)
+    cams = [W.scene_camera(64, pose, 203, 117, SEED) for pose in (0, 1, 2)]
+    low = W.camera_look_at((5.0, 8.0, 5.0), (40.0, 12.0, 40.0), 70.0, 203, 117)       # under overhangs: many occluded shadow rays
+    for cam in cams + [low]:
+        tr.set_sun_map(False)
+        plain = tr.trace_paths(cam, spp=6, max_bounces=3, frame_index=2)
+        tr.set_sun_map(True)
+        got = tr.trace_paths(cam, spp=6, max_bounces=3, frame_index=2)
+        for k in plain:
+            assert got[k].tobytes() == plain[k].tobytes(), k
+    # a new world replaces the map
+    cm = W.ChunkManager(128, 1.0)
+    cm.generate_scene(64, SEED)
+    cm.apply_brush((32.0, 70.0, 32.0), 9.0, 1.0, "add")          # a ball floating above the terrain casts a new shadow
+    cm.rebuild_dirty_chunks()
+    tr.update_world(cm.pack_chunks_to_gpu_svo(mats))
+    cam = cams[0]
+    tr.set_sun_map(False)
+    plain = tr.trace_paths(cam, spp=6, max_bounces=2, frame_index=3)
+    tr.set_sun_map(True)
+    got = tr.trace_paths(cam, spp=6, max_bounces=2, frame_index=3)
+    assert got["color"].tobytes() == plain["color"].tobytes()
+    tr.shutdown()
+    cm, pw = make_scene_world(1024)
+    tr = HipTracer(3840, 2160).init()
+    tr.add_world(pw)
+    rect = (1400, 800, 640, 320)
+    for pose in (0, 1):
+        cam = W.scene_camera(1024, pose, 3840, 2160, SEED)
+        tr.set_sun_map(False)
+        plain = tr.trace_paths(cam, spp=4, max_bounces=2, frame_index=1, rect=rect)
+        tr.set_sun_map(True)
+        got = tr.trace_paths(cam, spp=4, max_bounces=2, frame_index=1, rect=rect)
+        for k in plain:
+            assert got[k].tobytes() == plain[k].tobytes(), (k, pose)
+    tr.shutdown()
