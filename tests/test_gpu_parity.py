@@ -209,6 +209,42 @@ def test_beam_prepass_never_changes_a_record(tracer_cls, scene64, scene1024):
     tr.shutdown()
 
 
+def test_beam_prepass_random_cameras_and_odd_worlds(tracer_cls):
+    """Stress of the conservative pre-pass: 60 random cameras (anywhere from deep inside the volume to far outside, any
+    orientation, 4..150 degree fields of view, non-square odd frames) over a world that straddles the origin with negative
+    chunk coordinates, an isolated voxel far from the rest and a one-voxel-thick wall; records with beam tiles of 8 and
+    32 pixels equal the records without the pre-pass, and the oracle agrees on a sample of them."""
+    rng = np.random.default_rng(2024)
+    cm = W.ChunkManager(128, 1.0)
+    pts = rng.integers(-40, 40, size=(6000, 3)).astype(np.int32)
+    wall = np.array([(x, y, 17) for x in range(-60, 60) for y in range(-30, 30)], dtype=np.int32)
+    far = np.array([(-200, 90, -170), (211, -3, 140)], dtype=np.int32)
+    xyz = np.concatenate([pts, wall, far])
+    cm.set_voxels(xyz, (rng.integers(1, 200, size=len(xyz))).astype(np.uint32))
+    cm.rebuild_dirty_chunks()
+    pw = cm.pack_chunks_to_gpu_svo(W.scene_materials(SEED))
+    lat = O.Lattice(pw.nodes, pw.sub_chunks)
+    w, h = 161, 93
+    tr = tracer_cls(w, h).init()
+    tr.add_world(pw)
+    for k in range(60):
+        scale = (30.0, 80.0, 400.0)[k % 3]
+        eye = rng.normal(0.0, scale, 3)
+        target = eye + rng.normal(0.0, 1.0, 3) if k % 5 else rng.normal(0.0, 20.0, 3)
+        if np.linalg.norm(target - eye) < 1e-3:
+            target = eye + (1.0, 0.0, 0.0)
+        cam = W.camera_look_at(tuple(float(v) for v in eye), tuple(float(v) for v in target), float(rng.uniform(4.0, 150.0)), w, h)
+        tr.set_beam(0)
+        plain = tr.draw_frame(cam).reshape(-1)
+        for beam in (8, 32):
+            tr.set_beam(beam)
+            assert records_equal(tr.draw_frame(cam).reshape(-1), plain).all(), (k, beam)
+        if k % 10 == 0:
+            ref, _ = lat.trace(O.primary_rays(cam, w, h), threads=8)
+            assert records_equal(plain, ref).all(), k
+    tr.shutdown()
+
+
 def test_world_edge_cases(tracer_cls):
     """Empty world, single voxel, negative coordinates, material ids above 65535, replace-world, errors."""
     from blok_amd._ffi import BlokError
