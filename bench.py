@@ -43,9 +43,10 @@ def parse():
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0xB10C0001)
     ap.add_argument("--cpu-stride", type=int, default=1, help="CPU baseline traces every stride-th pixel in x and y")
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="pipeline depth; 0 = 2 for N <= 2, 3 for N <= 4, else 4 (reference: MAX_FRAMES_IN_FLIGHT = 2). "
-                         "Measured on one GPU with a rank's tile share (scripts/tile_depth_test.py): an 8-rank share is "
-                         "40 us of work under a kernel that lasts 114 us alone, and needs 4 frames in flight to hide it")
+                    help="pipeline depth; 0 = 2 for N = 1, 3 for N = 2, else 4 (reference: MAX_FRAMES_IN_FLIGHT = 2). "
+                         "Measured on one GPU with a rank's tile share (scripts/tile_depth_test.py): a frame-share is a "
+                         "beam + trace launch pair whose latency (~130 us alone) far exceeds its work (26-105 us), so "
+                         "3-4 frames must be in flight to hide it")
     ap.add_argument("--beam", type=int, default=32, help="beam pre-pass tile in pixels (0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-paths", action="store_true", help="skip the 64-spp path-tracing side measurement")
@@ -125,7 +126,7 @@ def main():
     tracer.set_beam(args.beam)
 
     if args.frames_in_flight <= 0:
-        args.frames_in_flight = 2 if world_size <= 2 else (3 if world_size <= 4 else 4)
+        args.frames_in_flight = 2 if world_size == 1 else (3 if world_size == 2 else 4)
     from blok_amd.multi_gpu import FramePipeline, HipBackend
     stream = torch.cuda.current_stream()
     pipe = FramePipeline(HipBackend(tracer, cam), W_, H_, rank, world_size, dist, tile=args.tile, depth=args.frames_in_flight)
