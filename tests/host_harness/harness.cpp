@@ -101,6 +101,24 @@ void hh_trace_primary_events(const void* h, const blok_camera* cam, uint32_t wid
     g_seq = nullptr;
 }
 
+// Same with a per-pixel start parameter (beam pre-pass experiments).
+void hh_trace_rect_events(const void* h, const blok_camera* cam, uint32_t width, uint32_t height, uint32_t x0, uint32_t y0,
+                          uint32_t w, uint32_t hgt, const float* tstart, uint32_t cap, unsigned char* events) {
+    const Harness* H = static_cast<const Harness*>(h);
+    TraceArgs a = make_args(H);
+    a.cam = *cam; a.frame_w = width; a.frame_h = height;
+    std::vector<uint4> stack(size_t(kMaxLevels) * 2 * kBlock);
+    blok_hit tmp;
+    for (uint32_t y = 0; y < hgt; ++y)
+        for (uint32_t x = 0; x < w; ++x) {
+            g_seq = events + (size_t(y) * w + x) * cap; g_seq_len = 0; g_seq_cap = cap;
+            RayIn r = primary_ray(a, x0 + x, y0 + y);
+            if (tstart) { const float t0 = tstart[size_t(y) * w + x]; if (t0 > 9.0e3f) continue; if (t0 > r.tmin) r.tmin = t0; }
+            trace_one(a, r, stack.data(), Sink{&tmp, nullptr});
+        }
+    g_seq = nullptr;
+}
+
 void hh_tonemap(const float* hdr, uint32_t n, float exposure, float saturation_boost, int op, uint32_t* out) {
     TonemapArgs t{hdr, out, n, exposure, saturation_boost, op};
     for (uint32_t i = 0; i < n; ++i) out[i] = tonemap_pixel(t, i);
