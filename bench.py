@@ -47,6 +47,8 @@ def parse():
                          "Measured on one GPU with a rank's tile share (scripts/tile_depth_test.py): a frame-share is a "
                          "beam + trace launch pair whose latency (~130 us alone) far exceeds its work (26-105 us), so "
                          "3-4 frames must be in flight to hide it")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for "
+                    "rehearsing the N > 1 code path with several ranks on one GPU, which RCCL refuses)")
     ap.add_argument("--beam", type=int, default=32, help="beam pre-pass tile in pixels (0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-paths", action="store_true", help="skip the 64-spp path-tracing side measurement")
@@ -113,7 +115,10 @@ def main():
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(args.backend)
 
     from blok_amd import world as W
     from blok_amd.tracer import HipTracer
@@ -207,7 +212,7 @@ def main():
                                    f"{stats.n_voxels} voxels, {stats.n_ref_nodes} reference SvoNodes, "
                                    f"{stats.n_sub_chunks} sub-chunks), {W_}x{H_} primary rays, camera pose "
                                    f"{'ABC'[args.pose]}, first-hit records 16 B/ray",
-                       "parallelism": f"single GPU, {args.frames_in_flight} frames in flight on alternating HIP streams" if world_size == 1 else f"{args.tile}x{args.tile} screen tiles round-robin over {world_size} GPUs, RCCL gather of RGBA8 tiles to rank 0, {args.frames_in_flight} frames in flight",
+                       "parallelism": f"single GPU, {args.frames_in_flight} frames in flight on alternating HIP streams" if world_size == 1 else f"{args.tile}x{args.tile} screen tiles round-robin over {world_size} GPUs, {'RCCL' if args.backend == 'nccl' else args.backend} gather of RGBA8 tiles to rank 0, {args.frames_in_flight} frames in flight",
                        "hits_per_frame": hits, "framebuffer_pixels_hit": lit_pixels,
                        "outputs": "16-B first-hit records (kept on the tracing GPU) + RGBA8 framebuffer on rank 0",
                        "frames_in_flight": args.frames_in_flight, "device_ms_per_step": device_ms / args.steps, "kernel_ms_alone": kernel_ms_avg, "beam_tile": args.beam,
