@@ -252,6 +252,12 @@ int launch_timed(blok_hip_ctx* ctx, blok::RayMode mode, blok::TraceArgs args, ui
 int check_trace(blok_hip_ctx* ctx, const blok_camera* cam) {
     if (!ctx) return BLOK_ERR_INVALID_ARG;
     if (!cam) return set_error(ctx, BLOK_ERR_INVALID_ARG, "camera is null");
+    {   // a camera that is not a finite, non-degenerate basis would make every ray NaN (and the beam pre-pass cull nothing)
+        const float* f = reinterpret_cast<const float*>(cam);
+        for (size_t i = 0; i < sizeof(blok_camera) / sizeof(float); ++i)
+            if (!std::isfinite(f[i])) return set_error(ctx, BLOK_ERR_INVALID_ARG, "camera has a non-finite component");
+        if (!(cam->tan_half_fov > 0.0f) || !(cam->aspect > 0.0f)) return set_error(ctx, BLOK_ERR_INVALID_ARG, "camera needs tan_half_fov > 0 and aspect > 0");
+    }
     if (!ctx->has_world) return set_error(ctx, BLOK_ERR_NO_WORLD, "no world uploaded");
     BLOK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return BLOK_OK;

@@ -29,6 +29,7 @@ namespace blok {
 #define BLOK_BEAM_STOP_LEVEL 1      // finest cells examined = children of a node of this level (1: voxels, 2: 4^3 bricks)
 #endif
 constexpr float kBeamSlack = 0.05f;
+constexpr uint32_t kBeamMaxVisits = 8192u;   // typical searches take 10-60 visits
 
 struct BeamVec { float x, y, z; };
 
@@ -74,7 +75,10 @@ __device__ __forceinline__ float beam_search(const TraceArgs& A, BeamVec ref, Be
     uint32_t stk_node = 0, stk_lo = 0, stk_hi = 0;     // lane l holds the entry of level l
     bool fresh = true;
     uint64_t cand = 0;
-    for (;;) {
+    // every wave reaches the exit: the search is a finite tree walk, and a visit budget bounds it even for a frustum whose
+    // planes cull nothing (degenerate inputs): running out is answered with "start at the ray origin", never with "none"
+    uint32_t budget = kBeamMaxVisits;
+    for (; budget != 0u; --budget) {
         const uint4 rec = A.nodes[node];
         const uint32_t mlo = beam_uniform(rec.x), mhi = beam_uniform(rec.y), base = beam_uniform(rec.z);
         const uint32_t shift = 2u * (level - 1u);
@@ -124,6 +128,7 @@ __device__ __forceinline__ float beam_search(const TraceArgs& A, BeamVec ref, Be
         --level;
         fresh = true;
     }
+    if (budget == 0u) return kClampAtZero ? 0.0f : -kBeamNone;
     return best;
 }
 

@@ -245,6 +245,28 @@ def test_beam_prepass_random_cameras_and_odd_worlds(tracer_cls):
     tr.shutdown()
 
 
+def test_degenerate_cameras_are_refused(tracer_cls, scene64):
+    """A camera with a non-finite component or a zero field of view is an argument error (every ray would be NaN and the
+    beam pre-pass could cull nothing), not a launch."""
+    from blok_amd._ffi import BlokError
+    cm, pw = scene64
+    tr = tracer_cls(64, 48).init()
+    tr.add_world(pw)
+    good = W.scene_camera(64, 0, 64, 48, SEED)
+    assert tr.draw_frame(good)["hit"].any()
+    for field, value in (("tan_half_fov", 0.0), ("tan_half_fov", float("nan")), ("aspect", -1.0), ("pos", float("inf")), ("fwd", float("nan"))):
+        bad = good.copy()
+        if field in ("pos", "fwd"):
+            bad[field][0][1] = value
+        else:
+            bad[field] = value
+        for call in (lambda: tr.draw_frame(bad), lambda: tr.trace_paths(bad, spp=1), lambda: tr.draw_frame_accumulate(bad, 1, 1)):
+            with pytest.raises(BlokError) as e:
+                call()
+            assert e.value.status == -1
+    tr.shutdown()
+
+
 def test_world_edge_cases(tracer_cls):
     """Empty world, single voxel, negative coordinates, material ids above 65535, replace-world, errors."""
     from blok_amd._ffi import BlokError
