@@ -164,6 +164,28 @@ void hh_trace_rect_stats(const void* h, const blok_camera* cam, uint32_t width, 
         }
 }
 
+// As hh_trace_rect_stats with an optional per-pixel far bound as well (tmax).
+void hh_trace_rect_stats2(const void* h, const blok_camera* cam, uint32_t width, uint32_t height, uint32_t x0, uint32_t y0,
+                          uint32_t w, uint32_t hgt, const float* tstart, const float* tfar, blok_hit* out, uint32_t* iters_per_ray) {
+    const Harness* H = static_cast<const Harness*>(h);
+    TraceArgs a = make_args(H);
+    a.cam = *cam; a.frame_w = width; a.frame_h = height;
+    std::vector<uint4> stack(size_t(kMaxLevels) * 2 * kBlock);
+    std::memset(g_stat, 0, sizeof(g_stat));
+    for (uint32_t y = 0; y < hgt; ++y)
+        for (uint32_t x = 0; x < w; ++x) {
+            uint64_t before = 0;
+            for (int l = 0; l < 8; ++l) before += g_stat[0][l];
+            RayIn r = primary_ray(a, x0 + x, y0 + y);
+            if (tstart && tstart[size_t(y) * w + x] > r.tmin) r.tmin = tstart[size_t(y) * w + x];
+            if (tfar && tfar[size_t(y) * w + x] < r.tmax) r.tmax = tfar[size_t(y) * w + x];
+            trace_one(a, r, stack.data(), Sink{out + size_t(y) * w + x, nullptr});
+            uint64_t after = 0;
+            for (int l = 0; l < 8; ++l) after += g_stat[0][l];
+            iters_per_ray[size_t(y) * w + x] = uint32_t(after - before);
+        }
+}
+
 void hh_stat_totals(uint64_t* totals) { std::memcpy(totals, g_stat, sizeof(g_stat)); }
 
 // Per-ray iteration counts for a frame (row-major), plus the event totals [4][8].

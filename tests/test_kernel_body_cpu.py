@@ -120,6 +120,29 @@ rays = np.concatenate([edge_case_rays(), random_rays(64, 2000, 5)])
 out = np.zeros(len(rays), dtype=O.HIT)
 L.hh_trace_rays(C.c_void_p(h), C.c_void_p(rays.ctypes.data), len(rays), C.c_void_p(out.ctypes.data))
 print('hits', int(out['hit'].sum()))
+# image-space chain: clamped 3x3 / 5x5 stencils with steps up to 16, bilinear history fetches at and beyond the frame border
+L.hh_post_new.restype = C.c_void_p
+L.hh_post_denoise.argtypes = [C.c_void_p] * 6 + [C.c_uint32, C.c_void_p, C.c_void_p]
+L.hh_post_taa.argtypes = [C.c_void_p] * 3 + [C.c_float, C.c_float, C.c_uint32, C.c_void_p]
+L.hh_post_sharpen.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_void_p]
+L.hh_post_free.argtypes = [C.c_void_p]
+w, h = 37, 23
+rng = np.random.default_rng(1)
+S = O.OrcDenoiseSettings.default(); S.atrousIterations = 5
+p = C.c_void_p(L.hh_post_new(w, h))
+ident = np.eye(4, dtype=np.float32).reshape(-1)
+for k in range(3):
+    color = rng.uniform(0, 2, (h, w, 4)).astype(np.float32)
+    wp = rng.uniform(-5, 5, (h, w, 4)).astype(np.float32); wp[..., 3] = rng.choice([20.0, 21.0, 10000.0], (h, w))
+    nr = np.zeros((h, w, 4), np.float32); nr[..., 1] = 1; nr[..., 3] = 0.5
+    motion = rng.normal(0, 0.3, (h, w, 2)).astype(np.float32)          # large: reprojection far outside the frame too
+    out = np.zeros((h, w, 4), np.float32); out2 = np.zeros((h, w, 4), np.float32)
+    L.hh_post_denoise(p, color.ctypes.data, wp.ctypes.data, nr.ctypes.data, motion.ctypes.data, ident.ctypes.data, k, C.byref(S), out.ctypes.data)
+    L.hh_post_taa(p, out.ctypes.data, None, 0.93, 0.98, k, out2.ctypes.data)
+img = rng.integers(0, 2 ** 32, (h, w), dtype=np.uint64).astype(np.uint32); sh = np.zeros_like(img)
+L.hh_post_sharpen(img.ctypes.data, w, h, 0.5, sh.ctypes.data)
+L.hh_post_free(p)
+print('post', float(out2.sum()) == float(out2.sum()))
 """
     import os
     env = dict(os.environ)
@@ -128,4 +151,4 @@ print('hits', int(out['hit'].sum()))
     env["ASAN_OPTIONS"] = "detect_leaks=0"
     proc = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
     assert proc.returncode == 0, proc.stderr[-3000:]
-    assert "hits" in proc.stdout and "runtime error" not in proc.stderr and "AddressSanitizer" not in proc.stderr
+    assert "hits" in proc.stdout and "post" in proc.stdout and "runtime error" not in proc.stderr and "AddressSanitizer" not in proc.stderr
