@@ -7,7 +7,8 @@
 // thousand waves per 4K frame).  The per-ray walk then runs with tmin' = max(tmin, t0).  That cannot change a record: a voxel is reported iff
 // max(entry, tmin) < min(exit, tmax) with t = max(entry, tmin) (trace_kernels.h), and raising tmin to a value
 // below every reportable voxel's entry leaves both the set of reported voxels and their t untouched.  If no
-// cell of the tree meets the frustum, all 64 rays miss and no walk runs.
+// cell of the tree meets the frustum, every ray of the tile misses: beam_kernel writes those pixels itself and the
+// tile's trace waves exit on their first instruction.
 //
 // Conservative by construction, not by tuning:
 //   * the frustum is the tile's pixel rectangle grown by one pixel on every side (covers the pixel centres, the

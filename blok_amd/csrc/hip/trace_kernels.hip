@@ -53,18 +53,24 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const TraceArgs A) {
         const uint32_t wave = tid >> 6, lane = tid & 63u;
         const uint32_t lx = (wave & 1u) * kWaveW + (lane % kWaveW);
         const uint32_t ly = (wave >> 1) * kWaveH + (lane / kWaveW);
-        uint32_t x, y, beam_index = 0;             // beam_index: this wave's entry of A.beam (wave-uniform)
-        size_t out_index;
+        // where this wave's 8x8 pixels start inside the block (wave-uniform)
+        const uint32_t wave_x = __builtin_amdgcn_readfirstlane((wave & 1u) * kWaveW), wave_y = __builtin_amdgcn_readfirstlane((wave >> 1) * kWaveH);
+        uint32_t x, y;
+        float t0 = 0.0f;                           // start parameter of this wave's beam tile (beam.h); kBeamNone: the pre-pass
+        size_t out_index;                          // has already written the tile's pixels as misses, nothing left to do
         bool inside;
         if constexpr (MODE == RayMode::Rect) {
             const uint32_t bx_count = (A.w + kTileW - 1u) / kTileW, by_count = (A.h + kTileH - 1u) / kTileH;
             uint32_t bx, by;
             if (!block_to_tile(blockIdx.x, gridDim.x, bx_count, by_count, bx, by)) return;
+            if (A.beam) {
+                t0 = A.beam[((by * kTileH + wave_y) / A.beam_tile) * A.beam_bx + (bx * kTileW + wave_x) / A.beam_tile];
+                if (t0 >= kBeamNone) return;
+            }
             const uint32_t rx = bx * kTileW + lx, ry = by * kTileH + ly;
             inside = rx < A.w && ry < A.h;
             x = A.x0 + rx; y = A.y0 + ry;
             out_index = static_cast<size_t>(ry) * A.w + rx;
-            if (A.beam) beam_index = ((ry - lane / kWaveW) / A.beam_tile) * A.beam_bx + (rx - lane % kWaveW) / A.beam_tile;
         } else {
             const uint32_t per_side = A.tile / kTileW;                  // blocks per tile row
             const uint32_t per_tile = per_side * (A.tile / kTileH);
@@ -75,13 +81,15 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const TraceArgs A) {
             x = tx * A.tile + ix; y = ty * A.tile + iy;
             out_index = static_cast<size_t>(local_tile) * A.tile * A.tile + static_cast<size_t>(iy) * A.tile + ix;
             inside = x < A.frame_w && y < A.frame_h;
-            if (A.beam) {
-                const uint32_t beams_per_side = A.tile / A.beam_tile;
-                beam_index = (local_tile * beams_per_side + (iy - lane / kWaveW) / A.beam_tile) * beams_per_side + (ix - lane % kWaveW) / A.beam_tile;
-            }
             if (global_tile >= A.tiles_total) {                        // whole workgroup: padding tile of the last round
                 write_miss(Sink{A.out ? A.out + out_index : nullptr, A.out_rgba ? A.out_rgba + out_index : nullptr});
                 return;
+            }
+            if (A.beam) {
+                const uint32_t beams_per_side = A.tile / A.beam_tile;
+                t0 = A.beam[(local_tile * beams_per_side + ((sub / per_side) * kTileH + wave_y) / A.beam_tile) * beams_per_side +
+                            ((sub % per_side) * kTileW + wave_x) / A.beam_tile];
+                if (t0 >= kBeamNone) return;
             }
         }
         const Sink sink{A.out ? A.out + out_index : nullptr, A.out_rgba ? A.out_rgba + out_index : nullptr};
@@ -90,11 +98,7 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const TraceArgs A) {
             return;
         }
         RayIn r = primary_ray(A, x, y);
-        if (A.beam) {                                                   // start parameter of this wave's beam tile (beam.h)
-            const float t0 = A.beam[__builtin_amdgcn_readfirstlane(beam_index)];
-            if (t0 >= kBeamNone) { write_miss(sink); return; }
-            r.tmin = fmaxf(r.tmin, t0);
-        }
+        r.tmin = fmaxf(r.tmin, t0);
         trace_one(A, r, stk, sink);
     }
 }
@@ -106,6 +110,8 @@ __global__ __launch_bounds__(64) void beam_kernel(const TraceArgs A, const uint3
     if (b >= n_beam_tiles) return;
     const uint32_t B = A.beam_tile;
     uint32_t px, py, px_end, py_end;                                   // frame pixels [px, px_end) x [py, py_end)
+    [[maybe_unused]] uint32_t tile_x0 = 0, tile_y0 = 0;                // Tiles: frame origin of the screen tile and its slot
+    [[maybe_unused]] size_t tile_base = 0;                             // in the rank's dense tile buffer
     if constexpr (MODE == RayMode::Rect) {
         px = A.x0 + (b % A.beam_bx) * B; py = A.y0 + (b / A.beam_bx) * B;
         px_end = min(px + B, A.x0 + A.w); py_end = min(py + B, A.y0 + A.h);
@@ -114,11 +120,24 @@ __global__ __launch_bounds__(64) void beam_kernel(const TraceArgs A, const uint3
         const uint32_t local_tile = b / per_tile, sub = b % per_tile;
         const uint32_t global_tile = A.rank + local_tile * A.n_ranks;
         if (global_tile >= A.tiles_total) { if (lane == 0) A.beam[b] = kBeamNone; return; }
-        px = (global_tile % A.tiles_x) * A.tile + (sub % per_side) * B; py = (global_tile / A.tiles_x) * A.tile + (sub / per_side) * B;
+        tile_x0 = (global_tile % A.tiles_x) * A.tile; tile_y0 = (global_tile / A.tiles_x) * A.tile;
+        tile_base = static_cast<size_t>(local_tile) * A.tile * A.tile;
+        px = tile_x0 + (sub % per_side) * B; py = tile_y0 + (sub / per_side) * B;
         px_end = px + B; py_end = py + B;
     }
     const float t0 = beam_start(A, static_cast<float>(px), static_cast<float>(py), static_cast<float>(px_end), static_cast<float>(py_end), lane);
     if (lane == 0) A.beam[b] = t0;
+    if (t0 >= kBeamNone && (A.out || A.out_rgba)) {
+        // no ray of this tile can hit anything: its pixels are written here, 64 at a time, and the tile's trace waves exit at once
+        const uint32_t tw = px_end - px, n = tw * (py_end - py);
+        for (uint32_t i = lane; i < n; i += 64u) {
+            const uint32_t x = px + i % tw, y = py + i / tw;
+            size_t out_index;
+            if constexpr (MODE == RayMode::Rect) out_index = static_cast<size_t>(y - A.y0) * A.w + (x - A.x0);
+            else out_index = tile_base + static_cast<size_t>(y - tile_y0) * A.tile + (x - tile_x0);
+            write_miss(Sink{A.out ? A.out + out_index : nullptr, A.out_rgba ? A.out_rgba + out_index : nullptr});
+        }
+    }
 }
 
 __global__ __launch_bounds__(64) void sun_map_kernel(const SunMapArgs a) {
