@@ -337,3 +337,44 @@ def test_gpu_chain_matches_oracle(gbuffer_frames):
     assert (hl[host["world_pos"][..., 3] < 9000] > 1).mean() > 0.5
     tr.post_reset()
     tr.shutdown()
+
+
+@pytest.mark.gpu
+def test_gpu_explicit_motion_planes_and_settings():
+    """Caller-provided motion planes (denoiser and TAA), non-default settings, 0 and 5 a-trous iterations, an odd frame size:
+    device chain vs oracle on synthetic planes (same tolerance as above)."""
+    import torch
+    from blok_amd.tracer import HipTracer
+    from blok_amd import _ffi
+    w, h = 101, 57
+    rng = np.random.default_rng(11)
+    ident = np.eye(4, dtype=np.float32).reshape(-1)
+    for iters in (0, 5):
+        S = O.OrcDenoiseSettings.default()
+        S.atrousIterations = iters; S.temporalAlpha = 0.15; S.phiColor = 2.0; S.phiDepth = 0.3; S.minHistoryLength = 6; S.varianceBoost = 2.5
+        ps = _ffi.DenoiseSettings(S.temporalAlpha, S.momentAlpha, S.varianceClipGamma, S.depthThreshold, S.normalThreshold, S.phiColor,
+                                  S.phiNormal, S.phiDepth, S.atrousIterations, S.varianceBoost, S.minHistoryLength)
+        tr = HipTracer(w, h).init()
+        o = O.OracleDenoiser(w, h, S)
+        for k in range(3):
+            color = rng.uniform(0, 2, (h, w, 4)).astype(np.float32)
+            wp = np.zeros((h, w, 4), np.float32)
+            ys, xs = np.mgrid[0:h, 0:w]
+            wp[..., 0] = xs * 0.05; wp[..., 2] = ys * 0.05; wp[..., 3] = np.where(ys < 6, 10000.0, 30.0 + 0.01 * xs)
+            nr = np.zeros((h, w, 4), np.float32); nr[..., 1] = 1.0; nr[:, w // 2:, :3] = (0.6, 0.8, 0.0); nr[..., 3] = 0.37
+            motion = rng.normal(0, 0.004, (h, w, 2)).astype(np.float32)
+            dev = [torch.from_numpy(a).cuda() for a in (color, wp, nr, motion)]
+            den = torch.zeros((h * w, 4), dtype=torch.float32, device="cuda"); res = torch.zeros_like(den)
+            tr.denoise_device(dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(), ident, k, den.data_ptr(), motion_ptr=dev[3].data_ptr(), settings=ps)
+            tr.taa_device(den.data_ptr(), res.data_ptr(), k, 0.8, 0.95, motion_ptr=dev[3].data_ptr())
+            torch.cuda.synchronize()
+            ref = o.denoise(color, wp, nr, ident, k, motion=motion)
+            ref_res = o.taa(ref, k, 0.8, 0.95, motion=motion)
+            for got, want, what in ((den.cpu().numpy().reshape(h, w, 4), ref, "denoised"), (res.cpu().numpy().reshape(h, w, 4), ref_res, "resolved")):
+                ok = (np.abs(got - want) <= 1e-5 + 1e-4 * np.abs(want)).all(axis=2)
+                assert ok.mean() >= 0.999, (iters, k, what, ok.mean())
+            hist, mom, hl, var, mot = tr.denoise_state()
+            assert np.array_equal(mot, np.vectorize(O.q16)(motion).astype(np.float32))
+            assert (hl == o.prev["hist_len"]).mean() >= 0.999
+        assert (hl > 1).mean() > 0.3                       # small motion: most of the surface keeps its history
+        tr.shutdown()
