@@ -80,11 +80,16 @@ def cpu_baseline(packed, cam, width, height, stride, min_seconds=1.0):
         if time.perf_counter() - t0 >= min_seconds or frames >= 64:
             break
     dt = time.perf_counter() - t0
+    single = None
+    if min_seconds > 0.0:                         # one-thread rate on a strided sample of the same frame
+        t1 = time.perf_counter()
+        _, c1 = lattice.trace_primary(cam, width, height, stride=4, threads=1, want_hits=False)
+        single = int(c1["rays"]) / (time.perf_counter() - t1) / 1e6
     ctr = totals
     rays = int(ctr["rays"])
     alg_bytes = 48 * int(ctr["sub_chunks_entered"]) + 16 * int(ctr["nodes_fetched"]) + 32 * int(ctr["hits"]) + 16 * rays
     return {
-        "value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+        "value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port", "single_thread_value": single,
         "sample": f"{frames} pass(es) over every {stride}th pixel in x and y of the {width}x{height} frame "
                   f"({rays} rays, {dt:.2f} s wall on {threads} threads = {dt * threads:.0f} core-seconds)",
     }, {
