@@ -231,6 +231,7 @@ int prepare_beam(blok_hip_ctx* ctx, blok::RayMode mode, blok::TraceArgs& args, h
     if (mode == blok::RayMode::Rays || !ctx->beam_tile) return BLOK_OK;
     args.beam_tile = ctx->beam_tile;
     if (mode == blok::RayMode::Tiles && args.tile % args.beam_tile) args.beam_tile = 16;   // tiles are multiples of 16
+    if (args.beam_tile % blok::kWaveW || args.beam_tile % blok::kWaveH) { args.beam_tile = 0; return BLOK_OK; }   // a wave must not straddle beam tiles (non-default footprints)
     args.beam_bx = (args.w + args.beam_tile - 1u) / args.beam_tile;
     *n_beams = blok::beam_tiles(mode, args, tiles_of_rank);
     return beam_buffer(ctx, stream, *n_beams, &args.beam);
