@@ -62,18 +62,27 @@ __device__ __forceinline__ float beam_search(const TraceArgs& A, BeamVec ref, Be
     const uint32_t mirror = beam_uniform((mid.x < 0.0f ? 0x03u : 0u) | (mid.y < 0.0f ? 0x0Cu : 0u) | (mid.z < 0.0f ? 0x30u : 0u));
     const uint32_t child = lane ^ mirror;
     const float cx = static_cast<float>(child & 3u), cy = static_cast<float>((child >> 2) & 3u), cz = static_cast<float>(child >> 4);
-    // per lane: plane value of the child's far (side planes) / near (depth) corner, in units of the child size
-    auto far_corner = [&](BeamVec n) { return beam_dot(n, cx + (n.x > 0.0f ? 1.0f : 0.0f), cy + (n.y > 0.0f ? 1.0f : 0.0f), cz + (n.z > 0.0f ? 1.0f : 0.0f)); };
-    const float b0 = far_corner(n0), b1 = far_corner(n1), b2 = far_corner(n2), b3 = far_corner(n3);
-    const float b4 = beam_dot(mid, cx + (mid.x < 0.0f ? 1.0f : 0.0f), cy + (mid.y < 0.0f ? 1.0f : 0.0f), cz + (mid.z < 0.0f ? 1.0f : 0.0f));
+    // Plane values are carried down the tree instead of being recomputed from coordinates: p_k is the value of plane k at the
+    // current node's min corner (wave-uniform), a_k the per-lane step to a child's min corner in units of the child size, so a
+    // child's value is g_k = p_k + s a_k, the value at its farthest (side planes) / nearest (depth) corner g_k + s far_k, and
+    // descending into child j is p_k <- readlane(g_k, j).  The drift over <= 7 levels is a few ulp of the coordinate
+    // magnitude (<= 1e-2 voxel at 16384^3), far inside kBeamSlack and the depth margin.
+    const float a0 = beam_dot(n0, cx, cy, cz), a1 = beam_dot(n1, cx, cy, cz), a2 = beam_dot(n2, cx, cy, cz), a3 = beam_dot(n3, cx, cy, cz);
+    const float a4 = beam_dot(mid, cx, cy, cz);
+    auto far_of = [](BeamVec n) { return (n.x > 0.0f ? n.x : 0.0f) + (n.y > 0.0f ? n.y : 0.0f) + (n.z > 0.0f ? n.z : 0.0f); };
+    const float far0 = far_of(n0), far1 = far_of(n1), far2 = far_of(n2), far3 = far_of(n3);
+    const float near4 = (mid.x < 0.0f ? mid.x : 0.0f) + (mid.y < 0.0f ? mid.y : 0.0f) + (mid.z < 0.0f ? mid.z : 0.0f);
     const bool child_hi = child >= 32u;
     const uint32_t child_bit = 1u << (child & 31u);
 
     const uint32_t root_level = A.levels;
     uint32_t level = root_level, node = 0;
-    int mx = 0, my = 0, mz = 0;                        // min corner of `node`, tree coordinates
+    const float ox = static_cast<float>(A.origin[0]) - ref.x, oy = static_cast<float>(A.origin[1]) - ref.y, oz = static_cast<float>(A.origin[2]) - ref.z;
+    float p0 = beam_dot(n0, ox, oy, oz) + c0, p1 = beam_dot(n1, ox, oy, oz) + c1, p2 = beam_dot(n2, ox, oy, oz) + c2, p3 = beam_dot(n3, ox, oy, oz) + c3;
+    float p4 = beam_dot(mid, ox, oy, oz);
     float best = kBeamNone;
     uint32_t stk_node = 0, stk_lo = 0, stk_hi = 0;     // lane l holds the entry of level l
+    float stk_p0 = 0.0f, stk_p1 = 0.0f, stk_p2 = 0.0f, stk_p3 = 0.0f, stk_p4 = 0.0f;
     bool fresh = true;
     uint64_t cand = 0;
     // every wave reaches the exit: the search is a finite tree walk, and a visit budget bounds it even for a frustum whose
@@ -84,20 +93,20 @@ __device__ __forceinline__ float beam_search(const TraceArgs& A, BeamVec ref, Be
         const uint32_t mlo = beam_uniform(rec.x), mhi = beam_uniform(rec.y), base = beam_uniform(rec.z);
         const uint32_t shift = 2u * (level - 1u);
         const float s = static_cast<float>(1u << shift);
-        const float rx = static_cast<float>(A.origin[0] + mx) - ref.x;
-        const float ry = static_cast<float>(A.origin[1] + my) - ref.y;
-        const float rz = static_cast<float>(A.origin[2] + mz) - ref.z;
-        const float depth = __builtin_fmaf(s, b4, beam_dot(mid, rx, ry, rz));         // lower bound of the child's depth
+        const float g4 = __builtin_fmaf(s, a4, p4);
+        const float depth = __builtin_fmaf(s, near4, g4);                              // lower bound of the child's depth
         const bool nearer = !(depth >= best);
+        float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f, g3 = 0.0f;
         if (fresh) {
-            const bool outside = (__builtin_fmaf(s, b0, beam_dot(n0, rx, ry, rz)) + c0 < -kBeamSlack) | (__builtin_fmaf(s, b1, beam_dot(n1, rx, ry, rz)) + c1 < -kBeamSlack) |
-                                 (__builtin_fmaf(s, b2, beam_dot(n2, rx, ry, rz)) + c2 < -kBeamSlack) | (__builtin_fmaf(s, b3, beam_dot(n3, rx, ry, rz)) + c3 < -kBeamSlack);
+            g0 = __builtin_fmaf(s, a0, p0); g1 = __builtin_fmaf(s, a1, p1); g2 = __builtin_fmaf(s, a2, p2); g3 = __builtin_fmaf(s, a3, p3);
+            const bool outside = (__builtin_fmaf(s, far0, g0) < -kBeamSlack) | (__builtin_fmaf(s, far1, g1) < -kBeamSlack) |
+                                 (__builtin_fmaf(s, far2, g2) < -kBeamSlack) | (__builtin_fmaf(s, far3, g3) < -kBeamSlack);
             const bool filled = ((child_hi ? mhi : mlo) & child_bit) != 0u;
             cand = __ballot(filled && !outside && nearer);
             if (level <= BLOK_BEAM_STOP_LEVEL) {
                 while (cand) {
                     const uint32_t j = static_cast<uint32_t>(__builtin_ctzll(cand));
-                    const float dj = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(depth), j));
+                    const float dj = beam_lane(depth, j);
                     if (kClampAtZero) best = dj >= 0.0f ? fminf(best, dj) : 0.0f;      // negative or NaN: start at the ray origin
                     else best = dj == dj ? fminf(best, dj) : -kBeamNone;               // NaN: the most conservative answer
                     cand &= cand - 1u;
@@ -113,19 +122,25 @@ __device__ __forceinline__ float beam_search(const TraceArgs& A, BeamVec ref, Be
             node = __builtin_amdgcn_readlane(stk_node, level);
             cand = static_cast<uint64_t>(__builtin_amdgcn_readlane(stk_lo, level)) |
                    (static_cast<uint64_t>(__builtin_amdgcn_readlane(stk_hi, level)) << 32);
-            const int keep = ~((1 << (2u * level)) - 1);
-            mx &= keep; my &= keep; mz &= keep;
+            p0 = beam_lane(stk_p0, level); p1 = beam_lane(stk_p1, level); p2 = beam_lane(stk_p2, level); p3 = beam_lane(stk_p3, level);
+            p4 = beam_lane(stk_p4, level);
             fresh = false;
             continue;
         }
         const uint32_t j = static_cast<uint32_t>(__builtin_ctzll(cand));
         cand &= cand - 1u;
-        if (lane == level) { stk_node = node; stk_lo = static_cast<uint32_t>(cand); stk_hi = static_cast<uint32_t>(cand >> 32); }
+        if (lane == level) {
+            stk_node = node; stk_lo = static_cast<uint32_t>(cand); stk_hi = static_cast<uint32_t>(cand >> 32);
+            stk_p0 = p0; stk_p1 = p1; stk_p2 = p2; stk_p3 = p3; stk_p4 = p4;
+        }
         const uint32_t cj = j ^ mirror;
         const uint32_t below_lo = cj < 32u ? (mlo & ((1u << cj) - 1u)) : mlo;
         const uint32_t below_hi = cj < 32u ? 0u : (mhi & ((1u << (cj & 31u)) - 1u));
         node = base + __builtin_popcount(below_lo) + __builtin_popcount(below_hi);
-        mx += static_cast<int>(cj & 3u) << shift; my += static_cast<int>((cj >> 2) & 3u) << shift; mz += static_cast<int>(cj >> 4) << shift;
+        if (!fresh) {                                                                  // revisited node: the side values were not formed
+            g0 = __builtin_fmaf(s, a0, p0); g1 = __builtin_fmaf(s, a1, p1); g2 = __builtin_fmaf(s, a2, p2); g3 = __builtin_fmaf(s, a3, p3);
+        }
+        p0 = beam_lane(g0, j); p1 = beam_lane(g1, j); p2 = beam_lane(g2, j); p3 = beam_lane(g3, j); p4 = beam_lane(g4, j);
         --level;
         fresh = true;
     }
