@@ -57,7 +57,7 @@ __device__ __forceinline__ BeamVec beam_lane(BeamVec v, uint32_t lane) { return 
 // or kBeamNone.  Must be called by all 64 lanes of the wave.
 template <bool kClampAtZero>
 __device__ __forceinline__ float beam_search(const TraceArgs& A, BeamVec ref, BeamVec n0, BeamVec n1, BeamVec n2, BeamVec n3,
-                                             float c0, float c1, float c2, float c3, BeamVec mid, uint32_t lane) {
+                                             float c0, float c1, float c2, float c3, BeamVec mid, uint32_t lane, float initial_best = kBeamNone) {
     // lanes are children in front-to-back order for the central direction: mirrored child index
     const uint32_t mirror = beam_uniform((mid.x < 0.0f ? 0x03u : 0u) | (mid.y < 0.0f ? 0x0Cu : 0u) | (mid.z < 0.0f ? 0x30u : 0u));
     const uint32_t child = lane ^ mirror;
@@ -80,7 +80,7 @@ __device__ __forceinline__ float beam_search(const TraceArgs& A, BeamVec ref, Be
     const float ox = static_cast<float>(A.origin[0]) - ref.x, oy = static_cast<float>(A.origin[1]) - ref.y, oz = static_cast<float>(A.origin[2]) - ref.z;
     float p0 = beam_dot(n0, ox, oy, oz) + c0, p1 = beam_dot(n1, ox, oy, oz) + c1, p2 = beam_dot(n2, ox, oy, oz) + c2, p3 = beam_dot(n3, ox, oy, oz) + c3;
     float p4 = beam_dot(mid, ox, oy, oz);
-    float best = kBeamNone;
+    float best = initial_best;                         // cells not nearer than this are never visited
     uint32_t stk_node = 0, stk_lo = 0, stk_hi = 0;     // lane l holds the entry of level l
     float stk_p0 = 0.0f, stk_p1 = 0.0f, stk_p2 = 0.0f, stk_p3 = 0.0f, stk_p4 = 0.0f;
     bool fresh = true;
@@ -150,7 +150,10 @@ __device__ __forceinline__ float beam_search(const TraceArgs& A, BeamVec ref, Be
 
 // Pixel rectangle [px_lo, px_hi] x [py_lo, py_hi] in continuous pixel coordinates of the frame (pixel x covers
 // [x, x+1]).  Must be called by all 64 lanes of the wave.  Returns kBeamNone or a start parameter >= 0.
-__device__ __forceinline__ float beam_start(const TraceArgs& A, float px_lo, float py_lo, float px_hi, float py_hi, uint32_t lane) {
+// depth_limit: only voxels nearer than this (along the tile's central direction) are looked for; when none is found the
+// answer is the limit itself (everything the rays can report lies at or beyond it) instead of kBeamNone.
+__device__ __forceinline__ float beam_start(const TraceArgs& A, float px_lo, float py_lo, float px_hi, float py_hi, uint32_t lane,
+                                            float depth_limit = kBeamNone) {
     const float inv_w = __builtin_amdgcn_rcpf(static_cast<float>(A.frame_w)), inv_h = __builtin_amdgcn_rcpf(static_cast<float>(A.frame_h));
     const BeamVec mid = beam_unit(beam_dir(A.cam, 0.5f * (px_lo + px_hi), 0.5f * (py_lo + py_hi), inv_w, inv_h));
     // lane k < 4 builds side plane k through corners k and k+1 of the grown rectangle (corner i: x high for i = 1, 2;
@@ -162,7 +165,7 @@ __device__ __forceinline__ float beam_start(const TraceArgs& A, float px_lo, flo
     if (beam_dot(side, mid.x, mid.y, mid.z) < 0.0f) side = {-side.x, -side.y, -side.z};
     const BeamVec n0 = beam_lane(side, 0), n1 = beam_lane(side, 1), n2 = beam_lane(side, 2), n3 = beam_lane(side, 3);
 
-    const float best = beam_search<true>(A, {A.cam.pos[0], A.cam.pos[1], A.cam.pos[2]}, n0, n1, n2, n3, 0.0f, 0.0f, 0.0f, 0.0f, mid, lane);
+    const float best = beam_search<true>(A, {A.cam.pos[0], A.cam.pos[1], A.cam.pos[2]}, n0, n1, n2, n3, 0.0f, 0.0f, 0.0f, 0.0f, mid, lane, depth_limit);
     if (best >= kBeamNone) return kBeamNone;
     return fmaxf(best * (1.0f - 1.0e-4f) - 2.0f * kBeamSlack, 0.0f);
 }
