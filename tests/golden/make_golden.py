@@ -7,6 +7,9 @@
   oracle/_ref/libref_morton.so; needs /root/reference).  These are true reference vectors.
 * svo_builder.json       — per-chunk node-array digests of the oracle's SvoTree/ChunkManager restatement for
   seeded voxel sets ("parity unpinned": the reference's svo.cpp cannot be compiled here, it needs glm).
+* post_chain.json        — SHA-256 of the oracle's path-traced planes and of every output of its image-space chain (denoised,
+  TAA-resolved, tonemapped + sharpened RGBA8) over a five-frame moving-camera sequence at 96x64 ("parity unpinned": a
+  regression pin of the restatement, generated with this image's libm).
 * first_hit_64.npz       — oracle first-hit records, 64^3 scene, 256x256 (BASELINE.json configs[0]): a 64x64
   centre crop of each pose + SHA-256 of the full buffers.
 The fixtures are data (inputs + expected outputs); no reference source text is stored.
@@ -88,8 +91,39 @@ def first_hit():
     (OUT / "first_hit_64.json").write_text(json.dumps({"scene": "G(64, 0xB10C0001)", "frame": [w, h], "crop": [96, 96, 64, 64], **meta}, indent=1))
 
 
+def post_chain_sequence():
+    """The sequence tests/test_post.py uses: (planes, prev view-proj) per frame, oracle outputs per frame."""
+    from tests.test_post import Wd, Ht, camera_path
+    cm = W.ChunkManager(128, 1.0)
+    cm.generate_scene(64, SEED)
+    cm.rebuild_dirty_chunks()
+    mats = W.scene_materials(SEED)
+    pw = cm.pack_chunks_to_gpu_svo(mats)
+    lat = O.Lattice(pw.nodes, pw.sub_chunks)
+    cams = camera_path(5)
+    o = O.OracleDenoiser(Wd, Ht)
+    digest = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    frames = []
+    for k, cam in enumerate(cams):
+        planes, _ = O.render_paths(lat, mats, cam, Wd, Ht, spp=1, max_bounces=2, frame_index=k, threads=8)
+        prev = W.view_proj_from_camera(cams[max(k - 1, 0)])
+        den = o.denoise(planes["color"], planes["world_pos"], planes["normal_roughness"], prev, k)
+        res = o.taa(den, k)
+        final = O.sharpen(O.tonemap(res).reshape(Ht, Wd))
+        frames.append({"frame": k, "color": digest(planes["color"]), "world_pos": digest(planes["world_pos"]),
+                       "normal_roughness": digest(planes["normal_roughness"]), "denoised": digest(den), "resolved": digest(res),
+                       "history_length": digest(o.prev["hist_len"]), "variance": digest(o.variance), "final_rgba8": digest(final)})
+    return frames
+
+
+def post_chain():
+    from tests.test_post import Wd, Ht
+    (OUT / "post_chain.json").write_text(json.dumps({"width": Wd, "height": Ht, "scene": "G(64, 0xB10C0001)", "frames": post_chain_sequence()}, indent=1))
+
+
 if __name__ == "__main__":
     morton()
     svo_builder()
     first_hit()
+    post_chain()
     print("golden fixtures written to", OUT)

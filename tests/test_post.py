@@ -218,6 +218,16 @@ def test_product_on_cpu_equals_oracle_over_a_sequence(gbuffer_frames):
     assert lap(a[..., :3]) < 0.8 * lap(noisy)            # (at 96x64 most of the remaining variation is voxel-face detail)
 
 
+def test_oracle_chain_matches_committed_digests():
+    """Regression pin of the restatement (tests/golden/post_chain.json, made by tests/golden/make_golden.py)."""
+    import json
+    from pathlib import Path
+    from tests.golden.make_golden import post_chain_sequence
+    want = json.loads((Path(__file__).parent / "golden" / "post_chain.json").read_text())
+    assert (want["width"], want["height"]) == (Wd, Ht)
+    assert post_chain_sequence() == want["frames"]
+
+
 def test_explicit_motion_plane_and_settings(gbuffer_frames):
     """A caller-provided motion plane replaces the computed one; non-default settings and 0 / 5 iterations."""
     frames, _, _, _ = gbuffer_frames
