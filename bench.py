@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0xB10C0001)
     ap.add_argument("--cpu-stride", type=int, default=1, help="CPU baseline traces every stride-th pixel in x and y")
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="pipeline depth; 0 = 2 for N = 1, 3 for N = 2, else 4 (reference: MAX_FRAMES_IN_FLIGHT = 2). "
+                    help="pipeline depth; 0 = 3 for N <= 2, else 4 (reference: MAX_FRAMES_IN_FLIGHT = 2; at N = 1 three measure +3-4 % over two). "
                          "Measured on one GPU with a rank's tile share (scripts/tile_depth_test.py): a frame-share is a "
                          "beam + trace launch pair whose latency (~130 us alone) far exceeds its work (26-105 us), so "
                          "3-4 frames must be in flight to hide it")
@@ -136,7 +136,7 @@ def main():
     tracer.set_beam(args.beam)
 
     if args.frames_in_flight <= 0:
-        args.frames_in_flight = 2 if world_size == 1 else (3 if world_size == 2 else 4)
+        args.frames_in_flight = 3 if world_size <= 2 else 4
     from blok_amd.multi_gpu import FramePipeline, HipBackend
     stream = torch.cuda.current_stream()
     pipe = FramePipeline(HipBackend(tracer, cam), W_, H_, rank, world_size, dist, tile=args.tile, depth=args.frames_in_flight)

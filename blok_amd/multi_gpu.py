@@ -46,7 +46,7 @@ class HipBackend:
 
 class FramePipeline:
     def __init__(self, backend, width: int, height: int, rank: int = 0, world_size: int = 1, dist=None,
-                 tile: int = 32, device="cuda", depth: int = 2):
+                 tile: int = 32, device="cuda", depth: int = 3):
         import torch
         self.torch = torch
         self.backend, self.width, self.height = backend, width, height
