@@ -10,7 +10,7 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 # one frame in flight: launches do not overlap, so per-kernel durations and counters are those of a launch running alone
 CMD="python3 bench.py --steps $STEPS --warmup 3 --frames-in-flight 1 --no-cpu-baseline --no-paths"
 echo "== kernel trace" && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $CMD > $OUT/trace.log 2>&1 || { echo trace failed; tail -5 $OUT/trace.log; exit 1; }
-echo "== kernel trace, 2 frames in flight (the default bench configuration)" && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace2 -o trace2 -- python3 bench.py --steps $STEPS --warmup 3 --no-cpu-baseline --no-paths > $OUT/trace2.log 2>&1 || echo "trace2 failed"
+echo "== kernel trace, default bench configuration (frames in flight)" && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace2 -o trace2 -- python3 bench.py --steps $STEPS --warmup 3 --no-cpu-baseline --no-paths > $OUT/trace2.log 2>&1 || echo "trace2 failed"
 i=0
 for PMC in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" \
            "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \

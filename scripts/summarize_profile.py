@@ -21,7 +21,7 @@ if stats:
     print(text)
 stats2 = list(src.glob("trace2/**/*kernel_stats.csv"))
 if stats2:
-    (dst / f"{tag}_kernel_stats_2_in_flight.csv").write_text(stats2[0].read_text())
+    (dst / f"{tag}_kernel_stats_pipelined.csv").write_text(stats2[0].read_text())
 trace = list(src.glob("trace/**/*kernel_trace.csv"))
 durations = defaultdict(list)
 if trace:
