@@ -172,21 +172,33 @@ BLOK_DEV void temporal_pixel(const TemporalArgs& T, int cx, int cy) {
         const bool pos_ok = vlength(vsub(world, xyz(pwp))) < 2.0f;                                       // :262-264
         if (depth_ok && normal_ok && pos_ok) {
             // neighbourhood statistics in YCoCg over the 3x3 pixels on the same surface (:120-193)
+            // (the nine taps' planes are fetched before any is used: memory-level parallelism, as in variance_pixel)
+            float tap_depth[9]; V3 tap_normal[9], tap_color[9];
+#if defined(__clang__)
+#pragma unroll
+#endif
+            for (int k = 0; k < 9; ++k) {
+                const size_t s = static_cast<size_t>(clampi(cy + k / 3 - 1, 0, h - 1)) * w + clampi(cx + k % 3 - 1, 0, w - 1);
+                tap_depth[k] = T.world_pos[4 * s + 3];
+                tap_normal[k] = load3(T.normal_roughness, s);
+                tap_color[k] = load3(T.color, s);
+            }
             V3 s1 = vsplat(0.0f), s2 = vsplat(0.0f), lo = vsplat(1e10f), hi = vsplat(-1e10f);
             float wsum = 0.0f;
-            for (int dy = -1; dy <= 1; ++dy)
-                for (int dx = -1; dx <= 1; ++dx) {
-                    const size_t s = static_cast<size_t>(clampi(cy + dy, 0, h - 1)) * w + clampi(cx + dx, 0, w - 1);
-                    const float dd = fabsf(depth - T.world_pos[4 * s + 3]);
-                    const float nd = vdot(normal, load3q(T.normal_roughness, s));
-                    const float wgt = (dd < (depth * 0.02f + 0.1f) ? 1.0f : 0.0f) * (nd > 0.9f ? 1.0f : 0.0f);
-                    if (wgt > 0.0f) {
-                        const V3 c = to_ycocg(load3(T.color, s));
-                        s1 = vadd(s1, vscale(c, wgt)); s2 = vadd(s2, vscale(vmul(c, c), wgt));
-                        lo = vmin3(lo, c); hi = vmax3(hi, c);
-                        wsum += wgt;
-                    }
+#if defined(__clang__)
+#pragma unroll
+#endif
+            for (int k = 0; k < 9; ++k) {
+                const float dd = fabsf(depth - tap_depth[k]);
+                const float nd = vdot(normal, v3(q16(tap_normal[k].x), q16(tap_normal[k].y), q16(tap_normal[k].z)));
+                const float wgt = (dd < (depth * 0.02f + 0.1f) ? 1.0f : 0.0f) * (nd > 0.9f ? 1.0f : 0.0f);
+                if (wgt > 0.0f) {
+                    const V3 c = to_ycocg(tap_color[k]);
+                    s1 = vadd(s1, vscale(c, wgt)); s2 = vadd(s2, vscale(vmul(c, c), wgt));
+                    lo = vmin3(lo, c); hi = vmax3(hi, c);
+                    wsum += wgt;
                 }
+            }
             V3 mean, sd;
             if (wsum > 0.0f) {
                 mean = vdivs(s1, wsum);
