@@ -75,3 +75,17 @@ def test_product_does_not_link_or_import_the_oracle():
     for so in (_ffi.HIP_LIB, _ffi.HOST_LIB):
         out = subprocess.run(["ldd", str(so)], capture_output=True, text=True).stdout
         assert "oracle" not in out
+
+
+def test_headers_compile_as_c11_and_the_mirror_as_cxx20(tmp_path):
+    """The boundary is a C ABI: both headers must be consumable from plain C (the reference-side binding could be C, cgo, JNI ...)."""
+    import subprocess
+    src = tmp_path / "abi.c"
+    src.write_text('#include "blok_hip.h"\n#include "blok_world.h"\nint main(void) { return (int)sizeof(blok_hit) - 16; }\n')
+    r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-pedantic", "-Werror", f"-I{ROOT / 'include'}", "-fsyntax-only", str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    cxx = tmp_path / "mirror.cpp"
+    cxx.write_text("#include <blok/hip_tracer.hpp>\nint main() { return 0; }\n")
+    r = subprocess.run(["g++", "-std=c++20", "-Wall", "-Wextra", f"-I{ROOT / 'include'}", "-fsyntax-only", str(cxx)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
