@@ -1,82 +1,8 @@
 // C ABI of the gfx950 backend (include/blok_hip.h).  Owns device memory; every HIP call is checked.
-#include <hip/hip_runtime.h>
+#include "api_internal.h"
 
-#include <cmath>
-#include <unordered_map>
-#include <utility>
-#include <cstdio>
-#include <cstring>
-#include <new>
-#include <string>
-#include <vector>
+namespace blok_api {
 
-#include "blok_hip.h"
-#include "gpu_build.h"
-#include <hip/hip_fp16.h>
-#include "post_kernels.h"
-#include "post_core.h"
-#include "reference_world.h"
-#include "trace_kernels.h"
-#include "path_args.h"
-#include "tree.h"
-
-struct blok_hip_ctx {
-    int device = 0;
-    uint32_t width = 0, height = 0;
-    // derived structure in HBM
-    uint4* d_nodes = nullptr;
-    uint32_t* d_tree_materials = nullptr;
-    blok_material* d_materials = nullptr;
-    size_t n_materials = 0;
-    bool has_world = false;
-    bool built_on_device = false;     // structure built by gpu_build.hip (else tree_build.cpp on the host)
-    bool force_host_build = false;
-    blok_world_stats stats{};
-    // scratch frame for the host-output entry points
-    blok_hit* d_frame = nullptr;
-    size_t frame_capacity = 0;
-    // progressive accumulation (CudaTracer::m_dAccum / m_frameIndex / m_prevCam, reference cuda_tracer.hpp:51-55)
-    float* d_accum = nullptr;
-    float* d_color = nullptr;
-    size_t accum_pixels = 0;
-    uint32_t accum_frames = 0;
-    blok_camera prev_cam{};
-    bool has_prev_cam = false;
-    // image-space chain (post_core.h): history ping-pong [2] and per-frame planes, all width x height
-    struct Post {
-        size_t pixels = 0;
-        float *hist_color[2] = {nullptr, nullptr}, *moments[2] = {nullptr, nullptr}, *world_pos[2] = {nullptr, nullptr};
-        uint16_t* hist_len[2] = {nullptr, nullptr};
-        float* unit_normals[2] = {nullptr, nullptr};   // float4: normalize(binary16 normal)
-        uint16_t* motion = nullptr;          // half2
-        float *variance = nullptr, *ping = nullptr, *pong = nullptr, *taa_hist[2] = {nullptr, nullptr};
-        float* widen = nullptr;              // scratch for state downloads
-        int cur = 0, taa_cur = 0;
-        bool has_motion = false, taa_has_history = false;
-        // blok_hip_draw_frame_rt: the frame's own planes and its camera history
-        float *rt_planes[4] = {nullptr, nullptr, nullptr, nullptr}, *rt_denoised = nullptr, *rt_resolved = nullptr;
-        uint32_t *rt_ldr = nullptr, *rt_final = nullptr;
-        uint32_t rt_frame = 0;
-        blok_camera rt_prev_cam{};
-    } post;
-    // device-resident dense store (gpu_build.h: GpuVolume)
-    blok::GpuVolume volume;
-    bool has_volume = false;
-    // "last occluder" map of the shadow rays (beam.h: prism_far), rebuilt with every world
-    float* d_sun_map = nullptr;
-    bool sun_map_enabled = true, has_sun_map = false;
-    blok::SunMapArgs sun{};
-    // beam pre-pass (beam.h): start parameters per beam tile, one buffer per stream (launches on one stream are
-    // ordered, frames in flight on different streams must not share)
-    uint32_t beam_tile = 32;
-    std::unordered_map<hipStream_t, std::pair<float*, size_t>> beam_buffers;
-    // timing
-    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
-    bool timing = false, timed = false;
-    std::string error;
-};
-
-namespace {
 
 thread_local std::string g_create_error;
 
@@ -85,13 +11,6 @@ int set_error(blok_hip_ctx* ctx, int status, const std::string& msg) {
     return status;
 }
 
-#define BLOK_HIP_TRY(ctx, call)                                                                    \
-    do {                                                                                           \
-        hipError_t e_ = (call);                                                                    \
-        if (e_ != hipSuccess)                                                                      \
-            return set_error(ctx, e_ == hipErrorOutOfMemory ? BLOK_ERR_OOM : BLOK_ERR_HIP,         \
-                             std::string(#call) + ": " + hipGetErrorString(e_));                   \
-    } while (0)
 
 void free_post(blok_hip_ctx* ctx) {
     auto& P = ctx->post;
@@ -124,7 +43,6 @@ int install_materials(blok_hip_ctx* ctx, const blok_material* materials, size_t 
     return BLOK_OK;
 }
 
-int rebuild_sun_map(blok_hip_ctx* ctx);
 
 int install_tree(blok_hip_ctx* ctx, const blok::HostTree& tree, const blok_material* materials, size_t n_materials) {
     free_world(ctx);
@@ -264,7 +182,9 @@ int check_trace(blok_hip_ctx* ctx, const blok_camera* cam) {
     return BLOK_OK;
 }
 
-}  // namespace
+}  // namespace blok_api
+
+using namespace blok_api;
 
 extern "C" {
 
@@ -695,335 +615,6 @@ int blok_hip_accum_download(blok_hip_ctx* ctx, float* out_rgba32f_host) {
     BLOK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     BLOK_HIP_TRY(ctx, hipMemcpy(out_rgba32f_host, ctx->d_accum, ctx->accum_pixels * 4 * sizeof(float), hipMemcpyDeviceToHost));
     return BLOK_OK;
-}
-
-// ---- image-space chain ------------------------------------------------------------------------------------------------
-namespace {
-int post_alloc_bytes(blok_hip_ctx* ctx, void** p, size_t bytes) {
-    BLOK_HIP_TRY(ctx, hipMalloc(p, bytes));
-    BLOK_HIP_TRY(ctx, hipMemset(*p, 0, bytes));
-    return BLOK_OK;
-}
-#define post_alloc(ctx, pp, count) post_alloc_bytes((ctx), reinterpret_cast<void**>(pp), (count) * sizeof(**(pp)))
-int ensure_post(blok_hip_ctx* ctx) {
-    const size_t n = static_cast<size_t>(ctx->width) * ctx->height;
-    auto& P = ctx->post;
-    if (P.pixels == n) return BLOK_OK;
-    free_post(ctx);
-    int rc = BLOK_OK;
-    for (int k = 0; k < 2 && rc == BLOK_OK; ++k) {
-        rc = post_alloc(ctx, &P.hist_color[k], 4 * n);
-        if (rc == BLOK_OK) rc = post_alloc(ctx, &P.moments[k], 2 * n);
-        if (rc == BLOK_OK) rc = post_alloc(ctx, &P.world_pos[k], 4 * n);
-        if (rc == BLOK_OK) rc = post_alloc(ctx, &P.hist_len[k], n);
-        if (rc == BLOK_OK) rc = post_alloc(ctx, &P.unit_normals[k], 4 * n);
-        if (rc == BLOK_OK) rc = post_alloc(ctx, &P.taa_hist[k], 4 * n);
-    }
-    if (rc == BLOK_OK) rc = post_alloc(ctx, &P.motion, 2 * n);
-    if (rc == BLOK_OK) rc = post_alloc(ctx, &P.variance, n);
-    if (rc == BLOK_OK) rc = post_alloc(ctx, &P.ping, 4 * n);
-    if (rc == BLOK_OK) rc = post_alloc(ctx, &P.pong, 4 * n);
-    if (rc == BLOK_OK) rc = post_alloc(ctx, &P.widen, 2 * n);
-    if (rc != BLOK_OK) { free_post(ctx); return rc; }
-    P.pixels = n;
-    return BLOK_OK;
-}
-blok::DenoiseSettings to_settings(const blok_denoise_settings& s) {
-    blok::DenoiseSettings d;
-    d.temporal_alpha = s.temporal_alpha; d.moment_alpha = s.moment_alpha; d.variance_clip_gamma = s.variance_clip_gamma;
-    d.depth_threshold = s.depth_threshold; d.normal_threshold = s.normal_threshold;
-    d.phi_color = s.phi_color; d.phi_normal = s.phi_normal; d.phi_depth = s.phi_depth;
-    d.atrous_iterations = s.atrous_iterations; d.variance_boost = s.variance_boost; d.min_history_length = s.min_history_length;
-    return d;
-}
-}  // namespace
-
-void blok_denoise_settings_default(blok_denoise_settings* s) {       // renderer_denoising.hpp:49-66
-    if (!s) return;
-    s->temporal_alpha = 0.05f; s->moment_alpha = 0.2f; s->variance_clip_gamma = 1.5f;
-    s->depth_threshold = 0.1f; s->normal_threshold = 0.95f;
-    s->phi_color = 0.5f; s->phi_normal = 128.0f; s->phi_depth = 0.1f;
-    s->atrous_iterations = 4; s->variance_boost = 1.5f; s->min_history_length = 4;
-}
-
-int blok_hip_denoise_device(blok_hip_ctx* ctx, const blok_gbuffer* planes, const float* motion_dev, const float prev_view_proj[16],
-                            uint32_t frame_count, const blok_denoise_settings* settings, float* out_color_dev, void* hip_stream) {
-    if (!ctx) return BLOK_ERR_INVALID_ARG;
-    if (!planes || !planes->color || !planes->world_pos || !planes->normal_roughness || !prev_view_proj || !out_color_dev)
-        return set_error(ctx, BLOK_ERR_INVALID_ARG, "denoise: colour, world position and normal planes, prevViewProj and an output are required");
-    blok_denoise_settings def;
-    blok_denoise_settings_default(&def);
-    const blok_denoise_settings& S = settings ? *settings : def;
-    if (S.atrous_iterations < 0 || S.atrous_iterations > 5) return set_error(ctx, BLOK_ERR_INVALID_ARG, "denoise: 0..5 a-trous iterations");
-    BLOK_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int rc = ensure_post(ctx);
-    if (rc != BLOK_OK) return rc;
-    auto& P = ctx->post;
-    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-    const int cur = P.cur, prev = cur ^ 1;
-    blok::PostFrame f{};
-    f.w = ctx->width; f.h = ctx->height; f.frame_count = frame_count; f.s = to_settings(S);
-    for (int k = 0; k < 16; ++k) f.prev_view_proj[k] = prev_view_proj[k];
-
-    blok::TemporalArgs t{};
-    t.f = f;
-    t.color = planes->color; t.world_pos = planes->world_pos; t.normal_roughness = planes->normal_roughness; t.motion_in = motion_dev;
-    t.prev_color = P.hist_color[prev]; t.prev_moments = P.moments[prev]; t.prev_world_pos = P.world_pos[prev];
-    t.prev_hist_len = P.hist_len[prev]; t.prev_unit_normals = P.unit_normals[prev];
-    t.out_color = P.hist_color[cur]; t.out_moments = P.moments[cur]; t.hist_world_pos = P.world_pos[cur];
-    t.out_hist_len = P.hist_len[cur]; t.unit_normals = P.unit_normals[cur]; t.motion = P.motion;
-    blok::launch_temporal(t, stream);
-
-    blok::VarianceArgs v{};
-    v.f = f;
-    v.color = P.hist_color[cur]; v.moments = P.moments[cur]; v.world_pos = P.world_pos[cur];
-    v.hist_len = P.hist_len[cur]; v.unit_normals = P.unit_normals[cur]; v.variance = P.variance;
-    blok::launch_variance(v, stream);
-
-    // iteration 0 reads the temporal output; then ping <-> pong (renderer_denoising.cpp:520-536); the last one writes the caller's plane
-    const float* in = P.hist_color[cur];
-    for (int it = 0; it < S.atrous_iterations; ++it) {
-        blok::AtrousArgs a{};
-        a.w = f.w; a.h = f.h; a.step = 1 << it; a.phi_color = S.phi_color; a.phi_depth = S.phi_depth;
-        a.color = in; a.variance = P.variance; a.world_pos = P.world_pos[cur]; a.unit_normals = P.unit_normals[cur];
-        a.out = it == S.atrous_iterations - 1 ? out_color_dev : ((it & 1) ? P.pong : P.ping);
-        blok::launch_atrous(a, stream);
-        in = a.out;
-    }
-    if (S.atrous_iterations == 0)
-        BLOK_HIP_TRY(ctx, hipMemcpyAsync(out_color_dev, P.hist_color[cur], P.pixels * 4 * sizeof(float), hipMemcpyDeviceToDevice, stream));
-    BLOK_HIP_TRY(ctx, hipGetLastError());
-    P.cur = prev;                                          // swapHistoryBuffers
-    P.has_motion = true;
-    return BLOK_OK;
-}
-
-int blok_hip_denoise_state(blok_hip_ctx* ctx, float* history_color, float* moments, float* history_length, float* variance, float* motion) {
-    if (!ctx) return BLOK_ERR_INVALID_ARG;
-    auto& P = ctx->post;
-    if (!P.pixels || !P.has_motion) return set_error(ctx, BLOK_ERR_INVALID_ARG, "no denoised frame yet");
-    BLOK_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    BLOK_HIP_TRY(ctx, hipDeviceSynchronize());
-    const int last = P.cur ^ 1;                            // the slot the last frame wrote
-    const size_t n = P.pixels;
-    if (history_color) BLOK_HIP_TRY(ctx, hipMemcpy(history_color, P.hist_color[last], 4 * n * sizeof(float), hipMemcpyDeviceToHost));
-    if (moments) BLOK_HIP_TRY(ctx, hipMemcpy(moments, P.moments[last], 2 * n * sizeof(float), hipMemcpyDeviceToHost));
-    if (variance) BLOK_HIP_TRY(ctx, hipMemcpy(variance, P.variance, n * sizeof(float), hipMemcpyDeviceToHost));
-    if (history_length) {
-        blok::launch_widen(P.hist_len[last], P.widen, n, nullptr);
-        BLOK_HIP_TRY(ctx, hipMemcpy(history_length, P.widen, n * sizeof(float), hipMemcpyDeviceToHost));
-    }
-    if (motion) {
-        blok::launch_widen(P.motion, P.widen, 2 * n, nullptr);
-        BLOK_HIP_TRY(ctx, hipMemcpy(motion, P.widen, 2 * n * sizeof(float), hipMemcpyDeviceToHost));
-    }
-    return BLOK_OK;
-}
-
-namespace {
-__global__ __launch_bounds__(256) void narrow_motion_kernel(const float* src, uint16_t* dst, size_t n) {
-    const size_t i = static_cast<size_t>(blockIdx.x) * 256u + threadIdx.x;
-    if (i < n) dst[i] = __half_as_ushort(__float2half_rn(src[i]));
-}
-}  // namespace
-
-int blok_hip_taa_device(blok_hip_ctx* ctx, const float* color_dev, const float* motion_dev, float feedback_min, float feedback_max,
-                        uint32_t frame_count, float* out_color_dev, void* hip_stream) {
-    if (!ctx) return BLOK_ERR_INVALID_ARG;
-    if (!color_dev || !out_color_dev) return set_error(ctx, BLOK_ERR_INVALID_ARG, "taa: null plane");
-    BLOK_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int rc = ensure_post(ctx);
-    if (rc != BLOK_OK) return rc;
-    auto& P = ctx->post;
-    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-    if (motion_dev) {
-        const size_t n = 2 * P.pixels;
-        hipLaunchKernelGGL(narrow_motion_kernel, dim3(static_cast<uint32_t>((n + 255) / 256)), dim3(256), 0, stream, motion_dev, P.motion, n);
-        P.has_motion = true;
-    } else if (!P.has_motion) {
-        return set_error(ctx, BLOK_ERR_INVALID_ARG, "taa: no motion vectors (pass a plane or denoise a frame first)");
-    }
-    blok::TaaArgs a{};
-    a.w = ctx->width; a.h = ctx->height; a.frame_count = frame_count; a.feedback_min = feedback_min; a.feedback_max = feedback_max;
-    a.color = color_dev; a.history = P.taa_hist[P.taa_cur ^ 1]; a.motion = P.motion;
-    a.out = out_color_dev; a.out_history = P.taa_hist[P.taa_cur];
-    blok::launch_taa(a, stream);
-    BLOK_HIP_TRY(ctx, hipGetLastError());
-    P.taa_cur ^= 1;
-    return BLOK_OK;
-}
-
-int blok_hip_sharpen_device(blok_hip_ctx* ctx, const uint32_t* rgba8_dev, float strength, uint32_t* out_rgba8_dev, void* hip_stream) {
-    if (!ctx) return BLOK_ERR_INVALID_ARG;
-    if (!rgba8_dev || !out_rgba8_dev || rgba8_dev == out_rgba8_dev) return set_error(ctx, BLOK_ERR_INVALID_ARG, "sharpen: two distinct planes are required");
-    BLOK_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    blok::SharpenArgs a{};
-    a.w = ctx->width; a.h = ctx->height; a.strength = strength; a.in = rgba8_dev; a.out = out_rgba8_dev;
-    blok::launch_sharpen(a, static_cast<hipStream_t>(hip_stream));
-    BLOK_HIP_TRY(ctx, hipGetLastError());
-    return BLOK_OK;
-}
-
-namespace {
-// Column-major prevViewProj of a camera basis: uv = ndc.xy * 0.5 + 0.5 reproduces the basis' own pixel mapping
-// (x + 0.5 = u * width, y + 0.5 = v * height), the role FrameUBO::prevViewProj plays for the reference's shaders.
-void view_proj_of(const blok_camera& c, float M[16]) {
-    const double ta = double(c.tan_half_fov) * double(c.aspect), t = double(c.tan_half_fov);
-    double rows[4][4] = {};
-    for (int a = 0; a < 3; ++a) {
-        rows[0][a] = double(c.right[a]) / ta; rows[0][3] -= double(c.right[a]) * double(c.pos[a]) / ta;
-        rows[1][a] = -double(c.up[a]) / t;    rows[1][3] += double(c.up[a]) * double(c.pos[a]) / t;
-        rows[2][a] = double(c.fwd[a]);        rows[2][3] -= double(c.fwd[a]) * double(c.pos[a]);
-    }
-    for (int a = 0; a < 4; ++a) rows[3][a] = rows[2][a];
-    for (int col = 0; col < 4; ++col) for (int r = 0; r < 4; ++r) M[col * 4 + r] = static_cast<float>(rows[r][col]);
-}
-}  // namespace
-
-void blok_camera_view_proj(const blok_camera* cam, float out_view_proj[16]) { if (cam && out_view_proj) view_proj_of(*cam, out_view_proj); }
-
-int blok_hip_draw_frame_rt(blok_hip_ctx* ctx, const blok_camera* cam, uint32_t spp, uint32_t max_bounces,
-                           const blok_denoise_settings* settings, uint32_t* out_rgba8_host, uint32_t* out_frame_count) {
-    int rc = check_trace(ctx, cam);
-    if (rc != BLOK_OK) return rc;
-    if (!spp || !max_bounces) return set_error(ctx, BLOK_ERR_INVALID_ARG, "spp and bounces must be positive");
-    rc = ensure_post(ctx);
-    if (rc != BLOK_OK) return rc;
-    auto& P = ctx->post;
-    const size_t n = P.pixels;
-    if (!P.rt_final) {
-        for (int k = 0; k < 4 && rc == BLOK_OK; ++k) rc = post_alloc(ctx, &P.rt_planes[k], 4 * n);
-        if (rc == BLOK_OK) rc = post_alloc(ctx, &P.rt_denoised, 4 * n);
-        if (rc == BLOK_OK) rc = post_alloc(ctx, &P.rt_resolved, 4 * n);
-        if (rc == BLOK_OK) rc = post_alloc(ctx, &P.rt_ldr, n);
-        if (rc == BLOK_OK) rc = post_alloc(ctx, &P.rt_final, n);
-        if (rc != BLOK_OK) { free_post(ctx); return rc; }
-        P.rt_frame = 0;
-    }
-    const uint32_t frame = P.rt_frame;
-    float prev_vp[16];
-    view_proj_of(frame ? P.rt_prev_cam : *cam, prev_vp);            // Denoiser::updatePreviousFrameData: last frame's matrices
-    const blok_gbuffer planes{P.rt_planes[0], P.rt_planes[1], P.rt_planes[2], P.rt_planes[3]};
-    rc = blok_hip_trace_paths_device(ctx, cam, 0, 0, ctx->width, ctx->height, spp, max_bounces, frame, &planes, nullptr);
-    if (rc == BLOK_OK) rc = blok_hip_denoise_device(ctx, &planes, nullptr, prev_vp, frame, settings, P.rt_denoised, nullptr);
-    if (rc == BLOK_OK) rc = blok_hip_taa_device(ctx, P.rt_denoised, nullptr, 0.93f, 0.98f, frame, P.rt_resolved, nullptr);       // renderer_postprocess.hpp:104-106
-    if (rc == BLOK_OK) rc = blok_hip_tonemap_device(ctx, P.rt_resolved, static_cast<uint32_t>(n), 1.0f, 1.15f, 1, P.rt_ldr, nullptr);   // :110-113
-    if (rc == BLOK_OK) rc = blok_hip_sharpen_device(ctx, P.rt_ldr, 0.5f, P.rt_final, nullptr);                                     // :117-118
-    if (rc != BLOK_OK) return rc;
-    P.rt_prev_cam = *cam;
-    P.rt_frame = frame + 1;
-    if (out_frame_count) *out_frame_count = P.rt_frame;
-    if (out_rgba8_host) BLOK_HIP_TRY(ctx, hipMemcpy(out_rgba8_host, P.rt_final, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    else BLOK_HIP_TRY(ctx, hipDeviceSynchronize());
-    return BLOK_OK;
-}
-
-int blok_hip_post_reset(blok_hip_ctx* ctx) {
-    if (!ctx) return BLOK_ERR_INVALID_ARG;
-    (void)hipSetDevice(ctx->device);
-    (void)hipDeviceSynchronize();
-    free_post(ctx);
-    return BLOK_OK;
-}
-
-namespace {
-int volume_status(blok_hip_ctx* ctx, blok::GpuBuildStatus st, const std::string& why) {
-    switch (st) {
-        case blok::GpuBuildStatus::Ok: return BLOK_OK;
-        case blok::GpuBuildStatus::Unsupported: return set_error(ctx, BLOK_ERR_UNSUPPORTED, why);
-        case blok::GpuBuildStatus::OutOfMemory: return set_error(ctx, BLOK_ERR_OOM, why);
-        case blok::GpuBuildStatus::HipError: return set_error(ctx, BLOK_ERR_HIP, why);
-        default: return set_error(ctx, BLOK_ERR_INVALID_ARG, why.empty() ? "volume operation not applicable" : why);
-    }
-}
-int need_volume(blok_hip_ctx* ctx) {
-    if (!ctx) return BLOK_ERR_INVALID_ARG;
-    if (!ctx->has_volume) return set_error(ctx, BLOK_ERR_NO_WORLD, "no resident volume (blok_hip_volume_create)");
-    BLOK_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    return BLOK_OK;
-}
-}  // namespace
-
-int blok_hip_volume_create(blok_hip_ctx* ctx, const int32_t origin[3], uint32_t nx, uint32_t ny, uint32_t nz,
-                           uint32_t chunk_size, float voxel_size) {
-    if (!ctx) return BLOK_ERR_INVALID_ARG;
-    BLOK_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (ctx->has_volume) { blok::gpu_volume_destroy(&ctx->volume); ctx->has_volume = false; }
-    const int32_t o[3] = {origin ? origin[0] : 0, origin ? origin[1] : 0, origin ? origin[2] : 0};
-    std::string why;
-    const blok::GpuBuildStatus st = blok::gpu_volume_create(o, nx, ny, nz, chunk_size, voxel_size, &ctx->volume, &why);
-    ctx->has_volume = st == blok::GpuBuildStatus::Ok;
-    return volume_status(ctx, st, why);
-}
-
-int blok_hip_volume_destroy(blok_hip_ctx* ctx) {
-    if (!ctx) return BLOK_ERR_INVALID_ARG;
-    if (ctx->has_volume) { (void)hipSetDevice(ctx->device); blok::gpu_volume_destroy(&ctx->volume); ctx->has_volume = false; }
-    return BLOK_OK;
-}
-
-int blok_hip_volume_upload(blok_hip_ctx* ctx, const float* density, const uint32_t* material_ids) {
-    int rc = need_volume(ctx);
-    if (rc != BLOK_OK) return rc;
-    std::string why;
-    return volume_status(ctx, blok::gpu_volume_upload(&ctx->volume, density, material_ids, &why), why);
-}
-
-int blok_hip_volume_download(blok_hip_ctx* ctx, float* density, uint32_t* material_ids) {
-    int rc = need_volume(ctx);
-    if (rc != BLOK_OK) return rc;
-    std::string why;
-    return volume_status(ctx, blok::gpu_volume_download(&ctx->volume, density, material_ids, &why), why);
-}
-
-int blok_hip_volume_set_voxels(blok_hip_ctx* ctx, const int32_t* xyz, const uint32_t* material_ids, const float* density, size_t n) {
-    int rc = need_volume(ctx);
-    if (rc != BLOK_OK) return rc;
-    if (n && !xyz) return set_error(ctx, BLOK_ERR_INVALID_ARG, "null voxel list");
-    std::string why;
-    return volume_status(ctx, blok::gpu_volume_set_voxels(&ctx->volume, xyz, material_ids, density, n, &why), why);
-}
-
-int blok_hip_volume_apply_brush(blok_hip_ctx* ctx, const float center[3], float radius, float value, int mode) {
-    int rc = need_volume(ctx);
-    if (rc != BLOK_OK) return rc;
-    if (!center || (mode != 0 && mode != 1) || !(radius >= 0.0f)) return set_error(ctx, BLOK_ERR_INVALID_ARG, "bad brush arguments");
-    std::string why;
-    rc = volume_status(ctx, blok::gpu_volume_brush(&ctx->volume, center, radius, value, mode, &why), why);
-    if (rc != BLOK_OK) return rc;
-    BLOK_HIP_TRY(ctx, hipDeviceSynchronize());
-    return BLOK_OK;
-}
-
-int blok_hip_volume_rebuild(blok_hip_ctx* ctx, const blok_material* materials, size_t n_materials) {
-    int rc = need_volume(ctx);
-    if (rc != BLOK_OK) return rc;
-    if (n_materials && !materials) return set_error(ctx, BLOK_ERR_INVALID_ARG, "null material table");
-    BLOK_HIP_TRY(ctx, hipDeviceSynchronize());            // frames still reading the previous tree
-    blok::GpuTree gpu;
-    std::string why;
-    const blok::GpuBuildStatus st = blok::gpu_volume_build(&ctx->volume, &gpu, &why);
-    if (st == blok::GpuBuildStatus::UseHostBuilder) {      // nothing filled: an empty world
-        blok::HostTree tree;
-        std::vector<blok::VoxelRec> none;
-        const char* w = "";
-        if (!blok::build_tree(none, tree, &w)) return set_error(ctx, BLOK_ERR_UNSUPPORTED, w);
-        return install_tree(ctx, tree, materials, n_materials);
-    }
-    if (st != blok::GpuBuildStatus::Ok) return volume_status(ctx, st, why);
-    free_world(ctx);
-    ctx->d_nodes = gpu.d_nodes;
-    ctx->d_tree_materials = gpu.d_materials;
-    rc = install_materials(ctx, materials, n_materials);
-    if (rc != BLOK_OK) { free_world(ctx); return rc; }
-    ctx->stats.n_voxels = gpu.n_voxels;
-    ctx->stats.n_tree_nodes = gpu.n_nodes;
-    ctx->stats.tree_bytes = gpu.n_nodes * sizeof(blok::TreeNode) + gpu.n_voxels * sizeof(uint32_t);
-    ctx->stats.levels = gpu.levels;
-    for (int a = 0; a < 3; ++a) ctx->stats.origin[a] = gpu.origin[a];
-    ctx->has_world = true;
-    ctx->built_on_device = true;
-    return rebuild_sun_map(ctx);
 }
 
 int blok_hip_set_sun_map(blok_hip_ctx* ctx, int enabled) {

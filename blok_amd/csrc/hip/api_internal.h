@@ -1,0 +1,105 @@
+// Internals shared by the translation units of the C ABI (api.hip, api_post.hip, api_volume.hip): the context, the error
+// macro and the helpers defined in api.hip.  Not installed; include/blok_hip.h is the interface.
+#ifndef BLOK_API_INTERNAL_H
+#define BLOK_API_INTERNAL_H
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <unordered_map>
+#include <utility>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "blok_hip.h"
+#include "gpu_build.h"
+#include <hip/hip_fp16.h>
+#include "post_kernels.h"
+#include "post_core.h"
+#include "reference_world.h"
+#include "trace_kernels.h"
+#include "path_args.h"
+#include "tree.h"
+
+struct blok_hip_ctx {
+    int device = 0;
+    uint32_t width = 0, height = 0;
+    // derived structure in HBM
+    uint4* d_nodes = nullptr;
+    uint32_t* d_tree_materials = nullptr;
+    blok_material* d_materials = nullptr;
+    size_t n_materials = 0;
+    bool has_world = false;
+    bool built_on_device = false;     // structure built by gpu_build.hip (else tree_build.cpp on the host)
+    bool force_host_build = false;
+    blok_world_stats stats{};
+    // scratch frame for the host-output entry points
+    blok_hit* d_frame = nullptr;
+    size_t frame_capacity = 0;
+    // progressive accumulation (CudaTracer::m_dAccum / m_frameIndex / m_prevCam, reference cuda_tracer.hpp:51-55)
+    float* d_accum = nullptr;
+    float* d_color = nullptr;
+    size_t accum_pixels = 0;
+    uint32_t accum_frames = 0;
+    blok_camera prev_cam{};
+    bool has_prev_cam = false;
+    // image-space chain (post_core.h): history ping-pong [2] and per-frame planes, all width x height
+    struct Post {
+        size_t pixels = 0;
+        float *hist_color[2] = {nullptr, nullptr}, *moments[2] = {nullptr, nullptr}, *world_pos[2] = {nullptr, nullptr};
+        uint16_t* hist_len[2] = {nullptr, nullptr};
+        float* unit_normals[2] = {nullptr, nullptr};   // float4: normalize(binary16 normal)
+        uint16_t* motion = nullptr;          // half2
+        float *variance = nullptr, *ping = nullptr, *pong = nullptr, *taa_hist[2] = {nullptr, nullptr};
+        float* widen = nullptr;              // scratch for state downloads
+        int cur = 0, taa_cur = 0;
+        bool has_motion = false, taa_has_history = false;
+        // blok_hip_draw_frame_rt: the frame's own planes and its camera history
+        float *rt_planes[4] = {nullptr, nullptr, nullptr, nullptr}, *rt_denoised = nullptr, *rt_resolved = nullptr;
+        uint32_t *rt_ldr = nullptr, *rt_final = nullptr;
+        uint32_t rt_frame = 0;
+        blok_camera rt_prev_cam{};
+    } post;
+    // device-resident dense store (gpu_build.h: GpuVolume)
+    blok::GpuVolume volume;
+    bool has_volume = false;
+    // "last occluder" map of the shadow rays (beam.h: prism_far), rebuilt with every world
+    float* d_sun_map = nullptr;
+    bool sun_map_enabled = true, has_sun_map = false;
+    blok::SunMapArgs sun{};
+    // beam pre-pass (beam.h): start parameters per beam tile, one buffer per stream (launches on one stream are
+    // ordered, frames in flight on different streams must not share)
+    uint32_t beam_tile = 32;
+    std::unordered_map<hipStream_t, std::pair<float*, size_t>> beam_buffers;
+    // timing
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    bool timing = false, timed = false;
+    std::string error;
+};
+
+namespace blok_api {
+
+int set_error(blok_hip_ctx* ctx, int status, const std::string& msg);
+
+#define BLOK_HIP_TRY(ctx, call)                                                                    \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return set_error(ctx, e_ == hipErrorOutOfMemory ? BLOK_ERR_OOM : BLOK_ERR_HIP,         \
+                             std::string(#call) + ": " + hipGetErrorString(e_));                   \
+    } while (0)
+
+void free_post(blok_hip_ctx* ctx);
+void free_world(blok_hip_ctx* ctx);
+int install_materials(blok_hip_ctx* ctx, const blok_material* materials, size_t n_materials);
+int install_tree(blok_hip_ctx* ctx, const blok::HostTree& tree, const blok_material* materials, size_t n_materials);
+int rebuild_sun_map(blok_hip_ctx* ctx);
+int ensure_frame(blok_hip_ctx* ctx, size_t records);
+blok::TraceArgs base_args(const blok_hip_ctx* ctx, const blok_camera* cam);
+int prepare_beam(blok_hip_ctx* ctx, blok::RayMode mode, blok::TraceArgs& args, hipStream_t stream, uint32_t tiles_of_rank, uint32_t* n_beams);
+int check_trace(blok_hip_ctx* ctx, const blok_camera* cam);
+
+}  // namespace blok_api
+#endif
