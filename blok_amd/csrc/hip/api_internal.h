@@ -55,7 +55,7 @@ struct blok_hip_ctx {
         float *variance = nullptr, *ping = nullptr, *pong = nullptr, *taa_hist[2] = {nullptr, nullptr};
         float* widen = nullptr;              // scratch for state downloads
         int cur = 0, taa_cur = 0;
-        bool has_motion = false, taa_has_history = false;
+        bool has_motion = false;
         // blok_hip_draw_frame_rt: the frame's own planes and its camera history
         float *rt_planes[4] = {nullptr, nullptr, nullptr, nullptr}, *rt_denoised = nullptr, *rt_resolved = nullptr;
         uint32_t *rt_ldr = nullptr, *rt_final = nullptr;

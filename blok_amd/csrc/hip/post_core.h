@@ -87,7 +87,6 @@ struct alignas(16) F4 { float x, y, z, w; };
 BLOK_DEV F4 load4(const float* plane, size_t i) { return reinterpret_cast<const F4*>(plane)[i]; }
 BLOK_DEV V3 xyz(F4 v) { return v3(v.x, v.y, v.z); }
 BLOK_DEV V3 load3(const float* plane, size_t i) { return xyz(load4(plane, i)); }
-BLOK_DEV V3 load3h(const uint16_t* plane, size_t i) { return v3(h2f(plane[4 * i]), h2f(plane[4 * i + 1]), h2f(plane[4 * i + 2])); }
 BLOK_DEV V3 load3q(const float* plane, size_t i) { const F4 v = load4(plane, i); return v3(q16(v.x), q16(v.y), q16(v.z)); }
 BLOK_DEV void store4(float* plane, size_t i, V3 c, float a) { F4 v; v.x = c.x; v.y = c.y; v.z = c.z; v.w = a; reinterpret_cast<F4*>(plane)[i] = v; }
 BLOK_DEV V3 vmin3(V3 a, V3 b) { return v3(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z)); }
