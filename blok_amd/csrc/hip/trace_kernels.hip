@@ -150,7 +150,10 @@ __global__ __launch_bounds__(64) void sun_map_kernel(const SunMapArgs a) {
 }
 
 // raygen.rgen main(): one lane per pixel of the rectangle, same 16x16 / 8x8 pixel mapping as the trace kernel.
-__global__ __launch_bounds__(kBlock) void path_kernel(const PathArgs P) {
+#ifndef BLOK_PATH_WAVES
+#define BLOK_PATH_WAVES 6        // waves per SIMD the path kernel is compiled for (register budget 512 / waves): 4 (109 VGPRs) 74.2 ms, 5 70.7, 6 69.9, 8 71.1 at 4K 64 spp
+#endif
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(BLOK_PATH_WAVES, BLOK_PATH_WAVES))) void path_kernel(const PathArgs P) {
     extern __shared__ uint4 lds_stack[];
     const TraceArgs& A = P.trace;
     const uint32_t tid = threadIdx.x;
