@@ -142,9 +142,16 @@ BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t in
     const V3 cam_f = v3(cam.fwd[0], cam.fwd[1], cam.fwd[2]);
     const V3 cam_r = v3(cam.right[0], cam.right[1], cam.right[2]);
     const V3 cam_u = v3(cam.up[0], cam.up[1], cam.up[2]);
-    V3 first_pos = v3(0, 0, 0), first_normal = v3(0, 0, 0), first_albedo = v3(0, 0, 0), first_emission = v3(0, 0, 0);   // :173-181
-    float first_roughness = 0.0f, first_metallic = 0.0f, first_depth = 0.0f;
-    bool had_first_hit = false, first_was_emissive = false;
+    // First-hit G-buffer (:173-181, :395-407).  Its values are final once sample 0's primary ray has been traced, so they are
+    // written at that moment instead of being carried in ~16 registers through every sample: the planes of a pixel whose
+    // primary ray misses are stored here, a first hit overwrites them below.
+    {
+        const V3 sky_pos = vadd(cam_pos, vscale(vnormalize(cam_f), 10000.0f));
+        const V3 sky_albedo = sky_color(vnormalize(vsub(sky_pos, cam_pos)));
+        store4(P.world_pos, index, sky_pos.x, sky_pos.y, sky_pos.z, 10000.0f);
+        store4(P.normal_roughness, index, 0.0f, 1.0f, 0.0f, 0.0f);
+        store4(P.albedo_metallic, index, sky_albedo.x, sky_albedo.y, sky_albedo.z, 0.0f);
+    }
     V3 accumulated = v3(0, 0, 0);
     const V3 sun_dir = sun_direction();
     const V3 sun_radiance = v3(3.0f, 2.9f, 2.7f);
@@ -242,11 +249,11 @@ BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t in
             metallic = static_cast<float>((mat.flags >> 24) & 0xFFu) / 255.0f;
             roughness = fmaxf(static_cast<float>((mat.flags >> 16) & 0xFFu) / 255.0f, 0.04f);
             if (vdot(n, ray_dir) > 0.0f) n = vneg(n);                                         // :248-250
-            if (bounce == 0u && s == 0u && !had_first_hit) {                                  // :253-263
-                had_first_hit = true;
-                first_pos = hit_pos; first_normal = n; first_albedo = albedo; first_emission = emission;
-                first_roughness = roughness; first_metallic = metallic; first_depth = hit.t;
-                first_was_emissive = is_emissive(emission);
+            if (bounce == 0u && s == 0u) {                                                    // :253-263, :403-407 (reached once)
+                const V3 final_albedo = is_emissive(emission) ? emission : albedo;
+                store4(P.world_pos, index, hit_pos.x, hit_pos.y, hit_pos.z, hit.t);
+                store4(P.normal_roughness, index, n.x, n.y, n.z, roughness);
+                store4(P.albedo_metallic, index, final_albedo.x, final_albedo.y, final_albedo.z, metallic);
             }
             if (is_emissive(emission)) {                                                      // :265-277
                 radiance = vadd(radiance, vmul(throughput, emission));
@@ -310,17 +317,7 @@ BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t in
     V3 color = vdivs(accumulated, static_cast<float>(P.spp));                                 // :383
     const float max_val = max3f(color);                                                       // :386-389
     if (max_val > 100.0f) color = vscale(color, 100.0f / max_val);
-    if (!had_first_hit) {                                                                     // :395-400
-        first_depth = 10000.0f;
-        first_pos = vadd(cam_pos, vscale(vnormalize(cam_f), 10000.0f));
-        first_normal = v3(0.0f, 1.0f, 0.0f);
-        first_albedo = sky_color(vnormalize(vsub(first_pos, cam_pos)));
-    }
-    const V3 final_albedo = first_was_emissive ? first_emission : first_albedo;               // :403
     store4(P.color, index, color.x, color.y, color.z, 1.0f);                                  // :392
-    store4(P.world_pos, index, first_pos.x, first_pos.y, first_pos.z, first_depth);           // :405
-    store4(P.normal_roughness, index, first_normal.x, first_normal.y, first_normal.z, first_roughness);   // :406
-    store4(P.albedo_metallic, index, final_albedo.x, final_albedo.y, final_albedo.z, first_metallic);    // :407
 }
 
 // ---------------------------------------------------------------------------------------------------
