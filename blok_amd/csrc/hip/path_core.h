@@ -11,7 +11,8 @@
 //  - MAX_BOUNCES (raygen.rgen:211, = 2) and sampleCount (forced to 8 by the host, renderer_denoising.cpp:683)
 //    are parameters, as BASELINE.json configs[4] needs 64 spp and deeper paths;
 //  - planes are written as float4 (the reference narrows normal+roughness to RGBA16F and albedo+metallic to
-//    RGBA8, raygen.rgen:57-58), and motion vectors (raygen.rgen:409-413) are not produced.
+//    RGBA8, raygen.rgen:57-58), at the moment the first hit is known rather than after the last sample (same values),
+//    and motion vectors (raygen.rgen:409-413) are produced by the temporal pass (post_core.h) from the position plane.
 #ifndef BLOK_PATH_CORE_H
 #define BLOK_PATH_CORE_H
 
