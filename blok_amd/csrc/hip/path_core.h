@@ -185,6 +185,21 @@ BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t in
     if (P.spp != 0u && P.max_bounces != 0u) begin_sample();
 
     while (s < P.spp && P.max_bounces != 0u) {
+#if !defined(BLOK_TRACE_HOST_HARNESS) && !defined(BLOK_PATH_NO_PHASES)
+        {
+            // The wave walks one kind of ray at a time — primary rays (coherent, short behind the beam pre-pass), then shadow
+            // rays (parallel, short behind the last-occluder map), then bounce rays (long, incoherent): a lane whose pending ray
+            // is of another kind sits the iteration out, instead of a few bounce rays stretching every iteration and the kinds
+            // spoiling each other's coherence.  Per lane nothing changes (same rays, same random numbers, same order), so
+            // results are identical.  Measured at 4K: 2 bounces 8.75 -> 7.28 ms per 8 spp, 64 spp 69.4 -> 58.8 ms; with one
+            // bounce there are only short rays and taking turns costs (3.8 -> 5.3 ms), so it is not done there.
+            if (P.max_bounces > 1u) {
+                const uint32_t kind = shadow_phase ? 1u : (bounce == 0u ? 0u : 2u);
+                const bool any_primary = __ballot(kind == 0u) != 0ull, any_shadow = __ballot(kind == 1u) != 0ull;
+                if (kind != (any_primary ? 0u : (any_shadow ? 1u : 2u))) continue;
+            }
+        }
+#endif
         RayIn r;
         if (shadow_phase) {
             const V3 so = vadd(hit_pos, vscale(n, 0.001f));                                   // :284
