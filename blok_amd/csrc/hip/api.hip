@@ -481,6 +481,7 @@ int blok_hip_trace_paths_device(blok_hip_ctx* ctx, const blok_camera* cam, uint3
     p.spp = spp; p.max_bounces = max_bounces; p.frame_count = frame_index;
     p.color = planes->color; p.world_pos = planes->world_pos;
     p.normal_roughness = planes->normal_roughness; p.albedo_metallic = planes->albedo_metallic;
+    p.batch_kinds = ctx->ray_batching ? 1u : 0u;
     if (ctx->sun_map_enabled && ctx->has_sun_map) {         // shadow rays stop at the last occluder of their column
         const blok::SunMapArgs& m = ctx->sun;
         p.sun_map = ctx->d_sun_map;
@@ -614,6 +615,12 @@ int blok_hip_accum_download(blok_hip_ctx* ctx, float* out_rgba32f_host) {
     if (!ctx->d_accum) return set_error(ctx, BLOK_ERR_INVALID_ARG, "no accumulation buffer yet");
     BLOK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     BLOK_HIP_TRY(ctx, hipMemcpy(out_rgba32f_host, ctx->d_accum, ctx->accum_pixels * 4 * sizeof(float), hipMemcpyDeviceToHost));
+    return BLOK_OK;
+}
+
+int blok_hip_set_ray_batching(blok_hip_ctx* ctx, int enabled) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    ctx->ray_batching = enabled != 0;
     return BLOK_OK;
 }
 

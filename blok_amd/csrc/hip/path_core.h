@@ -37,6 +37,7 @@ struct PathArgs {
     float sun_u[3], sun_v[3];
     float sun_u0, sun_v0, sun_inv_texel;
     uint32_t sun_nu, sun_nv;
+    uint32_t batch_kinds;            // 1: the wave walks one kind of ray at a time (see shade_pixel)
 };
 
 struct V3 { float x, y, z; };
@@ -193,7 +194,7 @@ BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t in
             // spoiling each other's coherence.  Per lane nothing changes (same rays, same random numbers, same order), so
             // results are identical.  Measured at 4K: 2 bounces 8.75 -> 7.28 ms per 8 spp, 64 spp 69.4 -> 58.8 ms; with one
             // bounce there are only short rays and taking turns costs (3.8 -> 5.3 ms), so it is not done there.
-            if (P.max_bounces > 1u) {
+            if (P.batch_kinds != 0u && P.max_bounces > 1u) {
                 const uint32_t kind = shadow_phase ? 1u : (bounce == 0u ? 0u : 2u);
                 const bool any_primary = __ballot(kind == 0u) != 0ull, any_shadow = __ballot(kind == 1u) != 0ull;
                 if (kind != (any_primary ? 0u : (any_shadow ? 1u : 2u))) continue;

@@ -341,6 +341,9 @@ int blok_hip_volume_apply_brush(blok_hip_ctx* ctx, const float center[3], float 
  * density > 0 and their material ids, with the given material table. */
 int blok_hip_volume_rebuild(blok_hip_ctx* ctx, const blok_material* materials, size_t n_materials);
 
+/* Scheduling knob of the path kernel (no reference counterpart): a wave walks one kind of ray at a time (primary, shadow, bounce)
+ * instead of whatever each lane has pending.  Per-lane work and results are identical either way (tests/test_paths.py). Default on. */
+int blok_hip_set_ray_batching(blok_hip_ctx* ctx, int enabled);
 /* "Last occluder" map of the path kernel's shadow rays (no reference counterpart): all shadow rays share the shader's constant sun
  * direction (raygen.rgen:142,185), so with every world the backend records, per 4-voxel texel of the plane perpendicular to
  * it, how far along that direction voxels exist at all; a shadow ray's tmax is capped there (rays above the last occluder skip

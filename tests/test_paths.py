@@ -226,7 +226,7 @@ def test_sun_map_does_not_change_path_traced_frames(world64):
 def test_prepasses_random_cameras_path_frames():
     """30 random cameras (inside, outside, grazing; 10..140 degree fields of view; odd frame) over a world with a thin wall,
     scattered voxels, isolated far voxels and negative coordinates: path-traced planes with the beam pre-pass and the
-    sun map on equal the planes with both off, bit for bit."""
+    sun map on and the wave walking one kind of ray at a time equal the planes with all three off, bit for bit."""
     from blok_amd.tracer import HipTracer
     rng = np.random.default_rng(77)
     cm = W.ChunkManager(128, 1.0)
@@ -245,9 +245,9 @@ def test_prepasses_random_cameras_path_frames():
         eye = rng.normal(0.0, (25.0, 70.0, 300.0)[k % 3], 3)
         target = rng.normal(0.0, 20.0, 3)
         cam = W.camera_look_at(tuple(float(v) for v in eye), tuple(float(v) for v in target), float(rng.uniform(10.0, 140.0)), w, h)
-        tr.set_beam(0); tr.set_sun_map(False)
+        tr.set_beam(0); tr.set_sun_map(False); tr.set_ray_batching(False)
         plain = tr.trace_paths(cam, spp=2, max_bounces=3, frame_index=k)
-        tr.set_beam(32); tr.set_sun_map(True)
+        tr.set_beam(32); tr.set_sun_map(True); tr.set_ray_batching(True)
         got = tr.trace_paths(cam, spp=2, max_bounces=3, frame_index=k)
         for name in plain:
             assert got[name].tobytes() == plain[name].tobytes(), (k, name)
