@@ -78,11 +78,11 @@ BLOK_DEV uint32_t mask_rank(const NodeRec& n, uint32_t bit) {
 struct RayIn { float ox, oy, oz, dx, dy, dz, tmin, tmax; };
 
 // Two-bit digit of a (non-negative) tree coordinate at bit offset `shift`: one v_bfe_u32.
-BLOK_DEV uint32_t digit2(int q, uint32_t shift) {
+BLOK_DEV uint32_t digit2(uint32_t q, uint32_t shift) {
 #ifdef BLOK_TRACE_HOST_HARNESS
-    return (static_cast<uint32_t>(q) >> shift) & 3u;
+    return (q >> shift) & 3u;
 #else
-    return __builtin_amdgcn_ubfe(static_cast<uint32_t>(q), shift, 2u);
+    return __builtin_amdgcn_ubfe(q, shift, 2u);
 #endif
 }
 
@@ -92,27 +92,43 @@ BLOK_DEV uint32_t digit2(int q, uint32_t shift) {
 // world plane  base + sgn * q  (sgn = +1: base = origin; sgn = -1: base = origin + W) before T is
 // evaluated, so T is the same canonical function of the same world integer as without mirroring, and
 // a node's child bit is the mirrored digit triple XOR a per-ray constant.
+//
+// A mirrored coordinate is held as the binary32 number  f = 2^23 + q  (0 <= q <= W <= 2^14): its mantissa
+// field IS q (ulp = 1 throughout [2^23, 2^24)), so the digit of a level is one v_bfe of the float's bits, the
+// level of a crossed boundary one v_ffbl, re-aligning to a coarser cell one v_and, and stepping by a cell size
+// an exact float add.  The world plane is  fma(sgn, f, base - sgn * 2^23)  — one fused operation whose exact
+// result, the integer base + sgn * q, is representable, hence equal to float(int plane) of the integer
+// formulation bit for bit — so a plane costs three full-rate float instructions where integer coordinates cost
+// v_mad_i32_i24 + v_cvt_f32_i32 (both half-rate on gfx950) + sub + mul.
+constexpr float kCoordBias = 8388608.0f;            // 2^23
+constexpr uint32_t kCoordBits = 0x4B000000u;        // bits of 2^23
+
 struct Axis {
     float o, inv;     // ray origin component, safe inverse direction (intersect.rint:79)
-    int base, sgn;    // mirrored plane q  ->  world plane base + sgn * q
+    float sgn, c;     // mirrored coordinate f = 2^23 + q  ->  world plane fma(sgn, f, c), c = base - sgn * 2^23
 };
 
-// T(a, q) for a mirrored plane q: t = fl(fl(float(world plane) - o) * inv), intersect.rint:48-49,179-180.
-BLOK_DEV float plane_t(const Axis& a, int q) {
-    return rn_mul(rn_sub(static_cast<float>(__mul24(a.sgn, q) + a.base), a.o), a.inv);
+BLOK_DEV float exact_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// T(a, q) for the mirrored plane held in f: t = fl(fl(float(world plane) - o) * inv), intersect.rint:48-49,179-180.
+BLOK_DEV float plane_t(const Axis& a, float f) {
+    return rn_mul(rn_sub(exact_fma(a.sgn, f, a.c), a.o), a.inv);
 }
 
-// One axis of "enter a node" whose near corner is q and whose children have size s = 1 << shift: how many
-// of the three interior planes have T <= tS (binary search, T is monotone in q), i.e. which child slab
-// holds the ray at tS, and the T of that slab's far plane.  t_far comes in as the node's own far plane.
-BLOK_DEV void enter_axis(const Axis& a, int& q, float& t_far, uint32_t shift, float tS) {
-    const float m2 = plane_t(a, q + (2 << shift));
+// Cell size 4^lvl as a float: 2^(2 lvl).
+BLOK_DEV float cell_size(uint32_t lvl) { return __uint_as_float(0x3F800000u + (lvl << 24)); }
+
+// One axis of "enter a node" whose near corner is f and whose children have size s: how many of the three
+// interior planes have T <= tS (binary search, T is monotone in q), i.e. which child slab holds the ray at tS,
+// and the T of that slab's far plane.  t_far comes in as the node's own far plane.  s2 = 2 s, s3 = 3 s.
+BLOK_DEV void enter_axis(const Axis& a, float& f, float& t_far, float s, float s2, float s3, float tS) {
+    const float m2 = plane_t(a, f + s2);
     const bool g = m2 <= tS;
-    const float mq = plane_t(a, q + ((g ? 3 : 1) << shift));
+    const float mq = plane_t(a, f + (g ? s3 : s));
     const bool g2 = mq <= tS;
     const float inner = g ? t_far : m2;          // far plane if mq is already crossed
     t_far = g2 ? inner : mq;
-    q += ((g ? 2 : 0) + (g2 ? 1 : 0)) << shift;
+    f += (g ? s2 : 0.0f) + (g2 ? s : 0.0f);
 }
 
 // What closest-hit sees of a procedural hit (intersect.rint:138-141, hit.rchit:58-74), in registers.
@@ -135,25 +151,30 @@ BLOK_DEV HitInfo walk(const TraceArgs& A, const RayIn& r, uint4* stk) {
     ax.o = r.ox; ay.o = r.oy; az.o = r.oz;
     ax.inv = safe_inv(r.dx); ay.inv = safe_inv(r.dy); az.inv = safe_inv(r.dz);
     const bool negx = !(ax.inv > 0.0f), negy = !(ay.inv > 0.0f), negz = !(az.inv > 0.0f);
-    ax.sgn = negx ? -1 : 1; ay.sgn = negy ? -1 : 1; az.sgn = negz ? -1 : 1;
-    ax.base = A.origin[0] + (negx ? W : 0); ay.base = A.origin[1] + (negy ? W : 0); az.base = A.origin[2] + (negz ? W : 0);
+    ax.sgn = negx ? -1.0f : 1.0f; ay.sgn = negy ? -1.0f : 1.0f; az.sgn = negz ? -1.0f : 1.0f;
+    // c = base - sgn * 2^23: integers below 2^24 in magnitude, exact
+    ax.c = static_cast<float>(A.origin[0] + (negx ? W : 0)) - ax.sgn * kCoordBias;
+    ay.c = static_cast<float>(A.origin[1] + (negy ? W : 0)) - ay.sgn * kCoordBias;
+    az.c = static_cast<float>(A.origin[2] + (negz ? W : 0)) - az.sgn * kCoordBias;
     const uint32_t mirror = (negx ? 3u : 0u) | (negy ? 12u : 0u) | (negz ? 48u : 0u);
 
     // world box: near planes q = 0, far planes q = W (T is monotone in q, so no min/max is needed)
-    float tFx = plane_t(ax, W), tFy = plane_t(ay, W), tFz = plane_t(az, W);
-    float tCur = fmaxf(fmaxf(fmaxf(plane_t(ax, 0), plane_t(ay, 0)), plane_t(az, 0)), r.tmin);
+    const float fW = kCoordBias + static_cast<float>(W);
+    float tFx = plane_t(ax, fW), tFy = plane_t(ay, fW), tFz = plane_t(az, fW);
+    float tCur = fmaxf(fmaxf(fmaxf(plane_t(ax, kCoordBias), plane_t(ay, kCoordBias)), plane_t(az, kCoordBias)), r.tmin);
     if (!(tCur < fminf(fminf(fminf(tFx, tFy), tFz), r.tmax))) return out;
 
-    int qx = 0, qy = 0, qz = 0;          // mirrored min corner of the current cell
+    float fx = kCoordBias, fy = kCoordBias, fz = kCoordBias;   // mirrored min corner of the current cell (2^23 + q)
     uint32_t lvl = L - 1;                // current cells have size 4^lvl; `node` is their parent
+    float size = cell_size(lvl);
     NodeRec node;
     {
         const uint4 q = A.nodes[0];
         node.lo = q.x; node.hi = q.y; node.base = q.z;
-        const uint32_t cs = 2 * lvl;
-        enter_axis(ax, qx, tFx, cs, tCur);
-        enter_axis(ay, qy, tFy, cs, tCur);
-        enter_axis(az, qz, tFz, cs, tCur);
+        const float s2 = size + size, s3 = s2 + size;
+        enter_axis(ax, fx, tFx, size, s2, s3, tCur);
+        enter_axis(ay, fy, tFy, size, s2, s3, tCur);
+        enter_axis(az, fz, tFz, size, s2, s3, tCur);
     }
 
     // Invariant: tCur starts at max(world entry, tmin) and never decreases — a cell's far planes are never
@@ -165,7 +186,7 @@ BLOK_DEV HitInfo walk(const TraceArgs& A, const RayIn& r, uint4* stk) {
     for (;;) {
         BLOK_STAT(0, lvl);
         const uint32_t shift = 2 * lvl;
-        bit = (digit2(qx, shift) | (digit2(qy, shift) << 2) | (digit2(qz, shift) << 4)) ^ mirror;
+        bit = (digit2(__float_as_uint(fx), shift) | (digit2(__float_as_uint(fy), shift) << 2) | (digit2(__float_as_uint(fz), shift) << 4)) ^ mirror;
         const bool occupied = mask_bit(node, bit);
         if (occupied && lvl != 0) {
             // descend: remember the node we are leaving, fetch the child, pick its start cell
@@ -174,10 +195,11 @@ BLOK_DEV HitInfo walk(const TraceArgs& A, const RayIn& r, uint4* stk) {
             const uint4 c = A.nodes[node.base + mask_rank(node, bit)];
             node.lo = c.x; node.hi = c.y; node.base = c.z;
             lvl -= 1;
-            const uint32_t cs = 2 * lvl;
-            enter_axis(ax, qx, tFx, cs, tCur);     // tCur >= tmin always (see the invariant above the loop)
-            enter_axis(ay, qy, tFy, cs, tCur);
-            enter_axis(az, qz, tFz, cs, tCur);
+            size *= 0.25f;
+            const float s2 = size + size, s3 = s2 + size;
+            enter_axis(ax, fx, tFx, size, s2, s3, tCur);     // tCur >= tmin always (see the invariant above the loop)
+            enter_axis(ay, fy, tFy, size, s2, s3, tCur);
+            enter_axis(az, fz, tFz, size, s2, s3, tCur);
             continue;
         }
         const float tExit = fminf(fminf(tFx, tFy), tFz);
@@ -192,40 +214,42 @@ BLOK_DEV HitInfo walk(const TraceArgs& A, const RayIn& r, uint4* stk) {
         const bool sx = tFx == tExit;
         const bool sy = !sx && tFy == tExit;
         const bool sz = !sx && !sy;
-        const int size = 1 << shift;
-        qx += sx ? size : 0; qy += sy ? size : 0; qz += sz ? size : 0;
-        // the stepped coordinate is now a multiple of 4^k for the level k whose cell boundary was crossed
-        const uint32_t up = static_cast<uint32_t>(__ffs(sx ? qx : (sy ? qy : qz)) - 1) >> 1;
+        fx += sx ? size : 0.0f; fy += sy ? size : 0.0f; fz += sz ? size : 0.0f;
+        // the stepped coordinate is now a multiple of 4^k for the level k whose cell boundary was crossed (its mantissa
+        // field is q > 0, so the lowest set bit of the float's bits is the lowest set bit of q)
+        const uint32_t up = static_cast<uint32_t>(__ffs(static_cast<int>(__float_as_uint(sx ? fx : (sy ? fy : fz)))) - 1) >> 1;
         if (up != lvl) {
             BLOK_STAT(3, lvl);
             if (up >= L) break;                                    // left the world box
             lvl = up;
-            const int keep = ~((1 << (2 * up)) - 1);
-            qx &= keep; qy &= keep; qz &= keep;
+            size = cell_size(lvl);
+            const uint32_t keep = ~((1u << (2 * up)) - 1u);        // clears mantissa bits only: the exponent field stays
+            fx = __uint_as_float(__float_as_uint(fx) & keep); fy = __uint_as_float(__float_as_uint(fy) & keep); fz = __uint_as_float(__float_as_uint(fz) & keep);
             const uint4 c = stk[(lvl - 1) * kBlock];               // node of level lvl+1
             node.lo = c.x; node.hi = c.y; node.base = c.z;
         }
-        const int far = 1 << (2 * lvl);
-        tFx = plane_t(ax, qx + far); tFy = plane_t(ay, qy + far); tFz = plane_t(az, qz + far);
+        tFx = plane_t(ax, fx + size); tFy = plane_t(ay, fy + size); tFz = plane_t(az, fz + size);
     }
     if (!found) return out;
 
     // reported: intersect.rint:136-141, hit.rchit:58-74
     const float tc = tCur;                                            // = max(entry, tmin), intersect.rint:189,141
     const uint32_t material = A.materials[node.base + mask_rank(node, bit)];
-    const int vx = ax.base + ax.sgn * qx - (negx ? 1 : 0);          // world voxel = mirrored cell un-mirrored
-    const int vy = ay.base + ay.sgn * qy - (negy ? 1 : 0);
-    const int vz = az.base + az.sgn * qz - (negz ? 1 : 0);
+    // world voxel = mirrored cell un-mirrored: base + sgn * q - (negative ? 1 : 0)
+    const int qx = static_cast<int>(__float_as_uint(fx) & 0x7FFFFFu), qy = static_cast<int>(__float_as_uint(fy) & 0x7FFFFFu), qz = static_cast<int>(__float_as_uint(fz) & 0x7FFFFFu);
+    const int vx = negx ? A.origin[0] + W - qx - 1 : A.origin[0] + qx;
+    const int vy = negy ? A.origin[1] + W - qy - 1 : A.origin[1] + qy;
+    const int vz = negz ? A.origin[2] + W - qz - 1 : A.origin[2] + qz;
     const float hx = rn_add(r.ox, rn_mul(r.dx, tc));
     const float hy = rn_add(r.oy, rn_mul(r.dy, tc));
     const float hz = rn_add(r.oz, rn_mul(r.dz, tc));
     const float ex = rn_sub(hx, rn_add(static_cast<float>(vx), 0.5f));
     const float ey = rn_sub(hy, rn_add(static_cast<float>(vy), 0.5f));
     const float ez = rn_sub(hz, rn_add(static_cast<float>(vz), 0.5f));
-    const float fx = fabsf(ex), fy = fabsf(ey), fz = fabsf(ez);
+    const float gx = fabsf(ex), gy = fabsf(ey), gz = fabsf(ez);
     uint32_t face;                                                   // getHitFace, intersect.rint:58-68
-    if (fx >= fy && fx >= fz) face = ex > 0.0f ? 0u : 1u;
-    else if (fy >= fz)        face = ey > 0.0f ? 2u : 3u;
+    if (gx >= gy && gx >= gz) face = ex > 0.0f ? 0u : 1u;
+    else if (gy >= gz)        face = ey > 0.0f ? 2u : 3u;
     else                      face = ez > 0.0f ? 4u : 5u;
     out.found = true; out.t = tc; out.material = material; out.face = face;
     out.vx = vx; out.vy = vy; out.vz = vz;
