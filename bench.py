@@ -12,6 +12,12 @@ has no multi-GPU path).  Total work per step is fixed as N gro
 
 Prints ONE JSON line on rank 0.  Inputs are synthetic (generator G(N, seed) of SURVEY.md §8(d)) and are
 resident in HBM before the timed region.
+
+`python bench.py --gpus N` from a bare shell (no WORLD_SIZE in the environment) starts the N ranks itself, as child
+processes under torch.distributed.run, BEFORE this process touches the GPU, and relays rank 0's JSON line.
+
+roofline.frac is quoted on the frame's launch running ALONE on the chip (HIP events around single launches, one at a
+time); the throughput-derived figure with several frames in flight is reported beside it as frac_overlapped.
 """
 from __future__ import annotations
 
@@ -50,9 +56,33 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for "
                     "rehearsing the N > 1 code path with several ranks on one GPU, which RCCL refuses)")
     ap.add_argument("--beam", type=int, default=32, help="beam pre-pass tile in pixels (0 = off)")
+    ap.add_argument("--fused", type=int, default=0, help="1 = one persistent launch per frame (pre-pass + walk; measured slower), 0 = beam kernel then trace kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-paths", action="store_true", help="skip the 64-spp path-tracing side measurement")
+    ap.add_argument("--no-poses", action="store_true", help="skip the per-pose side measurements (poses A, B, C)")
+    ap.add_argument("--sparse-gather", type=int, default=1, help="N > 1: gather only the tiles the pre-pass did not mark as sky")
     return ap.parse_args()
+
+
+def spawn_ranks(n: int) -> int:
+    """Bare `python bench.py --gpus N`: run the N ranks as children (one per GPU) and relay rank 0's line.  The parent
+    has not touched the GPU (torch is not even imported yet); nothing is exec'ed."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.fspath(Path(__file__).resolve()), *sys.argv[1:]]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    else:
+        sys.stdout.write(proc.stdout)
+    return proc.returncode if lines or proc.returncode else 1
 
 
 def build_world(n: int, seed: int):
@@ -63,54 +93,64 @@ def build_world(n: int, seed: int):
     return cm.pack_chunks_to_gpu_svo(W.scene_materials(seed))
 
 
-def cpu_baseline(packed, cam, width, height, stride, min_seconds=1.0):
-    """The oracle (oracle/blok_oracle.cpp: restated intersect.rint behind a front-to-back slot lattice)
-    timed on this box's host cores, on a strided sample of the same frame.  Baseline only."""
+def usable_cores() -> int:
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        return max(1, os.cpu_count() or 1)
+
+
+def oracle_counters(packed, cam, width, height, stride=1):
+    """Per-ray algorithmic byte count of SURVEY.md §8(d), by the oracle's counting build (formulation 2: restated
+    intersect.rint behind a front-to-back slot lattice) on the same scene and camera."""
     from tests import oracle_ffi as O
-    threads = max(1, min(16, os.cpu_count() or 1))
     lattice = O.Lattice(packed.nodes, packed.sub_chunks)
+    _, c = lattice.trace_primary(cam, width, height, stride=stride, threads=usable_cores(), want_hits=False)
+    rays = int(c["rays"])
+    alg_bytes = 48 * int(c["sub_chunks_entered"]) + 16 * int(c["nodes_fetched"]) + 32 * int(c["hits"]) + 16 * rays
+    return {"bytes_per_ray": alg_bytes / rays, "sub_chunks_per_ray": int(c["sub_chunks_entered"]) / rays,
+            "nodes_per_ray": int(c["nodes_fetched"]) / rays, "hit_fraction": int(c["hits"]) / rays}
+
+
+def cpu_baseline(packed, cam, width, height, stride, min_core_seconds=12.0):
+    """the CPU restatement of the reference traversal (oracle/blok_oracle.cpp, per-visit counters
+    compiled out, -O3 -march=native -ffp-contract=off, built on this machine) over the same frame, rows split over all
+    usable host cores; whole frames until >= ~12 core-seconds.  Baseline only."""
+    from tests import oracle_ffi as O
+    threads = usable_cores()
+    lattice = O.NativeLattice(packed.nodes, packed.sub_chunks)
     lattice.trace_primary(cam, width, height, stride=8, threads=threads, want_hits=False)       # warm caches
-    frames = 0
-    totals = None
+    frames, rays = 0, 0
     t0 = time.perf_counter()
-    while True:                                   # whole frames until >= ~1 s wall (>= 10 core-seconds on 16 cores)
+    while True:
         _, c = lattice.trace_primary(cam, width, height, stride=stride, threads=threads, want_hits=False)
         frames += 1
-        totals = {k: int(c[k]) + (totals[k] if totals else 0) for k in c.dtype.names}
-        if time.perf_counter() - t0 >= min_seconds or frames >= 64:
+        rays += int(c["rays"])
+        dt = time.perf_counter() - t0
+        if dt * threads >= min_core_seconds or frames >= 256:
             break
-    dt = time.perf_counter() - t0
-    single = None
-    if min_seconds > 0.0:                         # one-thread rate on a strided sample of the same frame (SURVEY.md §8(d))
-        t1 = time.perf_counter()
-        _, c1 = lattice.trace_primary(cam, width, height, stride=4, threads=1, want_hits=False)
-        single = int(c1["rays"]) / (time.perf_counter() - t1) / 1e6
-    ctr = totals
-    rays = int(ctr["rays"])
-    alg_bytes = 48 * int(ctr["sub_chunks_entered"]) + 16 * int(ctr["nodes_fetched"]) + 32 * int(ctr["hits"]) + 16 * rays
+    t1 = time.perf_counter()                      # one-thread rate on a strided sample of the same frame (SURVEY.md §8(d))
+    _, c1 = lattice.trace_primary(cam, width, height, stride=4, threads=1, want_hits=False)
+    single = int(c1["rays"]) / (time.perf_counter() - t1) / 1e6
     return {
         "value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port", "single_thread_value": single,
+        "build": "g++ -O3 -march=native -ffp-contract=off -DORC_NO_COUNTERS (oracle/Makefile: native), built on this host",
         "sample": f"{frames} pass(es) over every {stride}th pixel in x and y of the {width}x{height} frame "
-                  f"({rays} rays, {dt:.2f} s wall on {threads} threads = {dt * threads:.0f} core-seconds)",
-    }, {
-        "bytes_per_ray": alg_bytes / rays,
-        "sub_chunks_per_ray": int(ctr["sub_chunks_entered"]) / rays,
-        "nodes_per_ray": int(ctr["nodes_fetched"]) / rays,
-        "hit_fraction": int(ctr["hits"]) / rays,
+                  f"({rays} rays, {dt:.2f} s wall on {threads} threads = {dt * threads:.0f} core-seconds); "
+                  f"hardware threads on the host: {os.cpu_count()}, usable by this process: {threads}",
     }
 
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args.gpus))
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
-    if world_size != args.gpus:
-        if world_size == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world_size
+    args.gpus = world_size
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a gfx950 GPU (no CPU fallback exists)")
     device_index = local_rank % torch.cuda.device_count()      # a launcher may expose one device per rank
@@ -134,6 +174,7 @@ def main():
     tracer = HipTracer(W_, H_, device=device_index).init()
     stats = tracer.add_world(packed)                      # world resident in HBM from here on
     tracer.set_beam(args.beam)
+    tracer.set_fused(bool(args.fused))
 
     if args.frames_in_flight <= 0:
         args.frames_in_flight = 3 if world_size <= 2 else 4
@@ -170,24 +211,54 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, device_ms = float(t[0]), float(t[1])
 
-    # dominant kernel's average launch duration: HIP events around single launches on the same stream
-    tracer.set_timing(True)
-    kernel_ms = []
-    for _ in range(min(args.steps, 20)):
-        if world_size == 1:
-            pipe.backend.trace_full(pipe.hits, pipe._frame[0], stream.cuda_stream)
-        else:
-            pipe.backend.trace_tiles(args.tile, rank, world_size, pipe.hits, pipe.rgba[0], stream.cuda_stream)
-        torch.cuda.synchronize()
-        kernel_ms.append(tracer.last_kernel_ms())
-    tracer.set_timing(False)
-    kernel_ms_avg = float(np.mean(kernel_ms))
+    # the frame's launch running ALONE: HIP events around single launches on one stream, one at a time (what a rocprofv3
+    # kernel trace of `--frames-in-flight 1` shows; profiles/README.md).  One launch (frame_kernel) per frame in the
+    # one-launch form, the beam_kernel + trace_kernel pair otherwise.
+    def solitary_ms(backend, reps):
+        tracer.set_timing(True)
+        ms = []
+        for _ in range(reps):
+            if world_size == 1:
+                backend.trace_full(pipe.hits, pipe._frame[0], stream.cuda_stream)
+            else:
+                backend.trace_tiles(args.tile, rank, world_size, pipe.hits, pipe.rgba[0], stream.cuda_stream)
+            torch.cuda.synchronize()
+            ms.append(tracer.last_kernel_ms())
+        tracer.set_timing(False)
+        return float(np.mean(ms))
+
+    kernel_ms_avg = solitary_ms(pipe.backend, min(args.steps, 20))
     local_hits = (pipe.hits[:, 3] >> 24).sum()
     if dist is not None:
         dist.all_reduce(local_hits)
     hits = int(local_hits.item())
     sky = 0xFF000000 | (230 << 16) | (200 << 8) | 160
     lit_pixels = int((pipe.frame_rgba != (sky - (1 << 32))).sum().item()) if rank == 0 else 0
+
+    # the other camera poses of SURVEY.md §8(d), same world and frame: a short pipelined run and the solitary launch each
+    poses = {}
+    if world_size == 1 and not args.no_poses:
+        for pose in (0, 1, 2):
+            pcam = W.scene_camera(args.n, pose, W_, H_, args.seed)
+            pb = HipBackend(tracer, pcam)
+            pipe.backend = pb
+            for _ in range(5):
+                pipe.step()
+            pipe.flush(); torch.cuda.synchronize()
+            k = max(10, min(args.steps, 60))
+            t1 = time.perf_counter()
+            for _ in range(k):
+                pipe.step()
+            pipe.flush(); torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            entry = {"Mrays_per_s": W_ * H_ * k / dt / 1e6, "ms_per_frame": dt / k * 1e3, "ms_per_frame_alone": solitary_ms(pb, 10),
+                     "hits_per_frame": int((pipe.hits[:, 3] >> 24).sum().item())}
+            if not args.no_cpu_baseline:
+                c = oracle_counters(packed, pcam, W_, H_)
+                entry.update({"hit_fraction": c["hit_fraction"], "algorithmic_bytes_per_ray": c["bytes_per_ray"],
+                              "frac_hbm_alone": c["bytes_per_ray"] * W_ * H_ / (entry["ms_per_frame_alone"] * 1e-3) / 1e9 / HBM_PEAK_GBS})
+            poses["ABC"[pose]] = entry
+        pipe.backend = HipBackend(tracer, cam)
 
     # side measurement (not the headline value): BASELINE.json configs[4], the reference's sample/bounce loop at
     # 64 spp, 2 bounces, over the same world and frame — two frames, HIP events around the kernel
@@ -208,6 +279,8 @@ def main():
     if rank == 0:
         rays_per_step = W_ * H_
         value = rays_per_step * args.steps / elapsed / 1e6
+        launch = "one persistent launch per frame (frame_kernel: beam pre-pass + walk)" if args.fused and args.beam else \
+                 ("beam_kernel + trace_kernel per frame" if args.beam else "trace_kernel per frame")
         out = {
             "metric": "Mrays/sec, primary first-hit rays at 4K over a 1024^3 SVO",
             "value": value, "unit": "Mrays/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
@@ -217,37 +290,39 @@ def main():
                                    f"{stats.n_voxels} voxels, {stats.n_ref_nodes} reference SvoNodes, "
                                    f"{stats.n_sub_chunks} sub-chunks), {W_}x{H_} primary rays, camera pose "
                                    f"{'ABC'[args.pose]}, first-hit records 16 B/ray",
-                       "parallelism": f"single GPU, {args.frames_in_flight} frames in flight on alternating HIP streams" if world_size == 1 else f"{args.tile}x{args.tile} screen tiles round-robin over {world_size} GPUs, {'RCCL' if args.backend == 'nccl' else args.backend} gather of RGBA8 tiles to rank 0, {args.frames_in_flight} frames in flight",
+                       "parallelism": f"single GPU, {launch}, {args.frames_in_flight} frame(s) in flight" if world_size == 1 else f"{args.tile}x{args.tile} screen tiles round-robin over {world_size} GPUs, {'RCCL' if args.backend == 'nccl' else args.backend} gather of {'the live ' if args.sparse_gather else ''}RGBA8 tiles to rank 0, {args.frames_in_flight} frames in flight",
                        "hits_per_frame": hits, "framebuffer_pixels_hit": lit_pixels,
                        "outputs": "16-B first-hit records (kept on the tracing GPU) + RGBA8 framebuffer on rank 0",
                        "frames_in_flight": args.frames_in_flight, "device_ms_per_step": device_ms / args.steps, "kernel_ms_alone": kernel_ms_avg, "beam_tile": args.beam,
-                       "also_measured_paths": paths},
+                       "poses": poses, "also_measured_paths": paths},
         }
         alg = None
         if not args.no_cpu_baseline:
+            alg = oracle_counters(packed, cam, W_, H_, 1 if world_size == 1 else 4)
             if world_size == 1:
-                out["cpu_baseline"], alg = cpu_baseline(packed, cam, W_, H_, args.cpu_stride)
-            else:      # N > 1: only the per-ray byte counters (a quick strided oracle pass), no baseline object
-                _, alg = cpu_baseline(packed, cam, W_, H_, 4, min_seconds=0.0)
+                out["cpu_baseline"] = cpu_baseline(packed, cam, W_, H_, args.cpu_stride)
         rays_per_launch = rays_per_step / world_size
         if alg is not None:
-            # one launch per step and rank: average launch duration over the timed region (HIP events, frames in
-            # flight overlap) = device time / steps; the duration of a launch running alone is reported beside it
-            launch_ms = device_ms / args.steps
-            achieved = alg["bytes_per_ray"] * rays_per_launch / (launch_ms * 1e-3) / 1e9
+            # frac: algorithmic bytes of one launch / duration of that launch running alone.  The throughput-derived figure
+            # (device time of the timed region / steps, launches of several frames overlapping) is frac_overlapped.
+            achieved = alg["bytes_per_ray"] * rays_per_launch / (kernel_ms_avg * 1e-3) / 1e9
+            overlapped_ms = device_ms / args.steps
+            achieved_overlapped = alg["bytes_per_ray"] * rays_per_launch / (overlapped_ms * 1e-3) / 1e9
             traffic = None
             pmc = ROOT / "profiles" / "pmc_traffic.json"
             if pmc.exists() and world_size == 1 and (args.n, W_, H_, args.pose) == (1024, 3840, 2160, 0):
-                traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
+                traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_frame")
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                               "kernel": "trace_kernel (+ its beam_kernel pre-pass when --beam > 0): one launch pair per frame",
-                               "kernel_ms": launch_ms, "kernel_ms_alone": kernel_ms_avg, "beam_tile": args.beam,
-                               "algorithmic_bytes_per_ray": alg["bytes_per_ray"],
+                               "kernel": launch, "kernel_ms": kernel_ms_avg,
+                               "timing": "HIP events around single launches, one at a time on an otherwise idle chip",
+                               "frac_overlapped": achieved_overlapped / HBM_PEAK_GBS, "achieved_overlapped": achieved_overlapped,
+                               "kernel_ms_overlapped": overlapped_ms, "frames_in_flight": args.frames_in_flight,
+                               "beam_tile": args.beam, "algorithmic_bytes_per_ray": alg["bytes_per_ray"],
                                "rays_per_launch": rays_per_launch,
                                "sub_chunks_per_ray": alg["sub_chunks_per_ray"], "nodes_per_ray": alg["nodes_per_ray"],
                                "hit_fraction": alg["hit_fraction"]}
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     tracer.shutdown()
     if dist is not None:
         dist.destroy_process_group()

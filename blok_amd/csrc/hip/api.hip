@@ -1,5 +1,6 @@
 // C ABI of the gfx950 backend (include/blok_hip.h).  Owns device memory; every HIP call is checked.
 #include "api_internal.h"
+#include <cstdlib>
 
 namespace blok_api {
 
@@ -133,13 +134,48 @@ blok::TraceArgs base_args(const blok_hip_ctx* ctx, const blok_camera* cam) {
 // The stream's beam buffer, grown to n floats.
 int beam_buffer(blok_hip_ctx* ctx, hipStream_t stream, size_t n, float** out) {
     auto& slot = ctx->beam_buffers[stream];
-    if (slot.second < n) {
-        if (slot.first) { BLOK_HIP_TRY(ctx, hipStreamSynchronize(stream)); (void)hipFree(slot.first); }
-        slot = {nullptr, 0};
-        BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&slot.first), n * sizeof(float)));
-        slot.second = n;
+    if (slot.n_beam < n) {
+        if (slot.beam) { BLOK_HIP_TRY(ctx, hipStreamSynchronize(stream)); (void)hipFree(slot.beam); }
+        slot.beam = nullptr; slot.n_beam = 0;
+        BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&slot.beam), n * sizeof(float)));
+        slot.n_beam = n;
     }
-    *out = slot.first;
+    *out = slot.beam;
+    return BLOK_OK;
+}
+
+// The stream's work queue for a one-launch frame with n_beams beam tasks, and the size of its persistent grid.
+int prepare_queue(blok_hip_ctx* ctx, blok::RayMode mode, const blok::TraceArgs& args, hipStream_t stream, uint32_t n_beams,
+                  blok::FrameQueue* queue, uint32_t* n_blocks) {
+    const size_t per_beam = static_cast<size_t>(args.beam_tile / blok::kWaveW) * (args.beam_tile / blok::kWaveH);
+    const uint32_t parts = ctx->frame_parts;
+    const size_t part_capacity = static_cast<size_t>((n_beams + parts - 1u) / parts) * per_beam;
+    const size_t need = part_capacity * parts;
+    auto& slot = ctx->beam_buffers[stream];
+    if (!slot.ctl) {
+        BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&slot.ctl), blok::kFrameCtlWords * sizeof(uint32_t)));
+        BLOK_HIP_TRY(ctx, hipMemsetAsync(slot.ctl, 0, blok::kFrameCtlWords * sizeof(uint32_t), stream));      // in stream order, before the launch
+    }
+    if (slot.capacity < need) {
+        if (slot.entries) { BLOK_HIP_TRY(ctx, hipStreamSynchronize(stream)); (void)hipFree(slot.entries); }
+        slot.entries = nullptr; slot.capacity = 0;
+        BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&slot.entries), need * sizeof(unsigned long long)));
+        BLOK_HIP_TRY(ctx, hipMemsetAsync(slot.entries, 0xFF, need * sizeof(unsigned long long), stream));   // every slot empty; a launch leaves them so
+        slot.capacity = need;
+    }
+    queue->ctl = slot.ctl; queue->entries = slot.entries; queue->n_beam = n_beams; queue->part_capacity = static_cast<uint32_t>(part_capacity);
+    queue->n_parts = parts; queue->chunk = ctx->frame_chunk;
+    const int m = mode == blok::RayMode::Rect ? 0 : 1;
+    const uint32_t lv = args.levels < 16u ? args.levels : 15u;
+    if (!ctx->frame_blocks_per_cu[m][lv]) {
+        const int n = blok::frame_blocks_per_cu(mode, args);
+        if (n <= 0) return set_error(ctx, BLOK_ERR_HIP, "frame kernel does not fit a compute unit");
+        ctx->frame_blocks_per_cu[m][lv] = n;
+    }
+    // every resident wave slot of the chip, but never more waves than there are tasks; a multiple of the part count
+    const size_t resident = static_cast<size_t>(ctx->cu_count) * ctx->frame_blocks_per_cu[m][lv];
+    const size_t waves = std::min(resident, std::max<size_t>(static_cast<size_t>(n_beams) * per_beam, n_beams));
+    *n_blocks = static_cast<uint32_t>((waves + parts - 1u) / parts * parts);
     return BLOK_OK;
 }
 
@@ -160,9 +196,17 @@ int launch_timed(blok_hip_ctx* ctx, blok::RayMode mode, blok::TraceArgs args, ui
                  uint32_t tiles_of_rank = 0) {
     uint32_t n_beams = 0;
     if (blocks) { const int rc = prepare_beam(ctx, mode, args, stream, tiles_of_rank, &n_beams); if (rc != BLOK_OK) return rc; }
+    blok::FrameQueue queue{};
+    uint32_t frame_blocks = 0;
+    const bool one_launch = n_beams && ctx->fused;
+    if (one_launch) { const int rc = prepare_queue(ctx, mode, args, stream, n_beams, &queue, &frame_blocks); if (rc != BLOK_OK) return rc; }
     if (ctx->timing) BLOK_HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, stream));
-    if (n_beams) blok::launch_beam(mode, args, n_beams, stream);
-    blok::launch_trace(mode, args, blocks, stream);
+    if (one_launch) {
+        blok::launch_frame(mode, args, queue, frame_blocks, stream);
+    } else {
+        if (n_beams) blok::launch_beam(mode, args, n_beams, stream);
+        blok::launch_trace(mode, args, blocks, stream);
+    }
     BLOK_HIP_TRY(ctx, hipGetLastError());
     if (ctx->timing) { BLOK_HIP_TRY(ctx, hipEventRecord(ctx->ev_end, stream)); ctx->timed = true; }
     return BLOK_OK;
@@ -212,6 +256,9 @@ int blok_hip_create(blok_hip_ctx** out_ctx, int device_ordinal, uint32_t width, 
     auto* ctx = new (std::nothrow) blok_hip_ctx();
     if (!ctx) return set_error(nullptr, BLOK_ERR_OOM, "host allocation failed");
     ctx->device = device_ordinal; ctx->width = width; ctx->height = height;
+    ctx->cu_count = prop.multiProcessorCount;
+    if (const char* e = std::getenv("BLOK_FRAME_PARTS")) { const long v = std::atol(e); if (v >= 1 && v <= long(blok::kFrameParts)) ctx->frame_parts = uint32_t(v); }
+    if (const char* e = std::getenv("BLOK_FRAME_CHUNK")) { const long v = std::atol(e); if (v >= 1 && v <= 64) ctx->frame_chunk = uint32_t(v); }
     if (hipEventCreate(&ctx->ev_begin) != hipSuccess || hipEventCreate(&ctx->ev_end) != hipSuccess) {
         delete ctx;
         return set_error(nullptr, BLOK_ERR_HIP, "hipEventCreate failed");
@@ -234,7 +281,9 @@ void blok_hip_destroy(blok_hip_ctx* ctx) {
     if (ctx->d_frame) (void)hipFree(ctx->d_frame);
     free_post(ctx);
     if (ctx->has_volume) blok::gpu_volume_destroy(&ctx->volume);
-    for (auto& kv : ctx->beam_buffers) if (kv.second.first) (void)hipFree(kv.second.first);
+    for (auto& kv : ctx->beam_buffers)
+        for (void* p : {static_cast<void*>(kv.second.beam), static_cast<void*>(kv.second.ctl), static_cast<void*>(kv.second.entries)})
+            if (p) (void)hipFree(p);
     if (ctx->d_accum) (void)hipFree(ctx->d_accum);
     if (ctx->d_color) (void)hipFree(ctx->d_color);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
@@ -635,6 +684,28 @@ int blok_hip_set_beam(blok_hip_ctx* ctx, uint32_t beam_tile_pixels) {
     if (beam_tile_pixels != 0 && beam_tile_pixels != 8 && beam_tile_pixels != 16 && beam_tile_pixels != 32 && beam_tile_pixels != 64)
         return set_error(ctx, BLOK_ERR_INVALID_ARG, "beam tile must be 0 (off), 8, 16, 32 or 64 pixels");
     ctx->beam_tile = beam_tile_pixels;
+    return BLOK_OK;
+}
+
+int blok_hip_set_fused(blok_hip_ctx* ctx, int enabled) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    ctx->fused = enabled != 0;
+    return BLOK_OK;
+}
+
+int blok_hip_frame_queue_stalls(blok_hip_ctx* ctx, uint32_t* out_stalled_waves) {
+    if (!ctx || !out_stalled_waves) return BLOK_ERR_INVALID_ARG;
+    *out_stalled_waves = 0;
+    BLOK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    BLOK_HIP_TRY(ctx, hipDeviceSynchronize());
+    for (auto& kv : ctx->beam_buffers) {
+        if (!kv.second.ctl) continue;
+        for (uint32_t part = 0; part < blok::kFrameParts; ++part) {      // all possible parts: the words of unused ones stay 0
+            uint32_t n = 0;
+            BLOK_HIP_TRY(ctx, hipMemcpy(&n, kv.second.ctl + part * blok::kFramePartWords + blok::kFrameStalledWord, sizeof(n), hipMemcpyDeviceToHost));
+            *out_stalled_waves += n;
+        }
+    }
     return BLOK_OK;
 }
 

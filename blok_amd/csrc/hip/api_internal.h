@@ -72,7 +72,16 @@ struct blok_hip_ctx {
     // beam pre-pass (beam.h): start parameters per beam tile, one buffer per stream (launches on one stream are
     // ordered, frames in flight on different streams must not share)
     uint32_t beam_tile = 32;
-    std::unordered_map<hipStream_t, std::pair<float*, size_t>> beam_buffers;
+    struct StreamScratch {             // per launch stream
+        float* beam = nullptr; size_t n_beam = 0;                       // two-launch form: start parameters per beam tile
+        uint32_t* ctl = nullptr; unsigned long long* entries = nullptr; size_t capacity = 0;   // one-launch form: work queue (trace_kernels.h: FrameQueue)
+    };
+    std::unordered_map<hipStream_t, StreamScratch> beam_buffers;
+    // one-launch frame (frame_kernel): pre-pass and walk in one persistent grid; off (default, faster as measured) = beam_kernel, then trace_kernel
+    bool fused = false;
+    uint32_t frame_parts = 32, frame_chunk = 1;      // FrameQueue::n_parts / chunk (BLOK_FRAME_PARTS / BLOK_FRAME_CHUNK override, for experiments)
+    int cu_count = 0;
+    int frame_blocks_per_cu[2][16] = {};   // [mode][levels], 0 = not asked yet
     // timing
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool timing = false, timed = false;
@@ -99,6 +108,7 @@ int rebuild_sun_map(blok_hip_ctx* ctx);
 int ensure_frame(blok_hip_ctx* ctx, size_t records);
 blok::TraceArgs base_args(const blok_hip_ctx* ctx, const blok_camera* cam);
 int prepare_beam(blok_hip_ctx* ctx, blok::RayMode mode, blok::TraceArgs& args, hipStream_t stream, uint32_t tiles_of_rank, uint32_t* n_beams);
+int prepare_queue(blok_hip_ctx* ctx, blok::RayMode mode, const blok::TraceArgs& args, hipStream_t stream, uint32_t n_beams, blok::FrameQueue* queue, uint32_t* n_blocks);
 int check_trace(blok_hip_ctx* ctx, const blok_camera* cam);
 
 }  // namespace blok_api

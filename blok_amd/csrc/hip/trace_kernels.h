@@ -97,6 +97,22 @@ struct TraceArgs {
     uint32_t beam_tile, beam_bx;           // beam_bx: beam tiles per row of the rectangle (Rect)
 };
 
+// Work queues of the one-launch frame (frame_kernel, trace_kernels.hip), per stream: n_parts independent parts, each with its
+// own counters and its own slice of 64-bit task entries.
+constexpr uint32_t kFrameParts = 256;        // most parts a launch may be cut into (FrameQueue::n_parts <= this)
+constexpr uint32_t kFramePartWords = 192;    // per part: five counters and a sticky error word, one 128-byte line each
+constexpr uint32_t kFrameCtlWords = kFrameParts * kFramePartWords;
+constexpr uint32_t kFrameStalledWord = 160;  // within a part: waves that gave up waiting for a queue entry (0 in a working system); host-readable, never reset by the kernel
+constexpr uint32_t kFramePollBudget = 1u << 19;   // polls (~1 us apart) before a waiting wave gives up
+struct FrameQueue {
+    uint32_t* ctl;                  // kFrameCtlWords words, zero between launches (but for the sticky error words)
+    unsigned long long* entries;    // n_parts slices of part_capacity entries: task id | start parameter bits << 32; all ones = empty
+    uint32_t n_beam;                // beam tasks of this launch; part p owns tasks p, p + n_parts, ...
+    uint32_t part_capacity;         // entries per part (>= its beam tasks * sub-tiles per beam tile)
+    uint32_t n_parts;               // parts of this launch (workgroup b works in part b mod n_parts)
+    uint32_t chunk;                 // consecutive entries per trace ticket
+};
+
 struct UntileArgs {
     const void* gathered;
     void* frame;
@@ -123,6 +139,9 @@ void launch_trace(RayMode mode, const TraceArgs& args, uint32_t n_blocks, hipStr
 uint32_t beam_tiles(RayMode mode, const TraceArgs& args, uint32_t tiles_of_rank);
 void launch_beam(RayMode mode, const TraceArgs& args, uint32_t n_beam_tiles, hipStream_t stream);
 void launch_untile(const UntileArgs& args, hipStream_t stream);
+// One-launch frame: pre-pass and walk in one persistent grid of n_blocks waves (Rect and Tiles).
+void launch_frame(RayMode mode, const TraceArgs& args, const FrameQueue& queue, uint32_t n_blocks, hipStream_t stream);
+int frame_blocks_per_cu(RayMode mode, const TraceArgs& args);      // resident workgroups per CU for the launch's LDS size (0 on error)
 
 }  // namespace blok
 #endif

@@ -140,6 +140,213 @@ __global__ __launch_bounds__(64) void beam_kernel(const TraceArgs A, const uint3
     }
 }
 
+// ---- one-launch frame: pre-pass and walk in ONE persistent grid ------------------------------------------------------
+// No reference counterpart (the reference hands "which boxes does this ray meet" to RT hardware and issues one
+// traceRaysKHR per frame, blok/src/renderer_raytracing.cpp:666-685).  The two-launch form (beam_kernel, then trace_kernel)
+// leaves the chip idle twice per frame: the pre-pass is one round of latency-bound waves whose slowest search sets its
+// duration, and the trace launch spends its first instruction in ~3/4 of its waves (sky tiles the pre-pass has already
+// written) and ends in a tail of long grazing-ray waves.  Here a grid of resident waves pulls work from two counters:
+//   phase 1  beam tasks, ctl[kBeamNext]++: search one beam tile; "none" -> write the tile's miss pixels; else append
+//            the tile's wave-sized sub-tiles — only those, the live ones — to a queue (ctl[kReserved] += n, one 64-bit
+//            entry each = task id | start parameter << 32), then ctl[kBeamDone]++;
+//   phase 2  trace tickets, ctl[kHead]++: wait for entry i (producers publish it with one 8-byte store), walk its 64 rays.
+// Early finishers of phase 1 start walking while the long searches are still running, and the queue holds no dead tile.
+// Termination: a ticket beyond the final queue length (known once ctl[kBeamDone] == n_beam) ends the wave.  A waiting wave
+// only ever waits for beam tasks that running waves hold (it has seen ctl[kBeamNext] >= n_beam), and those never wait, so
+// every wave reaches its exit whatever part of the grid is resident, and a wait is bounded besides (kFramePollBudget).  All
+// communication is relaxed agent-scope atomics on the words themselves (an entry validates itself), no fence: values are
+// published with an exchange and polled with sc1 loads, which see another XCD's publication (the eight XCDs have one L2
+// each; scripts/microbench/xcd_poll.hip measures every publish / poll pairing across XCDs: all work).  Consumers put the
+// entry back to kNoTask and the last wave out zeroes the counters, so the buffers are ready for the next launch on the same
+// stream.  Every counter has its own 128-byte line.
+//
+// SEVERAL queues, not one.  Atomics on one address are served at ~88 M/s, 11.5 ns each, whichever XCDs they come from
+// (scripts/microbench/atomic_rate.hip; different addresses proceed in parallel): the first version, with one ticket counter
+// for the chip, spent 0.9 ms per 4K frame on its ~80 K atomics.  So the launch is cut into Q.n_parts parts — workgroup b works
+// in part b mod n_parts, which owns beam tiles part, part + n_parts, ..., its own slice of the entry array and its own
+// counters — and a trace ticket is good for Q.chunk consecutive entries.  Interleaving the tiles balances the parts the way the
+// round-robin dispatch of the two-launch form balances the XCDs.
+enum : uint32_t { kBeamNext = 0, kBeamDone = 32, kReserved = 64, kHead = 96, kExited = 128, kStalled = 160, kPartWords = kFramePartWords };
+static_assert(kStalled < kPartWords, "counter block");
+constexpr unsigned long long kNoTask = ~0ull;
+
+__device__ __forceinline__ uint32_t add_agent(uint32_t* p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t ld_agent(uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long ld_agent(unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(uint32_t* p, uint32_t v) { (void)__hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(unsigned long long* p, unsigned long long v) { (void)__hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// One fetch-add per WAVE, performed by lane 0, result wave-uniform (an SGPR).  Written as ONE opaque instruction sequence
+// because the source-level form — if (lane == 0) v = atomic; v = readfirstlane(v) — inside a loop is restructured by the
+// compiler (the condition is loop-invariant per lane, so the back edge of lanes 1-63 is threaded past the block): lane 0
+// leaves to perform the atomic while the other lanes go round the body again with the stale value.  Measured: the first
+// version of this kernel hung that way, also with the value handed over through LDS behind a (single-wave, hence elided)
+// barrier.  Must be called with all 64 lanes active.
+__device__ __forceinline__ uint32_t wave_fetch_add(uint32_t* counter, uint32_t v) {
+    uint32_t result, tmp;
+    unsigned long long saved;
+    asm volatile(
+        "s_mov_b64 %[saved], exec\n\t"
+        "s_mov_b64 exec, 1\n\t"
+        "v_mov_b32 %[tmp], %[val]\n\t"
+        "global_atomic_add %[tmp], %[zero], %[tmp], %[ptr] sc0\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "s_mov_b64 exec, %[saved]\n\t"
+        "s_nop 4\n\t"
+        "v_readfirstlane_b32 %[res], %[tmp]\n\t"
+        "s_nop 3"
+        : [res] "=s"(result), [tmp] "=&v"(tmp), [saved] "=&s"(saved)
+        : [val] "s"(v), [zero] "v"(0u), [ptr] "s"(counter)
+        : "memory");
+    return result;
+}
+
+// Pixels and output slots of beam tile b.
+struct BeamRect {
+    uint32_t px, py, px_end, py_end;       // frame pixels [px, px_end) x [py, py_end)
+    uint32_t ox, oy, stride;               // output index = obase + (y - oy) * stride + (x - ox)
+    size_t obase;
+    bool padding;                          // Tiles: a tile slot beyond the frame's last tile (all misses)
+};
+template <RayMode MODE>
+__device__ __forceinline__ BeamRect beam_rect(const TraceArgs& A, uint32_t b) {
+    const uint32_t B = A.beam_tile;
+    BeamRect r;
+    r.padding = false;
+    if constexpr (MODE == RayMode::Rect) {
+        r.px = A.x0 + (b % A.beam_bx) * B; r.py = A.y0 + (b / A.beam_bx) * B;
+        r.px_end = min(r.px + B, A.x0 + A.w); r.py_end = min(r.py + B, A.y0 + A.h);
+        r.ox = A.x0; r.oy = A.y0; r.stride = A.w; r.obase = 0;
+    } else {
+        const uint32_t per_side = A.tile / B, per_tile = per_side * per_side;
+        const uint32_t local_tile = b / per_tile, sub = b % per_tile;
+        const uint32_t global_tile = A.rank + local_tile * A.n_ranks;
+        r.padding = global_tile >= A.tiles_total;
+        r.ox = (global_tile % A.tiles_x) * A.tile; r.oy = (global_tile / A.tiles_x) * A.tile;
+        r.stride = A.tile; r.obase = static_cast<size_t>(local_tile) * A.tile * A.tile;
+        r.px = r.ox + (sub % per_side) * B; r.py = r.oy + (sub / per_side) * B;
+        r.px_end = r.px + B; r.py_end = r.py + B;
+    }
+    return r;
+}
+
+template <RayMode MODE>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void frame_kernel(const TraceArgs A, const FrameQueue Q) {
+    static_assert(kBlock == 64, "one wave per workgroup");
+    extern __shared__ uint4 lds_stack[];       // [levels-1][kBlock]
+    const uint32_t lane = threadIdx.x;
+    const uint32_t B = A.beam_tile;
+    const uint32_t subs_x = B / kWaveW, subs_y = B / kWaveH;
+    // this wave's part: its counters, its beam tiles (part, part + kFrameParts, ...), its slice of the entries
+    const uint32_t n_parts = Q.n_parts;
+    const uint32_t part = blockIdx.x % n_parts;
+    uint32_t* const ctl = Q.ctl + part * kPartWords;
+    const uint32_t n_beam = Q.n_beam > part ? (Q.n_beam - part + n_parts - 1u) / n_parts : 0u;
+    unsigned long long* const entries = Q.entries + static_cast<size_t>(part) * Q.part_capacity;
+
+    // ---- phase 1: beam tasks.  A search is one long chain of dependent instructions; at raised priority its instructions issue
+    // ahead of the walking waves of the same SIMD (VALU-bound, any order will do), so the searches finish as early as alone.
+    __builtin_amdgcn_s_setprio(3);
+    for (;;) {
+        if (__builtin_amdgcn_readfirstlane(ld_agent(ctl + kBeamNext)) >= n_beam) break;      // a load before the atomic: no wave takes a ticket only to learn that it is late
+        const uint32_t k = wave_fetch_add(ctl + kBeamNext, 1u);
+        if (k >= n_beam) break;
+        const uint32_t b = part + k * n_parts;
+        const BeamRect r = beam_rect<MODE>(A, b);
+        float t0 = kBeamNone;
+        if (!r.padding) t0 = beam_start(A, static_cast<float>(r.px), static_cast<float>(r.py), static_cast<float>(r.px_end), static_cast<float>(r.py_end), lane);
+        if (t0 >= kBeamNone) {
+            // no ray of this tile can hit anything: its pixels are written here, 64 at a time
+            const uint32_t tw = r.px_end - r.px, n = tw * (r.py_end - r.py);
+            for (uint32_t i = lane; i < n; i += 64u) {
+                const uint32_t x = r.px + i % tw, y = r.py + i / tw;
+                const size_t out_index = r.obase + static_cast<size_t>(y - r.oy) * r.stride + (x - r.ox);
+                write_miss(Sink{A.out ? A.out + out_index : nullptr, A.out_rgba ? A.out_rgba + out_index : nullptr});
+            }
+        } else {
+            // the tile's wave-sized sub-tiles that lie inside the rectangle (an edge tile of a Rect launch may be cut)
+            const uint32_t nx = (r.px_end - r.px + kWaveW - 1u) / kWaveW, ny = (r.py_end - r.py + kWaveH - 1u) / kWaveH;
+            const uint32_t n = nx * ny;                                   // <= subs_x * subs_y <= 64
+            const uint32_t pos = wave_fetch_add(ctl + kReserved, n);
+            if (lane < n && pos + lane < Q.part_capacity) {
+                const uint32_t task = b * (subs_x * subs_y) + (lane / nx) * subs_x + lane % nx;
+                st_agent(entries + pos + lane, (static_cast<unsigned long long>(__float_as_uint(t0)) << 32) | task);
+            }
+        }
+        (void)wave_fetch_add(ctl + kBeamDone, 1u);
+    }
+
+    // ---- phase 2: trace tickets
+    __builtin_amdgcn_s_setprio(0);
+    uint4* stk = lds_stack + lane;
+    for (;;) {
+        {   // nothing left for a new ticket?  (loads, so that the waves of a part do not each spend an atomic to find out)
+            const uint32_t done = __builtin_amdgcn_readfirstlane(ld_agent(ctl + kBeamDone));
+            if (done >= n_beam) {
+                const uint32_t total = __builtin_amdgcn_readfirstlane(ld_agent(ctl + kReserved));
+                if (__builtin_amdgcn_readfirstlane(ld_agent(ctl + kHead)) >= total) break;
+            }
+        }
+        // a ticket is good for Q.chunk consecutive entries (sub-tiles of one beam tile lie together): fewer same-address atomics
+        const uint32_t first = wave_fetch_add(ctl + kHead, Q.chunk);
+        bool ended = false;
+        for (uint32_t i = first; i < first + Q.chunk && !ended; ++i) {
+            if (i >= Q.part_capacity) { ended = true; break; }            // more tickets than tasks can exist
+            unsigned long long e = kNoTask;
+            for (uint32_t polls = 0;; ++polls) {
+                if (polls >= kFramePollBudget) {                          // never reached in a working system: give up rather than hang
+                    (void)wave_fetch_add(ctl + kStalled, 1u);
+                    ended = true;
+                    break;
+                }
+                // every lane loads the same address: one broadcast request, and no lane-0 branch for the compiler to thread
+                e = ld_agent(entries + i);
+                const uint32_t e_lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(e)), e_hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(e >> 32));
+                e = (static_cast<unsigned long long>(e_hi) << 32) | e_lo;
+                if (e != kNoTask) break;
+                if ((polls & 3u) == 3u) {
+                    const uint32_t done = __builtin_amdgcn_readfirstlane(ld_agent(ctl + kBeamDone));
+                    // a wave adds to kReserved before it issues its kBeamDone increment (the add has returned its value by then), so
+                    // once done == n_beam the queue length read AFTER it is final, and an entry below that length is on its way
+                    if (done >= n_beam) {
+                        const uint32_t total = __builtin_amdgcn_readfirstlane(ld_agent(ctl + kReserved));
+                        if (i >= total) { ended = true; break; }
+                    }
+                }
+                __builtin_amdgcn_s_sleep(32);                             // ~2000 clocks between polls of this wave
+            }
+            if (ended) break;
+            __hip_atomic_store(entries + i, kNoTask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every lane, same word: the slot is clean for the next launch
+            const uint32_t task = static_cast<uint32_t>(e);
+            const float t0 = __uint_as_float(static_cast<uint32_t>(e >> 32));
+            const uint32_t per_beam = subs_x * subs_y;
+            const uint32_t b = task / per_beam, sub = task % per_beam;
+            const BeamRect r = beam_rect<MODE>(A, b);
+            const uint32_t x = r.px + (sub % subs_x) * kWaveW + lane % kWaveW, y = r.py + (sub / subs_x) * kWaveH + lane / kWaveW;
+            const size_t out_index = r.obase + static_cast<size_t>(y - r.oy) * r.stride + (x - r.ox);
+            const Sink sink{A.out ? A.out + out_index : nullptr, A.out_rgba ? A.out_rgba + out_index : nullptr};
+            if (x < r.px_end && y < r.py_end) {
+                if (MODE == RayMode::Tiles && !(x < A.frame_w && y < A.frame_h)) {
+                    write_miss(sink);                                     // the tile buffer is dense
+                } else {
+                    RayIn ray = primary_ray(A, x, y);
+                    ray.tmin = fmaxf(ray.tmin, t0);
+                    trace_one(A, ray, stk, sink);
+                }
+            }
+        }
+        if (ended) break;
+    }
+
+    // ---- exit: the last wave of the part re-arms its counters
+    const uint32_t part_waves = (gridDim.x - part + n_parts - 1u) / n_parts;
+    const uint32_t gone = wave_fetch_add(ctl + kExited, 1u);
+    if (gone == part_waves - 1u && lane == 0) {
+        st_agent(ctl + kBeamNext, 0u); st_agent(ctl + kBeamDone, 0u); st_agent(ctl + kReserved, 0u);
+        st_agent(ctl + kHead, 0u); st_agent(ctl + kExited, 0u);
+    }
+}
+
 __global__ __launch_bounds__(64) void sun_map_kernel(const SunMapArgs a) {
     const uint32_t b = blockIdx.x, lane = threadIdx.x;
     if (b >= a.nu * a.nv) return;
@@ -213,6 +420,23 @@ void launch_beam(RayMode mode, const TraceArgs& args, uint32_t n_beam_tiles, hip
     if (n_beam_tiles == 0 || mode == RayMode::Rays) return;
     if (mode == RayMode::Rect) hipLaunchKernelGGL(beam_kernel<RayMode::Rect>, dim3(n_beam_tiles), dim3(64), 0, stream, args, n_beam_tiles);
     else hipLaunchKernelGGL(beam_kernel<RayMode::Tiles>, dim3(n_beam_tiles), dim3(64), 0, stream, args, n_beam_tiles);
+}
+
+size_t frame_lds_bytes(const TraceArgs& args) { return static_cast<size_t>(args.levels > 1 ? args.levels - 1 : 1) * kBlock * sizeof(uint4); }
+
+int frame_blocks_per_cu(RayMode mode, const TraceArgs& args) {
+    int n = 0;
+    const hipError_t e = mode == RayMode::Rect
+        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, frame_kernel<RayMode::Rect>, kBlock, frame_lds_bytes(args))
+        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, frame_kernel<RayMode::Tiles>, kBlock, frame_lds_bytes(args));
+    return e == hipSuccess ? n : 0;
+}
+
+void launch_frame(RayMode mode, const TraceArgs& args, const FrameQueue& queue, uint32_t n_blocks, hipStream_t stream) {
+    if (n_blocks == 0 || mode == RayMode::Rays) return;
+    const size_t lds = frame_lds_bytes(args);
+    if (mode == RayMode::Rect) hipLaunchKernelGGL(frame_kernel<RayMode::Rect>, dim3(n_blocks), dim3(kBlock), lds, stream, args, queue);
+    else hipLaunchKernelGGL(frame_kernel<RayMode::Tiles>, dim3(n_blocks), dim3(kBlock), lds, stream, args, queue);
 }
 
 void launch_sun_map(const SunMapArgs& args, hipStream_t stream) {

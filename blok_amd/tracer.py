@@ -155,6 +155,16 @@ class HipTracer:
         """Beam pre-pass granularity of the frame kernels in pixels (0 = off, default 32); never changes a result."""
         self._check(self._lib.blok_hip_set_beam(self._ctx, beam_tile_pixels))
 
+    def set_fused(self, enabled: bool):
+        """One-launch frame (pre-pass + walk in one persistent grid; opt-in) or the two-launch form (default); never changes a result."""
+        self._check(self._lib.blok_hip_set_fused(self._ctx, 1 if enabled else 0))
+
+    def frame_queue_stalls(self) -> int:
+        """Waves of one-launch frames that ever gave up waiting for a queue entry (0 in a working system); synchronises."""
+        n = C.c_uint32(0)
+        self._check(self._lib.blok_hip_frame_queue_stalls(self._ctx, C.byref(n)))
+        return int(n.value)
+
     def reset_accum(self):
         self._check(self._lib.blok_hip_reset_accum(self._ctx))
 

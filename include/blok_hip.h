@@ -354,6 +354,18 @@ int blok_hip_set_sun_map(blok_hip_ctx* ctx, int enabled);
  * conservative start parameter for that tile's rays, and tiles whose frustum meets no voxel are written as misses without
  * a walk.  Results are identical with and without it (tests/test_gpu_parity.py).  0 turns it off; default 32. */
 int blok_hip_set_beam(blok_hip_ctx* ctx, uint32_t beam_tile_pixels);
+/* One-launch frame (opt-in; default off): the pre-pass and the walk of a rectangle / tile launch run in ONE persistent grid
+ * — resident waves first take beam tiles, append the wave-sized sub-tiles of the live ones to per-part queues with an atomic
+ * reservation, then take walk tasks from those queues — so the walk starts while long searches are still running and no wave
+ * is launched for a tile the pre-pass has written (no reference counterpart: blok/src/renderer_raytracing.cpp:666-685 issues
+ * one traceRaysKHR per frame).  0 (default) = the two-launch form (beam kernel, then one walk wave per 8x8 pixels), which
+ * measures faster on MI355X (0.30 vs 0.32 ms per 4K frame alone; same-address atomics run at 88 M/s).  Results
+ * are identical (tests/test_gpu_parity.py). */
+int blok_hip_set_fused(blok_hip_ctx* ctx, int enabled);
+/* Health check of the one-launch frame's work queue: synchronises the device and returns how many waves ever gave up waiting
+ * for a queue entry (a bounded wait, ~0.5 s; 0 in a working system — anything else means frames since context creation may
+ * be incomplete). */
+int blok_hip_frame_queue_stalls(blok_hip_ctx* ctx, uint32_t* out_stalled_waves);
 /* Enable/disable the per-launch HIP event pair (default off: nothing but the kernel is
  * enqueued by the *_device entries). */
 int blok_hip_set_timing(blok_hip_ctx* ctx, int enabled);

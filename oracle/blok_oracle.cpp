@@ -84,6 +84,14 @@ struct Hit {                // include/blok_hip.h: blok_hit
 };
 static_assert(sizeof(Hit) == 16, "hit record is 16 bytes");
 
+// Per-visit accounting (defines the algorithmic byte count).  ORC_NO_COUNTERS: the timing build of bench.py's
+// cpu_baseline (same traversal, -O3 -march=native) drops the per-node / per-box increments; rays and hits stay.
+#ifdef ORC_NO_COUNTERS
+#define ORC_COUNT(stmt) do { } while (0)
+#else
+#define ORC_COUNT(stmt) do { stmt; } while (0)
+#endif
+
 struct Counters {
     uint64_t rays, hits;
     uint64_t subChunksEntered;   // S: intersection-shader invocations whose root slab test passed
@@ -437,7 +445,7 @@ bool intersectSubChunk(RayQuery& q, const SubChunkGpu& sub, const SvoNode* nodes
         if (item.tEntry >= q.tmax) continue;                                      // :128
         if (item.nodeIndex >= sub.nodeOffset + sub.nodeCount) continue;           // :132
         const SvoNode node = nodes[item.nodeIndex];                               // :133
-        c.nodesFetched++;
+        ORC_COUNT(c.nodesFetched++);
         if (node.childMask == 0u) {                                               // :136
             if (node.occupancy > 0.0f) {
                 const Vec3 hitPos = add3(rayOrg, scale3(rayDir, item.tEntry));    // :138
@@ -468,15 +476,15 @@ bool intersectSubChunk(RayQuery& q, const SubChunkGpu& sub, const SvoNode* nodes
                 if (stackPtr < MAX_STACK) {
                     stack[stackPtr++] = StackItem{sub.nodeOffset + node.firstChild + childIdx,
                                                   childCenter, nextHalf, cTmin, cTmax};
-                    if (stackPtr > c.maxStack) c.maxStack = stackPtr;
+                    ORC_COUNT(if (stackPtr > c.maxStack) c.maxStack = stackPtr);
                 } else {
-                    c.stackLimitHits++;
+                    ORC_COUNT(c.stackLimitHits++);
                 }
             }
         }
     }
-    if (iter > c.maxIter) c.maxIter = std::min(iter, MAX_ITER);
-    if (stackPtr > 0u) c.iterLimitHits++;
+    ORC_COUNT(if (iter > c.maxIter) c.maxIter = std::min(iter, MAX_ITER));
+    ORC_COUNT(if (stackPtr > 0u) c.iterLimitHits++);
     return true;
 }
 
@@ -551,7 +559,7 @@ void traceLattice(const Lattice& L, const SvoNode* nodes, const SubChunkGpu* sub
     for (;;) {
         if (tCur >= q.tmax) break;     // later slots start at or beyond the committed hit (:128 drops them)
         const int32_t s = L.at(idx[0], idx[1], idx[2]);
-        if (s >= 0 && intersectSubChunk(q, subs[s], nodes, c)) c.subChunksEntered++;
+        if (s >= 0 && intersectSubChunk(q, subs[s], nodes, c)) ORC_COUNT(c.subChunksEntered++);
         int a = 0;
         if (tNext[1] < tNext[a]) a = 1;
         if (tNext[2] < tNext[a]) a = 2;

@@ -227,6 +227,42 @@ class Lattice:
         return hits, ctr[0]
 
 
+class NativeLattice:
+    """The timing build of the traversal (`make -C oracle native`: counters compiled out, -O3 -march=native, built on the
+    machine that runs it, into a scratch directory) — bench.py's cpu_baseline only.  Same entry points as Lattice."""
+
+    def __init__(self, nodes, subs, out_dir=None):
+        import subprocess
+        import tempfile
+        self.dir = out_dir or tempfile.mkdtemp(prefix="blok_oracle_native_")
+        subprocess.run(["make", "-s", "-C", os.fspath(ROOT / "oracle"), "native", f"NATIVE_OUT={self.dir}"], check=True,
+                       capture_output=True)
+        self.L = C.CDLL(os.path.join(self.dir, "liboracle_native.so"))
+        self.L.orc_lattice_build.restype = C.c_void_p
+        self.L.orc_lattice_build.argtypes = [C.c_void_p, C.c_size_t]
+        self.L.orc_lattice_free.argtypes = [C.c_void_p]
+        self.L.orc_trace_primary.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_uint32] * 7 + \
+                                            [C.c_void_p, C.c_void_p, C.c_int]
+        self.nodes = np.ascontiguousarray(nodes)
+        self.subs = np.ascontiguousarray(subs)
+        self.h = C.c_void_p(self.L.orc_lattice_build(_p(self.subs), len(self.subs)))
+
+    def trace_primary(self, cam, width, height, x0=0, y0=0, w=None, h=None, stride=1, threads=1, want_hits=True):
+        w = width if w is None else w
+        h = height if h is None else h
+        n = ((w + stride - 1) // stride) * ((h + stride - 1) // stride)
+        hits = np.zeros(n, dtype=HIT) if want_hits else None
+        ctr = np.zeros(1, dtype=COUNTERS)
+        self.L.orc_trace_primary(self.h, _p(self.nodes), _p(self.subs), _p(cam), width, height, x0, y0, w, h,
+                                 stride, _p(hits) if want_hits else None, _p(ctr), threads)
+        return hits, ctr[0]
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_lattice_free(self.h)
+            self.h = None
+
+
 def render_paths(lattice: "Lattice", materials, cam, width, height, spp=8, max_bounces=2, frame_index=0, rect=None,
                  stride=1, threads=1):
     """raygen.rgen restatement: dict of (rows, cols, 4) float32 planes + counters."""

@@ -174,13 +174,16 @@ def test_beam_prepass_never_changes_a_record(tracer_cls, scene64, scene1024):
         plain_rect = tr.draw_frame(cam, rect)
         for beam in (8, 16, 32, 64):
             tr.set_beam(beam)
-            assert records_equal(tr.draw_frame(cam).reshape(-1), plain.reshape(-1)).all(), beam
-            assert records_equal(tr.draw_frame(cam, rect).reshape(-1), plain_rect.reshape(-1)).all(), beam
+            for fused in (True, False):                 # one persistent launch (pre-pass + walk) / beam kernel, then trace kernel
+                tr.set_fused(fused)
+                assert records_equal(tr.draw_frame(cam).reshape(-1), plain.reshape(-1)).all(), (beam, fused)
+                assert records_equal(tr.draw_frame(cam, rect).reshape(-1), plain_rect.reshape(-1)).all(), (beam, fused)
     cam = cams[1]
     tr.set_beam(0)
     plain = tr.draw_frame(cam)
-    for beam, tile, n_ranks in [(32, 32, 8), (32, 48, 3), (16, 64, 2), (64, 64, 5)]:
+    for beam, tile, n_ranks, fused in [(32, 32, 8, True), (32, 48, 3, True), (16, 64, 2, True), (64, 64, 5, True), (32, 32, 8, False), (16, 64, 2, False)]:
         tr.set_beam(beam)
+        tr.set_fused(fused)
         per = tr.tiles_for_rank(tile, 0, n_ranks)
         gathered = torch.zeros((n_ranks * per * tile * tile, 4), dtype=torch.int32, device="cuda")
         for r in range(n_ranks):
@@ -203,7 +206,9 @@ def test_beam_prepass_never_changes_a_record(tracer_cls, scene64, scene1024):
         plain = tr.draw_frame(cam)
         for beam in (8, 32):
             tr.set_beam(beam)
-            assert records_equal(tr.draw_frame(cam).reshape(-1), plain.reshape(-1)).all(), (k, beam)
+            for fused in (True, False):
+                tr.set_fused(fused)
+                assert records_equal(tr.draw_frame(cam).reshape(-1), plain.reshape(-1)).all(), (k, beam, fused)
     with pytest.raises(Exception):
         tr.set_beam(12)
     tr.shutdown()
@@ -238,10 +243,45 @@ def test_beam_prepass_random_cameras_and_odd_worlds(tracer_cls):
         plain = tr.draw_frame(cam).reshape(-1)
         for beam in (8, 32):
             tr.set_beam(beam)
-            assert records_equal(tr.draw_frame(cam).reshape(-1), plain).all(), (k, beam)
+            for fused in (True, False):
+                tr.set_fused(fused)
+                assert records_equal(tr.draw_frame(cam).reshape(-1), plain).all(), (k, beam, fused)
         if k % 10 == 0:
             ref, _ = lat.trace(O.primary_rays(cam, w, h), threads=8)
             assert records_equal(plain, ref).all(), k
+    tr.shutdown()
+
+
+def test_one_launch_frame_queue_rearms_itself(tracer_cls, scene1024):
+    """The persistent frame kernel (trace_kernels.hip: frame_kernel) leaves its work queue empty and its counters at zero:
+    forty frames back to back on one stream, then three streams with frames in flight and a change of frame size in
+    between, all equal the two-launch form's frame."""
+    import torch
+    cm, pw = scene1024
+    Wd, Ht = 1920, 1080
+    tr = tracer_cls(Wd, Ht).init()
+    tr.add_world(pw)
+    cam = W.scene_camera(1024, 0, Wd, Ht, SEED)
+    tr.set_fused(False)
+    want = torch.from_numpy(tr.draw_frame(cam).reshape(-1).view(np.int32).reshape(-1, 4)).cuda()
+    tr.set_fused(True)
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    outs = [torch.zeros((Ht * Wd, 4), dtype=torch.int32, device="cuda") for _ in range(3)]
+    for k in range(40):
+        tr.draw_frame_device(cam, outs[0].data_ptr(), 0, stream=streams[0].cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], want)
+    small = tr.draw_frame(cam, (64, 32, 200, 100))          # a different launch size on the default stream in between
+    for k in range(30):
+        outs[k % 3].zero_()
+        torch.cuda.synchronize()
+        for j in range(3):
+            tr.draw_frame_device(cam, outs[(k + j) % 3].data_ptr(), 0, stream=streams[(k + j) % 3].cuda_stream)
+        torch.cuda.synchronize()
+        for o in outs:
+            assert torch.equal(o, want), k
+    tr.set_fused(False)
+    assert records_equal(tr.draw_frame(cam, (64, 32, 200, 100)).reshape(-1), small.reshape(-1)).all()
     tr.shutdown()
 
 
