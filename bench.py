@@ -180,7 +180,8 @@ def main():
         args.frames_in_flight = 3 if world_size <= 2 else 4
     from blok_amd.multi_gpu import FramePipeline, HipBackend
     stream = torch.cuda.current_stream()
-    pipe = FramePipeline(HipBackend(tracer, cam), W_, H_, rank, world_size, dist, tile=args.tile, depth=args.frames_in_flight)
+    pipe = FramePipeline(HipBackend(tracer, cam), W_, H_, rank, world_size, dist, tile=args.tile, depth=args.frames_in_flight,
+                         sparse=bool(args.sparse_gather))
 
     def fence():
         if dist is not None:
@@ -293,6 +294,8 @@ def main():
                        "parallelism": f"single GPU, {launch}, {args.frames_in_flight} frame(s) in flight" if world_size == 1 else f"{args.tile}x{args.tile} screen tiles round-robin over {world_size} GPUs, {'RCCL' if args.backend == 'nccl' else args.backend} gather of {'the live ' if args.sparse_gather else ''}RGBA8 tiles to rank 0, {args.frames_in_flight} frames in flight",
                        "hits_per_frame": hits, "framebuffer_pixels_hit": lit_pixels,
                        "outputs": "16-B first-hit records (kept on the tracing GPU) + RGBA8 framebuffer on rank 0",
+                       "tile_records_gathered_per_frame_and_rank": (pipe.records_gathered / max(1, pipe.frames_done)) if world_size > 1 and args.sparse_gather else None,
+                       "tiles_per_rank": pipe.per_rank if world_size > 1 else None,
                        "frames_in_flight": args.frames_in_flight, "device_ms_per_step": device_ms / args.steps, "kernel_ms_alone": kernel_ms_avg, "beam_tile": args.beam,
                        "poses": poses, "also_measured_paths": paths},
         }

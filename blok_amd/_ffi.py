@@ -157,6 +157,9 @@ HIP_SYMBOLS = {
     "blok_hip_reset_accum": (C.c_int, [C.c_void_p]),
     "blok_hip_set_beam": (C.c_int, [C.c_void_p, C.c_uint32]),
     "blok_hip_set_fused": (C.c_int, [C.c_void_p, C.c_int]),
+    "blok_hip_compact_words": (C.c_size_t, [C.c_uint32, C.c_uint32]),
+    "blok_hip_compact_tiles_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "blok_hip_scatter_tiles_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "blok_hip_frame_queue_stalls": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "blok_hip_set_sun_map": (C.c_int, [C.c_void_p, C.c_int]),
     "blok_hip_set_ray_batching": (C.c_int, [C.c_void_p, C.c_int]),

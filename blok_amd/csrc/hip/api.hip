@@ -212,6 +212,11 @@ int launch_timed(blok_hip_ctx* ctx, blok::RayMode mode, blok::TraceArgs args, ui
     return BLOK_OK;
 }
 
+// A non-empty rectangle inside the frame; written so that x0 + w cannot wrap.
+bool rect_inside(const blok_hip_ctx* ctx, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h) {
+    return w && h && x0 < ctx->width && y0 < ctx->height && w <= ctx->width - x0 && h <= ctx->height - y0;
+}
+
 int check_trace(blok_hip_ctx* ctx, const blok_camera* cam) {
     if (!ctx) return BLOK_ERR_INVALID_ARG;
     if (!cam) return set_error(ctx, BLOK_ERR_INVALID_ARG, "camera is null");
@@ -412,7 +417,7 @@ int blok_hip_trace_primary_device(blok_hip_ctx* ctx, const blok_camera* cam, uin
                                   uint32_t w, uint32_t h, void* out_hits_dev, void* out_rgba_dev, void* hip_stream) {
     int rc = check_trace(ctx, cam);
     if (rc != BLOK_OK) return rc;
-    if ((!out_hits_dev && !out_rgba_dev) || !w || !h || x0 + w > ctx->width || y0 + h > ctx->height)
+    if ((!out_hits_dev && !out_rgba_dev) || !rect_inside(ctx, x0, y0, w, h))
         return set_error(ctx, BLOK_ERR_INVALID_ARG, "rectangle outside the frame or no output");
     blok::TraceArgs a = base_args(ctx, cam);
     a.x0 = x0; a.y0 = y0; a.w = w; a.h = h;
@@ -428,6 +433,7 @@ int blok_hip_trace_primary(blok_hip_ctx* ctx, const blok_camera* cam, uint32_t x
     if (!out_hits_host) return set_error(ctx, BLOK_ERR_INVALID_ARG, "null output");
     int rc = check_trace(ctx, cam);
     if (rc != BLOK_OK) return rc;
+    if (!rect_inside(ctx, x0, y0, w, h)) return set_error(ctx, BLOK_ERR_INVALID_ARG, "rectangle outside the frame");   // before anything is sized by it
     const size_t n = static_cast<size_t>(w) * h;
     rc = ensure_frame(ctx, n);
     if (rc != BLOK_OK) return rc;
@@ -478,6 +484,38 @@ int blok_hip_untile_device(blok_hip_ctx* ctx, const void* gathered_dev, uint32_t
     return BLOK_OK;
 }
 
+size_t blok_hip_compact_words(uint32_t tile, uint32_t n_tiles) { return 1u + static_cast<size_t>(n_tiles) * (1u + static_cast<size_t>(tile) * tile); }
+
+int blok_hip_compact_tiles_device(blok_hip_ctx* ctx, const void* rgba_tiles_dev, uint32_t tile, uint32_t n_tiles,
+                                  void* out_words_dev, void* hip_stream) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    if (!rgba_tiles_dev || !out_words_dev || !tile) return set_error(ctx, BLOK_ERR_INVALID_ARG, "bad compact arguments");
+    BLOK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    BLOK_HIP_TRY(ctx, hipMemsetAsync(out_words_dev, 0, sizeof(uint32_t), stream));          // the count word
+    blok::CompactArgs a{static_cast<const uint32_t*>(rgba_tiles_dev), static_cast<uint32_t*>(out_words_dev), tile, n_tiles};
+    blok::launch_compact_tiles(a, stream);
+    BLOK_HIP_TRY(ctx, hipGetLastError());
+    return BLOK_OK;
+}
+
+int blok_hip_scatter_tiles_device(blok_hip_ctx* ctx, const void* gathered_dev, uint32_t n_ranks, size_t rank_stride_words,
+                                  uint32_t tile, uint32_t max_records, void* out_frame_rgba_dev, void* hip_stream) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    if (!gathered_dev || !out_frame_rgba_dev || !tile || !n_ranks) return set_error(ctx, BLOK_ERR_INVALID_ARG, "bad scatter arguments");
+    BLOK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    const size_t n_px = static_cast<size_t>(ctx->width) * ctx->height;
+    BLOK_HIP_TRY(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(out_frame_rgba_dev), static_cast<int>(blok::sky_rgba()), n_px, stream));   // every tile nobody sent is sky
+    blok::ScatterArgs a{};
+    a.gathered = static_cast<const uint32_t*>(gathered_dev); a.frame = static_cast<uint32_t*>(out_frame_rgba_dev);
+    a.frame_w = ctx->width; a.frame_h = ctx->height; a.tile = tile; a.n_ranks = n_ranks;
+    a.tiles_x = (ctx->width + tile - 1) / tile; a.max_records = max_records; a.rank_stride = rank_stride_words;
+    blok::launch_scatter_tiles(a, stream);
+    BLOK_HIP_TRY(ctx, hipGetLastError());
+    return BLOK_OK;
+}
+
 int blok_hip_trace_rays(blok_hip_ctx* ctx, const blok_ray* rays_host, size_t n, blok_hit* out_hits_host) {
     if (!ctx) return BLOK_ERR_INVALID_ARG;
     if (!ctx->has_world) return set_error(ctx, BLOK_ERR_NO_WORLD, "no world uploaded");
@@ -507,6 +545,7 @@ int blok_hip_shade_rgba8(blok_hip_ctx* ctx, const blok_camera* cam, uint32_t x0,
     if (!out_rgba8_host) return set_error(ctx, BLOK_ERR_INVALID_ARG, "null output");
     int rc = check_trace(ctx, cam);
     if (rc != BLOK_OK) return rc;
+    if (!rect_inside(ctx, x0, y0, w, h)) return set_error(ctx, BLOK_ERR_INVALID_ARG, "rectangle outside the frame");
     const size_t n = static_cast<size_t>(w) * h;
     rc = ensure_frame(ctx, (n + 3) / 4);                       // n RGBA8 pixels fit in n/4 16-byte records
     if (rc != BLOK_OK) return rc;
@@ -521,7 +560,7 @@ int blok_hip_trace_paths_device(blok_hip_ctx* ctx, const blok_camera* cam, uint3
                                 const blok_gbuffer* planes, void* hip_stream) {
     int rc = check_trace(ctx, cam);
     if (rc != BLOK_OK) return rc;
-    if (!planes || !w || !h || x0 + w > ctx->width || y0 + h > ctx->height || !spp || !max_bounces)
+    if (!planes || !rect_inside(ctx, x0, y0, w, h) || !spp || !max_bounces)
         return set_error(ctx, BLOK_ERR_INVALID_ARG, "bad path-trace arguments");
     if (!ctx->n_materials) return set_error(ctx, BLOK_ERR_INVALID_ARG, "path tracing needs a material table");
     blok::PathArgs p{};
@@ -555,6 +594,7 @@ int blok_hip_trace_paths(blok_hip_ctx* ctx, const blok_camera* cam, uint32_t x0,
     if (!planes_host) return set_error(ctx, BLOK_ERR_INVALID_ARG, "null planes");
     int rc = check_trace(ctx, cam);
     if (rc != BLOK_OK) return rc;
+    if (!rect_inside(ctx, x0, y0, w, h)) return set_error(ctx, BLOK_ERR_INVALID_ARG, "rectangle outside the frame");
     const size_t n = static_cast<size_t>(w) * h, bytes = n * 4 * sizeof(float);
     float* host[4] = {planes_host->color, planes_host->world_pos, planes_host->normal_roughness, planes_host->albedo_metallic};
     float* dev[4] = {nullptr, nullptr, nullptr, nullptr};

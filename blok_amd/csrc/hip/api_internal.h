@@ -48,6 +48,7 @@ struct blok_hip_ctx {
     // image-space chain (post_core.h): history ping-pong [2] and per-frame planes, all width x height
     struct Post {
         size_t pixels = 0;
+        uint32_t width = 0, height = 0;      // the frame shape the planes were allocated for
         float *hist_color[2] = {nullptr, nullptr}, *moments[2] = {nullptr, nullptr}, *world_pos[2] = {nullptr, nullptr};
         uint16_t* hist_len[2] = {nullptr, nullptr};
         float* unit_normals[2] = {nullptr, nullptr};   // float4: normalize(binary16 normal)
@@ -110,6 +111,7 @@ blok::TraceArgs base_args(const blok_hip_ctx* ctx, const blok_camera* cam);
 int prepare_beam(blok_hip_ctx* ctx, blok::RayMode mode, blok::TraceArgs& args, hipStream_t stream, uint32_t tiles_of_rank, uint32_t* n_beams);
 int prepare_queue(blok_hip_ctx* ctx, blok::RayMode mode, const blok::TraceArgs& args, hipStream_t stream, uint32_t n_beams, blok::FrameQueue* queue, uint32_t* n_blocks);
 int check_trace(blok_hip_ctx* ctx, const blok_camera* cam);
+bool rect_inside(const blok_hip_ctx* ctx, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h);
 
 }  // namespace blok_api
 #endif

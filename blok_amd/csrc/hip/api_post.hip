@@ -16,8 +16,8 @@ int post_alloc_bytes(blok_hip_ctx* ctx, void** p, size_t bytes) {
 int ensure_post(blok_hip_ctx* ctx) {
     const size_t n = static_cast<size_t>(ctx->width) * ctx->height;
     auto& P = ctx->post;
-    if (P.pixels == n) return BLOK_OK;
-    free_post(ctx);
+    if (P.pixels == n && P.width == ctx->width && P.height == ctx->height) return BLOK_OK;     // same shape: history stays valid
+    free_post(ctx);       // any resize — also one that keeps the pixel count (320x200 -> 200x320) — drops the history planes
     int rc = BLOK_OK;
     for (int k = 0; k < 2 && rc == BLOK_OK; ++k) {
         rc = post_alloc(ctx, &P.hist_color[k], 4 * n);
@@ -33,7 +33,7 @@ int ensure_post(blok_hip_ctx* ctx) {
     if (rc == BLOK_OK) rc = post_alloc(ctx, &P.pong, 4 * n);
     if (rc == BLOK_OK) rc = post_alloc(ctx, &P.widen, 2 * n);
     if (rc != BLOK_OK) { free_post(ctx); return rc; }
-    P.pixels = n;
+    P.pixels = n; P.width = ctx->width; P.height = ctx->height;
     return BLOK_OK;
 }
 blok::DenoiseSettings to_settings(const blok_denoise_settings& s) {

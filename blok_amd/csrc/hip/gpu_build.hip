@@ -573,6 +573,10 @@ GpuBuildStatus gpu_volume_brush(GpuVolume* v, const float center[3], float radiu
     BrushCtx b{};
     b.density = v->d_density; b.nx = v->nx; b.ny = v->ny; b.nz = v->nz;
     uint32_t lo[3], hi[3];
+    // floor() of a NaN or of a value beyond int32 is undefined behaviour in the casts below: refuse such a brush up front
+    if (!std::isfinite(radius) || !(std::fabs(radius) < 1.0e9f)) { *why = "brush: radius is not a finite number of voxels"; return GpuBuildStatus::Unsupported; }
+    for (int a = 0; a < 3; ++a)
+        if (!std::isfinite(center[a]) || !(std::fabs(center[a]) < 1.0e9f)) { *why = "brush: centre is not finite"; return GpuBuildStatus::Unsupported; }
     for (int a = 0; a < 3; ++a) {
         b.origin[a] = v->origin[a];
         const int32_t gmin = static_cast<int32_t>(std::floor(center[a] - radius));               // brush.cpp:20

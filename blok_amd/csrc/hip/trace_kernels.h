@@ -119,6 +119,21 @@ struct UntileArgs {
     uint32_t frame_w, frame_h, tile, n_ranks, tiles_per_rank_max, tiles_x, elem_bytes;
 };
 
+struct CompactArgs {                       // rank's dense RGBA8 tiles -> {count, records {local tile index, tile^2 pixels}}
+    const uint32_t* tiles;
+    uint32_t* out;                         // word 0 = count (zero before the launch)
+    uint32_t tile, n_tiles;
+};
+struct ScatterArgs {                       // gathered compact buffers of all ranks -> row-major frame (pre-filled with sky)
+    const uint32_t* gathered;
+    uint32_t* frame;
+    uint32_t frame_w, frame_h, tile, n_ranks, tiles_x, max_records;
+    size_t rank_stride;                    // words between the ranks' buffers
+};
+void launch_compact_tiles(const CompactArgs& args, hipStream_t stream);
+void launch_scatter_tiles(const ScatterArgs& args, hipStream_t stream);
+uint32_t sky_rgba();                       // the RGBA8 a miss is shaded with (trace_core.h: kSkyRgba)
+
 struct SunMapArgs {                        // beam.h: prism_far, one wave per texel
     TraceArgs trace;
     float u[3], v[3], s[3];

@@ -399,7 +399,50 @@ __global__ __launch_bounds__(256) void untile_kernel(const UntileArgs U) {
     static_cast<Elem*>(U.frame)[i] = static_cast<const Elem*>(U.gathered)[src];
 }
 
+// ---- sparse framebuffer exchange (multi-GPU): only the tiles with at least one pixel that is not sky travel --------------
+// No reference counterpart (blok is single-GPU).  compact: one wave per tile of the rank's dense RGBA8 tile
+// buffer; a tile with a non-sky pixel takes the next record {local tile index, tile^2 pixels} behind the count word.
+// scatter (root): one wave per (rank, record slot); records beyond the rank's count exit; the frame was filled with sky before.
+__global__ __launch_bounds__(64) void compact_tiles_kernel(const CompactArgs a) {
+    const uint32_t b = blockIdx.x, lane = threadIdx.x, px = a.tile * a.tile;
+    if (b >= a.n_tiles) return;
+    const uint32_t* src = a.tiles + static_cast<size_t>(b) * px;
+    bool live = false;
+    for (uint32_t i = lane; i < px; i += 64u) live |= src[i] != kSkyRgba;
+    if (__ballot(live) == 0ull) return;
+    uint32_t slot = 0;
+    if (lane == 0) slot = atomicAdd(a.out, 1u);
+    slot = __builtin_amdgcn_readfirstlane(slot);
+    uint32_t* rec = a.out + 1u + static_cast<size_t>(slot) * (1u + px);
+    if (lane == 0) rec[0] = b;
+    for (uint32_t i = lane; i < px; i += 64u) rec[1u + i] = src[i];
+}
+
+__global__ __launch_bounds__(64) void scatter_tiles_kernel(const ScatterArgs a) {
+    const uint32_t r = blockIdx.x / a.max_records, j = blockIdx.x % a.max_records, lane = threadIdx.x, px = a.tile * a.tile;
+    const uint32_t* base = a.gathered + static_cast<size_t>(r) * a.rank_stride;
+    if (j >= base[0]) return;
+    const uint32_t* rec = base + 1u + static_cast<size_t>(j) * (1u + px);
+    const uint32_t g = r + rec[0] * a.n_ranks;
+    const uint32_t x0 = (g % a.tiles_x) * a.tile, y0 = (g / a.tiles_x) * a.tile;
+    for (uint32_t i = lane; i < px; i += 64u) {
+        const uint32_t x = x0 + i % a.tile, y = y0 + i / a.tile;
+        if (x < a.frame_w && y < a.frame_h) a.frame[static_cast<size_t>(y) * a.frame_w + x] = rec[1u + i];
+    }
+}
+
 }  // namespace
+
+uint32_t sky_rgba() { return kSkyRgba; }
+
+void launch_compact_tiles(const CompactArgs& args, hipStream_t stream) {
+    if (args.n_tiles) hipLaunchKernelGGL(compact_tiles_kernel, dim3(args.n_tiles), dim3(64), 0, stream, args);
+}
+
+void launch_scatter_tiles(const ScatterArgs& args, hipStream_t stream) {
+    const uint32_t n = args.n_ranks * args.max_records;
+    if (n) hipLaunchKernelGGL(scatter_tiles_kernel, dim3(n), dim3(64), 0, stream, args);
+}
 
 void launch_trace(RayMode mode, const TraceArgs& args, uint32_t n_blocks, hipStream_t stream) {
     if (n_blocks == 0) return;

@@ -11,6 +11,14 @@ HBM speed), so the frame time at N = 8 is bounded by bytes per link, not by the 
 put 16.6 MB on every link per 4K frame (~0.2 ms, longer than half the whole 1-GPU frame), RGBA8 4.1 MB; a gather
 uses each peer's own link to the root in parallel where an all-gather would move 7x the bytes.
 
+Sparse exchange (`sparse=True`): most tiles of a frame can be sky, and the root's seven links are the bound at 8 GPUs
+(29 MB of RGBA8 per 4K frame), so a rank compacts the tiles with at least one non-sky pixel into {count, {local tile index,
+pixels}...} on the device (blok_hip_compact_tiles_device) and only a prefix of that buffer is gathered: S records, S = the
+largest count over the ranks.  S has to be a host-side number (collective sizes are), so it is reduced (a one-word MAX
+all-reduce) when the frame is TRACED and read back, without waiting, when the frame is RETIRED `depth` frames later — by then
+the value has long arrived; the gather itself is issued at retirement.  The root fills the frame with sky and scatters the
+records (blok_hip_scatter_tiles_device).  Exact for any camera: the size exchange belongs to the same frame as the data.
+
 Frames in flight: `depth` slots, each with its own HIP stream and buffers.  A trace kernel ends with a long tail
 (waves holding grazing rays run up to ~80 us while the rest of the chip drains — a 480x270 frame costs 85 us
 against 360 us for 64x the rays), so consecutive frames go to alternating streams and the next frame's waves fill
@@ -43,34 +51,52 @@ class HipBackend:
     def untile(self, gathered, elem_bytes, tile, n_ranks, per_rank, out, stream):
         self.tracer.untile_device(gathered.data_ptr(), elem_bytes, tile, n_ranks, per_rank, out.data_ptr(), stream=stream)
 
+    def compact(self, rgba, tile, n_tiles, out, stream):
+        self.tracer.compact_tiles_device(rgba.data_ptr(), tile, n_tiles, out.data_ptr(), stream=stream)
+
+    def scatter(self, gathered, n_ranks, rank_stride, tile, max_records, out, stream):
+        self.tracer.scatter_tiles_device(gathered.data_ptr(), n_ranks, rank_stride, tile, max_records, out.data_ptr(), stream=stream)
+
 
 class FramePipeline:
     def __init__(self, backend, width: int, height: int, rank: int = 0, world_size: int = 1, dist=None,
-                 tile: int = 32, device="cuda", depth: int = 3):
+                 tile: int = 32, device="cuda", depth: int = 3, sparse: bool = False):
         import torch
         self.torch = torch
         self.backend, self.width, self.height = backend, width, height
         self.rank, self.world_size, self.dist, self.tile, self.depth = rank, world_size, dist, tile, depth
+        self.sparse = bool(sparse) and world_size > 1
         self.on_gpu = str(device).startswith("cuda")
         self.streams = [torch.cuda.Stream() for _ in range(depth)] if self.on_gpu else [None] * depth
         self.frames_submitted = 0
         self.frames_done = 0
         self.in_flight: List[tuple] = []          # (slot, work or None)
+        self.records_gathered = 0                 # sparse: tile records per rank asked for so far (sum of S)
         n_px = width * height
         # the newest completed frame: frame_rgba (rank 0) and hits (this rank's pixels) point at its slot
         self.frame_rgba = None
         self.hits = None
         if world_size == 1:
-            self._hits = [torch.empty((n_px, 4), dtype=torch.int32, device=device) for _ in range(depth)]
-            self._frame = [torch.empty(n_px, dtype=torch.int32, device=device) for _ in range(depth)]
+            self._hits = [torch.zeros((n_px, 4), dtype=torch.int32, device=device) for _ in range(depth)]
+            self._frame = [torch.zeros(n_px, dtype=torch.int32, device=device) for _ in range(depth)]
             return
         self.per_rank = backend.tiles_for_rank(tile, 0, world_size)          # rank 0 owns the most tiles
+        self.mine = backend.tiles_for_rank(tile, rank, world_size)
         n_tile_px = self.per_rank * tile * tile
-        self._hits = [torch.empty((n_tile_px, 4), dtype=torch.int32, device=device) for _ in range(depth)]
-        self.rgba = [torch.empty(n_tile_px, dtype=torch.int32, device=device) for _ in range(depth)]
+        # zero-initialised: the tile slots a rank does not own (rank counts that do not divide the tiles) are never written
+        self._hits = [torch.zeros((n_tile_px, 4), dtype=torch.int32, device=device) for _ in range(depth)]
+        self.rgba = [torch.zeros(n_tile_px, dtype=torch.int32, device=device) for _ in range(depth)]
+        if self.sparse:
+            self.words = 1 + self.per_rank * (1 + tile * tile)               # blok_hip_compact_words
+            self.compacted = [torch.zeros(self.words, dtype=torch.int32, device=device) for _ in range(depth)]
+            self.smax = [torch.zeros(1, dtype=torch.int32, device=device) for _ in range(depth)]
+            self.smax_host = [torch.zeros(1, dtype=torch.int32).pin_memory() if self.on_gpu else torch.zeros(1, dtype=torch.int32)
+                              for _ in range(depth)]
+            self.smax_event = [torch.cuda.Event() if self.on_gpu else None for _ in range(depth)]
         if rank == 0:
-            self.gathered = [torch.empty((world_size, n_tile_px), dtype=torch.int32, device=device) for _ in range(depth)]
-            self._frame = [torch.empty(n_px, dtype=torch.int32, device=device) for _ in range(depth)]
+            width_words = self.words if self.sparse else n_tile_px
+            self.gathered = [torch.zeros((world_size, width_words), dtype=torch.int32, device=device) for _ in range(depth)]
+            self._frame = [torch.zeros(n_px, dtype=torch.int32, device=device) for _ in range(depth)]
 
     def _on(self, slot):
         return self.torch.cuda.stream(self.streams[slot]) if self.on_gpu else contextlib.nullcontext()
@@ -78,7 +104,7 @@ class FramePipeline:
     def _handle(self, slot):
         return self.streams[slot].cuda_stream if self.on_gpu else 0
 
-    # one frame: enqueue its trace on the slot's stream, start its gather, retire frames beyond the depth
+    # one frame: enqueue its trace on the slot's stream, start its exchange, retire frames beyond the depth
     def step(self):
         while len(self.in_flight) >= self.depth:
             self._retire()
@@ -90,15 +116,37 @@ class FramePipeline:
             else:
                 self.backend.trace_tiles(self.tile, self.rank, self.world_size, self._hits[slot], self.rgba[slot],
                                          self._handle(slot))
-                gather_list = [self.gathered[slot][r] for r in range(self.world_size)] if self.rank == 0 else None
-                work = self.dist.gather(self.rgba[slot], gather_list=gather_list, dst=0, async_op=True)
+                if self.sparse:
+                    # compact on the device; the largest record count over the ranks starts its way to every host now
+                    self.backend.compact(self.rgba[slot], self.tile, self.mine, self.compacted[slot], self._handle(slot))
+                    self.smax[slot].copy_(self.compacted[slot][:1])
+                    w = self.dist.all_reduce(self.smax[slot], op=self.dist.ReduceOp.MAX, async_op=True)
+                    w.wait()                       # the slot's stream (or the host, on gloo) waits for that reduction only
+                    self.smax_host[slot].copy_(self.smax[slot], non_blocking=True)
+                    if self.on_gpu:
+                        self.smax_event[slot].record()
+                    work = None
+                else:
+                    gather_list = [self.gathered[slot][r] for r in range(self.world_size)] if self.rank == 0 else None
+                    work = self.dist.gather(self.rgba[slot], gather_list=gather_list, dst=0, async_op=True)
         self.in_flight.append((slot, work))
         self.frames_submitted += 1
 
     def _retire(self):
         slot, work = self.in_flight.pop(0)
         with self._on(slot):
-            if work is not None:
+            if self.sparse:
+                if self.on_gpu:
+                    self.smax_event[slot].synchronize()        # enqueued `depth` frames ago
+                records = int(self.smax_host[slot][0])
+                n = 1 + records * (1 + self.tile * self.tile)  # words: the count and the first `records` records
+                self.records_gathered += records
+                gather_list = [self.gathered[slot][r][:n] for r in range(self.world_size)] if self.rank == 0 else None
+                self.dist.gather(self.compacted[slot][:n], gather_list=gather_list, dst=0)
+                if self.rank == 0:
+                    self.backend.scatter(self.gathered[slot], self.world_size, self.words, self.tile, records,
+                                         self._frame[slot], self._handle(slot))
+            elif work is not None:
                 work.wait()                        # the slot's stream (or the host, on gloo) waits for that gather only
                 if self.rank == 0:
                     self.backend.untile(self.gathered[slot], 4, self.tile, self.world_size, self.per_rank,

@@ -30,3 +30,41 @@ def untile(gathered: np.ndarray, width: int, height: int, tile: int, n_ranks: in
     g = (y // tile) * tiles_x + x // tile
     src = ((g % n_ranks) * tiles_per_rank_max + g // n_ranks) * tile * tile + (y % tile) * tile + (x % tile)
     return gathered[src]
+
+
+SKY_RGBA = np.uint32(0xFF000000 | (230 << 16) | (200 << 8) | 160)      # trace_core.h: kSkyRgba
+
+
+def compact_words(tile: int, n_tiles: int) -> int:
+    return 1 + n_tiles * (1 + tile * tile)
+
+
+def compact_tiles(rgba_tiles: np.ndarray, tile: int, n_tiles: int) -> np.ndarray:
+    """Reference of blok_hip_compact_tiles_device: word 0 = count, then {local tile index, tile*tile pixels} per tile with a
+    non-sky pixel (ascending here; the kernel's order is arbitrary)."""
+    px = tile * tile
+    t = np.asarray(rgba_tiles).view(np.uint32).reshape(-1)[:n_tiles * px].reshape(n_tiles, px)
+    out = np.zeros(compact_words(tile, n_tiles), dtype=np.uint32)
+    live = np.flatnonzero((t != SKY_RGBA).any(axis=1))
+    out[0] = len(live)
+    rec = out[1:1 + len(live) * (1 + px)].reshape(len(live), 1 + px)
+    rec[:, 0] = live
+    rec[:, 1:] = t[live]
+    return out
+
+
+def scatter_tiles(gathered: np.ndarray, n_ranks: int, rank_stride: int, tile: int, max_records: int, width: int, height: int) -> np.ndarray:
+    """Reference of blok_hip_scatter_tiles_device: (height, width) uint32 frame."""
+    px = tile * tile
+    g = np.asarray(gathered).view(np.uint32).reshape(-1)
+    frame = np.full((height, width), SKY_RGBA, dtype=np.uint32)
+    tiles_x = (width + tile - 1) // tile
+    for r in range(n_ranks):
+        base = g[r * rank_stride:]
+        for j in range(min(int(base[0]), max_records)):
+            rec = base[1 + j * (1 + px):1 + (j + 1) * (1 + px)]
+            gt = r + int(rec[0]) * n_ranks
+            x0, y0 = (gt % tiles_x) * tile, (gt // tiles_x) * tile
+            h, w = min(tile, height - y0), min(tile, width - x0)
+            frame[y0:y0 + h, x0:x0 + w] = rec[1:].reshape(tile, tile)[:h, :w]
+    return frame

@@ -244,6 +244,15 @@ class HipTracer:
         self._check(self._lib.blok_hip_untile_device(self._ctx, C.c_void_p(gathered_ptr), elem_bytes, tile, n_ranks,
                                                      tiles_per_rank_max, C.c_void_p(out_ptr), C.c_void_p(stream)))
 
+    def compact_tiles_device(self, rgba_tiles_ptr: int, tile: int, n_tiles: int, out_ptr: int, stream: int = 0):
+        """Dense RGBA8 tiles of this rank -> {count, {local tile index, pixels} per tile with a non-sky pixel} (blok_hip.h)."""
+        self._check(self._lib.blok_hip_compact_tiles_device(self._ctx, C.c_void_p(rgba_tiles_ptr), tile, n_tiles, C.c_void_p(out_ptr), C.c_void_p(stream)))
+
+    def scatter_tiles_device(self, gathered_ptr: int, n_ranks: int, rank_stride_words: int, tile: int, max_records: int, out_ptr: int, stream: int = 0):
+        """Root: sky-filled frame + the compacted records of every rank (blok_hip.h)."""
+        self._check(self._lib.blok_hip_scatter_tiles_device(self._ctx, C.c_void_p(gathered_ptr), n_ranks, rank_stride_words, tile, max_records,
+                                                            C.c_void_p(out_ptr), C.c_void_p(stream)))
+
     def trace_rays(self, rays: np.ndarray) -> np.ndarray:
         rays = np.ascontiguousarray(rays, dtype=RAY)
         hits = np.zeros(len(rays), dtype=HIT)

@@ -210,6 +210,20 @@ int blok_hip_untile_device(blok_hip_ctx* ctx, const void* gathered_dev, uint32_t
                            uint32_t n_ranks, uint32_t tiles_per_rank_max,
                            void* out_frame_dev, void* hip_stream);
 
+/* Sparse framebuffer exchange for the tile partition (no reference counterpart: blok is single-GPU): most
+ * of a frame's tiles can be sky, and only bytes cross xGMI slowly.  compact: from a rank's dense RGBA8 tile buffer (as
+ * blok_hip_trace_tiles_device writes it) to  word 0 = number of tiles with at least one non-sky pixel, then one record
+ * {local tile index, tile*tile pixels} per such tile, in no particular order; `out_words_dev` holds
+ * blok_hip_compact_words(tile, n_tiles) 32-bit words.  A prefix of 1 + S * (1 + tile*tile) words carries the first S records.
+ * scatter (on the root): fills the context's width x height RGBA8 frame with the sky colour, then writes the records of every
+ * rank's buffer (rank r's buffer starts at word r * rank_stride_words; at most max_records records each are looked at;
+ * local tile index j of rank r is frame tile r + j * n_ranks).  Both asynchronous on `hip_stream`. */
+size_t blok_hip_compact_words(uint32_t tile, uint32_t n_tiles);
+int blok_hip_compact_tiles_device(blok_hip_ctx* ctx, const void* rgba_tiles_dev, uint32_t tile, uint32_t n_tiles,
+                                  void* out_words_dev, void* hip_stream);
+int blok_hip_scatter_tiles_device(blok_hip_ctx* ctx, const void* gathered_dev, uint32_t n_ranks, size_t rank_stride_words,
+                                  uint32_t tile, uint32_t max_records, void* out_frame_rgba_dev, void* hip_stream);
+
 /* The reference's per-pixel sample / bounce loop and G-buffer: raygen.rgen:167-414 with hit.rchit, miss.rmiss
  * and shadow.rmiss (reference assets/shaders/).  Planes are float4 per pixel of the rectangle, row-major; any
  * pointer may be NULL.  color = (rgb, 1); world_pos = (first-hit position, depth); normal_roughness;

@@ -37,6 +37,17 @@ def test_contexts_resizes_and_mode_switches():
     assert a.draw_frame(cam_a2).shape == (72, 128)
     a.resize(160, 90)
     assert records_equal(a.draw_frame(cam_a).reshape(-1), first.reshape(-1)).all()
+    # a resize that keeps the pixel count (160x90 -> 90x160) must drop the history planes too: the first denoised frame after it
+    # equals the first frame of a fresh context of that shape
+    a.draw_frame_rt(cam_a, spp=1); a.draw_frame_rt(cam_a, spp=1)
+    a.resize(90, 160)
+    cam_t = W.scene_camera(64, 0, 90, 160, SEED)
+    px_resized, n = a.draw_frame_rt(cam_t, spp=1)
+    fresh = HipTracer(90, 160).init(); fresh.add_world(pw)
+    px_fresh, _ = fresh.draw_frame_rt(cam_t, spp=1)
+    fresh.shutdown()
+    assert px_resized.shape == (160, 90) and (px_resized == px_fresh).all()
+    a.resize(160, 90)
     # a resident volume replaces the uploaded world; uploading a world again replaces the volume's tree
     ids = W.scene_dense(64, SEED)
     a.volume_create((0, 0, 0), (64, 64, 64), 128, 1.0)
@@ -44,6 +55,9 @@ def test_contexts_resizes_and_mode_switches():
     st = a.volume_rebuild(mats)
     assert st.n_voxels == int((ids != 0).sum())
     assert records_equal(a.draw_frame(cam_a).reshape(-1), first.reshape(-1)).all()            # same voxels, same picture
+    for centre, radius in (((float("nan"), 40.0, 32.0), 10.0), ((32.0, float("inf"), 32.0), 10.0), ((32.0, 40.0, 32.0), float("nan")), ((3.0e9, 40.0, 32.0), 1.0)):
+        with pytest.raises(BlokError):                                                        # not finite / beyond int32: refused, no launch
+            a.volume_apply_brush(centre, radius, 0.0, 1)
     a.volume_apply_brush((32.0, 40.0, 32.0), 10.0, 0.0, 1)
     a.volume_rebuild(mats)
     edited = a.draw_frame(cam_a)

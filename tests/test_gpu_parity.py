@@ -338,6 +338,15 @@ def test_world_edge_cases(tracer_cls):
     assert e.value.status == -5 and "lattice" in str(e.value)     # BLOK_ERR_UNSUPPORTED
     with pytest.raises(BlokError):
         tr.draw_frame(cam, (0, 0, 64, 64))                          # rectangle outside the frame
+    # x0 + w wraps in 32 bits: still INVALID_ARG (-1), and before anything is sized by w * h (straight through the C ABI: the
+    # Python mirror would try to allocate the output first)
+    from blok_amd import _ffi
+    camc = np.ascontiguousarray(cam, dtype=_ffi.CAMERA)
+    scratch = np.zeros(64 * 64, dtype=_ffi.HIT)
+    for rect in ((0xFFFFFFF0, 0, 32, 32), (0, 0xFFFFFFF0, 32, 32), (16, 16, 0xFFFFFFF8, 8), (0, 0, 0, 8), (32, 0, 1, 1)):
+        assert tr._lib.blok_hip_trace_primary(tr._ctx, _ffi.ptr(camc), *rect, _ffi.ptr(scratch)) == -1, rect
+        assert tr._lib.blok_hip_shade_rgba8(tr._ctx, _ffi.ptr(camc), *rect, _ffi.ptr(scratch)) == -1, rect
+        assert tr._lib.blok_hip_trace_primary_device(tr._ctx, _ffi.ptr(camc), *rect, _ffi.ptr(scratch), None, None) == -1, rect
     tr.resize(64, 48)
     assert tr.draw_frame(W.camera_look_at((0, 200, 0), (0, 0, 0), 60.0, 64, 48)).shape == (48, 64)
     tr.shutdown()
@@ -446,6 +455,50 @@ def test_config4_2048_svo_4k_tiles(tracer_cls):
     tr.untile_device(gathered.data_ptr(), 16, tile, n_ranks, per, out.data_ptr())
     torch.cuda.synchronize()
     assert (out.cpu().numpy().view(np.uint8).reshape(-1, 16) == full.reshape(-1).view(np.uint8).reshape(-1, 16)).all()
+    tr.shutdown()
+
+
+def test_sparse_tile_exchange_kernels(tracer_cls, scene1024):
+    """blok_hip_compact_tiles_device / blok_hip_scatter_tiles_device (the sparse framebuffer exchange of the tile partition):
+    every virtual rank's RGBA8 tiles compacted on the device, the prefixes laid side by side as a gather would, scattered
+    over a sky-filled frame == the full frame's RGBA8; the record counts are the ranks' non-sky tile counts (far below the
+    tile count for this 73 %-sky pose) and the records equal the numpy reference's."""
+    import torch
+    from blok_amd import tiles as T
+    cm, pw = scene1024
+    Wd, Ht = 3840, 2160
+    tr = tracer_cls(Wd, Ht).init()
+    tr.add_world(pw)
+    cam = W.scene_camera(1024, 0, Wd, Ht, SEED)
+    want = tr.shade_rgba8(cam)
+    for n_ranks, tile in ((8, 32), (3, 64)):
+        per = tr.tiles_for_rank(tile, 0, n_ranks)
+        words = T.compact_words(tile, per)
+        gathered = torch.zeros((n_ranks, words), dtype=torch.int32, device="cuda")
+        counts = []
+        for r in range(n_ranks):
+            mine = tr.tiles_for_rank(tile, r, n_ranks)
+            dense = torch.zeros(per * tile * tile, dtype=torch.int32, device="cuda")
+            tr.draw_tiles_device(cam, tile, r, n_ranks, rgba_ptr=dense.data_ptr())
+            tr.compact_tiles_device(dense.data_ptr(), tile, mine, gathered[r].data_ptr())
+            torch.cuda.synchronize()
+            got = gathered[r].cpu().numpy().view(np.uint32)
+            ref = T.compact_tiles(dense.cpu().numpy(), tile, mine)
+            counts.append(int(got[0]))
+            assert got[0] == ref[0]
+            px = tile * tile
+            rec_got = got[1:1 + counts[-1] * (1 + px)].reshape(-1, 1 + px)
+            rec_ref = ref[1:1 + counts[-1] * (1 + px)].reshape(-1, 1 + px)
+            assert (rec_got[np.argsort(rec_got[:, 0])] == rec_ref).all()        # same records, the kernel's order is arbitrary
+        most = max(counts)
+        assert 0 < most < 0.5 * per
+        # what a gather of the first `most` records of every rank delivers: the rest of each row is never transferred
+        prefix = 1 + most * (1 + tile * tile)
+        gathered[:, prefix:] = -1
+        frame = torch.zeros(Ht * Wd, dtype=torch.int32, device="cuda")
+        tr.scatter_tiles_device(gathered.data_ptr(), n_ranks, words, tile, most, frame.data_ptr())
+        torch.cuda.synchronize()
+        assert (frame.cpu().numpy().view(np.uint32).reshape(Ht, Wd) == want).all(), (n_ranks, tile)
     tr.shutdown()
 
 

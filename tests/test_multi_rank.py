@@ -105,20 +105,48 @@ class _FakeBackend:
         assert elem_bytes == 4
         out.copy_(torch.from_numpy(T.untile(gathered.numpy().reshape(-1), self.width, self.height, tile, n, per).reshape(-1)))
 
+    def compact(self, rgba, tile, n_tiles, out, stream):
+        import torch
+        from blok_amd import tiles as T
+        words = T.compact_tiles(rgba.numpy(), tile, n_tiles)
+        out[:len(words)].copy_(torch.from_numpy(words.view(np.int32)))
 
-def _pipeline_worker(rank, world_size, port, out_dir):
+    def scatter(self, gathered, n, rank_stride, tile, max_records, out, stream):
+        import torch
+        from blok_amd import tiles as T
+        frame = T.scatter_tiles(gathered.numpy().reshape(-1), n, rank_stride, tile, max_records, self.width, self.height)
+        out.copy_(torch.from_numpy(frame.view(np.int32).reshape(-1)))
+
+
+def _pipeline_worker(rank, world_size, port, out_dir, sparse=False):
     sys.path.insert(0, str(ROOT))
     import torch
     import torch.distributed as dist
     from blok_amd.multi_gpu import FramePipeline
+    from blok_amd import tiles as T
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world_size)
     width, height, tile = 200, 136, 32
     rng = np.random.default_rng(3)
     frames = [rng.integers(0, 1 << 30, size=(height, width)).astype(np.int32) for _ in range(5)]
+    if sparse:
+        # a different, uneven set of all-sky tiles in every frame (one frame all sky, one with a single live pixel): the two
+        # ranks' record counts differ, so the gathered prefix is sized by the larger one
+        sky = np.int32(T.SKY_RGBA.view(np.int32) if hasattr(T.SKY_RGBA, "view") else np.uint32(T.SKY_RGBA).astype(np.int32))
+        for k, f in enumerate(frames):
+            if k == 1:
+                f[:] = sky
+            elif k == 3:
+                f[:] = sky
+                f[70, 131] = 12345
+            else:
+                for ty in range(0, height, tile):
+                    for tx in range(0, width, tile):
+                        if rng.random() < 0.6:
+                            f[ty:ty + tile, tx:tx + tile] = sky
     pipe = FramePipeline(_FakeBackend(width, height, frames), width, height, rank, world_size, dist, tile=tile,
-                         device="cpu", depth=2)
+                         device="cpu", depth=2, sparse=sparse)
     seen = []
 
     def collect():
@@ -135,6 +163,8 @@ def _pipeline_worker(rank, world_size, port, out_dir):
         ok = len(seen) == 5 and all((a == b).all() for a, b in zip(seen, frames))
     else:
         ok = pipe.frames_done == 5
+    if sparse:      # fewer records travelled than a dense gather's 18 tiles per rank and frame, and none for the all-sky frame
+        ok = ok and 0 < pipe.records_gathered < 5 * 18 * 0.7
     (Path(out_dir) / f"pipe{rank}.txt").write_text(str(int(ok)))
     dist.destroy_process_group()
 
@@ -144,3 +174,39 @@ def test_frame_pipeline_two_ranks_in_order(tmp_path):
     import torch.multiprocessing as mp
     mp.spawn(_pipeline_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "pipe0.txt").read_text() == "1" and (tmp_path / "pipe1.txt").read_text() == "1"
+
+
+def test_frame_pipeline_sparse_gather_two_ranks(tmp_path):
+    """Sparse exchange (compact -> size reduction at trace time -> prefix gather at retirement -> sky fill + scatter): every
+    frame, in order, bit-identical on rank 0, with sky tiles that never travel."""
+    import torch.multiprocessing as mp
+    mp.spawn(_pipeline_worker, args=(2, _free_port(), str(tmp_path), True), nprocs=2, join=True)
+    assert (tmp_path / "pipe0.txt").read_text() == "1" and (tmp_path / "pipe1.txt").read_text() == "1"
+
+
+def test_compact_scatter_reference_round_trip():
+    """tiles.compact_tiles / scatter_tiles (the references of the two kernels): a frame cut into rank tiles, compacted per rank
+    and scattered back equals the frame, for ragged frames and rank counts that do not divide the tiles."""
+    from blok_amd import tiles as T
+    rng = np.random.default_rng(5)
+    for (w, h, tile, n) in [(200, 136, 32, 2), (100, 70, 16, 3), (64, 64, 32, 8)]:
+        frame = np.full((h, w), T.SKY_RGBA, dtype=np.uint32)
+        for ty in range(0, h, tile):
+            for tx in range(0, w, tile):
+                if rng.random() < 0.5:
+                    frame[ty:ty + tile, tx:tx + tile] = rng.integers(0, 1 << 31, size=frame[ty:ty + tile, tx:tx + tile].shape)
+        per = T.tiles_for_rank(w, h, tile, 0, n)
+        stride = T.compact_words(tile, per)
+        gathered = np.zeros(n * stride, dtype=np.uint32)
+        most = 0
+        for r in range(n):
+            mine = T.tiles_for_rank(w, h, tile, r, n)
+            dense = np.full(per * tile * tile, T.SKY_RGBA, dtype=np.uint32)
+            for k, (x0, y0) in enumerate(T.rank_tile_origins(w, h, tile, r, n)):
+                block = dense[k * tile * tile:(k + 1) * tile * tile].reshape(tile, tile)
+                hh, ww = min(tile, h - y0), min(tile, w - x0)
+                block[:hh, :ww] = frame[y0:y0 + hh, x0:x0 + ww]
+            c = T.compact_tiles(dense, tile, mine)
+            gathered[r * stride:r * stride + len(c)] = c
+            most = max(most, int(c[0]))
+        assert (T.scatter_tiles(gathered, n, stride, tile, most, w, h) == frame).all()
