@@ -117,6 +117,12 @@ HOST_SYMBOLS = {
                                              C.c_uint32, C.c_uint32, C.c_void_p]),
     "blok_camera_look_at": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float,
                                       C.c_uint32, C.c_uint32, C.c_void_p]),
+    "blok_camera_view": (None, [C.c_void_p, C.POINTER(C.c_float)]),
+    "blok_camera_projection": (None, [C.c_void_p, C.c_float, C.c_float, C.POINTER(C.c_float)]),
+    "blok_mat4_inverse": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "blok_taa_jitter": (None, [C.c_uint32, C.POINTER(C.c_float)]),
+    "blok_taa_jitter_clip": (None, [C.POINTER(C.c_float), C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]),
+    "blok_jittered_projection": (None, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]),
     "blok_scene_generate": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
     "blok_scene_generate_dense": (C.c_int, [C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64)]),
     "blok_scene_materials": (C.c_int, [C.c_uint32, C.c_void_p]),
@@ -157,6 +163,9 @@ HIP_SYMBOLS = {
     "blok_hip_reset_accum": (C.c_int, [C.c_void_p]),
     "blok_hip_set_beam": (C.c_int, [C.c_void_p, C.c_uint32]),
     "blok_hip_set_fused": (C.c_int, [C.c_void_p, C.c_int]),
+    "blok_hip_set_beam_budget": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "blok_hip_set_taa_jitter": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "blok_hip_set_rt_taa_jitter": (C.c_int, [C.c_void_p, C.c_int]),
     "blok_hip_compact_words": (C.c_size_t, [C.c_uint32, C.c_uint32]),
     "blok_hip_compact_tiles_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "blok_hip_scatter_tiles_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),

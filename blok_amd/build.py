@@ -13,7 +13,7 @@ INCLUDE = ROOT / "include"
 HOST_SRC = [PKG / "csrc/host/world.cpp", PKG / "csrc/host/scene.cpp", PKG / "csrc/host/vox.cpp"]
 HIP_SRC = [PKG / "csrc/hip/api.hip", PKG / "csrc/hip/api_post.hip", PKG / "csrc/hip/api_volume.hip", PKG / "csrc/hip/trace_kernels.hip", PKG / "csrc/hip/gpu_build.hip",
            PKG / "csrc/hip/post_kernels.hip", PKG / "csrc/hip/tree_build.cpp"]
-HIP_HDR = sorted((PKG / "csrc/hip").glob("*.h")) + [INCLUDE / "blok_hip.h", INCLUDE / "blok_world.h"]
+HIP_HDR = sorted((PKG / "csrc/hip").glob("*.h")) + sorted((PKG / "csrc/common").glob("*.h")) + [INCLUDE / "blok_hip.h", INCLUDE / "blok_world.h"]
 
 
 def _stale(target: Path, deps) -> bool:
@@ -38,7 +38,7 @@ def hipcc() -> str:
 
 def build_host(force: bool = False) -> Path:
     out = PKG / "libblok_host.so"
-    if force or _stale(out, HOST_SRC + [INCLUDE / "blok_world.h", INCLUDE / "blok_hip.h"]):
+    if force or _stale(out, HOST_SRC + sorted((PKG / "csrc/common").glob("*.h")) + [INCLUDE / "blok_world.h", INCLUDE / "blok_hip.h"]):
         _run(["g++", "-O2", "-std=c++20", "-fPIC", "-ffp-contract=off", "-Wall", "-Wextra", f"-I{INCLUDE}",
               "-shared", "-o", out, *HOST_SRC])
     return out

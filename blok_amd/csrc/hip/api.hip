@@ -125,9 +125,12 @@ blok::TraceArgs base_args(const blok_hip_ctx* ctx, const blok_camera* cam) {
     a.levels = ctx->stats.levels;
     if (cam) a.cam = *cam;
     a.frame_w = ctx->width; a.frame_h = ctx->height;
+    a.jitter_clip[0] = (2.0f * ctx->jitter_px[0]) / static_cast<float>(ctx->width);          // getJitterClipSpace, renderer_postprocess.cpp:234-241
+    a.jitter_clip[1] = (2.0f * ctx->jitter_px[1]) / static_cast<float>(ctx->height);
     a.mat_table = ctx->d_materials;
     a.n_materials = static_cast<uint32_t>(ctx->n_materials);
     a.tmin = BLOK_RAY_TMIN; a.tmax = BLOK_RAY_TMAX;
+    a.beam_budget = ctx->beam_budget;
     return a;
 }
 
@@ -727,6 +730,21 @@ int blok_hip_set_beam(blok_hip_ctx* ctx, uint32_t beam_tile_pixels) {
     return BLOK_OK;
 }
 
+int blok_hip_set_taa_jitter(blok_hip_ctx* ctx, const float jitter_px[2]) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    const float jx = jitter_px ? jitter_px[0] : 0.0f, jy = jitter_px ? jitter_px[1] : 0.0f;
+    // the beam pre-pass grows a tile's frustum by one pixel; the path kernel's own sub-pixel jitter takes +-0.25 of it
+    if (!(std::fabs(jx) <= 0.5f) || !(std::fabs(jy) <= 0.5f)) return set_error(ctx, BLOK_ERR_INVALID_ARG, "jitter must lie within +-0.5 pixel");
+    ctx->jitter_px[0] = jx; ctx->jitter_px[1] = jy;
+    return BLOK_OK;
+}
+
+int blok_hip_set_rt_taa_jitter(blok_hip_ctx* ctx, int enabled) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    ctx->rt_taa_jitter = enabled != 0;
+    return BLOK_OK;
+}
+
 int blok_hip_set_fused(blok_hip_ctx* ctx, int enabled) {
     if (!ctx) return BLOK_ERR_INVALID_ARG;
     ctx->fused = enabled != 0;
@@ -746,6 +764,12 @@ int blok_hip_frame_queue_stalls(blok_hip_ctx* ctx, uint32_t* out_stalled_waves) 
             *out_stalled_waves += n;
         }
     }
+    return BLOK_OK;
+}
+
+int blok_hip_set_beam_budget(blok_hip_ctx* ctx, uint32_t max_node_visits) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    ctx->beam_budget = max_node_visits;
     return BLOK_OK;
 }
 

@@ -73,6 +73,7 @@ struct blok_hip_ctx {
     // beam pre-pass (beam.h): start parameters per beam tile, one buffer per stream (launches on one stream are
     // ordered, frames in flight on different streams must not share)
     uint32_t beam_tile = 32;
+    uint32_t beam_budget = 0;           // 0 = beam.h's default visit budget
     struct StreamScratch {             // per launch stream
         float* beam = nullptr; size_t n_beam = 0;                       // two-launch form: start parameters per beam tile
         uint32_t* ctl = nullptr; unsigned long long* entries = nullptr; size_t capacity = 0;   // one-launch form: work queue (trace_kernels.h: FrameQueue)
@@ -83,6 +84,9 @@ struct blok_hip_ctx {
     uint32_t frame_parts = 32, frame_chunk = 1;      // FrameQueue::n_parts / chunk (BLOK_FRAME_PARTS / BLOK_FRAME_CHUNK override, for experiments)
     int cu_count = 0;
     int frame_blocks_per_cu[2][16] = {};   // [mode][levels], 0 = not asked yet
+    // TAA jitter of the next frames' primary rays, in pixels (blok_hip_set_taa_jitter); blok_hip_draw_frame_rt sets it per frame
+    float jitter_px[2] = {0.0f, 0.0f};
+    bool rt_taa_jitter = true;          // PostProcess::Settings::enableTAA (renderer_postprocess.hpp:103)
     // timing
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool timing = false, timed = false;

@@ -1,5 +1,6 @@
 // C ABI, image-space chain: denoiser, TAA, sharpen, the one-call ray-tracing frame (include/blok_hip.h; kernels in post_core.h).
 #include "api_internal.h"
+#include "../common/taa_jitter.h"
 
 using namespace blok_api;
 
@@ -212,7 +213,13 @@ int blok_hip_draw_frame_rt(blok_hip_ctx* ctx, const blok_camera* cam, uint32_t s
     float prev_vp[16];
     view_proj_of(frame ? P.rt_prev_cam : *cam, prev_vp);            // Denoiser::updatePreviousFrameData: last frame's matrices
     const blok_gbuffer planes{P.rt_planes[0], P.rt_planes[1], P.rt_planes[2], P.rt_planes[3]};
+    // the frame's projection carries jitterSequence[frame mod 16] (renderer_draw.cpp:64-81; the index advances once per frame,
+    // renderer_postprocess.cpp:660-663); prevViewProj above stays un-jittered, as Denoiser::updatePreviousFrameData is fed
+    // (renderer_draw.cpp:313-328 passes the base matrices)
+    const float saved_jitter[2] = {ctx->jitter_px[0], ctx->jitter_px[1]};
+    if (ctx->rt_taa_jitter) blok::taa_jitter_px(frame, ctx->jitter_px);
     rc = blok_hip_trace_paths_device(ctx, cam, 0, 0, ctx->width, ctx->height, spp, max_bounces, frame, &planes, nullptr);
+    ctx->jitter_px[0] = saved_jitter[0]; ctx->jitter_px[1] = saved_jitter[1];
     if (rc == BLOK_OK) rc = blok_hip_denoise_device(ctx, &planes, nullptr, prev_vp, frame, settings, P.rt_denoised, nullptr);
     if (rc == BLOK_OK) rc = blok_hip_taa_device(ctx, P.rt_denoised, nullptr, 0.93f, 0.98f, frame, P.rt_resolved, nullptr);       // renderer_postprocess.hpp:104-106
     if (rc == BLOK_OK) rc = blok_hip_tonemap_device(ctx, P.rt_resolved, static_cast<uint32_t>(n), 1.0f, 1.15f, 1, P.rt_ldr, nullptr);   // :110-113

@@ -30,7 +30,7 @@ namespace blok {
 #define BLOK_BEAM_STOP_LEVEL 1      // finest cells examined = children of a node of this level (1: voxels, 2: 4^3 bricks)
 #endif
 constexpr float kBeamSlack = 0.05f;
-constexpr uint32_t kBeamMaxVisits = 8192u;   // typical searches take 10-60 visits
+constexpr uint32_t kBeamMaxVisits = 8192u;   // typical searches take 10-60 visits; TraceArgs::beam_budget overrides (tests exhaust it on purpose)
 
 struct BeamVec { float x, y, z; };
 
@@ -87,7 +87,7 @@ __device__ __forceinline__ float beam_search(const TraceArgs& A, BeamVec ref, Be
     uint64_t cand = 0;
     // every wave reaches the exit: the search is a finite tree walk, and a visit budget bounds it even for a frustum whose
     // planes cull nothing (degenerate inputs): running out is answered with "start at the ray origin", never with "none"
-    uint32_t budget = kBeamMaxVisits;
+    uint32_t budget = A.beam_budget ? A.beam_budget : kBeamMaxVisits;
     for (; budget != 0u; --budget) {
         const uint4 rec = A.nodes[node];
         const uint32_t mlo = beam_uniform(rec.x), mhi = beam_uniform(rec.y), base = beam_uniform(rec.z);

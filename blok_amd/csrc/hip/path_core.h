@@ -176,8 +176,8 @@ BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t in
             pcx = static_cast<float>(px) + 0.5f + jx * 0.5f;
             pcy = static_cast<float>(py) + 0.5f + jy * 0.5f;
         }
-        const float u = (2.0f * (pcx / static_cast<float>(A.frame_w)) - 1.0f) * cam.tan_half_fov * cam.aspect;
-        const float v = (1.0f - 2.0f * (pcy / static_cast<float>(A.frame_h))) * cam.tan_half_fov;
+        float u, v;
+        camera_plane_uv(A, pcx, pcy, u, v);                                                  // incl. the frame's TAA jitter
         ray_dir = vnormalize(vadd(vadd(cam_f, vscale(cam_r, u)), vscale(cam_u, v)));
         ray_org = cam_pos;
         radiance = v3(0, 0, 0); throughput = v3(1, 1, 1);

@@ -269,14 +269,23 @@ BLOK_DEV void trace_one(const TraceArgs& A, const RayIn& r, uint4* stk, const Si
     if (dst.rgba) *dst.rgba = shade_rgba(A.mat_table, A.n_materials, h.material, h.face);
 }
 
-// Primary ray of pixel (x, y): reference blok/src/cuda_tracer.cu:276-282 with zero jitter
-// (algebraically assets/shaders/raygen.rgen:201-205), tmin/tmax raygen.rgen:225,227.
+// Camera-plane coordinates of the ray through continuous pixel (pcx, pcy): reference blok/src/cuda_tracer.cu:276-282,
+// algebraically assets/shaders/raygen.rgen:201-205 — ndc = 2 uv - 1 shifted by the TAA jitter the reference puts into
+// proj[2][0..1] (x_ndc = P00 x/-z - jx_clip, so the ray of NDC d is the un-jittered ray of d + jitter_clip; y alike, then the
+// Vulkan flip).  A zero jitter adds an exact 0: bit-identical to the un-jittered form.
+BLOK_DEV void camera_plane_uv(const TraceArgs& A, float pcx, float pcy, float& u, float& v) {
+    const blok_camera& c = A.cam;
+    const float qx = rn_div(pcx, static_cast<float>(A.frame_w));
+    const float qy = rn_div(pcy, static_cast<float>(A.frame_h));
+    u = rn_mul(rn_mul(rn_add(rn_sub(rn_mul(2.0f, qx), 1.0f), A.jitter_clip[0]), c.tan_half_fov), c.aspect);
+    v = rn_mul(rn_sub(rn_sub(1.0f, rn_mul(2.0f, qy)), A.jitter_clip[1]), c.tan_half_fov);
+}
+
+// Primary ray of pixel (x, y), tmin/tmax raygen.rgen:225,227.
 BLOK_DEV RayIn primary_ray(const TraceArgs& A, uint32_t x, uint32_t y) {
     const blok_camera& c = A.cam;
-    const float qx = rn_div(rn_add(static_cast<float>(x), 0.5f), static_cast<float>(A.frame_w));
-    const float qy = rn_div(rn_add(static_cast<float>(y), 0.5f), static_cast<float>(A.frame_h));
-    const float u = rn_mul(rn_mul(rn_sub(rn_mul(2.0f, qx), 1.0f), c.tan_half_fov), c.aspect);
-    const float v = rn_mul(rn_sub(1.0f, rn_mul(2.0f, qy)), c.tan_half_fov);
+    float u, v;
+    camera_plane_uv(A, rn_add(static_cast<float>(x), 0.5f), rn_add(static_cast<float>(y), 0.5f), u, v);
     const float dx = rn_add(rn_add(c.fwd[0], rn_mul(c.right[0], u)), rn_mul(c.up[0], v));
     const float dy = rn_add(rn_add(c.fwd[1], rn_mul(c.right[1], u)), rn_mul(c.up[1], v));
     const float dz = rn_add(rn_add(c.fwd[2], rn_mul(c.right[2], u)), rn_mul(c.up[2], v));

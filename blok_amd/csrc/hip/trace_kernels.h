@@ -81,6 +81,9 @@ struct TraceArgs {
     int32_t  origin[3];
     uint32_t levels;
     blok_camera cam;
+    // TAA jitter in clip space, (2 jx / frame_w, 2 jy / frame_h) (getJitterClipSpace, reference blok/src/renderer_postprocess.cpp:234-241):
+    // what getJitteredProjection adds to proj[2][0..1] (:264-265), i.e. to the NDC coordinate every primary ray is formed from
+    float jitter_clip[2];
     uint32_t frame_w, frame_h;
     uint32_t x0, y0, w, h;                 // Rect
     uint32_t tile, rank, n_ranks, tiles_x, tiles_total;   // Tiles
@@ -95,6 +98,7 @@ struct TraceArgs {
     // beam_kernel and read by the Rect / Tiles trace kernels of the same stream; null = no pre-pass
     float* beam;
     uint32_t beam_tile, beam_bx;           // beam_bx: beam tiles per row of the rectangle (Rect)
+    uint32_t beam_budget;                  // node visits a search may spend (0 = kBeamMaxVisits); running out is answered conservatively
 };
 
 // Work queues of the one-launch frame (frame_kernel, trace_kernels.hip), per stream: n_parts independent parts, each with its

@@ -7,6 +7,7 @@
 //
 // Scene: not reference behaviour.  Integer-only, seedable, identical on every host.
 #include "blok_world.h"
+#include "../common/taa_jitter.h"
 
 #include <algorithm>
 #include <cmath>
@@ -138,6 +139,79 @@ int blok_camera_look_at(const float pos[3], const float target[3], float fov_deg
     pitch = std::min(89.0f, std::max(-89.0f, pitch));       // reference camera.hpp:77-78
     const float yaw = std::atan2(dz, dx) / kDegToRad;
     return blok_camera_from_yaw_pitch(pos, yaw, pitch, fov_deg, width, height, out);
+}
+
+// ---- Camera matrices and the TAA jitter sequence (reference blok/include/camera.hpp:49-59, blok/src/renderer_postprocess.cpp:208-268).
+// glm is not in the reference tree (external/glm is an empty submodule); these are glm's published formulas for
+// lookAt (right-handed), perspective (right-handed, depth 0..1: camera.hpp:9 defines GLM_FORCE_DEPTH_ZERO_TO_ONE) and a
+// cofactor inverse, in float, column-major (M[col * 4 + row]).
+
+void blok_camera_view(const blok_camera* c, float M[16]) {
+    if (!c || !M) return;
+    // glm::lookAt(pos, pos + f, up): f = normalize(center - eye), s = normalize(cross(f, up)), u = cross(s, f)
+    const V3 f = unit({c->fwd[0], c->fwd[1], c->fwd[2]});
+    const V3 s = unit(cross(f, {c->up[0], c->up[1], c->up[2]}));
+    const V3 u = cross(s, f);
+    const V3 e = {c->pos[0], c->pos[1], c->pos[2]};
+    auto dot = [](V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; };
+    const float m[16] = {s.x, u.x, -f.x, 0.0f,  s.y, u.y, -f.y, 0.0f,  s.z, u.z, -f.z, 0.0f,  -dot(s, e), -dot(u, e), dot(f, e), 1.0f};
+    for (int i = 0; i < 16; ++i) M[i] = m[i];
+}
+
+void blok_camera_projection(const blok_camera* c, float z_near, float z_far, float M[16]) {
+    if (!c || !M) return;
+    // glm::perspectiveRH_ZO(fovy, aspect, near, far) with p[1][1] *= -1 (camera.hpp:57, "vulkan requirement")
+    for (int i = 0; i < 16; ++i) M[i] = 0.0f;
+    M[0] = 1.0f / (c->aspect * c->tan_half_fov);
+    M[5] = -(1.0f / c->tan_half_fov);
+    M[10] = z_far / (z_near - z_far);
+    M[11] = -1.0f;
+    M[14] = -(z_far * z_near) / (z_far - z_near);
+}
+
+int blok_mat4_inverse(const float m[16], float out[16]) {
+    if (!m || !out) return BLOK_ERR_INVALID_ARG;
+    double inv[16];
+    const double a[16] = {m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7], m[8], m[9], m[10], m[11], m[12], m[13], m[14], m[15]};
+    inv[0] = a[5] * a[10] * a[15] - a[5] * a[11] * a[14] - a[9] * a[6] * a[15] + a[9] * a[7] * a[14] + a[13] * a[6] * a[11] - a[13] * a[7] * a[10];
+    inv[4] = -a[4] * a[10] * a[15] + a[4] * a[11] * a[14] + a[8] * a[6] * a[15] - a[8] * a[7] * a[14] - a[12] * a[6] * a[11] + a[12] * a[7] * a[10];
+    inv[8] = a[4] * a[9] * a[15] - a[4] * a[11] * a[13] - a[8] * a[5] * a[15] + a[8] * a[7] * a[13] + a[12] * a[5] * a[11] - a[12] * a[7] * a[9];
+    inv[12] = -a[4] * a[9] * a[14] + a[4] * a[10] * a[13] + a[8] * a[5] * a[14] - a[8] * a[6] * a[13] - a[12] * a[5] * a[10] + a[12] * a[6] * a[9];
+    inv[1] = -a[1] * a[10] * a[15] + a[1] * a[11] * a[14] + a[9] * a[2] * a[15] - a[9] * a[3] * a[14] - a[13] * a[2] * a[11] + a[13] * a[3] * a[10];
+    inv[5] = a[0] * a[10] * a[15] - a[0] * a[11] * a[14] - a[8] * a[2] * a[15] + a[8] * a[3] * a[14] + a[12] * a[2] * a[11] - a[12] * a[3] * a[10];
+    inv[9] = -a[0] * a[9] * a[15] + a[0] * a[11] * a[13] + a[8] * a[1] * a[15] - a[8] * a[3] * a[13] - a[12] * a[1] * a[11] + a[12] * a[3] * a[9];
+    inv[13] = a[0] * a[9] * a[14] - a[0] * a[10] * a[13] - a[8] * a[1] * a[14] + a[8] * a[2] * a[13] + a[12] * a[1] * a[10] - a[12] * a[2] * a[9];
+    inv[2] = a[1] * a[6] * a[15] - a[1] * a[7] * a[14] - a[5] * a[2] * a[15] + a[5] * a[3] * a[14] + a[13] * a[2] * a[7] - a[13] * a[3] * a[6];
+    inv[6] = -a[0] * a[6] * a[15] + a[0] * a[7] * a[14] + a[4] * a[2] * a[15] - a[4] * a[3] * a[14] - a[12] * a[2] * a[7] + a[12] * a[3] * a[6];
+    inv[10] = a[0] * a[5] * a[15] - a[0] * a[7] * a[13] - a[4] * a[1] * a[15] + a[4] * a[3] * a[13] + a[12] * a[1] * a[7] - a[12] * a[3] * a[5];
+    inv[14] = -a[0] * a[5] * a[14] + a[0] * a[6] * a[13] + a[4] * a[1] * a[14] - a[4] * a[2] * a[13] - a[12] * a[1] * a[6] + a[12] * a[2] * a[5];
+    inv[3] = -a[1] * a[6] * a[11] + a[1] * a[7] * a[10] + a[5] * a[2] * a[11] - a[5] * a[3] * a[10] - a[9] * a[2] * a[7] + a[9] * a[3] * a[6];
+    inv[7] = a[0] * a[6] * a[11] - a[0] * a[7] * a[10] - a[4] * a[2] * a[11] + a[4] * a[3] * a[10] + a[8] * a[2] * a[7] - a[8] * a[3] * a[6];
+    inv[11] = -a[0] * a[5] * a[11] + a[0] * a[7] * a[9] + a[4] * a[1] * a[11] - a[4] * a[3] * a[9] - a[8] * a[1] * a[7] + a[8] * a[3] * a[5];
+    inv[15] = a[0] * a[5] * a[10] - a[0] * a[6] * a[9] - a[4] * a[1] * a[10] + a[4] * a[2] * a[9] + a[8] * a[1] * a[6] - a[8] * a[2] * a[5];
+    const double det = a[0] * inv[0] + a[1] * inv[4] + a[2] * inv[8] + a[3] * inv[12];
+    if (det == 0.0) return BLOK_ERR_INVALID_ARG;
+    for (int i = 0; i < 16; ++i) out[i] = static_cast<float>(inv[i] / det);
+    return BLOK_OK;
+}
+
+void blok_taa_jitter(uint32_t frame_index, float out_px[2]) {
+    if (out_px) blok::taa_jitter_px(frame_index, out_px);
+}
+
+void blok_taa_jitter_clip(const float jitter_px[2], uint32_t width, uint32_t height, float out_clip[2]) {
+    if (!jitter_px || !out_clip || !width || !height) return;
+    out_clip[0] = (2.0f * jitter_px[0]) / static_cast<float>(width);        // getJitterClipSpace, :234-241
+    out_clip[1] = (2.0f * jitter_px[1]) / static_cast<float>(height);
+}
+
+void blok_jittered_projection(const float proj[16], const float jitter_px[2], uint32_t width, uint32_t height, float out[16]) {
+    if (!proj || !jitter_px || !out) return;
+    float clip[2] = {0.0f, 0.0f};
+    blok_taa_jitter_clip(jitter_px, width, height, clip);
+    for (int i = 0; i < 16; ++i) out[i] = proj[i];
+    out[8] += clip[0];              // jitteredProj[2][0], :264
+    out[9] += clip[1];              // jitteredProj[2][1], :265
 }
 
 int blok_scene_generate(blok_world* w, uint32_t n, uint32_t seed, uint64_t* out_n_voxels) {

@@ -155,6 +155,22 @@ class HipTracer:
         """Beam pre-pass granularity of the frame kernels in pixels (0 = off, default 32); never changes a result."""
         self._check(self._lib.blok_hip_set_beam(self._ctx, beam_tile_pixels))
 
+    def set_taa_jitter(self, jitter_px=None):
+        """Sub-pixel TAA jitter (pixels, each within +-0.5) of the primary rays of all following frames; None = off."""
+        if jitter_px is None:
+            self._check(self._lib.blok_hip_set_taa_jitter(self._ctx, None))
+        else:
+            j = (C.c_float * 2)(float(jitter_px[0]), float(jitter_px[1]))
+            self._check(self._lib.blok_hip_set_taa_jitter(self._ctx, j))
+
+    def set_rt_taa_jitter(self, enabled: bool):
+        """draw_frame_rt applies jitter entry (frame mod 16) by itself (default on = PostProcess::Settings::enableTAA)."""
+        self._check(self._lib.blok_hip_set_rt_taa_jitter(self._ctx, 1 if enabled else 0))
+
+    def set_beam_budget(self, max_node_visits: int):
+        """Node visits a beam search may spend (0 = default); running out is answered conservatively, never changes a result."""
+        self._check(self._lib.blok_hip_set_beam_budget(self._ctx, max_node_visits))
+
     def set_fused(self, enabled: bool):
         """One-launch frame (pre-pass + walk in one persistent grid; opt-in) or the two-launch form (default); never changes a result."""
         self._check(self._lib.blok_hip_set_fused(self._ctx, 1 if enabled else 0))

@@ -168,3 +168,41 @@ def view_proj_from_camera(cam: np.ndarray) -> np.ndarray:
     rows[2, :3] = fwd;             rows[2, 3] = -np.dot(fwd, pos)
     rows[3, :3] = fwd;             rows[3, 3] = -np.dot(fwd, pos)
     return np.ascontiguousarray(rows.T.astype(np.float32)).reshape(-1)       # column-major: M[c * 4 + r]
+
+
+def camera_view(cam: np.ndarray) -> np.ndarray:
+    """FrameUBO::view: glm::lookAt(pos, pos + forward, up) (reference camera.hpp:49-52), column-major (4, 4).T flattened."""
+    m = (C.c_float * 16)()
+    _ffi.host_lib().blok_camera_view(_ffi.ptr(np.ascontiguousarray(cam, dtype=CAMERA)), m)
+    return np.array(m, dtype=np.float32)
+
+
+def camera_projection(cam: np.ndarray, z_near: float = 0.1, z_far: float = 10000.0) -> np.ndarray:
+    """FrameUBO::proj before jitter: glm::perspective (depth 0..1) with p[1][1] *= -1 (camera.hpp:54-59); near / far as
+    renderer_draw.cpp:55-56."""
+    m = (C.c_float * 16)()
+    _ffi.host_lib().blok_camera_projection(_ffi.ptr(np.ascontiguousarray(cam, dtype=CAMERA)), z_near, z_far, m)
+    return np.array(m, dtype=np.float32)
+
+
+def mat4_inverse(m: np.ndarray) -> np.ndarray:
+    a = (C.c_float * 16)(*[float(v) for v in np.asarray(m).reshape(-1)])
+    out = (C.c_float * 16)()
+    if _ffi.host_lib().blok_mat4_inverse(a, out) != 0:
+        raise BlokError(-1, "blok_mat4_inverse: singular matrix")
+    return np.array(out, dtype=np.float32)
+
+
+def taa_jitter(frame_index: int) -> np.ndarray:
+    """Entry frame_index mod 16 of the reference's Halton(2,3) - 0.5 sequence, in pixels."""
+    j = (C.c_float * 2)()
+    _ffi.host_lib().blok_taa_jitter(frame_index, j)
+    return np.array(j, dtype=np.float32)
+
+
+def jittered_projection(proj: np.ndarray, jitter_px, width: int, height: int) -> np.ndarray:
+    a = (C.c_float * 16)(*[float(v) for v in np.asarray(proj).reshape(-1)])
+    j = (C.c_float * 2)(float(jitter_px[0]), float(jitter_px[1]))
+    out = (C.c_float * 16)()
+    _ffi.host_lib().blok_jittered_projection(a, j, width, height, out)
+    return np.array(out, dtype=np.float32)

@@ -368,6 +368,18 @@ int blok_hip_set_sun_map(blok_hip_ctx* ctx, int enabled);
  * conservative start parameter for that tile's rays, and tiles whose frustum meets no voxel are written as misses without
  * a walk.  Results are identical with and without it (tests/test_gpu_parity.py).  0 turns it off; default 32. */
 int blok_hip_set_beam(blok_hip_ctx* ctx, uint32_t beam_tile_pixels);
+/* Node visits one beam search may spend (0 = the default, 8192; typical searches take 10-60).  A search that runs out answers
+ * "start at the ray origin", never "none", so the frame is the same whatever the budget (tests/test_gpu_parity.py runs with
+ * budgets of 1-7 visits); the knob exists for that test and for worlds whose searches are pathological. */
+int blok_hip_set_beam_budget(blok_hip_ctx* ctx, uint32_t max_node_visits);
+/* TAA jitter of the primary rays of all following frames, in pixels (each within +-0.5; NULL or {0,0} = none, the default and
+ * the parity / benchmark contract).  The reference applies its Halton(2,3) - 0.5 sequence through the projection matrix
+ * (getJitteredProjection, blok/src/renderer_postprocess.cpp:254-268: proj[2][0..1] += 2 j / size, handed to raygen.rgen as
+ * invProj, blok/src/renderer_draw.cpp:64-81); in the basis form of this backend that is the same ray as NDC + 2 j / size, i.e. a
+ * sub-pixel offset of +j pixels.  blok_taa_jitter (blok_world.h) gives the sequence.  blok_hip_draw_frame_rt applies entry
+ * (frame mod 16) by itself (blok_hip_set_rt_taa_jitter(ctx, 0) = PostProcess::Settings::enableTAA false for the jitter). */
+int blok_hip_set_taa_jitter(blok_hip_ctx* ctx, const float jitter_px[2]);
+int blok_hip_set_rt_taa_jitter(blok_hip_ctx* ctx, int enabled);
 /* One-launch frame (opt-in; default off): the pre-pass and the walk of a rectangle / tile launch run in ONE persistent grid
  * — resident waves first take beam tiles, append the wave-sized sub-tiles of the live ones to per-part queues with an atomic
  * reservation, then take walk tasks from those queues — so the walk starts while long searches are still running and no wave

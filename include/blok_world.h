@@ -139,6 +139,25 @@ int blok_camera_from_yaw_pitch(const float pos[3], float yaw_deg, float pitch_de
 int blok_camera_look_at(const float pos[3], const float target[3], float fov_deg,
                         uint32_t width, uint32_t height, blok_camera* out);
 
+/* The matrices the reference's Vulkan path hands its shaders (FrameUBO, blok/include/resources.hpp:103-150), from the same
+ * basis record: view = glm::lookAt(pos, pos + forward, up) (blok/include/camera.hpp:49-52), proj = glm::perspective(fov,
+ * aspect, near, far) with depth 0..1 and p[1][1] *= -1 (camera.hpp:9,54-59), inverse = glm::inverse (FrameUBO::invView /
+ * invProj, blok/src/renderer_denoising.cpp:669-670).  glm itself is absent from the reference tree (empty submodule): these
+ * follow its published formulas; all 4x4 are column-major floats (M[col * 4 + row]).
+ * With them a pixel's ray is  normalize(invView * (normalize((invProj * (ndc, 1, 1)).xyz), 0))  (raygen.rgen:201-205) — the
+ * same ray as the basis form the kernels use, and with blok_jittered_projection the same ray as the basis form with the
+ * jitter as a sub-pixel offset (tests/test_host_model.py). */
+void blok_camera_view(const blok_camera* cam, float out_view[16]);
+void blok_camera_projection(const blok_camera* cam, float z_near, float z_far, float out_proj[16]);
+int  blok_mat4_inverse(const float m[16], float out[16]);
+/* TAA jitter of frame `frame_index` in pixels: entry frame_index mod 16 of the Halton(2,3) - 0.5 sequence
+ * (PostProcess::initJitterSequence / halton / advanceJitter, blok/src/renderer_postprocess.cpp:208-228,243,660-663);
+ * frame 0 = (0, -1/6).  blok_taa_jitter_clip = getJitterClipSpace (:234-241); blok_jittered_projection = getJitteredProjection
+ * (:254-268): proj[2][0] += 2 jx / width, proj[2][1] += 2 jy / height. */
+void blok_taa_jitter(uint32_t frame_index, float out_px[2]);
+void blok_taa_jitter_clip(const float jitter_px[2], uint32_t width, uint32_t height, float out_clip[2]);
+void blok_jittered_projection(const float proj[16], const float jitter_px[2], uint32_t width, uint32_t height, float out[16]);
+
 /* ------------------------------------------------- synthetic benchmark scene */
 /* Integer-only generator G(N, seed) of SURVEY.md §8(d): terrain shell + 64 shell spheres,
  * materialId in [1,255].  Writes into `w` (chunk size as created), then the caller

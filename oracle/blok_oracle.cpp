@@ -571,10 +571,16 @@ void traceLattice(const Lattice& L, const SvoNode* nodes, const SubChunkGpu* sub
     }
 }
 
-// Primary ray, blok/src/cuda_tracer.cu:276-282 with jx = jy = 0.
+// The frame's TAA jitter in clip space, (2 jx / width, 2 jy / height): what getJitteredProjection adds to proj[2][0..1]
+// (blok/src/renderer_postprocess.cpp:234-241,254-268).  With proj' the NDC of a view-space point is the un-jittered NDC minus
+// the jitter, so the ray raygen.rgen:201-205 forms for NDC d under inverse(proj') is the un-jittered ray of d + jitter (y:
+// before the Vulkan flip).  Set per call sequence by the tests (orc_set_jitter_clip); 0 = TAA off (:255-257).
+float g_jitterClip[2] = {0.0f, 0.0f};
+
+// Primary ray, blok/src/cuda_tracer.cu:276-282 (its jx = jy = 0) in the NDC form of raygen.rgen:201-205.
 inline Ray primaryRay(const Camera& cam, uint32_t width, uint32_t height, uint32_t x, uint32_t y) {
-    const float u = (2.0f * ((float(x) + 0.5f) / float(width)) - 1.0f) * cam.fovScale * cam.aspect;
-    const float v = (1.0f - 2.0f * ((float(y) + 0.5f) / float(height))) * cam.fovScale;
+    const float u = ((2.0f * ((float(x) + 0.5f) / float(width)) - 1.0f) + g_jitterClip[0]) * cam.fovScale * cam.aspect;
+    const float v = ((1.0f - 2.0f * ((float(y) + 0.5f) / float(height))) - g_jitterClip[1]) * cam.fovScale;
     const Vec3 f = {cam.fwd[0], cam.fwd[1], cam.fwd[2]}, r = {cam.right[0], cam.right[1], cam.right[2]},
                up = {cam.up[0], cam.up[1], cam.up[2]};
     const Vec3 d = add3(add3(f, scale3(r, u)), scale3(up, v));
@@ -625,6 +631,8 @@ void parallelFor(size_t n, int threads, Fn&& fn) {
 
 // =============================================================================== C interface
 extern "C" {
+
+void orc_set_jitter_clip(float jx_clip, float jy_clip) { g_jitterClip[0] = jx_clip; g_jitterClip[1] = jy_clip; }
 
 uint64_t orc_morton_encode(int32_t x, int32_t y, int32_t z) { return mortonEncode(x, y, z); }
 void orc_morton_decode(uint64_t code, int32_t* x, int32_t* y, int32_t* z) {   // morton.hpp:46-53
@@ -983,8 +991,8 @@ GBufferPixel shadePixel(const Lattice& L, const SvoNode* nodes, const SubChunkGp
             pcy = float(py) + 0.5f + jy * 0.5f;
         }
         // :201-206 in camera-basis form (cuda_tracer.cu:276-282)
-        const float u = (2.0f * (pcx / float(width)) - 1.0f) * cam.fovScale * cam.aspect;
-        const float v = (1.0f - 2.0f * (pcy / float(height))) * cam.fovScale;
+        const float u = ((2.0f * (pcx / float(width)) - 1.0f) + g_jitterClip[0]) * cam.fovScale * cam.aspect;
+        const float v = ((1.0f - 2.0f * (pcy / float(height))) - g_jitterClip[1]) * cam.fovScale;
         Vec3 rayDir = normalize3(add3(add3(camF, scale3(camR, u)), scale3(camU, v)));
         Vec3 rayOrigin = camPos;
         Vec3 radiance{0, 0, 0}, throughput{1, 1, 1};

@@ -47,8 +47,12 @@ const void* hh_tree_nodes(const void* h, size_t* count, int32_t* origin) {
 uint32_t hh_levels(const void* h) { return static_cast<const Harness*>(h)->tree.levels; }
 uint64_t hh_voxels(const void* h) { return static_cast<const Harness*>(h)->tree.n_voxels; }
 
+static float g_jitter_clip[2] = {0.0f, 0.0f};
+void hh_set_jitter_clip(float jx, float jy) { g_jitter_clip[0] = jx; g_jitter_clip[1] = jy; }
+
 static TraceArgs make_args(const Harness* H) {
     TraceArgs a{};
+    a.jitter_clip[0] = g_jitter_clip[0]; a.jitter_clip[1] = g_jitter_clip[1];
     a.nodes = H->nodes.data();
     a.materials = H->tree.materials.data();
     for (int i = 0; i < 3; ++i) a.origin[i] = H->tree.origin[i];

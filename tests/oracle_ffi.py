@@ -199,6 +199,17 @@ def trace_bruteforce(nodes, subs, rays):
     return hits, ctr[0]
 
 
+def set_jitter_clip(jitter_px=None, width=1, height=1):
+    """TAA jitter of the oracle's primary rays (pixels -> clip space as getJitterClipSpace does); None = off."""
+    L = lib()
+    L.orc_set_jitter_clip.argtypes = [C.c_float, C.c_float]
+    if jitter_px is None:
+        L.orc_set_jitter_clip(0.0, 0.0)
+    else:
+        L.orc_set_jitter_clip(float(np.float32(2.0) * np.float32(jitter_px[0]) / np.float32(width)),
+                              float(np.float32(2.0) * np.float32(jitter_px[1]) / np.float32(height)))
+
+
 class Lattice:
     def __init__(self, nodes, subs):
         self.nodes = np.ascontiguousarray(nodes)

@@ -51,7 +51,7 @@ def test_progressive_frames_match_oracle_and_reset_on_camera_change(built):
         got = tr.accum_download()
         assert (got[..., 3] == frames_expected).all()
         ok = (np.abs(got[..., :3] - accum_ref[..., :3]) <= frames_expected * (1e-4 + 1e-3 * np.abs(accum_ref[..., :3]))).all(axis=2)
-        assert ok.mean() >= 0.995, ok.mean()
+        assert ok.all(), (ok.mean(), np.argwhere(~ok)[:8].tolist())
         d = np.abs(px.view(np.uint8).astype(int) - ref_px.view(np.uint8).astype(int)).reshape(h, w, 4)
         assert (d[ok] <= 1).all(), d[ok].max()
         assert (d[..., 3] == 0).all()

@@ -86,8 +86,8 @@ def scene1024():
 
 
 def test_config3_1024_svo_4k(tracer_cls, scene1024):
-    """BASELINE.json configs[2] at full size: 4K over the 1024^3 SVO.  Oracle on a strided sample of every
-    pose; rectangle tiling, tile partition + untile, and determinism on the full frame."""
+    """BASELINE.json configs[2] at full size: 4K over the 1024^3 SVO.  Oracle on EVERY pixel of every pose;
+    rectangle tiling, tile partition + untile, and determinism on the full frame."""
     import torch
     cm, pw = scene1024
     Wd, Ht = 3840, 2160
@@ -100,10 +100,9 @@ def test_config3_1024_svo_4k(tracer_cls, scene1024):
         cam = W.scene_camera(1024, pose, Wd, Ht, SEED)
         full = tr.draw_frame(cam)
         frames[pose] = full
-        stride = 5
-        ref, ctr = lat.trace_primary(cam, Wd, Ht, stride=stride, threads=16)
-        assert ctr["hits"] > 20000 and ctr["iter_limit_hits"] == 0 and ctr["stack_limit_hits"] == 0
-        assert records_equal(full[::stride, ::stride].reshape(-1), ref).all(), f"pose {pose}"
+        ref, ctr = lat.trace_primary(cam, Wd, Ht, stride=1, threads=16)              # every pixel of the 4K frame
+        assert ctr["rays"] == Wd * Ht and ctr["hits"] > 2000000 and ctr["iter_limit_hits"] == 0 and ctr["stack_limit_hits"] == 0
+        assert records_equal(full.reshape(-1), ref).all(), f"pose {pose}"
     cam = W.scene_camera(1024, 0, Wd, Ht, SEED)
     full = frames[0]
     # idempotence / determinism
@@ -285,6 +284,40 @@ def test_one_launch_frame_queue_rearms_itself(tracer_cls, scene1024):
     tr.shutdown()
 
 
+def test_beam_visit_budget_exhaustion_is_conservative(tracer_cls, scene1024):
+    """A beam search that runs out of its visit budget answers "start at the ray origin" (beam.h), never "none": with budgets
+    of 1, 2, 3, 7 and 20 node visits (typical searches need 10-60, so nearly every tile runs out at the small ones) the 4K
+    frames of all three poses, a rectangle and a rank's tiles are the frames of the default budget, bit for bit."""
+    import torch
+    cm, pw = scene1024
+    Wd, Ht = 3840, 2160
+    tr = tracer_cls(Wd, Ht).init()
+    tr.add_world(pw)
+    for pose in (0, 1, 2):
+        cam = W.scene_camera(1024, pose, Wd, Ht, SEED)
+        tr.set_beam_budget(0)
+        want = tr.draw_frame(cam).reshape(-1)
+        rect = (777, 333, 640, 480)
+        want_rect = tr.draw_frame(cam, rect).reshape(-1)
+        for budget in (1, 2, 3, 7, 20):
+            tr.set_beam_budget(budget)
+            assert records_equal(tr.draw_frame(cam).reshape(-1), want).all(), (pose, budget)
+            assert records_equal(tr.draw_frame(cam, rect).reshape(-1), want_rect).all(), (pose, budget)
+            for fused in (True, False):
+                tr.set_fused(fused)
+                assert records_equal(tr.draw_frame(cam).reshape(-1), want).all(), (pose, budget, fused)
+    cam = W.scene_camera(1024, 1, Wd, Ht, SEED)
+    tr.set_beam_budget(0)
+    per = tr.tiles_for_rank(32, 3, 8)
+    a = torch.zeros((per * 1024, 4), dtype=torch.int32, device="cuda"); b = torch.zeros_like(a)
+    tr.draw_tiles_device(cam, 32, 3, 8, hits_ptr=a.data_ptr())
+    tr.set_beam_budget(2)
+    tr.draw_tiles_device(cam, 32, 3, 8, hits_ptr=b.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    tr.shutdown()
+
+
 def test_degenerate_cameras_are_refused(tracer_cls, scene64):
     """A camera with a non-finite component or a zero field of view is an argument error (every ray would be NaN and the
     beam pre-pass could cull nothing), not a launch."""
@@ -433,7 +466,7 @@ def test_device_build_odd_worlds(tracer_cls):
 
 def test_config4_2048_svo_4k_tiles(tracer_cls):
     """BASELINE.json configs[3] geometry: 2048^3 SVO (6 tree levels, 633 MB of reference nodes) at 4K, the
-    8-GPU tile partition rehearsed with virtual ranks on one device, oracle on a strided sample."""
+    8-GPU tile partition rehearsed with virtual ranks on one device, oracle on every pixel; wide-angle and grazing cameras."""
     import torch
     cm, pw = make_scene_world(2048)
     Wd, Ht = 3840, 2160
@@ -442,10 +475,21 @@ def test_config4_2048_svo_4k_tiles(tracer_cls):
     assert st.levels == 6 and tr.built_on_device() and st.n_ref_nodes == len(pw.nodes)
     cam = W.scene_camera(2048, 0, Wd, Ht, SEED)
     full = tr.draw_frame(cam)
-    stride = 8
-    ref, ctr = O.Lattice(pw.nodes, pw.sub_chunks).trace_primary(cam, Wd, Ht, stride=stride, threads=16)
-    assert ctr["hits"] > 20000
-    assert records_equal(full[::stride, ::stride].reshape(-1), ref).all()
+    lat = O.Lattice(pw.nodes, pw.sub_chunks)
+    ref, ctr = lat.trace_primary(cam, Wd, Ht, stride=1, threads=16)                   # every pixel of the 4K frame
+    assert ctr["rays"] == Wd * Ht and ctr["hits"] > 1500000 and ctr["iter_limit_hits"] == 0
+    assert records_equal(full.reshape(-1), ref).all()
+    # the pre-pass at its limits in the big world: a 150-degree field of view from inside the volume, and a camera grazing
+    # the terrain from a corner (long rays through half-empty cells), each against the oracle on every 2nd pixel
+    for cam_x in (W.camera_look_at((1024.3, 700.2, 1024.9), (1500.0, 300.0, 1700.0), 150.0, Wd, Ht),
+                  W.camera_look_at((-40.0, 1040.0, -35.0), (2048.0, 980.0, 2048.0), 60.0, Wd, Ht)):
+        got = tr.draw_frame(cam_x)
+        refx, cx = lat.trace_primary(cam_x, Wd, Ht, stride=2, threads=16)
+        assert cx["hits"] > 100000
+        assert records_equal(got[::2, ::2].reshape(-1), refx).all()
+        tr.set_beam(0)
+        assert records_equal(tr.draw_frame(cam_x).reshape(-1), got.reshape(-1)).all()
+        tr.set_beam(32)
     n_ranks, tile = 8, 32
     per = tr.tiles_for_rank(tile, 0, n_ranks)
     gathered = torch.zeros((n_ranks * per * tile * tile, 4), dtype=torch.int32, device="cuda")

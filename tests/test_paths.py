@@ -103,7 +103,7 @@ def test_gpu_paths_within_tolerance_64(world64, pose, spp, bounces):
     for k in ("world_pos", "normal_roughness", "albedo_metallic"):
         assert np.array_equal(got[k], ref[k]), k                                  # first hit: exact
     ok = within_tolerance(got["color"], ref["color"]).all(axis=2)
-    assert ok.mean() >= 0.995, f"only {ok.mean():.5f} of pixels within tolerance"
+    assert ok.all(), f"only {ok.mean():.6f} of pixels within the stated tolerance: {np.argwhere(~ok)[:8].tolist()}"
     assert np.abs(got["color"] - ref["color"]).mean() < 2e-4
     tr.shutdown()
 
@@ -112,7 +112,7 @@ def test_gpu_paths_within_tolerance_64(world64, pose, spp, bounces):
 def test_gpu_paths_1024_4k_sample_and_tonemapped_lsb():
     """BASELINE.json configs[4] geometry (1024^3, 4K) on a rectangle; after a tonemap to 8 bits (ACES fit +
     gamma 2.2 as in the reference's compute backend, cuda_tracer.cu:209-216,385-386) the images agree to 1 LSB on
-    >= 99.5 % of pixels."""
+    every pixel, and every pixel of the linear image is inside the stated tolerance."""
     from blok_amd.tracer import HipTracer
     from tests.conftest import make_scene_world
     cm, pw = make_scene_world(1024)
@@ -128,14 +128,41 @@ def test_gpu_paths_1024_4k_sample_and_tonemapped_lsb():
     for k in ("world_pos", "normal_roughness", "albedo_metallic"):
         assert np.array_equal(got[k], ref[k]), k
     ok = within_tolerance(got["color"], ref["color"]).all(axis=2)
-    assert ok.mean() >= 0.995
+    assert ok.all(), (ok.mean(), np.argwhere(~ok)[:8].tolist())
 
     def tonemap8(c):
         c = c[..., :3].astype(np.float64)
         a = (c * (2.51 * c + 0.03)) / (c * (2.43 * c + 0.59) + 0.14)
         return np.round(np.clip(a, 0, 1) ** (1 / 2.2) * 255).astype(np.int32)
     lsb = np.abs(tonemap8(got["color"]) - tonemap8(ref["color"])).max(axis=2)
-    assert (lsb <= 1).mean() >= 0.995
+    assert (lsb <= 1).all(), ((lsb <= 1).mean(), int(lsb.max()))
+    tr.shutdown()
+
+
+@pytest.mark.gpu
+def test_gpu_paths_config5_at_64_spp():
+    """BASELINE.json configs[4] as stated — 1024^3 SVO, 4K frame, 64 samples per pixel, 2 bounces — on a rectangle of the
+    frame against orc_render_paths: the RNG streams of samples 0..63, every pixel inside the stated tolerance, G-buffer
+    planes exact; and a second rectangle at the horizon (grazing bounce rays)."""
+    from blok_amd.tracer import HipTracer
+    from tests.conftest import make_scene_world
+    cm, pw = make_scene_world(1024)
+    mats = pw.materials
+    lat = O.Lattice(pw.nodes, pw.sub_chunks)
+    tr = HipTracer(3840, 2160).init()
+    tr.add_world(pw)
+    cam = W.scene_camera(1024, 0, 3840, 2160, SEED)
+    column, _ = lat.trace_primary(cam, 3840, 2160, x0=1900, y0=0, w=1, h=2160, threads=4)
+    top = int(np.flatnonzero(column["hit"] == 1)[0])                 # the silhouette of the terrain in column 1900
+    for rect in ((1700, 1000, 192, 96), (1836, max(0, top - 32), 128, 64)):
+        got = tr.trace_paths(cam, spp=64, max_bounces=2, frame_index=3, rect=rect)
+        ref, ctr = O.render_paths(lat, mats, cam, 3840, 2160, spp=64, max_bounces=2, frame_index=3, rect=rect, threads=16)
+        assert ctr["rays"] > rect[2] * rect[3] * 64
+        for k in ("world_pos", "normal_roughness", "albedo_metallic"):
+            assert np.array_equal(got[k], ref[k]), (rect, k)
+        ok = within_tolerance(got["color"], ref["color"]).all(axis=2)
+        assert ok.all(), (rect, ok.mean(), np.argwhere(~ok)[:8].tolist())
+        assert (got["color"][..., 3] == 1).all() and np.isfinite(got["color"]).all()
     tr.shutdown()
 
 

@@ -281,6 +281,7 @@ def test_draw_frame_rt_is_the_composition_of_the_passes(gbuffer_frames):
     for k, cam in enumerate(cams[:4]):
         got, frames = one.draw_frame_rt(cam, spp=2)
         assert frames == k + 1
+        many.set_taa_jitter(W.taa_jitter(k))                 # frame k's projection carries jitterSequence[k mod 16] (renderer_draw.cpp:64-81)
         many.trace_paths_device(cam, P["color"].data_ptr(), spp=2, max_bounces=2, frame_index=k, world_pos_ptr=P["world_pos"].data_ptr(),
                                 normal_roughness_ptr=P["normal_roughness"].data_ptr(), albedo_metallic_ptr=P["albedo_metallic"].data_ptr())
         many.denoise_device(P["color"].data_ptr(), P["world_pos"].data_ptr(), P["normal_roughness"].data_ptr(),
@@ -293,7 +294,63 @@ def test_draw_frame_rt_is_the_composition_of_the_passes(gbuffer_frames):
     one.post_reset()
     _, frames = one.draw_frame_rt(cams[0], spp=1)
     assert frames == 1
+    # the jitter is what makes frame k differ from the un-jittered composition (frame 1: (-0.25, +1/6) px), and it can be turned off
+    one.post_reset(); many.post_reset()
+    one.set_rt_taa_jitter(False); many.set_taa_jitter(None)
+    for k, cam in enumerate(cams[:2]):
+        got, _ = one.draw_frame_rt(cam, spp=2)
+        many.trace_paths_device(cam, P["color"].data_ptr(), spp=2, max_bounces=2, frame_index=k, world_pos_ptr=P["world_pos"].data_ptr(),
+                                normal_roughness_ptr=P["normal_roughness"].data_ptr(), albedo_metallic_ptr=P["albedo_metallic"].data_ptr())
+        many.denoise_device(P["color"].data_ptr(), P["world_pos"].data_ptr(), P["normal_roughness"].data_ptr(),
+                            many.camera_view_proj(cams[max(k - 1, 0)]), k, den.data_ptr())
+        many.taa_device(den.data_ptr(), taa.data_ptr(), k)
+        many.tonemap_device(taa.data_ptr(), ldr.data_ptr())
+        many.sharpen_device(ldr.data_ptr(), sharp.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(got.reshape(-1), sharp.cpu().numpy().view(np.uint32))
     one.shutdown(); many.shutdown()
+
+
+@pytest.mark.gpu
+def test_taa_jitter_on_the_gpu_matches_the_oracle():
+    """A8 on the device: first-hit frames and path-traced G-buffers with the frame's Halton jitter equal the oracle's with
+    the same jitter (first hits bit for bit, G-buffer planes exactly, colour within the stated tolerance), for frames 0-3 and
+    13; with the beam pre-pass on (its frustum is grown by a whole pixel: jitter <= 0.5 plus the sample jitter <= 0.25)."""
+    from blok_amd.tracer import HipTracer
+    from tests.conftest import make_scene_world, records_equal, SEED
+    cm, pw = make_scene_world(64)
+    w, h = 200, 120
+    tr = HipTracer(w, h).init()
+    tr.add_world(pw)
+    lat = O.Lattice(pw.nodes, pw.sub_chunks)
+    cam = W.scene_camera(64, 0, w, h, SEED)
+    plain = tr.draw_frame(cam).reshape(-1)
+    try:
+        for frame in (0, 1, 2, 3, 13):
+            j = W.taa_jitter(frame)
+            tr.set_taa_jitter(j)
+            O.set_jitter_clip(j, w, h)
+            got = tr.draw_frame(cam).reshape(-1)
+            ref, _ = lat.trace_primary(cam, w, h, threads=8)
+            assert records_equal(got, ref).all(), frame
+            assert not records_equal(got, plain).all(), frame
+            tr.set_beam(0)
+            assert records_equal(tr.draw_frame(cam).reshape(-1), ref).all(), frame
+            tr.set_beam(32)
+            planes = tr.trace_paths(cam, spp=4, max_bounces=2, frame_index=frame)
+            want, _ = O.render_paths(lat, pw.materials, cam, w, h, spp=4, max_bounces=2, frame_index=frame, threads=8)
+            for k in ("world_pos", "normal_roughness", "albedo_metallic"):
+                assert np.array_equal(planes[k], want[k]), (frame, k)
+            err = np.abs(planes["color"] - want["color"])
+            assert (err <= 1e-4 + 1e-3 * np.abs(want["color"])).all(), (frame, float(err.max()))
+        with pytest.raises(Exception):
+            tr.set_taa_jitter((0.75, 0.0))
+        tr.set_taa_jitter(None)
+        O.set_jitter_clip(None)
+        assert records_equal(tr.draw_frame(cam).reshape(-1), plain).all()
+    finally:
+        O.set_jitter_clip(None)
+    tr.shutdown()
 
 
 
