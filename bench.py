@@ -57,6 +57,7 @@ def parse():
                     "rehearsing the N > 1 code path with several ranks on one GPU, which RCCL refuses)")
     ap.add_argument("--beam", type=int, default=32, help="beam pre-pass tile in pixels (0 = off)")
     ap.add_argument("--fused", type=int, default=0, help="1 = one persistent launch per frame (pre-pass + walk; measured slower), 0 = beam kernel then trace kernel")
+    ap.add_argument("--orbit", type=float, default=0.0, help="degrees the camera turns around the world's centre per frame (0 = static camera)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-paths", action="store_true", help="skip the 64-spp path-tracing side measurement")
     ap.add_argument("--no-poses", action="store_true", help="skip the per-pose side measurements (poses A, B, C)")
@@ -188,8 +189,28 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # --orbit: the camera of frame k stands on a circle around the vertical axis through the world's centre, orbit degrees
+    # further per frame, there and back (ping-pong over 64 positions, so consecutive frames always differ by one step)
+    orbit_cams = None
+    if args.orbit > 0.0:
+        n_f = float(args.n)
+        centre = np.array([0.5 * n_f, 0.25 * n_f, 0.5 * n_f]); start = np.array([-0.35 * n_f, 0.85 * n_f, -0.35 * n_f]) - centre
+        arc = []
+        for i in range(64):
+            a = np.radians(args.orbit * i)
+            p = centre + np.array([start[0] * np.cos(a) - start[2] * np.sin(a), start[1], start[0] * np.sin(a) + start[2] * np.cos(a)])
+            arc.append(W.camera_look_at(tuple(float(v) for v in p), tuple(float(v) for v in centre), 60.0, W_, H_))
+        orbit_cams = arc + arc[-2:0:-1]
+    frame_no = [0]
+
+    def next_frame():
+        if orbit_cams is not None:
+            pipe.backend.cam = orbit_cams[frame_no[0] % len(orbit_cams)]
+            frame_no[0] += 1
         pipe.step()
+
+    for _ in range(args.warmup):
+        next_frame()
     pipe.flush()
     fence()
     # HIP events on the streams the kernels are launched on: one at the head of slot 0's stream, one at the tail of
@@ -199,7 +220,7 @@ def main():
     t0 = time.perf_counter()
     ev0.record(pipe.streams[0])
     for _ in range(args.steps):
-        pipe.step()
+        next_frame()
     pipe.flush()                                 # every frame's trace, gather and un-permute are inside the timed region
     for e, st in zip(ev1, pipe.streams):
         e.record(st)
@@ -218,7 +239,9 @@ def main():
     def solitary_ms(backend, reps):
         tracer.set_timing(True)
         ms = []
-        for _ in range(reps):
+        for k in range(reps):
+            if orbit_cams is not None:
+                backend.cam = orbit_cams[k % len(orbit_cams)]
             if world_size == 1:
                 backend.trace_full(pipe.hits, pipe._frame[0], stream.cuda_stream)
             else:
@@ -296,6 +319,7 @@ def main():
                        "outputs": "16-B first-hit records (kept on the tracing GPU) + RGBA8 framebuffer on rank 0",
                        "tile_records_gathered_per_frame_and_rank": (pipe.records_gathered / max(1, pipe.frames_done)) if world_size > 1 and args.sparse_gather else None,
                        "tiles_per_rank": pipe.per_rank if world_size > 1 else None,
+                       "camera_orbit_deg_per_frame": args.orbit,
                        "frames_in_flight": args.frames_in_flight, "device_ms_per_step": device_ms / args.steps, "kernel_ms_alone": kernel_ms_avg, "beam_tile": args.beam,
                        "poses": poses, "also_measured_paths": paths},
         }

@@ -49,6 +49,12 @@ class GBuffer(C.Structure):
                 ("albedo_metallic", C.c_void_p)]
 
 
+class GBufferRef(C.Structure):
+    """= blok_gbuffer_ref: the reference's image formats (RGBA32F x 2, RGBA16F, RGBA8, RG16F)."""
+    _fields_ = [("color", C.c_void_p), ("world_pos", C.c_void_p), ("normal_roughness", C.c_void_p),
+                ("albedo_metallic", C.c_void_p), ("motion", C.c_void_p)]
+
+
 class DenoiseSettings(C.Structure):
     """= blok_denoise_settings (Denoiser::Settings, reference blok/include/renderer_denoising.hpp:49-66)."""
     _fields_ = [("temporal_alpha", C.c_float), ("moment_alpha", C.c_float), ("variance_clip_gamma", C.c_float),
@@ -153,6 +159,8 @@ HIP_SYMBOLS = {
                                          C.c_void_p, C.c_void_p]),
     "blok_hip_trace_paths_device": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_uint32] * 7 + [C.POINTER(GBuffer), C.c_void_p]),
     "blok_hip_trace_paths": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_uint32] * 7 + [C.POINTER(GBuffer)]),
+    "blok_hip_trace_paths_ref_device": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_uint32] * 7 + [C.POINTER(C.c_float), C.POINTER(GBufferRef), C.c_void_p]),
+    "blok_hip_denoise_ref_device": (C.c_int, [C.c_void_p, C.POINTER(GBufferRef), C.POINTER(C.c_float), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "blok_hip_tonemap_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
     "blok_hip_tonemap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_int, C.c_void_p]),
     "blok_hip_trace_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -21,7 +21,8 @@ void free_post(blok_hip_ctx* ctx) {
             if (p) (void)hipFree(p);
     for (void* p : {static_cast<void*>(P.motion), static_cast<void*>(P.variance), static_cast<void*>(P.ping), static_cast<void*>(P.pong), static_cast<void*>(P.widen),
                     static_cast<void*>(P.rt_planes[0]), static_cast<void*>(P.rt_planes[1]), static_cast<void*>(P.rt_planes[2]), static_cast<void*>(P.rt_planes[3]),
-                    static_cast<void*>(P.rt_denoised), static_cast<void*>(P.rt_resolved), static_cast<void*>(P.rt_ldr), static_cast<void*>(P.rt_final)})
+                    static_cast<void*>(P.rt_denoised), static_cast<void*>(P.rt_resolved), static_cast<void*>(P.rt_ldr), static_cast<void*>(P.rt_final),
+                    static_cast<void*>(P.rt_normal_roughness_h), static_cast<void*>(P.rt_motion_h), static_cast<void*>(P.rt_albedo_metallic_u8)})
         if (p) (void)hipFree(p);
     P = blok_hip_ctx::Post{};
 }
@@ -558,20 +559,18 @@ int blok_hip_shade_rgba8(blok_hip_ctx* ctx, const blok_camera* cam, uint32_t x0,
     return BLOK_OK;
 }
 
-int blok_hip_trace_paths_device(blok_hip_ctx* ctx, const blok_camera* cam, uint32_t x0, uint32_t y0, uint32_t w,
-                                uint32_t h, uint32_t spp, uint32_t max_bounces, uint32_t frame_index,
-                                const blok_gbuffer* planes, void* hip_stream) {
+// Launch of the path kernel (pre-pass first) for either plane set; `planes` carries the output pointers and prev_view_proj.
+static int launch_path_frame(blok_hip_ctx* ctx, const blok_camera* cam, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint32_t spp,
+                             uint32_t max_bounces, uint32_t frame_index, const blok::PathArgs& planes, void* hip_stream) {
     int rc = check_trace(ctx, cam);
     if (rc != BLOK_OK) return rc;
-    if (!planes || !rect_inside(ctx, x0, y0, w, h) || !spp || !max_bounces)
+    if (!rect_inside(ctx, x0, y0, w, h) || !spp || !max_bounces)
         return set_error(ctx, BLOK_ERR_INVALID_ARG, "bad path-trace arguments");
     if (!ctx->n_materials) return set_error(ctx, BLOK_ERR_INVALID_ARG, "path tracing needs a material table");
-    blok::PathArgs p{};
+    blok::PathArgs p = planes;
     p.trace = base_args(ctx, cam);
     p.trace.x0 = x0; p.trace.y0 = y0; p.trace.w = w; p.trace.h = h;
     p.spp = spp; p.max_bounces = max_bounces; p.frame_count = frame_index;
-    p.color = planes->color; p.world_pos = planes->world_pos;
-    p.normal_roughness = planes->normal_roughness; p.albedo_metallic = planes->albedo_metallic;
     p.batch_kinds = ctx->ray_batching ? 1u : 0u;
     if (ctx->sun_map_enabled && ctx->has_sun_map) {         // shadow rays stop at the last occluder of their column
         const blok::SunMapArgs& m = ctx->sun;
@@ -589,6 +588,29 @@ int blok_hip_trace_paths_device(blok_hip_ctx* ctx, const blok_camera* cam, uint3
     BLOK_HIP_TRY(ctx, hipGetLastError());
     if (ctx->timing) { BLOK_HIP_TRY(ctx, hipEventRecord(ctx->ev_end, stream)); ctx->timed = true; }
     return BLOK_OK;
+}
+
+int blok_hip_trace_paths_device(blok_hip_ctx* ctx, const blok_camera* cam, uint32_t x0, uint32_t y0, uint32_t w,
+                                uint32_t h, uint32_t spp, uint32_t max_bounces, uint32_t frame_index,
+                                const blok_gbuffer* planes, void* hip_stream) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    if (!planes) return set_error(ctx, BLOK_ERR_INVALID_ARG, "bad path-trace arguments");
+    blok::PathArgs p{};
+    p.color = planes->color; p.world_pos = planes->world_pos;
+    p.normal_roughness = planes->normal_roughness; p.albedo_metallic = planes->albedo_metallic;
+    return launch_path_frame(ctx, cam, x0, y0, w, h, spp, max_bounces, frame_index, p, hip_stream);
+}
+
+int blok_hip_trace_paths_ref_device(blok_hip_ctx* ctx, const blok_camera* cam, uint32_t x0, uint32_t y0, uint32_t w,
+                                    uint32_t h, uint32_t spp, uint32_t max_bounces, uint32_t frame_index,
+                                    const float prev_view_proj[16], const blok_gbuffer_ref* planes, void* hip_stream) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    if (!planes || (planes->motion && !prev_view_proj)) return set_error(ctx, BLOK_ERR_INVALID_ARG, "bad path-trace arguments (a motion plane needs prevViewProj)");
+    blok::PathArgs p{};
+    p.color = planes->color; p.world_pos = planes->world_pos;
+    p.normal_roughness_h = planes->normal_roughness; p.albedo_metallic_u8 = planes->albedo_metallic; p.motion_h = planes->motion;
+    if (prev_view_proj) for (int k = 0; k < 16; ++k) p.prev_view_proj[k] = prev_view_proj[k];
+    return launch_path_frame(ctx, cam, x0, y0, w, h, spp, max_bounces, frame_index, p, hip_stream);
 }
 
 int blok_hip_trace_paths(blok_hip_ctx* ctx, const blok_camera* cam, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,

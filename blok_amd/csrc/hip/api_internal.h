@@ -58,7 +58,9 @@ struct blok_hip_ctx {
         int cur = 0, taa_cur = 0;
         bool has_motion = false;
         // blok_hip_draw_frame_rt: the frame's own planes and its camera history
-        float *rt_planes[4] = {nullptr, nullptr, nullptr, nullptr}, *rt_denoised = nullptr, *rt_resolved = nullptr;
+        float *rt_planes[4] = {nullptr, nullptr, nullptr, nullptr}, *rt_denoised = nullptr, *rt_resolved = nullptr;   // [0] colour, [1] world position
+        uint16_t *rt_normal_roughness_h = nullptr, *rt_motion_h = nullptr;      // RGBA16F, RG16F
+        uint32_t* rt_albedo_metallic_u8 = nullptr;                              // RGBA8
         uint32_t *rt_ldr = nullptr, *rt_final = nullptr;
         uint32_t rt_frame = 0;
         blok_camera rt_prev_cam{};

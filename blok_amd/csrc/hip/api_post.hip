@@ -55,10 +55,11 @@ void blok_denoise_settings_default(blok_denoise_settings* s) {       // renderer
     s->atrous_iterations = 4; s->variance_boost = 1.5f; s->min_history_length = 4;
 }
 
-int blok_hip_denoise_device(blok_hip_ctx* ctx, const blok_gbuffer* planes, const float* motion_dev, const float prev_view_proj[16],
-                            uint32_t frame_count, const blok_denoise_settings* settings, float* out_color_dev, void* hip_stream) {
-    if (!ctx) return BLOK_ERR_INVALID_ARG;
-    if (!planes || !planes->color || !planes->world_pos || !planes->normal_roughness || !prev_view_proj || !out_color_dev)
+// One frame through temporal accumulation, variance and the a-trous iterations; the frame's planes come in `in` (float4 planes,
+// or the reference-format halves of normal + roughness / motion).
+static int denoise_frame(blok_hip_ctx* ctx, const blok::TemporalArgs& in, const float prev_view_proj[16], uint32_t frame_count,
+                         const blok_denoise_settings* settings, float* out_color_dev, void* hip_stream) {
+    if (!in.color || !in.world_pos || (!in.normal_roughness && !in.normal_roughness_h) || !prev_view_proj || !out_color_dev)
         return set_error(ctx, BLOK_ERR_INVALID_ARG, "denoise: colour, world position and normal planes, prevViewProj and an output are required");
     blok_denoise_settings def;
     blok_denoise_settings_default(&def);
@@ -74,9 +75,9 @@ int blok_hip_denoise_device(blok_hip_ctx* ctx, const blok_gbuffer* planes, const
     f.w = ctx->width; f.h = ctx->height; f.frame_count = frame_count; f.s = to_settings(S);
     for (int k = 0; k < 16; ++k) f.prev_view_proj[k] = prev_view_proj[k];
 
-    blok::TemporalArgs t{};
+    blok::TemporalArgs t = in;
     t.f = f;
-    t.color = planes->color; t.world_pos = planes->world_pos; t.normal_roughness = planes->normal_roughness; t.motion_in = motion_dev;
+
     t.prev_color = P.hist_color[prev]; t.prev_moments = P.moments[prev]; t.prev_world_pos = P.world_pos[prev];
     t.prev_hist_len = P.hist_len[prev]; t.prev_unit_normals = P.unit_normals[prev];
     t.out_color = P.hist_color[cur]; t.out_moments = P.moments[cur]; t.hist_world_pos = P.world_pos[cur];
@@ -90,14 +91,14 @@ int blok_hip_denoise_device(blok_hip_ctx* ctx, const blok_gbuffer* planes, const
     blok::launch_variance(v, stream);
 
     // iteration 0 reads the temporal output; then ping <-> pong (renderer_denoising.cpp:520-536); the last one writes the caller's plane
-    const float* in = P.hist_color[cur];
+    const float* src = P.hist_color[cur];
     for (int it = 0; it < S.atrous_iterations; ++it) {
         blok::AtrousArgs a{};
         a.w = f.w; a.h = f.h; a.step = 1 << it; a.phi_color = S.phi_color; a.phi_depth = S.phi_depth;
-        a.color = in; a.variance = P.variance; a.world_pos = P.world_pos[cur]; a.unit_normals = P.unit_normals[cur];
+        a.color = src; a.variance = P.variance; a.world_pos = P.world_pos[cur]; a.unit_normals = P.unit_normals[cur];
         a.out = it == S.atrous_iterations - 1 ? out_color_dev : ((it & 1) ? P.pong : P.ping);
         blok::launch_atrous(a, stream);
-        in = a.out;
+        src = a.out;
     }
     if (S.atrous_iterations == 0)
         BLOK_HIP_TRY(ctx, hipMemcpyAsync(out_color_dev, P.hist_color[cur], P.pixels * 4 * sizeof(float), hipMemcpyDeviceToDevice, stream));
@@ -105,6 +106,24 @@ int blok_hip_denoise_device(blok_hip_ctx* ctx, const blok_gbuffer* planes, const
     P.cur = prev;                                          // swapHistoryBuffers
     P.has_motion = true;
     return BLOK_OK;
+}
+
+int blok_hip_denoise_device(blok_hip_ctx* ctx, const blok_gbuffer* planes, const float* motion_dev, const float prev_view_proj[16],
+                            uint32_t frame_count, const blok_denoise_settings* settings, float* out_color_dev, void* hip_stream) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    if (!planes) return set_error(ctx, BLOK_ERR_INVALID_ARG, "denoise: null planes");
+    blok::TemporalArgs t{};
+    t.color = planes->color; t.world_pos = planes->world_pos; t.normal_roughness = planes->normal_roughness; t.motion_in = motion_dev;
+    return denoise_frame(ctx, t, prev_view_proj, frame_count, settings, out_color_dev, hip_stream);
+}
+
+int blok_hip_denoise_ref_device(blok_hip_ctx* ctx, const blok_gbuffer_ref* planes, const float prev_view_proj[16],
+                                uint32_t frame_count, const blok_denoise_settings* settings, float* out_color_dev, void* hip_stream) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    if (!planes) return set_error(ctx, BLOK_ERR_INVALID_ARG, "denoise: null planes");
+    blok::TemporalArgs t{};
+    t.color = planes->color; t.world_pos = planes->world_pos; t.normal_roughness_h = planes->normal_roughness; t.motion_in_h = planes->motion;
+    return denoise_frame(ctx, t, prev_view_proj, frame_count, settings, out_color_dev, hip_stream);
 }
 
 int blok_hip_denoise_state(blok_hip_ctx* ctx, float* history_color, float* moments, float* history_length, float* variance, float* motion) {
@@ -201,7 +220,11 @@ int blok_hip_draw_frame_rt(blok_hip_ctx* ctx, const blok_camera* cam, uint32_t s
     auto& P = ctx->post;
     const size_t n = P.pixels;
     if (!P.rt_final) {
-        for (int k = 0; k < 4 && rc == BLOK_OK; ++k) rc = post_alloc(ctx, &P.rt_planes[k], 4 * n);
+        // the frame's G-buffer in the reference's image formats (raygen.rgen:55-59): 2 x RGBA32F, RGBA16F, RGBA8, RG16F = 48 B/pixel
+        for (int k = 0; k < 2 && rc == BLOK_OK; ++k) rc = post_alloc(ctx, &P.rt_planes[k], 4 * n);
+        if (rc == BLOK_OK) rc = post_alloc(ctx, &P.rt_normal_roughness_h, 4 * n);
+        if (rc == BLOK_OK) rc = post_alloc(ctx, &P.rt_albedo_metallic_u8, n);
+        if (rc == BLOK_OK) rc = post_alloc(ctx, &P.rt_motion_h, 2 * n);
         if (rc == BLOK_OK) rc = post_alloc(ctx, &P.rt_denoised, 4 * n);
         if (rc == BLOK_OK) rc = post_alloc(ctx, &P.rt_resolved, 4 * n);
         if (rc == BLOK_OK) rc = post_alloc(ctx, &P.rt_ldr, n);
@@ -212,15 +235,15 @@ int blok_hip_draw_frame_rt(blok_hip_ctx* ctx, const blok_camera* cam, uint32_t s
     const uint32_t frame = P.rt_frame;
     float prev_vp[16];
     view_proj_of(frame ? P.rt_prev_cam : *cam, prev_vp);            // Denoiser::updatePreviousFrameData: last frame's matrices
-    const blok_gbuffer planes{P.rt_planes[0], P.rt_planes[1], P.rt_planes[2], P.rt_planes[3]};
+    const blok_gbuffer_ref planes{P.rt_planes[0], P.rt_planes[1], P.rt_normal_roughness_h, P.rt_albedo_metallic_u8, P.rt_motion_h};
     // the frame's projection carries jitterSequence[frame mod 16] (renderer_draw.cpp:64-81; the index advances once per frame,
     // renderer_postprocess.cpp:660-663); prevViewProj above stays un-jittered, as Denoiser::updatePreviousFrameData is fed
     // (renderer_draw.cpp:313-328 passes the base matrices)
     const float saved_jitter[2] = {ctx->jitter_px[0], ctx->jitter_px[1]};
     if (ctx->rt_taa_jitter) blok::taa_jitter_px(frame, ctx->jitter_px);
-    rc = blok_hip_trace_paths_device(ctx, cam, 0, 0, ctx->width, ctx->height, spp, max_bounces, frame, &planes, nullptr);
+    rc = blok_hip_trace_paths_ref_device(ctx, cam, 0, 0, ctx->width, ctx->height, spp, max_bounces, frame, prev_vp, &planes, nullptr);
     ctx->jitter_px[0] = saved_jitter[0]; ctx->jitter_px[1] = saved_jitter[1];
-    if (rc == BLOK_OK) rc = blok_hip_denoise_device(ctx, &planes, nullptr, prev_vp, frame, settings, P.rt_denoised, nullptr);
+    if (rc == BLOK_OK) rc = blok_hip_denoise_ref_device(ctx, &planes, prev_vp, frame, settings, P.rt_denoised, nullptr);
     if (rc == BLOK_OK) rc = blok_hip_taa_device(ctx, P.rt_denoised, nullptr, 0.93f, 0.98f, frame, P.rt_resolved, nullptr);       // renderer_postprocess.hpp:104-106
     if (rc == BLOK_OK) rc = blok_hip_tonemap_device(ctx, P.rt_resolved, static_cast<uint32_t>(n), 1.0f, 1.15f, 1, P.rt_ldr, nullptr);   // :110-113
     if (rc == BLOK_OK) rc = blok_hip_sharpen_device(ctx, P.rt_ldr, 0.5f, P.rt_final, nullptr);                                     // :117-118

@@ -17,6 +17,7 @@
 #define BLOK_PATH_CORE_H
 
 #include "trace_core.h"
+#include "half_bits.h"
 
 #if defined(__clang__)
 #pragma clang fp contract(off)
@@ -38,6 +39,13 @@ struct PathArgs {
     float sun_u0, sun_v0, sun_inv_texel;
     uint32_t sun_nu, sun_nv;
     uint32_t batch_kinds;            // 1: the wave walks one kind of ray at a time (see shade_pixel)
+    // The same G-buffer in the reference's own image formats (raygen.rgen:55-59; renderer_denoising.cpp:110-170), each optional:
+    // normal + roughness RGBA16F, albedo + metallic RGBA8 (unorm), motion vectors RG16F (raygen.rgen:150-155, 409-413; needs
+    // prev_view_proj = FrameUBO::prevViewProj, column-major).  48 B/pixel with the two float4 planes instead of 64.
+    uint16_t* normal_roughness_h;
+    uint32_t* albedo_metallic_u8;
+    uint16_t* motion_h;
+    float prev_view_proj[16];
 };
 
 struct V3 { float x, y, z; };
@@ -127,6 +135,31 @@ BLOK_DEV void store4(float* plane, size_t i, float a, float b, float c, float d)
     p[0] = a; p[1] = b; p[2] = c; p[3] = d;
 }
 
+BLOK_DEV uint32_t unorm8(float v);
+// The narrow planes of one pixel: RGBA16F normal + roughness, RGBA8 albedo + metallic (imageStore conversions: round to nearest
+// even binary16; clamp, scale, round for unorm8), RG16F motion = currentUV - prevUV (computeMotionVector, raygen.rgen:150-155) or
+// 0 for the sky (:409-412).
+BLOK_DEV void store_narrow(const PathArgs& P, size_t index, uint32_t px, uint32_t py, V3 pos, float depth, bool had_hit, V3 normal, float roughness,
+                           V3 albedo, float metallic) {
+    if (P.normal_roughness_h) {
+        uint16_t* o = P.normal_roughness_h + 4 * index;
+        o[0] = f2h(normal.x); o[1] = f2h(normal.y); o[2] = f2h(normal.z); o[3] = f2h(roughness);
+    }
+    if (P.albedo_metallic_u8) P.albedo_metallic_u8[index] = unorm8(albedo.x) | (unorm8(albedo.y) << 8) | (unorm8(albedo.z) << 16) | (unorm8(metallic) << 24);
+    if (P.motion_h) {
+        float mu = 0.0f, mv = 0.0f;
+        if (had_hit && depth < 9999.0f) {
+            const float* M = P.prev_view_proj;
+            const float cx = ((M[0] * pos.x + M[4] * pos.y) + M[8] * pos.z) + M[12];
+            const float cy = ((M[1] * pos.x + M[5] * pos.y) + M[9] * pos.z) + M[13];
+            const float cw = ((M[3] * pos.x + M[7] * pos.y) + M[11] * pos.z) + M[15];
+            const float cu = (static_cast<float>(px) + 0.5f) / static_cast<float>(P.trace.frame_w), cv = (static_cast<float>(py) + 0.5f) / static_cast<float>(P.trace.frame_h);
+            mu = cu - ((cx / cw) * 0.5f + 0.5f); mv = cv - ((cy / cw) * 0.5f + 0.5f);
+        }
+        P.motion_h[2 * index] = f2h(mu); P.motion_h[2 * index + 1] = f2h(mv);
+    }
+}
+
 // raygen.rgen:167-414 for pixel (px, py) of the full frame; `index` is its slot in the output planes.
 //
 // The shader's nested loops (samples x bounces, each bounce a radiance trace and possibly a shadow trace) are
@@ -153,6 +186,7 @@ BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t in
         store4(P.world_pos, index, sky_pos.x, sky_pos.y, sky_pos.z, 10000.0f);
         store4(P.normal_roughness, index, 0.0f, 1.0f, 0.0f, 0.0f);
         store4(P.albedo_metallic, index, sky_albedo.x, sky_albedo.y, sky_albedo.z, 0.0f);
+        store_narrow(P, index, px, py, sky_pos, 10000.0f, false, v3(0.0f, 1.0f, 0.0f), 0.0f, sky_albedo, 0.0f);
     }
     V3 accumulated = v3(0, 0, 0);
     const V3 sun_dir = sun_direction();
@@ -271,6 +305,7 @@ BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t in
                 store4(P.world_pos, index, hit_pos.x, hit_pos.y, hit_pos.z, hit.t);
                 store4(P.normal_roughness, index, n.x, n.y, n.z, roughness);
                 store4(P.albedo_metallic, index, final_albedo.x, final_albedo.y, final_albedo.z, metallic);
+                store_narrow(P, index, px, py, hit_pos, hit.t, true, n, roughness, final_albedo, metallic);
             }
             if (is_emissive(emission)) {                                                      // :265-277
                 radiance = vadd(radiance, vmul(throughput, emission));

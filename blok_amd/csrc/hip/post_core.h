@@ -34,37 +34,6 @@
 
 namespace blok {
 
-// ---- binary16 <-> binary32 (round to nearest even), bit patterns in uint16_t
-#ifdef BLOK_TRACE_HOST_HARNESS
-inline uint16_t f2h(float f) {
-    uint32_t x = __float_as_uint(f);
-    const uint16_t sign = static_cast<uint16_t>((x >> 16) & 0x8000u);
-    x &= 0x7FFFFFFFu;
-    if (x >= 0x7F800000u) return sign | (x > 0x7F800000u ? 0x7E00u : 0x7C00u);
-    if (x >= 0x477FF000u) return sign | 0x7C00u;
-    if (x < 0x33000001u) return sign;
-    const int e = static_cast<int>(x >> 23) - 127;
-    const uint32_t m = (x & 0x007FFFFFu) | 0x00800000u;
-    const int drop = e < -14 ? 13 + (-14 - e) : 13;
-    uint32_t r = m >> drop;
-    const uint32_t rem = m & ((1u << drop) - 1u), half = 1u << (drop - 1);
-    if (rem > half || (rem == half && (r & 1u))) ++r;
-    // r counts units of 2^(e-23+drop); normal halves: exponent field = e + 15 with the leading one of r at bit 10
-    if (e < -14) return sign | static_cast<uint16_t>(r);                        // subnormal (or rounds up into the first normal)
-    return sign | static_cast<uint16_t>((static_cast<uint32_t>(e + 15) << 10) + (r - 0x400u));   // mantissa carry bumps the exponent
-}
-inline float h2f(uint16_t h) {
-    const uint32_t sign = static_cast<uint32_t>(h & 0x8000u) << 16;
-    const uint32_t e = (h >> 10) & 31u, m = h & 0x3FFu;
-    if (e == 31u) return __uint_as_float(sign | 0x7F800000u | (m << 13));
-    if (e == 0u) { const float v = static_cast<float>(m) * 5.9604644775390625e-8f; return sign ? -v : v; }      // m * 2^-24
-    return __uint_as_float(sign | ((e + 112u) << 23) | (m << 13));
-}
-#else
-__device__ __forceinline__ uint16_t f2h(float f) { return __half_as_ushort(__float2half_rn(f)); }
-__device__ __forceinline__ float h2f(uint16_t h) { return __half2float(__ushort_as_half(h)); }
-#endif
-BLOK_DEV float q16(float f) { return h2f(f2h(f)); }
 
 struct DenoiseSettings {           // = blok_denoise_settings (include/blok_hip.h), Denoiser::Settings renderer_denoising.hpp:49-66
     float temporal_alpha, moment_alpha, variance_clip_gamma, depth_threshold, normal_threshold, phi_color, phi_normal, phi_depth;
@@ -122,12 +91,29 @@ struct TemporalArgs {
     PostFrame f;
     const float *color, *world_pos, *normal_roughness;      // this frame, float4 planes from the path kernel
     const float* motion_in;                                 // float2 per pixel or null (then computed from world_pos)
+    // alternatives in the reference's image formats (path kernel: PathArgs::normal_roughness_h / motion_h): RGBA16F instead of
+    // normal_roughness, RG16F instead of motion_in.  Same values: the float4 plane is narrowed to binary16 on read below.
+    const uint16_t* normal_roughness_h;
+    const uint16_t* motion_in_h;
     const float *prev_color, *prev_moments, *prev_world_pos; // history of the previous frame
     const uint16_t* prev_hist_len;                          // half
     const float* prev_unit_normals;                         // float4: normalize(binary16 normal) of the previous frame
     float *out_color, *out_moments, *hist_world_pos, *unit_normals;   // history of this frame
     uint16_t *out_hist_len, *motion;                        // half, half2
 };
+
+// normal + roughness of pixel i as the rgba16f image holds them
+BLOK_DEV F4 load_nr16(const TemporalArgs& T, size_t i) {
+    F4 r;
+    if (T.normal_roughness_h) {
+        const uint16_t* p = T.normal_roughness_h + 4 * i;
+        r.x = h2f(p[0]); r.y = h2f(p[1]); r.z = h2f(p[2]); r.w = h2f(p[3]);
+    } else {
+        const F4 f = load4(T.normal_roughness, i);
+        r.x = q16(f.x); r.y = q16(f.y); r.z = q16(f.z); r.w = q16(f.w);
+    }
+    return r;
+}
 
 BLOK_DEV void temporal_pixel(const TemporalArgs& T, int cx, int cy) {
     const int w = static_cast<int>(T.f.w), h = static_cast<int>(T.f.h);
@@ -139,14 +125,15 @@ BLOK_DEV void temporal_pixel(const TemporalArgs& T, int cx, int cy) {
     const float cu = (static_cast<float>(cx) + 0.5f) / static_cast<float>(w), cv = (static_cast<float>(cy) + 0.5f) / static_cast<float>(h);
 
     // geometry of this frame into the history slot; the unit normal of the binary16-narrowed normal, once for all passes
-    const F4 nr = load4(T.normal_roughness, i);
-    const V3 normal = vnormalize(v3(q16(nr.x), q16(nr.y), q16(nr.z)));
-    store4(T.unit_normals, i, normal, q16(nr.w));
+    const F4 nr = load_nr16(T, i);
+    const V3 normal = vnormalize(v3(nr.x, nr.y, nr.z));
+    store4(T.unit_normals, i, normal, nr.w);
     store4(T.hist_world_pos, i, world, depth);
 
     // motion vector (raygen.rgen:409-413), held as half2
     float mu = 0.0f, mv = 0.0f;
-    if (T.motion_in) { mu = T.motion_in[2 * i]; mv = T.motion_in[2 * i + 1]; }
+    if (T.motion_in_h) { mu = h2f(T.motion_in_h[2 * i]); mv = h2f(T.motion_in_h[2 * i + 1]); }
+    else if (T.motion_in) { mu = T.motion_in[2 * i]; mv = T.motion_in[2 * i + 1]; }
     else if (depth < 9999.0f) { float pu, pv; project_prev(T.f.prev_view_proj, world, pu, pv); mu = cu - pu; mv = cv - pv; }
     const uint16_t hu = f2h(mu), hv = f2h(mv);
     T.motion[2 * i] = hu; T.motion[2 * i + 1] = hv;
@@ -179,7 +166,7 @@ BLOK_DEV void temporal_pixel(const TemporalArgs& T, int cx, int cy) {
             for (int k = 0; k < 9; ++k) {
                 const size_t s = static_cast<size_t>(clampi(cy + k / 3 - 1, 0, h - 1)) * w + clampi(cx + k % 3 - 1, 0, w - 1);
                 tap_depth[k] = T.world_pos[4 * s + 3];
-                tap_normal[k] = load3(T.normal_roughness, s);
+                { const F4 tn = load_nr16(T, s); tap_normal[k] = v3(tn.x, tn.y, tn.z); }
                 tap_color[k] = load3(T.color, s);
             }
             V3 s1 = vsplat(0.0f), s2 = vsplat(0.0f), lo = vsplat(1e10f), hi = vsplat(-1e10f);
@@ -189,7 +176,7 @@ BLOK_DEV void temporal_pixel(const TemporalArgs& T, int cx, int cy) {
 #endif
             for (int k = 0; k < 9; ++k) {
                 const float dd = fabsf(depth - tap_depth[k]);
-                const float nd = vdot(normal, v3(q16(tap_normal[k].x), q16(tap_normal[k].y), q16(tap_normal[k].z)));
+                const float nd = vdot(normal, tap_normal[k]);
                 const float wgt = (dd < (depth * 0.02f + 0.1f) ? 1.0f : 0.0f) * (nd > 0.9f ? 1.0f : 0.0f);
                 if (wgt > 0.0f) {
                     const V3 c = to_ycocg(tap_color[k]);

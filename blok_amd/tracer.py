@@ -295,6 +295,25 @@ class HipTracer:
         self._check(self._lib.blok_hip_trace_paths_device(self._ctx, _ffi.ptr(cam), x0, y0, w, h, spp, max_bounces,
                                                           frame_index, C.byref(g), C.c_void_p(stream)))
 
+    def trace_paths_ref_device(self, cam: np.ndarray, color_ptr: int = 0, world_pos_ptr: int = 0, normal_roughness_h_ptr: int = 0,
+                               albedo_metallic_u8_ptr: int = 0, motion_h_ptr: int = 0, prev_view_proj=None, spp: int = 8,
+                               max_bounces: int = 2, frame_index: int = 0, rect=None, stream: int = 0):
+        """Path-traced frame with the G-buffer in the reference's image formats (RGBA32F x 2, RGBA16F, RGBA8, RG16F motion)."""
+        x0, y0, w, h = rect if rect is not None else (0, 0, self.width, self.height)
+        cam = np.ascontiguousarray(cam, dtype=CAMERA)
+        g = _ffi.GBufferRef(color_ptr, world_pos_ptr, normal_roughness_h_ptr, albedo_metallic_u8_ptr, motion_h_ptr)
+        m = None if prev_view_proj is None else (C.c_float * 16)(*[float(v) for v in np.asarray(prev_view_proj, dtype=np.float32).reshape(-1)])
+        self._check(self._lib.blok_hip_trace_paths_ref_device(self._ctx, _ffi.ptr(cam), x0, y0, w, h, spp, max_bounces, frame_index,
+                                                              m, C.byref(g), C.c_void_p(stream)))
+
+    def denoise_ref_device(self, color_ptr: int, world_pos_ptr: int, normal_roughness_h_ptr: int, motion_h_ptr: int, prev_view_proj,
+                           frame_count: int, out_color_ptr: int, settings=None, stream: int = 0):
+        """Denoiser::denoise for one frame over reference-format planes (as trace_paths_ref_device writes them)."""
+        planes = _ffi.GBufferRef(color_ptr, world_pos_ptr, normal_roughness_h_ptr, 0, motion_h_ptr)
+        m = (C.c_float * 16)(*[float(v) for v in np.asarray(prev_view_proj, dtype=np.float32).reshape(-1)])
+        self._check(self._lib.blok_hip_denoise_ref_device(self._ctx, C.byref(planes), m, int(frame_count),
+                                                          C.byref(settings) if settings is not None else None, out_color_ptr, stream or None))
+
     def draw_frame_accumulate(self, cam: np.ndarray, spp_per_frame: int = 1, max_bounces: int = 2):
         """Progressive frame of the compute backend (CudaTracer::drawFrame): returns (RGBA8 (h, w) uint32, frames accumulated)."""
         cam = np.ascontiguousarray(cam, dtype=CAMERA)

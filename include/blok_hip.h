@@ -240,6 +240,23 @@ int blok_hip_trace_paths_device(blok_hip_ctx* ctx, const blok_camera* cam,
                                 uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
                                 uint32_t spp, uint32_t max_bounces, uint32_t frame_index,
                                 const blok_gbuffer* planes_dev, void* hip_stream);
+/* The same frame with the G-buffer in the reference's own image formats (raygen.rgen:55-59; created at
+ * blok/src/renderer_denoising.cpp:110-170): colour RGBA32F, world position + depth RGBA32F, normal + roughness RGBA16F, albedo +
+ * metallic RGBA8 (unorm), motion vectors RG16F written by the path kernel itself (computeMotionVector, raygen.rgen:150-155,
+ * 409-413, from prev_view_proj = FrameUBO::prevViewProj, column-major; 0 on the sky).  48 B/pixel instead of 64.  Any plane may
+ * be NULL; a motion plane needs prev_view_proj.  Conversions as the image stores do them: binary16 round to nearest even, unorm8
+ * = floor(clamp(x, 0, 1) * 255 + 0.5).  blok_hip_denoise_ref_device takes these planes; blok_hip_draw_frame_rt uses them. */
+typedef struct blok_gbuffer_ref {
+    float*    color;             /* RGBA32F */
+    float*    world_pos;         /* RGBA32F: xyz, depth */
+    uint16_t* normal_roughness;  /* RGBA16F */
+    uint32_t* albedo_metallic;   /* RGBA8: r | g << 8 | b << 16 | metallic << 24 */
+    uint16_t* motion;            /* RG16F */
+} blok_gbuffer_ref;
+int blok_hip_trace_paths_ref_device(blok_hip_ctx* ctx, const blok_camera* cam,
+                                    uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
+                                    uint32_t spp, uint32_t max_bounces, uint32_t frame_index,
+                                    const float prev_view_proj[16], const blok_gbuffer_ref* planes_dev, void* hip_stream);
 /* Blocking form with host planes. */
 int blok_hip_trace_paths(blok_hip_ctx* ctx, const blok_camera* cam,
                          uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
@@ -304,6 +321,9 @@ void blok_denoise_settings_default(blok_denoise_settings* out);
 int blok_hip_denoise_device(blok_hip_ctx* ctx, const blok_gbuffer* planes_dev, const float* motion_dev,
                             const float prev_view_proj[16], uint32_t frame_count, const blok_denoise_settings* settings,
                             float* out_color_dev, void* hip_stream);
+/* The same for planes in the reference's image formats (blok_gbuffer_ref; motion NULL = computed from world_pos). */
+int blok_hip_denoise_ref_device(blok_hip_ctx* ctx, const blok_gbuffer_ref* planes_dev, const float prev_view_proj[16],
+                                uint32_t frame_count, const blok_denoise_settings* settings, float* out_color_dev, void* hip_stream);
 /* Host copies of the denoiser's state after the last blok_hip_denoise_device (blocking; NULL pointers are skipped):
  * history colour float4, moments float2, history length float, variance float, motion vectors float2 (per pixel). */
 int blok_hip_denoise_state(blok_hip_ctx* ctx, float* history_color, float* moments, float* history_length,

@@ -312,6 +312,60 @@ def test_draw_frame_rt_is_the_composition_of_the_passes(gbuffer_frames):
 
 
 @pytest.mark.gpu
+def test_reference_format_gbuffer_planes(gbuffer_frames):
+    """blok_hip_trace_paths_ref_device: the G-buffer in the reference's image formats (A15: RGBA16F normal + roughness, RGBA8
+    albedo + metallic, RG16F motion written by the path kernel, raygen.rgen:55-59,392-413) holds exactly the oracle's float
+    planes narrowed the way the image stores narrow them, the motion vectors of computeMotionVector (raygen.rgen:150-155) for a
+    moved previous camera, and the denoiser fed with them gives the frame it gives for the float4 planes, bit for bit."""
+    import torch
+    from blok_amd.tracer import HipTracer
+    _, pw, mats, cams = gbuffer_frames
+    n = Wd * Ht
+    tr, tf = HipTracer(Wd, Ht).init(), HipTracer(Wd, Ht).init()
+    tr.add_world(pw); tf.add_world(pw)
+    lat = O.Lattice(pw.nodes, pw.sub_chunks)
+    col = torch.zeros((n, 4), dtype=torch.float32, device="cuda"); pos = torch.zeros_like(col)
+    nr_h = torch.zeros((n, 4), dtype=torch.int16, device="cuda"); am = torch.zeros(n, dtype=torch.int32, device="cuda")
+    mo_h = torch.zeros((n, 2), dtype=torch.int16, device="cuda")
+    F = {k: torch.zeros((n, 4), dtype=torch.float32, device="cuda") for k in ("color", "world_pos", "normal_roughness", "albedo_metallic")}
+    out_r = torch.zeros((n, 4), dtype=torch.float32, device="cuda"); out_f = torch.zeros_like(out_r)
+    for k in range(3):
+        cam, prev = cams[k + 1], cams[k]
+        vp = tr.camera_view_proj(prev)
+        tr.trace_paths_ref_device(cam, col.data_ptr(), pos.data_ptr(), nr_h.data_ptr(), am.data_ptr(), mo_h.data_ptr(), prev_view_proj=vp,
+                                  spp=2, max_bounces=2, frame_index=k)
+        torch.cuda.synchronize()
+        want, _ = O.render_paths(lat, mats, cam, Wd, Ht, spp=2, max_bounces=2, frame_index=k, threads=8)
+        assert np.array_equal(pos.cpu().numpy().reshape(Ht, Wd, 4), want["world_pos"])
+        assert np.array_equal(nr_h.cpu().numpy().view(np.uint16).reshape(Ht, Wd, 4), want["normal_roughness"].astype(np.float16).view(np.uint16))
+        a = np.floor(np.clip(want["albedo_metallic"], 0.0, 1.0).astype(np.float32) * np.float32(255.0) + np.float32(0.5)).astype(np.uint32)
+        packed = a[..., 0] | (a[..., 1] << 8) | (a[..., 2] << 16) | (a[..., 3] << 24)
+        assert np.array_equal(am.cpu().numpy().view(np.uint32).reshape(Ht, Wd), packed)
+        # computeMotionVector in binary32, one rounded operation at a time
+        M = np.asarray(vp, dtype=np.float32)
+        p = want["world_pos"]
+        x, y, z, depth = (p[..., i].astype(np.float32) for i in range(4))
+        cx = ((M[0] * x + M[4] * y) + M[8] * z) + M[12]; cy = ((M[1] * x + M[5] * y) + M[9] * z) + M[13]; cw = ((M[3] * x + M[7] * y) + M[11] * z) + M[15]
+        yy, xx = np.mgrid[0:Ht, 0:Wd]
+        cu = (xx.astype(np.float32) + np.float32(0.5)) / np.float32(Wd); cv = (yy.astype(np.float32) + np.float32(0.5)) / np.float32(Ht)
+        with np.errstate(all="ignore"):
+            mu = cu - ((cx / cw) * np.float32(0.5) + np.float32(0.5)); mv = cv - ((cy / cw) * np.float32(0.5) + np.float32(0.5))
+        sky = ~(depth < np.float32(9999.0))
+        mu[sky] = 0; mv[sky] = 0
+        got_m = mo_h.cpu().numpy().view(np.uint16).reshape(Ht, Wd, 2)
+        assert np.array_equal(got_m[..., 0], mu.astype(np.float16).view(np.uint16)) and np.array_equal(got_m[..., 1], mv.astype(np.float16).view(np.uint16))
+        assert (got_m[~sky] != 0).any()
+        # the denoiser over these planes == the denoiser over the float4 planes
+        tf.trace_paths_device(cam, F["color"].data_ptr(), spp=2, max_bounces=2, frame_index=k, world_pos_ptr=F["world_pos"].data_ptr(),
+                              normal_roughness_ptr=F["normal_roughness"].data_ptr(), albedo_metallic_ptr=F["albedo_metallic"].data_ptr())
+        tr.denoise_ref_device(col.data_ptr(), pos.data_ptr(), nr_h.data_ptr(), mo_h.data_ptr(), vp, k, out_r.data_ptr())
+        tf.denoise_device(F["color"].data_ptr(), F["world_pos"].data_ptr(), F["normal_roughness"].data_ptr(), vp, k, out_f.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(col, F["color"]) and torch.equal(out_r, out_f), k
+    tr.shutdown(); tf.shutdown()
+
+
+@pytest.mark.gpu
 def test_taa_jitter_on_the_gpu_matches_the_oracle():
     """A8 on the device: first-hit frames and path-traced G-buffers with the frame's Halton jitter equal the oracle's with
     the same jitter (first hits bit for bit, G-buffer planes exactly, colour within the stated tolerance), for frames 0-3 and
