@@ -171,6 +171,17 @@ HIP_SYMBOLS = {
     "blok_hip_reset_accum": (C.c_int, [C.c_void_p]),
     "blok_hip_set_beam": (C.c_int, [C.c_void_p, C.c_uint32]),
     "blok_hip_set_fused": (C.c_int, [C.c_void_p, C.c_int]),
+    "blok_hip_multi_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]),
+    "blok_hip_multi_destroy": (None, [C.c_void_p]),
+    "blok_hip_multi_last_error": (C.c_char_p, [C.c_void_p]),
+    "blok_hip_multi_device_count": (C.c_uint32, [C.c_void_p]),
+    "blok_hip_multi_transport": (C.c_char_p, [C.c_void_p]),
+    "blok_hip_multi_context": (C.c_void_p, [C.c_void_p, C.c_uint32]),
+    "blok_hip_multi_upload_world": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
+    "blok_hip_multi_draw_frame_device": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "blok_hip_multi_synchronize": (C.c_int, [C.c_void_p]),
+    "blok_hip_multi_draw_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "blok_hip_multi_download_hits": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]),
     "blok_hip_set_beam_budget": (C.c_int, [C.c_void_p, C.c_uint32]),
     "blok_hip_set_taa_jitter": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "blok_hip_set_rt_taa_jitter": (C.c_int, [C.c_void_p, C.c_int]),

@@ -31,6 +31,68 @@ import contextlib
 from typing import List
 
 
+class HipMultiTracer:
+    """Several devices, ONE process: mirror of blok::HipMultiTracer (include/blok/hip_tracer.hpp) over blok_hip_multi_*
+    (include/blok_hip.h) — the C++20 host's way to drive the tile partition; the one-process-per-GPU FramePipeline below is what
+    bench.py runs under torch.distributed.  `devices` may repeat an ordinal (ranks rehearsed on one GPU, peer-copy transport)."""
+
+    def __init__(self, devices, width: int, height: int, tile: int = 32, allow_rccl: bool = True):
+        import ctypes as C
+        from . import _ffi
+        self._C, self._ffi, self._lib = C, _ffi, _ffi.hip_lib()
+        self.width, self.height, self.tile, self.n = width, height, tile, len(devices)
+        self._m = C.c_void_p()
+        arr = (C.c_int * len(devices))(*devices)
+        rc = self._lib.blok_hip_multi_create(C.byref(self._m), arr, len(devices), width, height, tile, 1 if allow_rccl else 0)
+        if rc != 0:
+            raise _ffi.BlokError(rc, (self._lib.blok_hip_multi_last_error(None) or b"").decode())
+
+    def _check(self, rc):
+        if rc != 0:
+            raise self._ffi.BlokError(rc, (self._lib.blok_hip_multi_last_error(self._m) or b"").decode())
+
+    @property
+    def transport(self) -> str:
+        return (self._lib.blok_hip_multi_transport(self._m) or b"").decode()
+
+    def add_world(self, packed):
+        import numpy as np
+        nodes, subs, mats = (np.ascontiguousarray(a) for a in (packed.nodes, packed.sub_chunks, packed.materials))
+        self._check(self._lib.blok_hip_multi_upload_world(self._m, self._ffi.ptr(nodes), len(nodes), self._ffi.ptr(subs), len(subs),
+                                                          self._ffi.ptr(mats), len(mats)))
+
+    def set_beam(self, beam_tile_pixels: int):
+        for r in range(self.n):
+            rc = self._lib.blok_hip_set_beam(self._C.c_void_p(self._lib.blok_hip_multi_context(self._m, r)), beam_tile_pixels)
+            if rc != 0:
+                raise self._ffi.BlokError(rc, "blok_hip_set_beam")
+
+    def draw_frame(self, cam):
+        import numpy as np
+        cam = np.ascontiguousarray(cam, dtype=self._ffi.CAMERA)
+        out = np.zeros((self.height, self.width), dtype=np.uint32)
+        self._check(self._lib.blok_hip_multi_draw_frame(self._m, self._ffi.ptr(cam), self._ffi.ptr(out)))
+        return out
+
+    def rank_hits(self, rank: int):
+        import numpy as np
+        n = int(self._lib.blok_hip_tiles_for_rank(self.width, self.height, self.tile, rank, self.n)) * self.tile * self.tile
+        out = np.zeros(n, dtype=self._ffi.HIT)
+        self._check(self._lib.blok_hip_multi_download_hits(self._m, rank, self._ffi.ptr(out), n))
+        return out
+
+    def shutdown(self):
+        if self._m:
+            self._lib.blok_hip_multi_destroy(self._m)
+            self._m = None
+
+    def __del__(self):
+        try:
+            self.shutdown()
+        except Exception:
+            pass
+
+
 class HipBackend:
     """Adapter from torch tensors to the C-ABI entry points of a HipTracer."""
 

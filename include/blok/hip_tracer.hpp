@@ -267,5 +267,49 @@ private:
     std::vector<uint32_t> m_pixels;
 };
 
+// Several devices of one node, one process (blok_hip_multi_*, blok_hip.h): the frame is cut into tile x tile screen tiles dealt
+// round-robin to the devices, the world is replicated, the RGBA8 tiles are gathered on the first device over xGMI (RCCL
+// send / receive group, or peer copies) and un-permuted there.  No reference counterpart: blok is single-GPU.
+class HipMultiTracer {
+public:
+    HipMultiTracer(const std::vector<int>& devices, unsigned width, unsigned height, unsigned tile = 32, bool allowRccl = true)
+        : m_width(width), m_height(height) {
+        if (blok_hip_multi_create(&m_multi, devices.data(), static_cast<uint32_t>(devices.size()), width, height, tile, allowRccl ? 1 : 0) != BLOK_OK)
+            throw std::runtime_error(std::string("HipMultiTracer: ") + blok_hip_multi_last_error(nullptr));
+    }
+    ~HipMultiTracer() { shutdown(); }
+    HipMultiTracer(const HipMultiTracer&) = delete;
+    HipMultiTracer& operator=(const HipMultiTracer&) = delete;
+
+    void shutdown() { if (m_multi) { blok_hip_multi_destroy(m_multi); m_multi = nullptr; } }
+    unsigned deviceCount() const { return blok_hip_multi_device_count(m_multi); }
+    std::string transport() const { return blok_hip_multi_transport(m_multi); }
+    blok_hip_ctx* context(unsigned rank) { return blok_hip_multi_context(m_multi, rank); }
+
+    void addWorld(const WorldSvoGpu& w) {                       // = Renderer::addWorld on every device
+        check(blok_hip_multi_upload_world(m_multi, w.globalNodes.data(), w.globalNodes.size(), w.globalSubChunks.data(), w.globalSubChunks.size(),
+                                          w.materials.data(), w.materials.size()));
+    }
+    // One frame: RGBA8, row-major, width x height, on the host.
+    void drawFrame(const Camera& c, std::vector<uint32_t>& rgba8) {
+        rgba8.resize(static_cast<size_t>(m_width) * m_height);
+        const blok_camera basis = c.basis(m_width, m_height);
+        check(blok_hip_multi_draw_frame(m_multi, &basis, rgba8.data()));
+    }
+    // Asynchronous form: the frame stays on the root device.
+    const uint32_t* drawFrameDevice(const Camera& c) {
+        const blok_camera basis = c.basis(m_width, m_height);
+        const uint32_t* frame = nullptr;
+        check(blok_hip_multi_draw_frame_device(m_multi, &basis, &frame));
+        return frame;
+    }
+    void synchronize() { check(blok_hip_multi_synchronize(m_multi)); }
+
+private:
+    void check(int rc) const { if (rc != BLOK_OK) throw std::runtime_error(std::string("HipMultiTracer: ") + blok_hip_multi_last_error(m_multi)); }
+    blok_hip_multi* m_multi = nullptr;
+    unsigned m_width, m_height;
+};
+
 }  // namespace blok
 #endif

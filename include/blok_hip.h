@@ -419,6 +419,36 @@ int blok_hip_set_timing(blok_hip_ctx* ctx, int enabled);
 /* Library/ABI version: (major<<16)|minor. */
 uint32_t blok_hip_abi_version(void);
 
+/* ------------------------------------------------------------- several devices, one process
+ * The tile partition of the frame over the GPUs of one node driven from one host thread (no reference
+ * counterpart — blok is single-GPU): one context and one stream per device in `device_ordinals` (the first is the root), the
+ * world replicated on each, every device traces tiles rank, rank + G, ... of the tile x tile grid, the RGBA8 tiles are gathered
+ * on the root and un-permuted into the row-major frame; first-hit records stay on the device that traced them.
+ * Transport: RCCL when allow_rccl != 0, librccl is found at run time (dlopen; no link-time dependency) and the devices are
+ * distinct — one communicator per device (ncclCommInitAll), one ncclGroupStart/End per frame with every peer's ncclSend and the
+ * root's ncclRecvs, each on its device's stream; otherwise hipMemcpyPeerAsync from every peer into the root's buffer (also how
+ * a one-GPU box rehearses several ranks: the same ordinal may be listed more than once); one device: none.
+ * blok_hip_multi_transport() says which ("rccl", "peer-copy", "none").  The per-device contexts are ordinary contexts
+ * (blok_hip_multi_context) for settings such as blok_hip_set_beam. */
+typedef struct blok_hip_multi blok_hip_multi;
+int  blok_hip_multi_create(blok_hip_multi** out, const int* device_ordinals, uint32_t n_devices, uint32_t width, uint32_t height,
+                           uint32_t tile, int allow_rccl);
+void blok_hip_multi_destroy(blok_hip_multi* m);
+const char* blok_hip_multi_last_error(const blok_hip_multi* m);      /* NULL: the last failed create on this thread */
+uint32_t blok_hip_multi_device_count(const blok_hip_multi* m);
+const char* blok_hip_multi_transport(const blok_hip_multi* m);
+blok_hip_ctx* blok_hip_multi_context(blok_hip_multi* m, uint32_t rank);
+/* = Renderer::addWorld on every device (replicated). */
+int  blok_hip_multi_upload_world(blok_hip_multi* m, const blok_svo_node* nodes, size_t n_nodes, const blok_sub_chunk* sub_chunks,
+                                 size_t n_sub_chunks, const blok_material* materials, size_t n_materials);
+/* One frame, asynchronous: enqueues trace, exchange and un-permute; *out_rgba8_dev_on_root (may be NULL) = the root's
+ * width x height RGBA8 frame, valid after blok_hip_multi_synchronize.  blok_hip_multi_draw_frame = that + synchronise + copy. */
+int  blok_hip_multi_draw_frame_device(blok_hip_multi* m, const blok_camera* cam, const uint32_t** out_rgba8_dev_on_root);
+int  blok_hip_multi_synchronize(blok_hip_multi* m);
+int  blok_hip_multi_draw_frame(blok_hip_multi* m, const blok_camera* cam, uint32_t* out_rgba8_host);
+/* Rank `rank`'s first-hit records of the last synchronised frame, in its tile order (blok_hip_tiles_for_rank x tile^2). */
+int  blok_hip_multi_download_hits(blok_hip_multi* m, uint32_t rank, blok_hit* out_host, size_t capacity_records);
+
 #ifdef __cplusplus
 }
 #endif

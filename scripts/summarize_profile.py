@@ -34,7 +34,7 @@ for f in sorted(src.glob("pmc*/**/*counter_collection.csv")):
         pmc[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
 summary = {}
 for kernel, counters in pmc.items():
-    if "trace_kernel" not in kernel and "beam_kernel" not in kernel:
+    if not any(name in kernel for name in ("trace_kernel", "beam_kernel", "frame_kernel")):
         continue
     summary[kernel] = {c: {"mean": sum(v) / len(v), "n": len(v)} for c, v in counters.items()}
     d = durations.get(kernel)
@@ -43,14 +43,18 @@ for kernel, counters in pmc.items():
         summary[kernel]["launches"] = len(d)
 (dst / f"{tag}_pmc.json").write_text(json.dumps(summary, indent=1))
 print(json.dumps(summary, indent=1))
-for kernel, s in summary.items():
-    if "FETCH_SIZE" in s and "WRITE_SIZE" in s and ("RayModeE0" in kernel or "(blok::RayMode)0" in kernel):
-        # FETCH_SIZE / WRITE_SIZE are in KiB... rocprofv3 reports them in kilobytes (derived: *64/1024).
-        fetch_kb, write_kb = s["FETCH_SIZE"]["mean"], s["WRITE_SIZE"]["mean"]
-        out = {"kernel": kernel, "fetch_size_kb_raw": fetch_kb, "write_size_kb": write_kb,
-               "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM only for wide coalesced streams; this kernel's reads are "
-                       "16-B node gathers (uncalibrated width), so the raw value is reported as a lower bound and 2x as an upper bound",
-               "hbm_bytes_per_launch": (fetch_kb + write_kb) * 1024.0,
-               "hbm_bytes_per_launch_upper": (2 * fetch_kb + write_kb) * 1024.0}
-        (dst / "pmc_traffic.json").write_text(json.dumps(out, indent=1))
-        print(json.dumps(out, indent=1))
+# HBM traffic per FRAME: FETCH_SIZE + WRITE_SIZE of every kernel of the frame's launch sequence (beam_kernel + trace_kernel of the
+# Rect mode, or frame_kernel in the one-launch form), per launch.  rocprofv3 reports both in KiB.
+frame_kernels = {k: s for k, s in summary.items() if ("RayModeE0" in k or "(blok::RayMode)0" in k) and "FETCH_SIZE" in s and "WRITE_SIZE" in s}
+if frame_kernels:
+    fetch_kb = sum(s["FETCH_SIZE"]["mean"] for s in frame_kernels.values())
+    write_kb = sum(s["WRITE_SIZE"]["mean"] for s in frame_kernels.values())
+    out = {"kernels": {k: {"fetch_size_kb_raw": s["FETCH_SIZE"]["mean"], "write_size_kb": s["WRITE_SIZE"]["mean"],
+                           "duration_ns_mean": s.get("duration_ns_mean_unprofiled_pass")} for k, s in frame_kernels.items()},
+           "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM only for wide coalesced streams; these kernels' reads are "
+                   "16-B node gathers (uncalibrated width), so the raw value is reported as a lower bound and 2x as an upper bound",
+           "hbm_bytes_per_frame": (fetch_kb + write_kb) * 1024.0,
+           "hbm_bytes_per_frame_upper": (2 * fetch_kb + write_kb) * 1024.0,
+           "frame_kernel_ns_sum": sum(s.get("duration_ns_mean_unprofiled_pass", 0.0) for s in frame_kernels.values())}
+    (dst / "pmc_traffic.json").write_text(json.dumps(out, indent=1))
+    print(json.dumps(out, indent=1))

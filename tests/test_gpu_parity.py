@@ -546,6 +546,41 @@ def test_sparse_tile_exchange_kernels(tracer_cls, scene1024):
     tr.shutdown()
 
 
+def test_multi_device_entry_one_process(tracer_cls, scene1024):
+    """blok_hip_multi_* (C ABI; one process, one context and stream per rank): 1, 3 and 8 ranks on device 0 — transport "none" /
+    "peer-copy" — give the single-device RGBA8 frame, and each rank's first-hit records are its tiles of the single-device
+    records; creation with RCCL allowed but a repeated device falls back to peer copies; bad arguments are refused."""
+    from blok_amd.multi_gpu import HipMultiTracer
+    from blok_amd._ffi import BlokError
+    from blok_amd import tiles as T
+    cm, pw = scene1024
+    Wd, Ht = 1920, 1080
+    tr = tracer_cls(Wd, Ht).init()
+    tr.add_world(pw)
+    cam = W.scene_camera(1024, 0, Wd, Ht, SEED)
+    want = tr.shade_rgba8(cam)
+    hits = tr.draw_frame(cam)
+    for devices, tile, transport in (([0], 32, "none"), ([0, 0, 0], 64, "peer-copy"), ([0] * 8, 32, "peer-copy")):
+        mt = HipMultiTracer(devices, Wd, Ht, tile=tile, allow_rccl=True)
+        assert mt.transport == transport
+        mt.add_world(pw)
+        for _ in range(2):
+            assert (mt.draw_frame(cam) == want).all(), devices
+        n = len(devices)
+        for r in (0, n - 1):
+            got = mt.rank_hits(r)
+            for k, (x0, y0) in enumerate(T.rank_tile_origins(Wd, Ht, tile, r, n)):
+                h, w = min(tile, Ht - y0), min(tile, Wd - x0)
+                block = got[k * tile * tile:(k + 1) * tile * tile].reshape(tile, tile)[:h, :w]
+                assert records_equal(block.reshape(-1), hits[y0:y0 + h, x0:x0 + w].reshape(-1)).all(), (devices, r, k)
+        mt.shutdown()
+    with pytest.raises(BlokError):
+        HipMultiTracer([0, 99], Wd, Ht)
+    with pytest.raises(BlokError):
+        HipMultiTracer([0], Wd, Ht, tile=20)
+    tr.shutdown()
+
+
 def test_dense_upload_device_build(tracer_cls):
     """blok_hip_upload_dense builds on the device straight from the id grid: ragged extents, negative origin,
     same frames as the general host path; 256^3 timing printed."""

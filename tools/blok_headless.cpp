@@ -3,6 +3,9 @@
 // packChunksToGpuSvo, addWorld, then a frame loop of drawFrame; writes the last frame as a PPM.
 //   blok_headless [--n 256 | --vox model.vox] [--size 1280x720] [--pose 0|1|2] [--frames 10] [--out frame.ppm] [--rt [--spp 8]]
 //   --rt: every frame goes through the reference's full ray-tracing path (path trace, denoise, TAA, tonemap, sharpen)
+//   --devices 0,1,2,...: the frame is tile-partitioned over these devices of the node by ONE process (blok::HipMultiTracer:
+//                        RCCL send / receive group or peer copies to the first device); an ordinal may repeat (rehearsal on one GPU)
+//   --no-rccl: peer copies even when RCCL is there
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -22,6 +25,8 @@ struct Options {
     bool rt = false;                      // full ray-tracing path per frame instead of first-hit frames
     uint32_t spp = 8;                     // samples per pixel and frame in --rt mode (the reference forces 8)
     std::string vox;                      // optional .vox model instead of the synthetic scene (app.cpp:105-113)
+    std::vector<int> devices;             // more than one entry: the multi-device tracer
+    bool rccl = true;
 };
 
 class App {
@@ -54,6 +59,11 @@ private:
                     blok_scene_materials(0xB10C0001u, m_world.materials.data());
                 }
                 m_tracer->addWorld(m_world);                                              // app.cpp:122-124
+                if (m_opt.devices.size() > 1) {
+                    m_multi = std::make_unique<blok::HipMultiTracer>(m_opt.devices, m_opt.width, m_opt.height, 32, m_opt.rccl);
+                    m_multi->addWorld(m_world);
+                    std::cout << "multi-device: " << m_multi->deviceCount() << " ranks, transport " << m_multi->transport() << "\n";
+                }
                 const blok_world_stats s = m_tracer->worldStats();
                 std::cout << "world: " << s.n_voxels << " voxels, " << s.n_ref_nodes << " SVO nodes, " << s.n_sub_chunks
                           << " sub-chunks -> " << s.n_tree_nodes << " tree nodes (" << s.tree_bytes / 1e6 << " MB), "
@@ -74,16 +84,26 @@ private:
         for (uint32_t f = 0; f < m_opt.frames; ++f) {
             const auto t0 = clock::now();
             m_tracer->beginFrame();
-            if (m_opt.rt) m_tracer->drawFrameRT(m_camera, m_opt.spp);
+            if (m_multi) m_multi->drawFrame(m_camera, m_multiFrame);
+            else if (m_opt.rt) m_tracer->drawFrameRT(m_camera, m_opt.spp);
             else m_tracer->drawFrame(m_camera);
             m_tracer->endFrame();
             const double ms = std::chrono::duration<double, std::milli>(clock::now() - t0).count();
-            if (m_opt.rt) std::cout << "frame " << f << ": " << ms << " ms (path trace " << m_opt.spp << " spp, denoise, TAA, tonemap, sharpen; incl. device->host copy)\n";
+            if (m_multi) std::cout << "frame " << f << ": " << ms << " ms (" << m_multi->deviceCount() << " ranks, incl. device->host copy of the RGBA8 frame)\n";
+            else if (m_opt.rt) std::cout << "frame " << f << ": " << ms << " ms (path trace " << m_opt.spp << " spp, denoise, TAA, tonemap, sharpen; incl. device->host copy)\n";
             else std::cout << "frame " << f << ": " << ms << " ms (incl. device->host copy of "
                            << m_tracer->hits().size() * sizeof(blok_hit) / 1e6 << " MB)\n";
             if (f + 1 < m_opt.frames || !m_opt.rt) m_camera.processKeyboard('W', 0.016f);
         }
-        const auto& px = m_opt.rt ? m_tracer->drawFrameRT(m_camera, m_opt.spp) : m_tracer->drawFrameRgba8(m_camera);
+        const auto& single = m_opt.rt ? m_tracer->drawFrameRT(m_camera, m_opt.spp) : m_tracer->drawFrameRgba8(m_camera);
+        if (m_multi) {                                       // the partitioned frame must be the single-device frame
+            m_multi->drawFrame(m_camera, m_multiFrame);
+            size_t differ = 0;
+            for (size_t i = 0; i < single.size(); ++i) differ += single[i] != m_multiFrame[i];
+            std::cout << "multi-device frame vs single-device frame: " << differ << " pixels differ\n";
+            if (differ) throw std::runtime_error("multi-device frame differs from the single-device frame");
+        }
+        const auto& px = m_multi ? m_multiFrame : single;
         std::ofstream ppm(m_opt.out, std::ios::binary);
         ppm << "P6\n" << m_opt.width << " " << m_opt.height << "\n255\n";
         for (uint32_t p : px) { const char rgb[3] = {char(p & 255), char((p >> 8) & 255), char((p >> 16) & 255)}; ppm.write(rgb, 3); }
@@ -98,6 +118,8 @@ private:
     blok::WorldSvoGpu m_world;                     // App owns the world, the tracer its device copy (app.hpp:40)
     blok::Camera m_camera;
     std::unique_ptr<blok::HipTracer> m_tracer;
+    std::unique_ptr<blok::HipMultiTracer> m_multi;
+    std::vector<uint32_t> m_multiFrame;
 };
 
 }  // namespace
@@ -114,6 +136,8 @@ int main(int argc, char** argv) {
         else if (!std::strcmp(argv[i], "--vox")) opt.vox = next();
         else if (!std::strcmp(argv[i], "--rt")) opt.rt = true;
         else if (!std::strcmp(argv[i], "--spp")) opt.spp = std::strtoul(next(), nullptr, 10);
+        else if (!std::strcmp(argv[i], "--no-rccl")) opt.rccl = false;
+        else if (!std::strcmp(argv[i], "--devices")) { for (const char* p = next(); *p;) { opt.devices.push_back(std::atoi(p)); while (*p && *p != ',') ++p; if (*p == ',') ++p; } }
         else { std::fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
     }
     try {
