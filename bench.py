@@ -296,9 +296,26 @@ def main():
             torch.cuda.synchronize()
             ms.append(tracer.last_kernel_ms())
         tracer.set_timing(False)
-        paths = {"config": "3840x2160 x 64 spp, 2 bounces + sun shadow ray (raygen.rgen loop)", "ms_per_frame": float(np.mean(ms[1:])),
-                 "Gpaths_per_s": W_ * H_ * 64 / (float(np.mean(ms[1:])) * 1e-3) / 1e9}
+        path_ms = float(np.mean(ms[1:]))
+        paths = {"config": "3840x2160 x 64 spp, 2 bounces + sun shadow ray (raygen.rgen loop)", "ms_per_frame": path_ms,
+                 "Gpaths_per_s": W_ * H_ * 64 / (path_ms * 1e-3) / 1e9}
         del color
+        if rank == 0 and not args.no_cpu_baseline:
+            # algorithmic bytes of the path loop, by the oracle's counters on every 8th pixel in x and y at the same 64 spp: per ray
+            # segment (radiance or shadow) 48 B per sub-chunk descriptor entered + 16 B per node fetched, 32 B of material per
+            # radiance hit, and per pixel the 48-B G-buffer of raygen.rgen:392-413
+            from tests import oracle_ffi as O
+            lat = O.Lattice(packed.nodes, packed.sub_chunks)
+            _, pc = O.render_paths(lat, packed.materials, cam, W_, H_, spp=64, max_bounces=2, frame_index=1, stride=8, threads=usable_cores())
+            px = ((W_ + 7) // 8) * ((H_ + 7) // 8)
+            seg_bytes = 48 * int(pc["sub_chunks_entered"]) + 16 * int(pc["nodes_fetched"]) + 32 * int(pc["hits"])
+            per_pixel = seg_bytes / px + 48.0
+            achieved = per_pixel * W_ * H_ / (path_ms * 1e-3) / 1e9
+            paths["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                                 "kernel": "path_kernel (behind its beam_kernel), one launch per frame, alone", "kernel_ms": path_ms,
+                                 "algorithmic_bytes_per_pixel": per_pixel, "ray_segments_per_pixel": int(pc["rays"]) / px,
+                                 "Gsegments_per_s": int(pc["rays"]) / px * W_ * H_ / (path_ms * 1e-3) / 1e9,
+                                 "sample": f"oracle counters on every 8th pixel in x and y ({px} pixels, 64 spp)"}
 
     if rank == 0:
         rays_per_step = W_ * H_
