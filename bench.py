@@ -95,10 +95,25 @@ def build_world(n: int, seed: int):
 
 
 def usable_cores() -> int:
+    """Host cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (a GPU box of the pool shows
+    256 hardware threads but grants a 16-CPU share per GPU; threads beyond the quota are only throttled)."""
     try:
-        return max(1, len(os.sched_getaffinity(0)))
+        n = max(1, len(os.sched_getaffinity(0)))
     except AttributeError:
-        return max(1, os.cpu_count() or 1)
+        n = max(1, os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            text = Path(path).read_text().split()
+            if path.endswith("cpu.max"):
+                quota, period = text[0], text[1]
+            else:
+                quota, period = text[0], Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text().split()[0]
+            if quota not in ("max", "-1"):
+                n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
 
 
 def oracle_counters(packed, cam, width, height, stride=1):
@@ -128,7 +143,7 @@ def cpu_baseline(packed, cam, width, height, stride, min_core_seconds=12.0):
         frames += 1
         rays += int(c["rays"])
         dt = time.perf_counter() - t0
-        if dt * threads >= min_core_seconds or frames >= 256:
+        if (dt * threads >= min_core_seconds and dt >= 1.0) or frames >= 256:
             break
     t1 = time.perf_counter()                      # one-thread rate on a strided sample of the same frame
     _, c1 = lattice.trace_primary(cam, width, height, stride=4, threads=1, want_hits=False)
@@ -138,7 +153,7 @@ def cpu_baseline(packed, cam, width, height, stride, min_core_seconds=12.0):
         "build": "g++ -O3 -march=native -ffp-contract=off -DORC_NO_COUNTERS (oracle/Makefile: native), built on this host",
         "sample": f"{frames} pass(es) over every {stride}th pixel in x and y of the {width}x{height} frame "
                   f"({rays} rays, {dt:.2f} s wall on {threads} threads = {dt * threads:.0f} core-seconds); "
-                  f"hardware threads on the host: {os.cpu_count()}, usable by this process: {threads}",
+                  f"hardware threads on the host: {os.cpu_count()}, usable by this process (affinity and cgroup CPU quota): {threads}",
     }
 
 

@@ -35,6 +35,7 @@ void free_world(blok_hip_ctx* ctx) {
     ctx->d_sun_map = nullptr; ctx->has_sun_map = false;
     ctx->d_nodes = nullptr; ctx->d_tree_materials = nullptr; ctx->d_materials = nullptr;
     ctx->n_materials = 0; ctx->has_world = false; ctx->built_on_device = false; ctx->stats = blok_world_stats{};
+    ctx->world_voxel_size = 1.0f;
 }
 
 int install_materials(blok_hip_ctx* ctx, const blok_material* materials, size_t n_materials) {
@@ -64,6 +65,7 @@ int install_tree(blok_hip_ctx* ctx, const blok::HostTree& tree, const blok_mater
     ctx->stats.levels = tree.levels;
     for (int a = 0; a < 3; ++a) ctx->stats.origin[a] = tree.origin[a];
     ctx->has_world = true;
+    ctx->world_voxel_size = ctx->pending_voxel_size;
     return rebuild_sun_map(ctx);
 }
 
@@ -73,11 +75,13 @@ int rebuild_sun_map(blok_hip_ctx* ctx) {
     if (ctx->d_sun_map) { (void)hipDeviceSynchronize(); (void)hipFree(ctx->d_sun_map); ctx->d_sun_map = nullptr; }
     ctx->has_sun_map = false;
     if (!ctx->has_world || ctx->stats.levels == 0 || ctx->stats.n_voxels == 0) return BLOK_OK;
+    if (ctx->world_voxel_size != 1.0f) return BLOK_OK;      // the map is laid out in world units = voxel units; other voxel sizes go without it
     blok::SunMapArgs& m = ctx->sun;
     m = blok::SunMapArgs{};
     m.trace.nodes = ctx->d_nodes; m.trace.materials = ctx->d_tree_materials;
     for (int a = 0; a < 3; ++a) m.trace.origin[a] = ctx->stats.origin[a];
     m.trace.levels = ctx->stats.levels;
+    m.trace.voxel_size = 1.0f; m.trace.inv_voxel_size = 1.0f;
     // the shader's sun: normalize(vec3(0.5, 0.8, 0.3)) (raygen.rgen:142,185) with path_core.h's operation order
     const float sx = 0.5f, sy = 0.8f, sz = 0.3f;
     const float len = std::sqrt(sx * sx + sy * sy + sz * sz);
@@ -124,6 +128,7 @@ blok::TraceArgs base_args(const blok_hip_ctx* ctx, const blok_camera* cam) {
     a.materials = ctx->d_tree_materials;
     for (int i = 0; i < 3; ++i) a.origin[i] = ctx->stats.origin[i];
     a.levels = ctx->stats.levels;
+    a.voxel_size = ctx->world_voxel_size; a.inv_voxel_size = 1.0f / ctx->world_voxel_size;
     if (cam) a.cam = *cam;
     a.frame_w = ctx->width; a.frame_h = ctx->height;
     a.jitter_clip[0] = (2.0f * ctx->jitter_px[0]) / static_cast<float>(ctx->width);          // getJitterClipSpace, renderer_postprocess.cpp:234-241
@@ -307,6 +312,20 @@ int blok_hip_upload_world(blok_hip_ctx* ctx, const blok_svo_node* nodes, size_t 
     if ((n_nodes && !nodes) || (n_sub_chunks && !sub_chunks) || (n_materials && !materials))
         return set_error(ctx, BLOK_ERR_INVALID_ARG, "null array with non-zero count");
     BLOK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // ChunkManager(chunkSize, voxelSize) with voxelSize != 1 (reference chunk_manager.cpp:19-25, 234-314): the descriptors' bounds
+    // are voxel coordinates times voxelSize.  For a power of two the division is exact, the structure is built in voxel units
+    // as for voxelSize 1, and the walk multiplies its integer planes by voxelSize (trace_core.h).
+    const float vs = ctx->voxel_size;
+    std::vector<blok_sub_chunk> scaled;
+    if (vs != 1.0f) {
+        scaled.assign(sub_chunks, sub_chunks + n_sub_chunks);
+        const float inv = 1.0f / vs;
+        for (auto& sc : scaled) {
+            for (int a = 0; a < 3; ++a) { sc.world_min[a] *= inv; sc.world_max[a] *= inv; }
+            sc.sub_chunk_size *= inv;
+        }
+        sub_chunks = scaled.data();
+    }
     // device-side build (gpu_build.hip); worlds it does not cover take the general host path below
     if (!ctx->force_host_build) {
         blok::GpuTree gpu;
@@ -330,6 +349,7 @@ int blok_hip_upload_world(blok_hip_ctx* ctx, const blok_svo_node* nodes, size_t 
             ctx->stats.n_sub_chunks = n_sub_chunks;
             ctx->has_world = true;
             ctx->built_on_device = true;
+            ctx->world_voxel_size = vs;
             return rebuild_sun_map(ctx);
         }
     }
@@ -339,10 +359,22 @@ int blok_hip_upload_world(blok_hip_ctx* ctx, const blok_svo_node* nodes, size_t 
         return set_error(ctx, BLOK_ERR_UNSUPPORTED, why);
     blok::HostTree tree;
     if (!blok::build_tree(voxels, tree, &why)) return set_error(ctx, BLOK_ERR_UNSUPPORTED, why);
+    ctx->pending_voxel_size = vs;                      // install_tree frees the old world (voxel size back to 1), then takes this one
     const int rc = install_tree(ctx, tree, materials, n_materials);
+    ctx->pending_voxel_size = 1.0f;
     if (rc != BLOK_OK) return rc;
     ctx->stats.n_ref_nodes = n_nodes;
     ctx->stats.n_sub_chunks = n_sub_chunks;
+    return BLOK_OK;
+}
+
+int blok_hip_set_voxel_size(blok_hip_ctx* ctx, float voxel_size) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    int e = 0;
+    const float m = std::frexp(voxel_size, &e);
+    if (!(voxel_size > 0.0f) || m != 0.5f || e < -7 || e > 9)        // 2^-8 .. 2^8
+        return set_error(ctx, BLOK_ERR_UNSUPPORTED, "voxel size must be a power of two in [1/256, 256]: any other size puts box planes off the exactly representable lattice the bit-exact walk relies on");
+    ctx->voxel_size = voxel_size;
     return BLOK_OK;
 }
 

@@ -35,6 +35,9 @@ struct blok_hip_ctx {
     bool built_on_device = false;     // structure built by gpu_build.hip (else tree_build.cpp on the host)
     bool force_host_build = false;
     blok_world_stats stats{};
+    float voxel_size = 1.0f;            // for the next blok_hip_upload_world (blok_hip_set_voxel_size)
+    float world_voxel_size = 1.0f;      // of the installed world
+    float pending_voxel_size = 1.0f;    // handed from blok_hip_upload_world to install_tree
     // scratch frame for the host-output entry points
     blok_hit* d_frame = nullptr;
     size_t frame_capacity = 0;

@@ -165,9 +165,13 @@ __device__ __forceinline__ float beam_start(const TraceArgs& A, float px_lo, flo
     if (beam_dot(side, mid.x, mid.y, mid.z) < 0.0f) side = {-side.x, -side.y, -side.z};
     const BeamVec n0 = beam_lane(side, 0), n1 = beam_lane(side, 1), n2 = beam_lane(side, 2), n3 = beam_lane(side, 3);
 
-    const float best = beam_search<true>(A, {A.cam.pos[0], A.cam.pos[1], A.cam.pos[2]}, n0, n1, n2, n3, 0.0f, 0.0f, 0.0f, 0.0f, mid, lane, depth_limit);
+    // the search runs in voxel units (tree coordinates): the camera position is scaled into them (a power of two: exact), the
+    // directions are unit-free, and the depth found, less its margins, goes back to the rays' world parameter
+    const float iv = A.inv_voxel_size;
+    const float best = beam_search<true>(A, {A.cam.pos[0] * iv, A.cam.pos[1] * iv, A.cam.pos[2] * iv}, n0, n1, n2, n3, 0.0f, 0.0f, 0.0f, 0.0f, mid, lane,
+                                         depth_limit >= kBeamNone ? kBeamNone : depth_limit * iv);
     if (best >= kBeamNone) return kBeamNone;
-    return fmaxf(best * (1.0f - 1.0e-4f) - 2.0f * kBeamSlack, 0.0f);
+    return fmaxf(best * (1.0f - 1.0e-4f) - 2.0f * kBeamSlack, 0.0f) * A.voxel_size;
 }
 
 // ---- "last occluder" map for the shadow rays of the path kernel ------------------------------------------------------

@@ -151,11 +151,13 @@ BLOK_DEV HitInfo walk(const TraceArgs& A, const RayIn& r, uint4* stk) {
     ax.o = r.ox; ay.o = r.oy; az.o = r.oz;
     ax.inv = safe_inv(r.dx); ay.inv = safe_inv(r.dy); az.inv = safe_inv(r.dz);
     const bool negx = !(ax.inv > 0.0f), negy = !(ay.inv > 0.0f), negz = !(az.inv > 0.0f);
-    ax.sgn = negx ? -1.0f : 1.0f; ay.sgn = negy ? -1.0f : 1.0f; az.sgn = negz ? -1.0f : 1.0f;
-    // c = base - sgn * 2^23: integers below 2^24 in magnitude, exact
-    ax.c = static_cast<float>(A.origin[0] + (negx ? W : 0)) - ax.sgn * kCoordBias;
-    ay.c = static_cast<float>(A.origin[1] + (negy ? W : 0)) - ay.sgn * kCoordBias;
-    az.c = static_cast<float>(A.origin[2] + (negz ? W : 0)) - az.sgn * kCoordBias;
+    // world plane = (base + sgn q) * voxel_size with a power-of-two voxel_size: sgn and c carry the factor, every product exact
+    const float vs = A.voxel_size;
+    ax.sgn = negx ? -vs : vs; ay.sgn = negy ? -vs : vs; az.sgn = negz ? -vs : vs;
+    // c = (base -+ 2^23) * voxel_size: an integer below 2^24 in magnitude times a power of two, exact
+    ax.c = (static_cast<float>(A.origin[0] + (negx ? W : 0)) + (negx ? kCoordBias : -kCoordBias)) * vs;
+    ay.c = (static_cast<float>(A.origin[1] + (negy ? W : 0)) + (negy ? kCoordBias : -kCoordBias)) * vs;
+    az.c = (static_cast<float>(A.origin[2] + (negz ? W : 0)) + (negz ? kCoordBias : -kCoordBias)) * vs;
     const uint32_t mirror = (negx ? 3u : 0u) | (negy ? 12u : 0u) | (negz ? 48u : 0u);
 
     // world box: near planes q = 0, far planes q = W (T is monotone in q, so no min/max is needed)
@@ -243,9 +245,10 @@ BLOK_DEV HitInfo walk(const TraceArgs& A, const RayIn& r, uint4* stk) {
     const float hx = rn_add(r.ox, rn_mul(r.dx, tc));
     const float hy = rn_add(r.oy, rn_mul(r.dy, tc));
     const float hz = rn_add(r.oz, rn_mul(r.dz, tc));
-    const float ex = rn_sub(hx, rn_add(static_cast<float>(vx), 0.5f));
-    const float ey = rn_sub(hy, rn_add(static_cast<float>(vy), 0.5f));
-    const float ez = rn_sub(hz, rn_add(static_cast<float>(vz), 0.5f));
+    // leaf centre = (voxel + 1/2) * voxel_size: exact, and the value the shader reaches by halving from the sub-chunk centre
+    const float ex = rn_sub(hx, rn_mul(rn_add(static_cast<float>(vx), 0.5f), vs));
+    const float ey = rn_sub(hy, rn_mul(rn_add(static_cast<float>(vy), 0.5f), vs));
+    const float ez = rn_sub(hz, rn_mul(rn_add(static_cast<float>(vz), 0.5f), vs));
     const float gx = fabsf(ex), gy = fabsf(ey), gz = fabsf(ez);
     uint32_t face;                                                   // getHitFace, intersect.rint:58-68
     if (gx >= gy && gx >= gz) face = ex > 0.0f ? 0u : 1u;

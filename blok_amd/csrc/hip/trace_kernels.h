@@ -78,8 +78,10 @@ constexpr float kBeamNone = 3.0e38f;   // beam pre-pass result: "no cell of the 
 struct TraceArgs {
     const uint4*    nodes;
     const uint32_t* materials;
-    int32_t  origin[3];
+    int32_t  origin[3];                    // corner of the tree in VOXEL units (world coordinate = voxel coordinate * voxel_size)
     uint32_t levels;
+    float voxel_size, inv_voxel_size;      // ChunkManager's voxelSize (reference chunk_manager.cpp:19-25): a power of two, so that
+                                           // every plane (integer * voxel_size) stays exactly representable; 1 for the reference app
     blok_camera cam;
     // TAA jitter in clip space, (2 jx / frame_w, 2 jy / frame_h) (getJitterClipSpace, reference blok/src/renderer_postprocess.cpp:234-241):
     // what getJitteredProjection adds to proj[2][0..1] (:264-265), i.e. to the NDC coordinate every primary ray is formed from

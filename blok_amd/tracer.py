@@ -171,6 +171,10 @@ class HipTracer:
         """Node visits a beam search may spend (0 = default); running out is answered conservatively, never changes a result."""
         self._check(self._lib.blok_hip_set_beam_budget(self._ctx, max_node_visits))
 
+    def set_voxel_size(self, voxel_size: float):
+        """ChunkManager's voxelSize for the next add_world: a power of two in [1/256, 256] (default 1)."""
+        self._check(self._lib.blok_hip_set_voxel_size(self._ctx, float(voxel_size)))
+
     def set_fused(self, enabled: bool):
         """One-launch frame (pre-pass + walk in one persistent grid; opt-in) or the two-launch form (default); never changes a result."""
         self._check(self._lib.blok_hip_set_fused(self._ctx, 1 if enabled else 0))

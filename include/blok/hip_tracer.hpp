@@ -172,6 +172,8 @@ public:
     void resetAccum() { check(blok_hip_reset_accum(m_ctx)); m_frameIndex = 0; }
 
     // = Renderer::addWorld: keeps a non-owning pointer to the caller's world, owns the device copies
+    // ChunkManager's voxelSize for the worlds added from now on (a power of two; reference chunk_manager.cpp:19-25, app.cpp:37)
+    void setVoxelSize(float voxelSize) { check(blok_hip_set_voxel_size(m_ctx, voxelSize)); }
     void addWorld(WorldSvoGpu& gpuWorld) { m_world = &gpuWorld; updateWorld(); }
     void updateWorld() {
         if (!m_world) return;

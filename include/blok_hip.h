@@ -129,6 +129,15 @@ const char* blok_hip_last_error(const blok_hip_ctx* ctx);
 
 /* ------------------------------------------------------------------- world */
 
+/* ChunkManager's voxelSize for the NEXT blok_hip_upload_world (reference blok/src/chunk_manager.cpp:19-25: voxel coordinates
+ * times voxelSize are the world coordinates in every SubChunkGpu).  Default 1 (the reference app, app.cpp:37).  Powers of two
+ * in [1/256, 256] are supported: the structure is built on the voxel lattice and the walk scales its integer planes, every
+ * product exact, so first hits stay bit-exact; hit records carry the voxel's lattice coordinates.  Any other size returns
+ * BLOK_ERR_UNSUPPORTED: its box planes are not exactly representable, and the reference's own result then depends on the
+ * rounding of every intermediate box, which no other traversal order reproduces.  The shadow rays' last-occluder map and the
+ * resident volume exist for size 1 only. */
+int blok_hip_set_voxel_size(blok_hip_ctx* ctx, float voxel_size);
+
 /* = Renderer::addWorld / updateWorld  (reference blok/include/renderer.hpp:40-72,
  *   uploadSvoBuffers + uploadMaterialBuffer, blok/src/renderer_upload.cpp:237-312).
  * Takes the three host arrays of WorldSvoGpu (reference blok/include/resources.hpp:195-203)

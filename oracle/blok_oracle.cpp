@@ -407,10 +407,11 @@ struct RayQuery {
     float hitT = -1.0f;
     uint32_t hitKind = 0xFF, materialId = 0;
     Vec3 leafCenter{0, 0, 0};
+    float leafSize = 1.0f;       // edge of the reported leaf = ChunkManager's voxelSize
     // reportIntersectionEXT
-    bool report(float t, uint32_t kind, uint32_t mat, Vec3 center) {
+    bool report(float t, uint32_t kind, uint32_t mat, Vec3 center, float size = 1.0f) {
         if (!(t >= tmin && t <= tmax)) return false;
-        tmax = t; committed = true; hitT = t; hitKind = kind; materialId = mat; leafCenter = center;
+        tmax = t; committed = true; hitT = t; hitKind = kind; materialId = mat; leafCenter = center; leafSize = size;
         return true;
     }
 };
@@ -450,7 +451,7 @@ bool intersectSubChunk(RayQuery& q, const SubChunkGpu& sub, const SvoNode* nodes
             if (node.occupancy > 0.0f) {
                 const Vec3 hitPos = add3(rayOrg, scale3(rayDir, item.tEntry));    // :138
                 const uint32_t faceID = getHitFace(hitPos, item.center);
-                q.report(item.tEntry, faceID, node.materialId, item.center);      // :139-141
+                q.report(item.tEntry, faceID, node.materialId, item.center, item.halfSize * 2.0f);      // :139-141
             }
             continue;
         }
@@ -496,9 +497,10 @@ inline void commitHit(const RayQuery& q, Hit& out) {
     }
     out.t = q.hitT;                                       // hit.rchit:74
     out.materialId = q.materialId;                        // hit.rchit:62 input
-    out.voxel[0] = static_cast<int16_t>(std::floor(q.leafCenter.x));
-    out.voxel[1] = static_cast<int16_t>(std::floor(q.leafCenter.y));
-    out.voxel[2] = static_cast<int16_t>(std::floor(q.leafCenter.z));
+    // the record's voxel is the leaf's index on the voxel lattice: floor(centre / voxelSize) (= floor(centre) for the app's size 1)
+    out.voxel[0] = static_cast<int16_t>(std::floor(q.leafCenter.x / q.leafSize));
+    out.voxel[1] = static_cast<int16_t>(std::floor(q.leafCenter.y / q.leafSize));
+    out.voxel[2] = static_cast<int16_t>(std::floor(q.leafCenter.z / q.leafSize));
     out.face = static_cast<uint8_t>(q.hitKind);           // hit.rchit:58
     out.hit = 1;
 }

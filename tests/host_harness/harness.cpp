@@ -53,6 +53,7 @@ void hh_set_jitter_clip(float jx, float jy) { g_jitter_clip[0] = jx; g_jitter_cl
 static TraceArgs make_args(const Harness* H) {
     TraceArgs a{};
     a.jitter_clip[0] = g_jitter_clip[0]; a.jitter_clip[1] = g_jitter_clip[1];
+    a.voxel_size = 1.0f; a.inv_voxel_size = 1.0f;
     a.nodes = H->nodes.data();
     a.materials = H->tree.materials.data();
     for (int i = 0; i < 3; ++i) a.origin[i] = H->tree.origin[i];

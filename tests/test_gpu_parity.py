@@ -546,6 +546,67 @@ def test_sparse_tile_exchange_kernels(tracer_cls, scene1024):
     tr.shutdown()
 
 
+@pytest.mark.parametrize("vs", [0.5, 2.0, 0.125])
+def test_power_of_two_voxel_sizes(tracer_cls, vs):
+    """ChunkManager(chunkSize, voxelSize) with voxelSize != 1 (reference chunk_manager.cpp:19-25): for a power of two every box
+    plane stays exactly representable, the walk scales its integer planes, and first hits equal the oracle's (which walks the
+    scaled SubChunkGpu records literally) bit for bit — frames from outside and inside, explicit rays, with and without the
+    pre-pass; the record's voxel is the lattice coordinate.  Other sizes, and a world whose size was not announced, are refused."""
+    from blok_amd._ffi import BlokError
+    rng = np.random.default_rng(int(vs * 1000))
+    cm = W.ChunkManager(128, vs)
+    pts = rng.integers(-70, 90, size=(5000, 3)).astype(np.int32)
+    wall = np.array([(x, 21, z) for x in range(-50, 60) for z in range(-40, 50)], dtype=np.int32)
+    xyz = np.concatenate([pts, wall, np.array([(-190, 60, 140)], dtype=np.int32)])
+    cm.set_voxels(xyz, rng.integers(1, 200, size=len(xyz)).astype(np.uint32))
+    cm.rebuild_dirty_chunks()
+    pw = cm.pack_chunks_to_gpu_svo(W.scene_materials(SEED))
+    assert float(pw.sub_chunks["sub_chunk_size"][0]) == 16 * vs
+    lat = O.Lattice(pw.nodes, pw.sub_chunks)
+    w, h = 320, 180
+    tr = tracer_cls(w, h).init()
+    with pytest.raises(BlokError) as e:
+        tr.add_world(pw)                                    # voxel size not announced: the leaves are not at unit level
+    assert e.value.status == -5
+    for bad in (0.3, 3.0, 0.0, -2.0, 1024.0):
+        with pytest.raises(BlokError) as e:
+            tr.set_voxel_size(bad)
+        assert e.value.status == -5
+    tr.set_voxel_size(vs)
+    st = tr.add_world(pw)
+    assert st.n_voxels == len(np.unique(xyz, axis=0))
+    cams = [W.camera_look_at((150.0 * vs, 120.0 * vs, -160.0 * vs), (0.0, 10.0 * vs, 0.0), 60.0, w, h),
+            W.camera_look_at((3.3 * vs, 40.2 * vs, 7.7 * vs), (60.0 * vs, 0.0, 31.0 * vs), 95.0, w, h),
+            W.camera_look_at((-400.0 * vs, 90.0 * vs, 300.0 * vs), (-190.0 * vs, 60.5 * vs, 140.5 * vs), 8.0, w, h)]
+    for k, cam in enumerate(cams):
+        ref, ctr = lat.trace(O.primary_rays(cam, w, h), threads=8)
+        assert ctr["hits"] > 50
+        for beam in (32, 0, 8):
+            tr.set_beam(beam)
+            for fused in (False, True):
+                tr.set_fused(fused)
+                assert records_equal(tr.draw_frame(cam).reshape(-1), ref).all(), (k, beam, fused)
+        tr.set_beam(32); tr.set_fused(False)
+        hit = ref[ref["hit"] == 1]
+        assert np.isin(hit["voxel"].astype(np.int32).view([("", np.int32)] * 3), np.ascontiguousarray(xyz).view([("", np.int32)] * 3)).all()   # lattice coordinates
+    rays = random_rays(int(160 * vs) + 8, 6000, 3)
+    rays["org"] -= np.float32(40 * vs)
+    ref, ctr = lat.trace(rays, threads=8)
+    assert ctr["hits"] > 20 and records_equal(tr.trace_rays(rays), ref).all()
+    planes = tr.trace_paths(cams[0], spp=2, max_bounces=2, frame_index=1)
+    want, _ = O.render_paths(lat, pw.materials, cams[0], w, h, spp=2, max_bounces=2, frame_index=1, threads=8)
+    for key in ("world_pos", "normal_roughness", "albedo_metallic"):
+        assert np.array_equal(planes[key], want[key]), key
+    assert (np.abs(planes["color"] - want["color"]) <= 1e-4 + 1e-3 * np.abs(want["color"])).all()
+    tr.set_voxel_size(1.0)                                  # and back: the unit-voxel world again
+    cm1, pw1 = make_scene_world(64)
+    tr.add_world(pw1)
+    cam1 = W.scene_camera(64, 0, w, h, SEED)
+    ref1, _ = O.Lattice(pw1.nodes, pw1.sub_chunks).trace(O.primary_rays(cam1, w, h), threads=8)
+    assert records_equal(tr.draw_frame(cam1).reshape(-1), ref1).all()
+    tr.shutdown()
+
+
 def test_multi_device_entry_one_process(tracer_cls, scene1024):
     """blok_hip_multi_* (C ABI; one process, one context and stream per rank): 1, 3 and 8 ranks on device 0 — transport "none" /
     "peer-copy" — give the single-device RGBA8 frame, and each rank's first-hit records are its tiles of the single-device
