@@ -58,6 +58,7 @@ def parse():
     ap.add_argument("--beam", type=int, default=32, help="beam pre-pass tile in pixels (0 = off)")
     ap.add_argument("--fused", type=int, default=0, help="1 = one persistent launch per frame (pre-pass + walk; measured slower), 0 = beam kernel then trace kernel")
     ap.add_argument("--orbit", type=float, default=0.0, help="degrees the camera turns around the world's centre per frame (0 = static camera)")
+    ap.add_argument("--dense-dda", action="store_true", help="BASELINE configs[1]: upload the scene as a dense id grid and trace with the dense-grid kernel (N = 1, --n <= 512)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-paths", action="store_true", help="skip the 64-spp path-tracing side measurement")
     ap.add_argument("--no-poses", action="store_true", help="skip the per-pose side measurements (poses A, B, C)")
@@ -188,7 +189,12 @@ def main():
     packed = build_world(args.n, args.seed)
     cam = W.scene_camera(args.n, args.pose, W_, H_, args.seed)
     tracer = HipTracer(W_, H_, device=device_index).init()
-    stats = tracer.add_world(packed)                      # world resident in HBM from here on
+    if args.dense_dda:
+        tracer.set_dense_dda(True)
+        stats = tracer.add_dense(W.scene_dense(args.n, args.seed), (0, 0, 0), W.scene_materials(args.seed))
+        stats.n_ref_nodes, stats.n_sub_chunks = len(packed.nodes), len(packed.sub_chunks)
+    else:
+        stats = tracer.add_world(packed)                  # world resident in HBM from here on
     tracer.set_beam(args.beam)
     tracer.set_fused(bool(args.fused))
 
@@ -335,7 +341,8 @@ def main():
     if rank == 0:
         rays_per_step = W_ * H_
         value = rays_per_step * args.steps / elapsed / 1e6
-        launch = "one persistent launch per frame (frame_kernel: beam pre-pass + walk)" if args.fused and args.beam else \
+        launch = "dense_kernel per frame (id grid in 8^3 tiles, tile bits in LDS, two-level DDA)" if args.dense_dda else \
+                 "one persistent launch per frame (frame_kernel: beam pre-pass + walk)" if args.fused and args.beam else \
                  ("beam_kernel + trace_kernel per frame" if args.beam else "trace_kernel per frame")
         out = {
             "metric": "Mrays/sec, primary first-hit rays at 4K over a 1024^3 SVO",

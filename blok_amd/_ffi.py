@@ -171,6 +171,7 @@ HIP_SYMBOLS = {
     "blok_hip_reset_accum": (C.c_int, [C.c_void_p]),
     "blok_hip_set_beam": (C.c_int, [C.c_void_p, C.c_uint32]),
     "blok_hip_set_fused": (C.c_int, [C.c_void_p, C.c_int]),
+    "blok_hip_set_dense_dda": (C.c_int, [C.c_void_p, C.c_int]),
     "blok_hip_set_voxel_size": (C.c_int, [C.c_void_p, C.c_float]),
     "blok_hip_multi_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]),
     "blok_hip_multi_destroy": (None, [C.c_void_p]),

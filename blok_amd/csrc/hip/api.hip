@@ -33,6 +33,9 @@ void free_world(blok_hip_ctx* ctx) {
     if (ctx->d_materials) (void)hipFree(ctx->d_materials);
     if (ctx->d_sun_map) (void)hipFree(ctx->d_sun_map);
     ctx->d_sun_map = nullptr; ctx->has_sun_map = false;
+    if (ctx->d_dense_tiled) (void)hipFree(ctx->d_dense_tiled);
+    if (ctx->d_dense_bits) (void)hipFree(ctx->d_dense_bits);
+    ctx->d_dense_tiled = ctx->d_dense_bits = nullptr; ctx->has_dense = false;
     ctx->d_nodes = nullptr; ctx->d_tree_materials = nullptr; ctx->d_materials = nullptr;
     ctx->n_materials = 0; ctx->has_world = false; ctx->built_on_device = false; ctx->stats = blok_world_stats{};
     ctx->world_voxel_size = 1.0f;
@@ -399,6 +402,37 @@ int blok_hip_download_tree(const blok_hip_ctx* ctx, void* nodes_out, size_t node
     return BLOK_OK;
 }
 
+// Keeps the id grid itself on the device for the dense-grid kernel: 8^3-cell tiles + one occupancy bit per tile.
+static int keep_dense_grid(blok_hip_ctx* ctx, const uint32_t* ids, uint32_t nx, uint32_t ny, uint32_t nz, const int32_t o[3]) {
+    const uint32_t tx = (nx + 7u) / 8u, ty = (ny + 7u) / 8u, tz = (nz + 7u) / 8u;
+    const uint64_t tiles = static_cast<uint64_t>(tx) * ty * tz;
+    if (tiles > 0x7FFFFFFFull / 512u * 8u) return set_error(ctx, BLOK_ERR_UNSUPPORTED, "dense grid too large for the dense-grid path");
+    const size_t cells = static_cast<size_t>(nx) * ny * nz, words = (tiles + 31u) / 32u;
+    uint32_t* d_ids = nullptr;
+    BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d_ids), cells * sizeof(uint32_t)));
+    hipError_t e = hipMemcpy(d_ids, ids, cells * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_dense_tiled), tiles * 512u * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_dense_bits), words * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(ctx->d_dense_bits, 0, words * sizeof(uint32_t));
+    if (e == hipSuccess) {
+        blok::launch_dense_tile(d_ids, nx, ny, nz, tx, ty, tz, ctx->d_dense_tiled, ctx->d_dense_bits, nullptr);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+    }
+    (void)hipFree(d_ids);
+    if (e != hipSuccess) return set_error(ctx, e == hipErrorOutOfMemory ? BLOK_ERR_OOM : BLOK_ERR_HIP, std::string("dense grid: ") + hipGetErrorString(e));
+    ctx->dense_tiles[0] = tx; ctx->dense_tiles[1] = ty; ctx->dense_tiles[2] = tz;
+    for (int a = 0; a < 3; ++a) ctx->dense_origin[a] = o[a];
+    ctx->has_dense = true;
+    return BLOK_OK;
+}
+
+int blok_hip_set_dense_dda(blok_hip_ctx* ctx, int enabled) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    ctx->dense_dda = enabled != 0;
+    return BLOK_OK;
+}
+
 int blok_hip_upload_dense(blok_hip_ctx* ctx, const uint32_t* ids, uint32_t nx, uint32_t ny, uint32_t nz,
                           const int32_t origin[3], const blok_material* materials, size_t n_materials) {
     if (!ctx) return BLOK_ERR_INVALID_ARG;
@@ -426,7 +460,9 @@ int blok_hip_upload_dense(blok_hip_ctx* ctx, const uint32_t* ids, uint32_t nx, u
             for (int a = 0; a < 3; ++a) ctx->stats.origin[a] = gpu.origin[a];
             ctx->has_world = true;
             ctx->built_on_device = true;
-            return rebuild_sun_map(ctx);
+            const int rc_sun = rebuild_sun_map(ctx);
+            if (rc_sun != BLOK_OK || !ctx->dense_dda) return rc_sun;
+            return keep_dense_grid(ctx, ids, nx, ny, nz, o);
         }
     }
     std::vector<blok::VoxelRec> voxels;
@@ -439,7 +475,9 @@ int blok_hip_upload_dense(blok_hip_ctx* ctx, const uint32_t* ids, uint32_t nx, u
     blok::HostTree tree;
     const char* why = "";
     if (!blok::build_tree(voxels, tree, &why)) return set_error(ctx, BLOK_ERR_UNSUPPORTED, why);
-    return install_tree(ctx, tree, materials, n_materials);
+    const int rc_tree = install_tree(ctx, tree, materials, n_materials);
+    if (rc_tree != BLOK_OK || !ctx->dense_dda) return rc_tree;
+    return keep_dense_grid(ctx, ids, nx, ny, nz, o);
 }
 
 int blok_hip_world_stats(const blok_hip_ctx* ctx, blok_world_stats* out) {
@@ -459,6 +497,20 @@ int blok_hip_trace_primary_device(blok_hip_ctx* ctx, const blok_camera* cam, uin
     a.x0 = x0; a.y0 = y0; a.w = w; a.h = h;
     a.out = static_cast<blok_hit*>(out_hits_dev);
     a.out_rgba = static_cast<uint32_t*>(out_rgba_dev);
+    if (ctx->dense_dda && ctx->has_dense) {               // the dense-grid kernel over the uploaded grid itself (dense_kernels.hip)
+        blok::DenseArgs d{};
+        d.trace = a;
+        for (int k = 0; k < 3; ++k) d.trace.origin[k] = ctx->dense_origin[k];
+        d.tiled = ctx->d_dense_tiled; d.tile_bits = ctx->d_dense_bits;
+        d.tx = ctx->dense_tiles[0]; d.ty = ctx->dense_tiles[1]; d.tz = ctx->dense_tiles[2];
+        d.bit_words = static_cast<uint32_t>((static_cast<uint64_t>(d.tx) * d.ty * d.tz + 31u) / 32u);
+        hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+        if (ctx->timing) BLOK_HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, stream));
+        blok::launch_dense(d, stream);
+        BLOK_HIP_TRY(ctx, hipGetLastError());
+        if (ctx->timing) { BLOK_HIP_TRY(ctx, hipEventRecord(ctx->ev_end, stream)); ctx->timed = true; }
+        return BLOK_OK;
+    }
     const uint32_t blocks = blok::rect_grid_blocks(w, h);
     return launch_timed(ctx, blok::RayMode::Rect, a, blocks, static_cast<hipStream_t>(hip_stream));
 }

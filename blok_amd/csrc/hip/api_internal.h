@@ -20,6 +20,7 @@
 #include "post_core.h"
 #include "reference_world.h"
 #include "trace_kernels.h"
+#include "dense_kernels.h"
 #include "path_args.h"
 #include "tree.h"
 
@@ -38,6 +39,13 @@ struct blok_hip_ctx {
     float voxel_size = 1.0f;            // for the next blok_hip_upload_world (blok_hip_set_voxel_size)
     float world_voxel_size = 1.0f;      // of the installed world
     float pending_voxel_size = 1.0f;    // handed from blok_hip_upload_world to install_tree
+    // dense-grid path (dense_kernels.hip): the uploaded id grid in 8^3-cell tiles and one occupancy bit per tile; kept when
+    // blok_hip_set_dense_dda was on at blok_hip_upload_dense, and then used by the rectangle entries of the primary trace
+    bool dense_dda = false, has_dense = false;
+    uint32_t* d_dense_tiled = nullptr;
+    uint32_t* d_dense_bits = nullptr;
+    uint32_t dense_tiles[3] = {0, 0, 0};
+    int32_t dense_origin[3] = {0, 0, 0};
     // scratch frame for the host-output entry points
     blok_hit* d_frame = nullptr;
     size_t frame_capacity = 0;

@@ -175,6 +175,11 @@ class HipTracer:
         """ChunkManager's voxelSize for the next add_world: a power of two in [1/256, 256] (default 1)."""
         self._check(self._lib.blok_hip_set_voxel_size(self._ctx, float(voxel_size)))
 
+    def set_dense_dda(self, enabled: bool):
+        """Dense-grid path: when on at add_dense, rectangle traces walk the uploaded grid itself (tiles + LDS occupancy bits)
+        with a two-level DDA instead of the derived tree; records are identical."""
+        self._check(self._lib.blok_hip_set_dense_dda(self._ctx, 1 if enabled else 0))
+
     def set_fused(self, enabled: bool):
         """One-launch frame (pre-pass + walk in one persistent grid; opt-in) or the two-launch form (default); never changes a result."""
         self._check(self._lib.blok_hip_set_fused(self._ctx, 1 if enabled else 0))

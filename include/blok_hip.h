@@ -157,6 +157,12 @@ int blok_hip_upload_world(blok_hip_ctx* ctx,
 int blok_hip_upload_dense(blok_hip_ctx* ctx, const uint32_t* material_ids,
                           uint32_t nx, uint32_t ny, uint32_t nz, const int32_t origin[3],
                           const blok_material* materials, size_t n_materials);
+/* Dense-grid path (BASELINE.json configs[1]: "256^3 dense grid ... primary-ray DDA ... coalesced HBM, no SVO"; no reference
+ * counterpart, the reference has no DDA): when on at the time of blok_hip_upload_dense, the grid itself stays on the device in
+ * 8x8x8-cell tiles with one occupancy bit per tile (staged into LDS by the kernel), and blok_hip_trace_primary* (rectangle
+ * entries) walk it with a two-level DDA over the same canonical plane sequence instead of the derived tree; the tile / ray /
+ * path entries keep using the tree.  Records are identical either way (tests/test_gpu_parity.py).  Default off. */
+int blok_hip_set_dense_dda(blok_hip_ctx* ctx, int enabled);
 
 /* The traversal structure is built on the device (blok_amd/csrc/hip/gpu_build.hip).  Worlds outside what those
  * kernels cover (empty worlds, sub-chunks smaller than 4 voxels or of mixed sizes) are built by the general host

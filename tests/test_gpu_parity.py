@@ -80,6 +80,55 @@ def test_config2_dense_256_1080p(tracer_cls, scene256):
     tr.shutdown()
 
 
+def test_config2_dense_grid_dda_kernel(tracer_cls, scene256):
+    """BASELINE.json configs[1] through the dense-grid kernel itself (dense_kernels.hip: the id grid in 8^3-cell tiles, tile
+    occupancy bits in LDS, two-level DDA over the canonical plane sequence): full 1080p frames of all three poses and odd
+    rectangles equal the oracle, the tree kernel and the RGBA8 shading bit for bit; a ragged grid at a negative origin with the
+    camera inside, outside and axis-parallel does too; the other entry points keep working beside it."""
+    import time
+    cm, pw = scene256
+    ids = W.scene_dense(256, SEED)
+    mats = W.scene_materials(SEED)
+    tr = tracer_cls(1920, 1080).init()
+    tr.set_dense_dda(True)
+    tr.add_dense(ids, (0, 0, 0), mats)
+    tree = tracer_cls(1920, 1080).init()
+    tree.add_dense(ids, (0, 0, 0), mats)
+    lat = O.Lattice(pw.nodes, pw.sub_chunks)
+    for pose in (0, 1, 2):
+        cam = W.scene_camera(256, pose, 1920, 1080, SEED)
+        got = tr.draw_frame(cam)
+        ref, ctr = lat.trace_primary(cam, 1920, 1080, threads=16)
+        assert ctr["hits"] > 100000
+        assert records_equal(got.reshape(-1), ref).all(), pose
+        assert (tr.shade_rgba8(cam) == tree.shade_rgba8(cam)).all(), pose
+        for rect in ((0, 0, 17, 9), (1001, 503, 333, 211), (1920 - 50, 1080 - 30, 50, 30)):
+            x0, y0, w, h = rect
+            assert records_equal(tr.draw_frame(cam, rect).reshape(-1), got[y0:y0 + h, x0:x0 + w].reshape(-1)).all(), (pose, rect)
+    cam = W.scene_camera(256, 0, 1920, 1080, SEED)
+    for name, t in (("dense-grid kernel", tr), ("tree kernel behind the pre-pass", tree)):
+        t.set_timing(True)
+        for _ in range(3):
+            t.draw_frame(cam)
+        print(f"256^3, 1920x1080, {name}: {t.last_kernel_ms():.3f} ms")
+        t.set_timing(False)
+    planes = tr.trace_paths(cam, spp=1, max_bounces=1, rect=(800, 500, 64, 32))          # the tree serves the other entries
+    assert np.array_equal(planes["world_pos"], tree.trace_paths(cam, spp=1, max_bounces=1, rect=(800, 500, 64, 32))["world_pos"])
+    tr.shutdown(); tree.shutdown()
+    # ragged grid, negative origin
+    rng = np.random.default_rng(12)
+    g = np.where(rng.random((37, 22, 51)) < 0.03, rng.integers(1, 300, size=(37, 22, 51)), 0).astype(np.uint32)   # [z][y][x]
+    origin = (-20, 5, -9)
+    a, b = tracer_cls(203, 117).init(), tracer_cls(203, 117).init()
+    a.set_dense_dda(True)
+    a.add_dense(g, origin, mats); b.add_dense(g, origin, mats)
+    cams = [W.camera_look_at((80.0, 60.0, -70.0), (5.0, 15.0, 9.0), 60.0, 203, 117), W.camera_look_at((3.3, 14.2, 7.7), (40.0, 9.0, 31.0), 110.0, 203, 117),
+            W.camera_look_at((5.5, 200.0, 9.5), (5.5, 0.0, 9.5), 30.0, 203, 117), W.camera_look_at((-100.0, 16.0, 9.5), (100.0, 16.0, 9.5), 40.0, 203, 117)]
+    for k, c in enumerate(cams):
+        assert records_equal(a.draw_frame(c).reshape(-1), b.draw_frame(c).reshape(-1)).all(), k
+    a.shutdown(); b.shutdown()
+
+
 @pytest.fixture(scope="module")
 def scene1024():
     return make_scene_world(1024)
