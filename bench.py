@@ -57,6 +57,7 @@ def parse():
                     "rehearsing the N > 1 code path with several ranks on one GPU, which RCCL refuses)")
     ap.add_argument("--beam", type=int, default=32, help="beam pre-pass tile in pixels (0 = off)")
     ap.add_argument("--fused", type=int, default=0, help="1 = one persistent launch per frame (pre-pass + walk; measured slower), 0 = beam kernel then trace kernel")
+    ap.add_argument("--tile-ordering", type=int, default=8, help="longest-first scheduling of the walk from earlier frames' per-wave clocks, re-sorted every N frames (0 = off)")
     ap.add_argument("--orbit", type=float, default=0.0, help="degrees the camera turns around the world's centre per frame (0 = static camera)")
     ap.add_argument("--dense-dda", action="store_true", help="BASELINE configs[1]: upload the scene as a dense id grid and trace with the dense-grid kernel (N = 1, --n <= 512)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -197,6 +198,7 @@ def main():
         stats = tracer.add_world(packed)                  # world resident in HBM from here on
     tracer.set_beam(args.beam)
     tracer.set_fused(bool(args.fused))
+    tracer.set_tile_ordering(args.tile_ordering)
 
     if args.frames_in_flight <= 0:
         args.frames_in_flight = 3 if world_size <= 2 else 4
@@ -358,7 +360,7 @@ def main():
                        "outputs": "16-B first-hit records (kept on the tracing GPU) + RGBA8 framebuffer on rank 0",
                        "tile_records_gathered_per_frame_and_rank": (pipe.records_gathered / max(1, pipe.frames_done)) if world_size > 1 and args.sparse_gather else None,
                        "tiles_per_rank": pipe.per_rank if world_size > 1 else None,
-                       "camera_orbit_deg_per_frame": args.orbit,
+                       "camera_orbit_deg_per_frame": args.orbit, "tile_ordering_resort_every_n_frames": args.tile_ordering,
                        "frames_in_flight": args.frames_in_flight, "device_ms_per_step": device_ms / args.steps, "kernel_ms_alone": kernel_ms_avg, "beam_tile": args.beam,
                        "poses": poses, "also_measured_paths": paths},
         }

@@ -203,6 +203,99 @@ int prepare_beam(blok_hip_ctx* ctx, blok::RayMode mode, blok::TraceArgs& args, h
     return beam_buffer(ctx, stream, *n_beams, &args.beam);
 }
 
+// Has the view hardly changed?  An order sorted from another view is worse than the natural one (measured: a camera orbiting by
+// 1 degree per frame loses 5 % under an order up to 8 frames old), so an order is used only within ~0.25 degree of the view it
+// was measured in: direction, position as seen from the world's centre, and the same lens.
+static bool camera_near(const blok_hip_ctx* ctx, const blok_camera& a, const blok_camera& b) {
+    const float dot = a.fwd[0] * b.fwd[0] + a.fwd[1] * b.fwd[1] + a.fwd[2] * b.fwd[2];
+    const float half = 0.5f * std::ldexp(1.0f, 2 * static_cast<int>(ctx->stats.levels)) * ctx->world_voxel_size;
+    float d2 = 0.0f, r2 = 0.0f;
+    for (int k = 0; k < 3; ++k) {
+        const float centre = static_cast<float>(ctx->stats.origin[k]) * ctx->world_voxel_size + half;
+        d2 += (a.pos[k] - b.pos[k]) * (a.pos[k] - b.pos[k]);
+        r2 += (a.pos[k] - centre) * (a.pos[k] - centre);
+    }
+    return dot > 0.99999f && d2 <= 1.6e-5f * std::max(r2, 1.0f) && std::fabs(a.tan_half_fov - b.tan_half_fov) < 1e-6f && std::fabs(a.aspect - b.aspect) < 1e-6f;
+}
+
+// Longest-first order for a Rect launch of `blocks` wave tiles (api_internal.h: tile ordering).  Before the launch: buffers for
+// the launch geometry, adoption of a finished sort, args.order / args.cost_out.  After it (order_after_launch): the stream's
+// "last use" event and, every order_interval frames, the next sort on the auxiliary stream.
+int order_before_launch(blok_hip_ctx* ctx, blok::TraceArgs& args, uint32_t blocks, hipStream_t stream) {
+    const uint32_t key[6] = {args.x0, args.y0, args.w, args.h, ctx->width, ctx->height};
+    if (ctx->tile_cost_capacity < blocks || std::memcmp(key, ctx->order_key, sizeof(key)) != 0) {
+        BLOK_HIP_TRY(ctx, hipDeviceSynchronize());                     // frames in flight and a pending sort use the old buffers
+        if (ctx->tile_cost_capacity < blocks) {
+            for (void* p : {static_cast<void*>(ctx->d_tile_cost), static_cast<void*>(ctx->d_tile_iota), static_cast<void*>(ctx->d_order[0]),
+                            static_cast<void*>(ctx->d_order[1]), static_cast<void*>(ctx->d_order_keys), ctx->d_order_temp})
+                if (p) (void)hipFree(p);
+            ctx->d_tile_cost = ctx->d_tile_iota = ctx->d_order[0] = ctx->d_order[1] = ctx->d_order_keys = nullptr; ctx->d_order_temp = nullptr;
+            ctx->tile_cost_capacity = 0;
+            const size_t bytes = static_cast<size_t>(blocks) * sizeof(uint32_t);
+            BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_tile_cost), bytes));
+            BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_tile_iota), bytes));
+            BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_order[0]), bytes));
+            BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_order[1]), bytes));
+            BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_order_keys), bytes));
+            ctx->order_temp_bytes = blok::tile_order_temp_bytes(blocks);
+            BLOK_HIP_TRY(ctx, hipMalloc(&ctx->d_order_temp, ctx->order_temp_bytes ? ctx->order_temp_bytes : 16));
+            ctx->tile_cost_capacity = blocks;
+        }
+        if (!ctx->order_done) BLOK_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->order_done, hipEventDisableTiming));
+        BLOK_HIP_TRY(ctx, blok::launch_iota(ctx->d_tile_iota, blocks, nullptr));
+        BLOK_HIP_TRY(ctx, hipMemset(ctx->d_tile_cost, 0, static_cast<size_t>(blocks) * sizeof(uint32_t)));
+        BLOK_HIP_TRY(ctx, hipDeviceSynchronize());
+        std::memcpy(ctx->order_key, key, sizeof(key));
+        ctx->order_current = -1; ctx->order_pending = false; ctx->frames_since_sort = 0;     // a new geometry starts in natural order
+        ctx->order_still_frames = 0;
+    }
+    if (ctx->order_pending && hipEventQuery(ctx->order_done) == hipSuccess) {              // the sort launched some frames ago has finished
+        ctx->order_current = ctx->order_target;
+        ctx->order_pending = false;
+        ctx->frames_since_sort = 0;
+    }
+    args.order = ctx->order_current >= 0 && camera_near(ctx, args.cam, ctx->order_cam[ctx->order_current]) ? ctx->d_order[ctx->order_current] : nullptr;
+    ctx->order_still_frames = camera_near(ctx, args.cam, ctx->order_last_cam) ? ctx->order_still_frames + 1u : 0u;
+    ctx->order_last_cam = args.cam;
+    args.cost_out = ctx->order_still_frames >= 1u ? ctx->d_tile_cost : nullptr;     // a camera in motion is not measured (nor sorted for)
+
+    // Longest first pays when the launch has the chip to itself (its tail is then idle time: 0.295 -> 0.252 ms for the benchmark
+    // frame).  With frames in flight on other streams the tail is already filled by their waves, and front-loading every frame's
+    // heavy tiles measures 14 % SLOWER (43.9 -> 37.9 Grays/s): such a launch keeps the natural order.
+    ctx->order_busy = false;
+    for (auto& kv : ctx->order_last_use)
+        if (kv.first != stream && hipEventQuery(kv.second) == hipErrorNotReady) { ctx->order_busy = true; break; }
+    (void)hipGetLastError();                               // hipErrorNotReady is an answer, not a failure
+    if (ctx->order_busy) args.order = nullptr;             // (and no sort is started behind this launch: its kernels would only compete)
+    return BLOK_OK;
+}
+
+int order_after_launch(blok_hip_ctx* ctx, const blok::TraceArgs& args, uint32_t blocks, hipStream_t stream) {
+    hipEvent_t& last = ctx->order_last_use[stream];
+    if (!last) BLOK_HIP_TRY(ctx, hipEventCreateWithFlags(&last, hipEventDisableTiming));
+    BLOK_HIP_TRY(ctx, hipEventRecord(last, stream));
+    ctx->frames_since_sort += 1;
+    // sort when there is no order for this view yet (none at all, or the camera has come to rest somewhere else) or the current one
+    // is order_interval frames old — but never for a camera in motion: the order would be stale before it is adopted
+    const bool have = ctx->order_current >= 0 && camera_near(ctx, args.cam, ctx->order_cam[ctx->order_current]);
+    const bool due = !have || ctx->frames_since_sort >= ctx->order_interval;
+    if (!ctx->order_pending && !ctx->order_busy && ctx->order_interval && ctx->order_still_frames >= 1u && args.cost_out && due) {
+        const int target = ctx->order_current == 0 ? 1 : 0;
+        // The sort runs on the LAUNCH stream, behind the frame (a stream of its own would be one HIP stream more than the hardware
+        // queues the three frame streams and the null stream already occupy: measured, that alone costs 18 % of the pipelined
+        // rate).  Nothing still running may read the target buffer: it was last current before the previous adoption, and every
+        // launch since then on every stream is behind that stream's last-use event (all complete: the context is not busy).
+        for (auto& kv : ctx->order_last_use) if (kv.first != stream) BLOK_HIP_TRY(ctx, hipStreamWaitEvent(stream, kv.second, 0));
+        BLOK_HIP_TRY(ctx, blok::launch_tile_order_sort(ctx->d_tile_cost, ctx->d_order_keys, ctx->d_tile_iota, ctx->d_order[target], ctx->d_order_temp,
+                                                       ctx->order_temp_bytes, blocks, stream));
+        BLOK_HIP_TRY(ctx, hipEventRecord(ctx->order_done, stream));
+        ctx->order_target = target;
+        ctx->order_cam[target] = args.cam;
+        ctx->order_pending = true;
+    }
+    return BLOK_OK;
+}
+
 // Rect / Tiles launches run the beam pre-pass first, on the same stream (tiles_of_rank: Tiles only).
 int launch_timed(blok_hip_ctx* ctx, blok::RayMode mode, blok::TraceArgs args, uint32_t blocks, hipStream_t stream,
                  uint32_t tiles_of_rank = 0) {
@@ -216,8 +309,20 @@ int launch_timed(blok_hip_ctx* ctx, blok::RayMode mode, blok::TraceArgs args, ui
     if (one_launch) {
         blok::launch_frame(mode, args, queue, frame_blocks, stream);
     } else {
+        bool ordered = n_beams && ctx->tile_ordering && mode == blok::RayMode::Rect && blocks >= 4096u;     // small launches have no tail worth a sort
+        if (ordered) {
+            // a caller that alternates between rectangles would pay a device synchronisation per change of geometry: after two
+            // changes in quick succession ordering sits out the next 64 eligible launches
+            const uint32_t key[6] = {args.x0, args.y0, args.w, args.h, ctx->width, ctx->height};
+            const bool same = std::memcmp(key, ctx->order_key, sizeof(key)) == 0 && ctx->tile_cost_capacity >= blocks;
+            if (!same && ctx->tile_cost_capacity && ctx->order_streak < 8u) ctx->order_backoff = 64u;
+            if (ctx->order_backoff) { ctx->order_backoff -= 1u; ordered = false; }
+            else ctx->order_streak = same ? ctx->order_streak + 1u : 0u;
+        }
+        if (ordered) { const int rc = order_before_launch(ctx, args, blocks, stream); if (rc != BLOK_OK) return rc; }
         if (n_beams) blok::launch_beam(mode, args, n_beams, stream);
         blok::launch_trace(mode, args, blocks, stream);
+        if (ordered) { const int rc = order_after_launch(ctx, args, blocks, stream); if (rc != BLOK_OK) return rc; }
     }
     BLOK_HIP_TRY(ctx, hipGetLastError());
     if (ctx->timing) { BLOK_HIP_TRY(ctx, hipEventRecord(ctx->ev_end, stream)); ctx->timed = true; }
@@ -301,6 +406,12 @@ void blok_hip_destroy(blok_hip_ctx* ctx) {
     for (auto& kv : ctx->beam_buffers)
         for (void* p : {static_cast<void*>(kv.second.beam), static_cast<void*>(kv.second.ctl), static_cast<void*>(kv.second.entries)})
             if (p) (void)hipFree(p);
+    if (ctx->order_done) (void)hipEventDestroy(ctx->order_done);
+    for (auto& kv : ctx->order_last_use) if (kv.second) (void)hipEventDestroy(kv.second);
+    for (void* p : {static_cast<void*>(ctx->d_order[0]), static_cast<void*>(ctx->d_order[1]), static_cast<void*>(ctx->d_order_keys), ctx->d_order_temp})
+        if (p) (void)hipFree(p);
+    if (ctx->d_tile_cost) (void)hipFree(ctx->d_tile_cost);
+    if (ctx->d_tile_iota) (void)hipFree(ctx->d_tile_iota);
     if (ctx->d_accum) (void)hipFree(ctx->d_accum);
     if (ctx->d_color) (void)hipFree(ctx->d_color);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
@@ -870,6 +981,14 @@ int blok_hip_frame_queue_stalls(blok_hip_ctx* ctx, uint32_t* out_stalled_waves) 
             *out_stalled_waves += n;
         }
     }
+    return BLOK_OK;
+}
+
+int blok_hip_set_tile_ordering(blok_hip_ctx* ctx, int resort_every_n_frames) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    if (resort_every_n_frames < 0) return set_error(ctx, BLOK_ERR_INVALID_ARG, "tile ordering: interval must be >= 0");
+    ctx->tile_ordering = resort_every_n_frames != 0;
+    if (resort_every_n_frames) ctx->order_interval = static_cast<uint32_t>(resort_every_n_frames);
     return BLOK_OK;
 }
 

@@ -21,6 +21,7 @@
 #include "reference_world.h"
 #include "trace_kernels.h"
 #include "dense_kernels.h"
+#include "tile_order.h"
 #include "path_args.h"
 #include "tree.h"
 
@@ -87,6 +88,27 @@ struct blok_hip_ctx {
     // ordered, frames in flight on different streams must not share)
     uint32_t beam_tile = 32;
     uint32_t beam_budget = 0;           // 0 = beam.h's default visit budget
+    // Longest-first scheduling of the walk (tile_order.h; Rect launches of the two-launch form): every wave leaves the clocks it
+    // spent in d_tile_cost (one buffer per context, for the launch geometry in order_key).  Every order_interval frames — and only
+    // while no other stream of the context has frames in flight — a radix sort of those costs follows the frame on its stream: it
+    // writes the order buffer that is NOT in use, and a later launch adopts it once hipEventQuery says it is complete.
+    bool tile_ordering = true;
+    uint32_t order_interval = 8;
+    uint32_t* d_tile_cost = nullptr;
+    uint32_t* d_tile_iota = nullptr;
+    uint32_t* d_order[2] = {nullptr, nullptr};
+    uint32_t* d_order_keys = nullptr;
+    void* d_order_temp = nullptr;
+    size_t order_temp_bytes = 0, tile_cost_capacity = 0;
+    uint32_t order_key[6] = {};
+    int order_current = -1, order_target = 0;     // -1: no order yet (natural)
+    bool order_pending = false, order_busy = false;   // busy: another stream of the context had frames in flight at the last launch
+    uint32_t frames_since_sort = 0;
+    blok_camera order_cam[2] = {}, order_last_cam{};     // camera whose frame's costs each order buffer was sorted from; camera of the last launch
+    uint32_t order_still_frames = 0;                     // consecutive launches whose camera hardly moved
+    uint32_t order_streak = 0, order_backoff = 0;     // launches of the current geometry; launches to skip after geometries alternated
+    hipEvent_t order_done = nullptr;
+    std::unordered_map<hipStream_t, hipEvent_t> order_last_use;     // per launch stream: behind its latest walk
     struct StreamScratch {             // per launch stream
         float* beam = nullptr; size_t n_beam = 0;                       // two-launch form: start parameters per beam tile
         uint32_t* ctl = nullptr; unsigned long long* entries = nullptr; size_t capacity = 0;   // one-launch form: work queue (trace_kernels.h: FrameQueue)

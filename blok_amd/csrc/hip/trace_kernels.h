@@ -100,6 +100,8 @@ struct TraceArgs {
     // beam_kernel and read by the Rect / Tiles trace kernels of the same stream; null = no pre-pass
     float* beam;
     uint32_t beam_tile, beam_bx;           // beam_bx: beam tiles per row of the rectangle (Rect)
+    const uint32_t* order;                 // Rect: workgroup b walks tile order[b] (null = b): longest-first scheduling
+    uint32_t* cost_out;                    // Rect: per tile, the clocks its wave spent (null = not recorded)
     uint32_t beam_budget;                  // node visits a search may spend (0 = kBeamMaxVisits); running out is answered conservatively
 };
 

@@ -56,16 +56,23 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const TraceArgs A) {
         // where this wave's 8x8 pixels start inside the block (wave-uniform)
         const uint32_t wave_x = __builtin_amdgcn_readfirstlane((wave & 1u) * kWaveW), wave_y = __builtin_amdgcn_readfirstlane((wave >> 1) * kWaveH);
         uint32_t x, y;
+        [[maybe_unused]] uint64_t clock0 = 0;      // Rect: the wave's cost (clocks from here to its last record) goes to cost_slot
+        [[maybe_unused]] uint32_t* cost_slot = nullptr;
         float t0 = 0.0f;                           // start parameter of this wave's beam tile (beam.h); kBeamNone: the pre-pass
         size_t out_index;                          // has already written the tile's pixels as misses, nothing left to do
         bool inside;
         if constexpr (MODE == RayMode::Rect) {
             const uint32_t bx_count = (A.w + kTileW - 1u) / kTileW, by_count = (A.h + kTileH - 1u) / kTileH;
             uint32_t bx, by;
-            if (!block_to_tile(blockIdx.x, gridDim.x, bx_count, by_count, bx, by)) return;
+            // longest first: workgroup i walks tile order[i] (the tiles by descending cost of their wave in the previous frame of the
+            // same launch geometry, api.hip); any permutation gives the same frame
+            const uint32_t b = A.order ? A.order[blockIdx.x] : blockIdx.x;
+            if (!block_to_tile(b, gridDim.x, bx_count, by_count, bx, by)) return;
+            if (A.cost_out && tid == 0) clock0 = __builtin_amdgcn_s_memtime();
+            cost_slot = A.cost_out ? A.cost_out + b : nullptr;
             if (A.beam) {
                 t0 = A.beam[((by * kTileH + wave_y) / A.beam_tile) * A.beam_bx + (bx * kTileW + wave_x) / A.beam_tile];
-                if (t0 >= kBeamNone) return;
+                if (t0 >= kBeamNone) { if (cost_slot && tid == 0) *cost_slot = 0u; return; }
             }
             const uint32_t rx = bx * kTileW + lx, ry = by * kTileH + ly;
             inside = rx < A.w && ry < A.h;
@@ -100,6 +107,9 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const TraceArgs A) {
         RayIn r = primary_ray(A, x, y);
         r.tmin = fmaxf(r.tmin, t0);
         trace_one(A, r, stk, sink);
+        if constexpr (MODE == RayMode::Rect) {
+            if (cost_slot && tid == 0) *cost_slot = static_cast<uint32_t>(__builtin_amdgcn_s_memtime() - clock0);
+        }
     }
 }
 

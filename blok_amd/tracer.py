@@ -167,6 +167,12 @@ class HipTracer:
         """draw_frame_rt applies jitter entry (frame mod 16) by itself (default on = PostProcess::Settings::enableTAA)."""
         self._check(self._lib.blok_hip_set_rt_taa_jitter(self._ctx, 1 if enabled else 0))
 
+    def set_tile_ordering(self, resort_every_n_frames):
+        """Longest-first scheduling of the walk from earlier frames' per-wave clocks, re-sorted asynchronously every N frames
+        (default 8; 0 / False = off; True = 8); applied only to launches that have the chip to themselves; never changes a result."""
+        n = 8 if resort_every_n_frames is True else int(resort_every_n_frames or 0)
+        self._check(self._lib.blok_hip_set_tile_ordering(self._ctx, n))
+
     def set_beam_budget(self, max_node_visits: int):
         """Node visits a beam search may spend (0 = default); running out is answered conservatively, never changes a result."""
         self._check(self._lib.blok_hip_set_beam_budget(self._ctx, max_node_visits))

@@ -367,6 +367,42 @@ def test_beam_visit_budget_exhaustion_is_conservative(tracer_cls, scene1024):
     tr.shutdown()
 
 
+def test_tile_ordering_is_pure_scheduling(tracer_cls, scene1024):
+    """Longest-first scheduling (tile_order.hip): the walk's workgroups take their tiles in descending order of the clocks the
+    tiles' waves spent in the previous frame.  Whatever the history — first frame, repeated camera, a camera that jumps between
+    poses (stale costs), rectangles in between (another geometry resets the history), three streams with frames in flight
+    sharing the cost buffer while sorts read it — every frame equals the frame of a context with ordering off."""
+    import torch
+    cm, pw = scene1024
+    Wd, Ht = 3840, 2160
+    a, b = tracer_cls(Wd, Ht).init(), tracer_cls(Wd, Ht).init()
+    b.set_tile_ordering(False)
+    a.add_world(pw); b.add_world(pw)
+    cams = [W.scene_camera(1024, p, Wd, Ht, SEED) for p in (0, 0, 0, 1, 2, 0, 1, 1)]
+    want = {}
+    for k, cam in enumerate(cams):
+        key = cam.tobytes()
+        if key not in want:
+            want[key] = b.draw_frame(cam).reshape(-1)
+        assert records_equal(a.draw_frame(cam).reshape(-1), want[key]).all(), k
+        if k in (2, 5):
+            rect = (512, 256, 2048, 1024)                       # 32768 wave tiles: ordered too, own geometry
+            for _ in range(2):
+                assert records_equal(a.draw_frame(cam, rect).reshape(-1), b.draw_frame(cam, rect).reshape(-1)).all(), k
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    outs = [torch.zeros((Ht * Wd, 4), dtype=torch.int32, device="cuda") for _ in range(3)]
+    ref = {p: torch.from_numpy(want[W.scene_camera(1024, p, Wd, Ht, SEED).tobytes()].view(np.int32).reshape(-1, 4)).cuda() for p in (0, 1)}
+    for k in range(12):
+        pose = (k // 3) % 2
+        cam = W.scene_camera(1024, pose, Wd, Ht, SEED)
+        for j in range(3):
+            a.draw_frame_device(cam, outs[j].data_ptr(), 0, stream=streams[j].cuda_stream)
+        torch.cuda.synchronize()
+        for o in outs:
+            assert torch.equal(o, ref[pose]), k
+    a.shutdown(); b.shutdown()
+
+
 def test_degenerate_cameras_are_refused(tracer_cls, scene64):
     """A camera with a non-finite component or a zero field of view is an argument error (every ray would be NaN and the
     beam pre-pass could cull nothing), not a launch."""
