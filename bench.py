@@ -383,7 +383,10 @@ def main():
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                "kernel": launch, "kernel_ms": kernel_ms_avg,
-                               "timing": "HIP events around single launches, one at a time on an otherwise idle chip",
+                               "timing": "HIP events around single launches, one at a time on an otherwise idle chip (longest-first tile "
+                                         "ordering active there, incl. its radix sort every 8th frame; it switches itself off in the timed "
+                                         "region, where other streams have frames in flight)" if args.tile_ordering and not args.fused and not args.dense_dda else
+                                         "HIP events around single launches, one at a time on an otherwise idle chip",
                                "frac_overlapped": achieved_overlapped / HBM_PEAK_GBS, "achieved_overlapped": achieved_overlapped,
                                "kernel_ms_overlapped": overlapped_ms, "frames_in_flight": args.frames_in_flight,
                                "beam_tile": args.beam, "algorithmic_bytes_per_ray": alg["bytes_per_ray"],
