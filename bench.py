@@ -63,6 +63,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-paths", action="store_true", help="skip the 64-spp path-tracing side measurement")
     ap.add_argument("--no-poses", action="store_true", help="skip the per-pose side measurements (poses A, B, C)")
+    ap.add_argument("--gather-frames", type=int, default=0, help="N > 1: frames per exchange (0: 1 for N <= 2, 4 above)")
     ap.add_argument("--sparse-gather", type=int, default=1, help="N > 1: gather only the tiles the pre-pass did not mark as sky")
     return ap.parse_args()
 
@@ -205,7 +206,7 @@ def main():
     from blok_amd.multi_gpu import FramePipeline, HipBackend
     stream = torch.cuda.current_stream()
     pipe = FramePipeline(HipBackend(tracer, cam), W_, H_, rank, world_size, dist, tile=args.tile, depth=args.frames_in_flight,
-                         sparse=bool(args.sparse_gather))
+                         sparse=bool(args.sparse_gather), batch=args.gather_frames or (1 if world_size <= 2 else 4))
 
     def fence():
         if dist is not None:

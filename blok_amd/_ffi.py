@@ -189,6 +189,14 @@ HIP_SYMBOLS = {
     "blok_hip_set_taa_jitter": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "blok_hip_set_rt_taa_jitter": (C.c_int, [C.c_void_p, C.c_int]),
     "blok_hip_compact_words": (C.c_size_t, [C.c_uint32, C.c_uint32]),
+    "blok_hip_trace_tile_frames_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                    C.c_void_p, C.c_void_p, C.c_void_p]),
+    "blok_hip_untile_frames_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                C.c_void_p, C.c_void_p]),
+    "blok_hip_compact_tile_frames_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
+                                                      C.c_size_t, C.c_void_p]),
+    "blok_hip_scatter_tile_frames_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                      C.c_size_t, C.c_void_p, C.c_void_p]),
     "blok_hip_compact_tiles_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "blok_hip_scatter_tiles_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "blok_hip_frame_queue_stalls": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),

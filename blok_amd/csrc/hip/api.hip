@@ -648,71 +648,120 @@ uint32_t blok_hip_tiles_for_rank(uint32_t width, uint32_t height, uint32_t tile,
     return total > rank ? (total - rank + n_ranks - 1) / n_ranks : 0;
 }
 
-int blok_hip_trace_tiles_device(blok_hip_ctx* ctx, const blok_camera* cam, uint32_t tile, uint32_t rank,
-                                uint32_t n_ranks, void* out_hits_dev, void* out_rgba_dev, void* hip_stream) {
-    int rc = check_trace(ctx, cam);
-    if (rc != BLOK_OK) return rc;
+// Shared by the one-frame and the several-frame entry: n_frames cameras, one beam + trace launch pair.
+static int trace_tile_frames(blok_hip_ctx* ctx, const blok_camera* cams, uint32_t n_frames, uint32_t tile, uint32_t rank, uint32_t n_ranks,
+                             uint32_t frame_stride_tiles, void* out_hits_dev, void* out_rgba_dev, void* hip_stream) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    if (!cams || !n_frames || n_frames > blok::kMaxTileFrames) return set_error(ctx, BLOK_ERR_INVALID_ARG, "1 to 8 cameras per launch");
+    for (uint32_t f = 0; f < n_frames; ++f) { const int rc = check_trace(ctx, cams + f); if (rc != BLOK_OK) return rc; }
     if ((!out_hits_dev && !out_rgba_dev) || tile < 16 || (tile % blok::kTileW) || (tile % blok::kTileH) || (tile & 15u) || !n_ranks || rank >= n_ranks)
         return set_error(ctx, BLOK_ERR_INVALID_ARG, "tile must be a multiple of 16 and rank < n_ranks");
-    blok::TraceArgs a = base_args(ctx, cam);
+    const uint32_t mine = blok_hip_tiles_for_rank(ctx->width, ctx->height, tile, rank, n_ranks);
+    if (n_frames > 1 && frame_stride_tiles < mine) return set_error(ctx, BLOK_ERR_INVALID_ARG, "frame stride is smaller than the rank's tile count");
+    blok::TraceArgs a = base_args(ctx, cams);
     a.tile = tile; a.rank = rank; a.n_ranks = n_ranks;
     a.tiles_x = (ctx->width + tile - 1) / tile;
     a.tiles_total = a.tiles_x * ((ctx->height + tile - 1) / tile);
     a.out = static_cast<blok_hit*>(out_hits_dev);
     a.out_rgba = static_cast<uint32_t*>(out_rgba_dev);
-    const uint32_t mine = blok_hip_tiles_for_rank(ctx->width, ctx->height, tile, rank, n_ranks);
     const uint32_t blocks = mine * (tile / blok::kTileW) * (tile / blok::kTileH);
-    return launch_timed(ctx, blok::RayMode::Tiles, a, blocks, static_cast<hipStream_t>(hip_stream), mine);
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    if (n_frames == 1) return launch_timed(ctx, blok::RayMode::Tiles, a, blocks, stream, mine);
+    if (!blocks) return BLOK_OK;
+    uint32_t n_beams = 0;
+    int rc = prepare_beam(ctx, blok::RayMode::Tiles, a, stream, mine, &n_beams);
+    if (rc != BLOK_OK) return rc;
+    if (n_beams) { rc = beam_buffer(ctx, stream, static_cast<size_t>(n_beams) * n_frames, &a.beam); if (rc != BLOK_OK) return rc; }
+    blok::TileFrames frames{};
+    for (uint32_t f = 0; f < n_frames; ++f) frames.cam[f] = cams[f];
+    frames.n_frames = n_frames; frames.blocks_per_frame = blocks; frames.beams_per_frame = n_beams;
+    frames.frame_stride = static_cast<size_t>(frame_stride_tiles) * tile * tile;
+    if (ctx->timing) BLOK_HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, stream));
+    blok::launch_tile_frames(a, frames, stream);
+    BLOK_HIP_TRY(ctx, hipGetLastError());
+    if (ctx->timing) { BLOK_HIP_TRY(ctx, hipEventRecord(ctx->ev_end, stream)); ctx->timed = true; }
+    return BLOK_OK;
 }
 
-int blok_hip_untile_device(blok_hip_ctx* ctx, const void* gathered_dev, uint32_t elem_bytes, uint32_t tile,
-                           uint32_t n_ranks, uint32_t tiles_per_rank_max, void* out_frame_dev, void* hip_stream) {
+int blok_hip_trace_tiles_device(blok_hip_ctx* ctx, const blok_camera* cam, uint32_t tile, uint32_t rank,
+                                uint32_t n_ranks, void* out_hits_dev, void* out_rgba_dev, void* hip_stream) {
+    return trace_tile_frames(ctx, cam, 1, tile, rank, n_ranks, 0, out_hits_dev, out_rgba_dev, hip_stream);
+}
+
+int blok_hip_trace_tile_frames_device(blok_hip_ctx* ctx, const blok_camera* cams, uint32_t n_frames, uint32_t tile, uint32_t rank,
+                                      uint32_t n_ranks, uint32_t frame_stride_tiles, void* out_hits_dev, void* out_rgba_dev, void* hip_stream) {
+    return trace_tile_frames(ctx, cams, n_frames, tile, rank, n_ranks, frame_stride_tiles, out_hits_dev, out_rgba_dev, hip_stream);
+}
+
+int blok_hip_untile_frames_device(blok_hip_ctx* ctx, const void* gathered_dev, uint32_t elem_bytes, uint32_t tile, uint32_t n_ranks,
+                                  uint32_t tiles_per_rank_max, uint32_t n_frames, uint32_t frame_stride_tiles, void* out_frames_dev, void* hip_stream) {
     if (!ctx) return BLOK_ERR_INVALID_ARG;
-    if (!gathered_dev || !out_frame_dev || !tile || !n_ranks || !tiles_per_rank_max || (elem_bytes != 16 && elem_bytes != 4))
+    if (!gathered_dev || !out_frames_dev || !tile || !n_ranks || !tiles_per_rank_max || !n_frames || (elem_bytes != 16 && elem_bytes != 4))
         return set_error(ctx, BLOK_ERR_INVALID_ARG, "bad untile arguments (elem_bytes must be 16 or 4)");
     BLOK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     blok::UntileArgs u{};
     u.gathered = gathered_dev;
-    u.frame = out_frame_dev;
+    u.frame = out_frames_dev;
     u.elem_bytes = elem_bytes;
     u.frame_w = ctx->width; u.frame_h = ctx->height; u.tile = tile; u.n_ranks = n_ranks;
     u.tiles_per_rank_max = tiles_per_rank_max;
     u.tiles_x = (ctx->width + tile - 1) / tile;
-    blok::launch_untile(u, static_cast<hipStream_t>(hip_stream));
+    u.gathered_frame_stride = static_cast<size_t>(frame_stride_tiles) * tile * tile;
+    blok::launch_untile(u, n_frames, static_cast<hipStream_t>(hip_stream));
     BLOK_HIP_TRY(ctx, hipGetLastError());
     return BLOK_OK;
 }
 
+int blok_hip_untile_device(blok_hip_ctx* ctx, const void* gathered_dev, uint32_t elem_bytes, uint32_t tile,
+                           uint32_t n_ranks, uint32_t tiles_per_rank_max, void* out_frame_dev, void* hip_stream) {
+    return blok_hip_untile_frames_device(ctx, gathered_dev, elem_bytes, tile, n_ranks, tiles_per_rank_max, 1, 0, out_frame_dev, hip_stream);
+}
+
 size_t blok_hip_compact_words(uint32_t tile, uint32_t n_tiles) { return 1u + static_cast<size_t>(n_tiles) * (1u + static_cast<size_t>(tile) * tile); }
+
+int blok_hip_compact_tile_frames_device(blok_hip_ctx* ctx, const void* rgba_tiles_dev, uint32_t tile, uint32_t n_tiles, uint32_t n_frames,
+                                        uint32_t frame_stride_tiles, void* out_words_dev, size_t out_frame_stride_words, void* hip_stream) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    if (!rgba_tiles_dev || !out_words_dev || !tile || !n_frames || (n_frames > 1 && (frame_stride_tiles < n_tiles || out_frame_stride_words < blok_hip_compact_words(tile, n_tiles))))
+        return set_error(ctx, BLOK_ERR_INVALID_ARG, "bad compact arguments");
+    BLOK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    // the count words, one per frame
+    if (n_frames == 1) BLOK_HIP_TRY(ctx, hipMemsetAsync(out_words_dev, 0, sizeof(uint32_t), stream));
+    else BLOK_HIP_TRY(ctx, hipMemset2DAsync(out_words_dev, out_frame_stride_words * sizeof(uint32_t), 0, sizeof(uint32_t), n_frames, stream));
+    blok::CompactArgs a{static_cast<const uint32_t*>(rgba_tiles_dev), static_cast<uint32_t*>(out_words_dev), tile, n_tiles,
+                        static_cast<size_t>(frame_stride_tiles) * tile * tile, out_frame_stride_words};
+    blok::launch_compact_tiles(a, n_frames, stream);
+    BLOK_HIP_TRY(ctx, hipGetLastError());
+    return BLOK_OK;
+}
 
 int blok_hip_compact_tiles_device(blok_hip_ctx* ctx, const void* rgba_tiles_dev, uint32_t tile, uint32_t n_tiles,
                                   void* out_words_dev, void* hip_stream) {
+    return blok_hip_compact_tile_frames_device(ctx, rgba_tiles_dev, tile, n_tiles, 1, 0, out_words_dev, 0, hip_stream);
+}
+
+int blok_hip_scatter_tile_frames_device(blok_hip_ctx* ctx, const void* gathered_dev, uint32_t n_ranks, size_t rank_stride_words, uint32_t tile,
+                                        uint32_t max_records, uint32_t n_frames, size_t frame_stride_words, void* out_frames_rgba_dev, void* hip_stream) {
     if (!ctx) return BLOK_ERR_INVALID_ARG;
-    if (!rgba_tiles_dev || !out_words_dev || !tile) return set_error(ctx, BLOK_ERR_INVALID_ARG, "bad compact arguments");
+    if (!gathered_dev || !out_frames_rgba_dev || !tile || !n_ranks || !n_frames) return set_error(ctx, BLOK_ERR_INVALID_ARG, "bad scatter arguments");
     BLOK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-    BLOK_HIP_TRY(ctx, hipMemsetAsync(out_words_dev, 0, sizeof(uint32_t), stream));          // the count word
-    blok::CompactArgs a{static_cast<const uint32_t*>(rgba_tiles_dev), static_cast<uint32_t*>(out_words_dev), tile, n_tiles};
-    blok::launch_compact_tiles(a, stream);
+    const size_t n_px = static_cast<size_t>(ctx->width) * ctx->height;
+    BLOK_HIP_TRY(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(out_frames_rgba_dev), static_cast<int>(blok::sky_rgba()), n_px * n_frames, stream));   // every tile nobody sent is sky
+    blok::ScatterArgs a{};
+    a.gathered = static_cast<const uint32_t*>(gathered_dev); a.frame = static_cast<uint32_t*>(out_frames_rgba_dev);
+    a.frame_w = ctx->width; a.frame_h = ctx->height; a.tile = tile; a.n_ranks = n_ranks;
+    a.tiles_x = (ctx->width + tile - 1) / tile; a.max_records = max_records; a.rank_stride = rank_stride_words;
+    a.gathered_frame_stride = frame_stride_words;
+    blok::launch_scatter_tiles(a, n_frames, stream);
     BLOK_HIP_TRY(ctx, hipGetLastError());
     return BLOK_OK;
 }
 
 int blok_hip_scatter_tiles_device(blok_hip_ctx* ctx, const void* gathered_dev, uint32_t n_ranks, size_t rank_stride_words,
                                   uint32_t tile, uint32_t max_records, void* out_frame_rgba_dev, void* hip_stream) {
-    if (!ctx) return BLOK_ERR_INVALID_ARG;
-    if (!gathered_dev || !out_frame_rgba_dev || !tile || !n_ranks) return set_error(ctx, BLOK_ERR_INVALID_ARG, "bad scatter arguments");
-    BLOK_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-    const size_t n_px = static_cast<size_t>(ctx->width) * ctx->height;
-    BLOK_HIP_TRY(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(out_frame_rgba_dev), static_cast<int>(blok::sky_rgba()), n_px, stream));   // every tile nobody sent is sky
-    blok::ScatterArgs a{};
-    a.gathered = static_cast<const uint32_t*>(gathered_dev); a.frame = static_cast<uint32_t*>(out_frame_rgba_dev);
-    a.frame_w = ctx->width; a.frame_h = ctx->height; a.tile = tile; a.n_ranks = n_ranks;
-    a.tiles_x = (ctx->width + tile - 1) / tile; a.max_records = max_records; a.rank_stride = rank_stride_words;
-    blok::launch_scatter_tiles(a, stream);
-    BLOK_HIP_TRY(ctx, hipGetLastError());
-    return BLOK_OK;
+    return blok_hip_scatter_tile_frames_device(ctx, gathered_dev, n_ranks, rank_stride_words, tile, max_records, 1, 0, out_frame_rgba_dev, hip_stream);
 }
 
 int blok_hip_trace_rays(blok_hip_ctx* ctx, const blok_ray* rays_host, size_t n, blok_hit* out_hits_host) {

@@ -121,25 +121,40 @@ struct FrameQueue {
     uint32_t chunk;                 // consecutive entries per trace ticket
 };
 
+// Several frames of one rank's tile share in ONE beam + trace launch pair (Tiles mode; multi-GPU).  At N ranks a frame's share is
+// 1/N of a launch whose duration is mostly latency (the pre-pass is one round of waves; the walk ends in a tail of grazing-ray
+// waves), so a rank traces kMaxTileFrames consecutive frames — each with its own camera — as one launch of the single-GPU size.
+constexpr uint32_t kMaxTileFrames = 8;
+struct TileFrames {
+    blok_camera cam[kMaxTileFrames];
+    uint32_t n_frames;
+    uint32_t blocks_per_frame;             // trace workgroups of one frame
+    uint32_t beams_per_frame;              // beam tiles (and floats of TraceArgs::beam) of one frame
+    size_t   frame_stride;                 // records / pixels between consecutive frames in out and out_rgba
+};
+
 struct UntileArgs {
     const void* gathered;
     void* frame;
     uint32_t frame_w, frame_h, tile, n_ranks, tiles_per_rank_max, tiles_x, elem_bytes;
+    size_t gathered_frame_stride;          // elements between consecutive frames (grid y) inside the gathered buffer; output frames are contiguous
 };
 
 struct CompactArgs {                       // rank's dense RGBA8 tiles -> {count, records {local tile index, tile^2 pixels}}
     const uint32_t* tiles;
     uint32_t* out;                         // word 0 = count (zero before the launch)
     uint32_t tile, n_tiles;
+    size_t tiles_frame_stride, out_frame_stride;   // words between consecutive frames (grid y)
 };
 struct ScatterArgs {                       // gathered compact buffers of all ranks -> row-major frame (pre-filled with sky)
     const uint32_t* gathered;
     uint32_t* frame;
     uint32_t frame_w, frame_h, tile, n_ranks, tiles_x, max_records;
     size_t rank_stride;                    // words between the ranks' buffers
+    size_t gathered_frame_stride;          // words between consecutive frames (grid y) inside a rank's buffer; output frames are contiguous
 };
-void launch_compact_tiles(const CompactArgs& args, hipStream_t stream);
-void launch_scatter_tiles(const ScatterArgs& args, hipStream_t stream);
+void launch_compact_tiles(const CompactArgs& args, uint32_t n_frames, hipStream_t stream);
+void launch_scatter_tiles(const ScatterArgs& args, uint32_t n_frames, hipStream_t stream);
 uint32_t sky_rgba();                       // the RGBA8 a miss is shaded with (trace_core.h: kSkyRgba)
 
 struct SunMapArgs {                        // beam.h: prism_far, one wave per texel
@@ -161,7 +176,9 @@ void launch_trace(RayMode mode, const TraceArgs& args, uint32_t n_blocks, hipStr
 // Number of beam tiles of a launch (= floats of TraceArgs::beam) and the pre-pass itself; Rect and Tiles only.
 uint32_t beam_tiles(RayMode mode, const TraceArgs& args, uint32_t tiles_of_rank);
 void launch_beam(RayMode mode, const TraceArgs& args, uint32_t n_beam_tiles, hipStream_t stream);
-void launch_untile(const UntileArgs& args, hipStream_t stream);
+void launch_untile(const UntileArgs& args, uint32_t n_frames, hipStream_t stream);
+// Beam pre-pass (if args.beam) and walk of frames.n_frames frames of the rank's tiles, one launch each (Tiles mode).
+void launch_tile_frames(const TraceArgs& args, const TileFrames& frames, hipStream_t stream);
 // One-launch frame: pre-pass and walk in one persistent grid of n_blocks waves (Rect and Tiles).
 void launch_frame(RayMode mode, const TraceArgs& args, const FrameQueue& queue, uint32_t n_blocks, hipStream_t stream);
 int frame_blocks_per_cu(RayMode mode, const TraceArgs& args);      // resident workgroups per CU for the launch's LDS size (0 on error)

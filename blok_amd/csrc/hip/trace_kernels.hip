@@ -35,14 +35,14 @@ __device__ __forceinline__ bool block_to_tile(uint32_t b, uint32_t grid, uint32_
 #endif
 }
 
+// Workgroup `block` of a launch of `grid` workgroups (the kernels below differ in where the arguments come from).
 template <RayMode MODE>
-__global__ __launch_bounds__(kBlock) void trace_kernel(const TraceArgs A) {
-    extern __shared__ uint4 lds_stack[];       // [levels-1][kBlock]
+__device__ __forceinline__ void trace_block(const TraceArgs& A, const uint32_t block, const uint32_t grid, uint4* lds_stack) {
     const uint32_t tid = threadIdx.x;
     uint4* stk = lds_stack + tid;
 
     if constexpr (MODE == RayMode::Rays) {
-        const uint32_t i = blockIdx.x * kBlock + tid;
+        const uint32_t i = block * kBlock + tid;
         if (i >= A.n_rays) return;
         const blok_ray ray = A.rays[i];
         RayIn r{ray.org[0], ray.org[1], ray.org[2], ray.dir[0], ray.dir[1], ray.dir[2], ray.tmin, ray.tmax};
@@ -66,8 +66,8 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const TraceArgs A) {
             uint32_t bx, by;
             // longest first: workgroup i walks tile order[i] (the tiles by descending cost of their wave in the previous frame of the
             // same launch geometry, api.hip); any permutation gives the same frame
-            const uint32_t b = A.order ? A.order[blockIdx.x] : blockIdx.x;
-            if (!block_to_tile(b, gridDim.x, bx_count, by_count, bx, by)) return;
+            const uint32_t b = A.order ? A.order[block] : block;
+            if (!block_to_tile(b, grid, bx_count, by_count, bx, by)) return;
             if (A.cost_out && tid == 0) clock0 = __builtin_amdgcn_s_memtime();
             cost_slot = A.cost_out ? A.cost_out + b : nullptr;
             if (A.beam) {
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const TraceArgs A) {
         } else {
             const uint32_t per_side = A.tile / kTileW;                  // blocks per tile row
             const uint32_t per_tile = per_side * (A.tile / kTileH);
-            const uint32_t local_tile = blockIdx.x / per_tile, sub = blockIdx.x % per_tile;
+            const uint32_t local_tile = block / per_tile, sub = block % per_tile;
             const uint32_t global_tile = A.rank + local_tile * A.n_ranks;
             const uint32_t tx = global_tile % A.tiles_x, ty = global_tile / A.tiles_x;
             const uint32_t ix = (sub % per_side) * kTileW + lx, iy = (sub / per_side) * kTileH + ly;
@@ -113,10 +113,35 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const TraceArgs A) {
     }
 }
 
+template <RayMode MODE>
+__global__ __launch_bounds__(kBlock) void trace_kernel(const TraceArgs A) {
+    extern __shared__ uint4 lds_stack[];       // [levels-1][kBlock]
+    trace_block<MODE>(A, blockIdx.x, gridDim.x, lds_stack);
+}
+
+// The arguments of frame f of a several-frame launch: its camera, its slice of the outputs and of the beam buffer.
+__device__ __forceinline__ TraceArgs frame_args(const TraceArgs& A, const TileFrames& F, const uint32_t f) {
+    TraceArgs L = A;
+    L.cam = F.cam[f];
+    if (L.out) L.out += f * F.frame_stride;
+    if (L.out_rgba) L.out_rgba += f * F.frame_stride;
+    if (L.beam) L.beam += static_cast<size_t>(f) * F.beams_per_frame;
+    return L;
+}
+
+// TileFrames::n_frames frames of the rank's tiles in one launch: workgroups [f * blocks_per_frame, (f + 1) * blocks_per_frame) are frame f.
+__global__ __launch_bounds__(kBlock) void trace_frames_kernel(const TraceArgs A, const TileFrames F) {
+    extern __shared__ uint4 lds_stack[];
+    const uint32_t f = blockIdx.x / F.blocks_per_frame;
+    if (f >= F.n_frames) return;
+    const TraceArgs L = frame_args(A, F, f);
+    trace_block<RayMode::Tiles>(L, blockIdx.x - f * F.blocks_per_frame, F.blocks_per_frame, lds_stack);
+}
+
 // One wave per beam tile: TraceArgs::beam[tile] = conservative start parameter of the tile's rays, or kBeamNone.
 template <RayMode MODE>
-__global__ __launch_bounds__(64) void beam_kernel(const TraceArgs A, const uint32_t n_beam_tiles) {
-    const uint32_t b = blockIdx.x, lane = threadIdx.x;
+__device__ __forceinline__ void beam_block(const TraceArgs& A, const uint32_t b, const uint32_t n_beam_tiles) {
+    const uint32_t lane = threadIdx.x;
     if (b >= n_beam_tiles) return;
     const uint32_t B = A.beam_tile;
     uint32_t px, py, px_end, py_end;                                   // frame pixels [px, px_end) x [py, py_end)
@@ -148,6 +173,18 @@ __global__ __launch_bounds__(64) void beam_kernel(const TraceArgs A, const uint3
             write_miss(Sink{A.out ? A.out + out_index : nullptr, A.out_rgba ? A.out_rgba + out_index : nullptr});
         }
     }
+}
+
+template <RayMode MODE>
+__global__ __launch_bounds__(64) void beam_kernel(const TraceArgs A, const uint32_t n_beam_tiles) {
+    beam_block<MODE>(A, blockIdx.x, n_beam_tiles);
+}
+
+__global__ __launch_bounds__(64) void beam_frames_kernel(const TraceArgs A, const TileFrames F) {
+    const uint32_t f = blockIdx.x / F.beams_per_frame;
+    if (f >= F.n_frames) return;
+    const TraceArgs L = frame_args(A, F, f);
+    beam_block<RayMode::Tiles>(L, blockIdx.x - f * F.beams_per_frame, F.beams_per_frame);
 }
 
 // ---- one-launch frame: pre-pass and walk in ONE persistent grid ------------------------------------------------------
@@ -399,14 +436,14 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const AccumArgs T) {
 
 template <typename Elem>
 __global__ __launch_bounds__(256) void untile_kernel(const UntileArgs U) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= U.frame_w * U.frame_h) return;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x, n_px = U.frame_w * U.frame_h;
+    if (i >= n_px) return;
     const uint32_t x = i % U.frame_w, y = i / U.frame_w;
     const uint32_t g = (y / U.tile) * U.tiles_x + x / U.tile;
     const uint32_t rank = g % U.n_ranks, local = g / U.n_ranks;
     const size_t src = (static_cast<size_t>(rank) * U.tiles_per_rank_max + local) * U.tile * U.tile +
                        static_cast<size_t>(y % U.tile) * U.tile + (x % U.tile);
-    static_cast<Elem*>(U.frame)[i] = static_cast<const Elem*>(U.gathered)[src];
+    static_cast<Elem*>(U.frame)[static_cast<size_t>(blockIdx.y) * n_px + i] = static_cast<const Elem*>(U.gathered)[blockIdx.y * U.gathered_frame_stride + src];
 }
 
 // ---- sparse framebuffer exchange (multi-GPU): only the tiles with at least one pixel that is not sky travel --------------
@@ -416,28 +453,30 @@ __global__ __launch_bounds__(256) void untile_kernel(const UntileArgs U) {
 __global__ __launch_bounds__(64) void compact_tiles_kernel(const CompactArgs a) {
     const uint32_t b = blockIdx.x, lane = threadIdx.x, px = a.tile * a.tile;
     if (b >= a.n_tiles) return;
-    const uint32_t* src = a.tiles + static_cast<size_t>(b) * px;
+    const uint32_t* src = a.tiles + blockIdx.y * a.tiles_frame_stride + static_cast<size_t>(b) * px;
+    uint32_t* out = a.out + blockIdx.y * a.out_frame_stride;
     bool live = false;
     for (uint32_t i = lane; i < px; i += 64u) live |= src[i] != kSkyRgba;
     if (__ballot(live) == 0ull) return;
     uint32_t slot = 0;
-    if (lane == 0) slot = atomicAdd(a.out, 1u);
+    if (lane == 0) slot = atomicAdd(out, 1u);
     slot = __builtin_amdgcn_readfirstlane(slot);
-    uint32_t* rec = a.out + 1u + static_cast<size_t>(slot) * (1u + px);
+    uint32_t* rec = out + 1u + static_cast<size_t>(slot) * (1u + px);
     if (lane == 0) rec[0] = b;
     for (uint32_t i = lane; i < px; i += 64u) rec[1u + i] = src[i];
 }
 
 __global__ __launch_bounds__(64) void scatter_tiles_kernel(const ScatterArgs a) {
     const uint32_t r = blockIdx.x / a.max_records, j = blockIdx.x % a.max_records, lane = threadIdx.x, px = a.tile * a.tile;
-    const uint32_t* base = a.gathered + static_cast<size_t>(r) * a.rank_stride;
+    const uint32_t* base = a.gathered + static_cast<size_t>(r) * a.rank_stride + blockIdx.y * a.gathered_frame_stride;
+    uint32_t* frame = a.frame + static_cast<size_t>(blockIdx.y) * a.frame_w * a.frame_h;
     if (j >= base[0]) return;
     const uint32_t* rec = base + 1u + static_cast<size_t>(j) * (1u + px);
     const uint32_t g = r + rec[0] * a.n_ranks;
     const uint32_t x0 = (g % a.tiles_x) * a.tile, y0 = (g / a.tiles_x) * a.tile;
     for (uint32_t i = lane; i < px; i += 64u) {
         const uint32_t x = x0 + i % a.tile, y = y0 + i / a.tile;
-        if (x < a.frame_w && y < a.frame_h) a.frame[static_cast<size_t>(y) * a.frame_w + x] = rec[1u + i];
+        if (x < a.frame_w && y < a.frame_h) frame[static_cast<size_t>(y) * a.frame_w + x] = rec[1u + i];
     }
 }
 
@@ -445,13 +484,21 @@ __global__ __launch_bounds__(64) void scatter_tiles_kernel(const ScatterArgs a) 
 
 uint32_t sky_rgba() { return kSkyRgba; }
 
-void launch_compact_tiles(const CompactArgs& args, hipStream_t stream) {
-    if (args.n_tiles) hipLaunchKernelGGL(compact_tiles_kernel, dim3(args.n_tiles), dim3(64), 0, stream, args);
+void launch_compact_tiles(const CompactArgs& args, uint32_t n_frames, hipStream_t stream) {
+    if (args.n_tiles && n_frames) hipLaunchKernelGGL(compact_tiles_kernel, dim3(args.n_tiles, n_frames), dim3(64), 0, stream, args);
 }
 
-void launch_scatter_tiles(const ScatterArgs& args, hipStream_t stream) {
+void launch_scatter_tiles(const ScatterArgs& args, uint32_t n_frames, hipStream_t stream) {
     const uint32_t n = args.n_ranks * args.max_records;
-    if (n) hipLaunchKernelGGL(scatter_tiles_kernel, dim3(n), dim3(64), 0, stream, args);
+    if (n && n_frames) hipLaunchKernelGGL(scatter_tiles_kernel, dim3(n, n_frames), dim3(64), 0, stream, args);
+}
+
+void launch_tile_frames(const TraceArgs& args, const TileFrames& frames, hipStream_t stream) {
+    if (frames.n_frames == 0 || frames.blocks_per_frame == 0) return;
+    const size_t lds = static_cast<size_t>(args.levels > 1 ? args.levels - 1 : 1) * kBlock * sizeof(uint4);
+    if (args.beam && frames.beams_per_frame)
+        hipLaunchKernelGGL(beam_frames_kernel, dim3(frames.n_frames * frames.beams_per_frame), dim3(64), 0, stream, args, frames);
+    hipLaunchKernelGGL(trace_frames_kernel, dim3(frames.n_frames * frames.blocks_per_frame), dim3(kBlock), lds, stream, args, frames);
 }
 
 void launch_trace(RayMode mode, const TraceArgs& args, uint32_t n_blocks, hipStream_t stream) {
@@ -512,10 +559,11 @@ void launch_accumulate(const AccumArgs& args, hipStream_t stream) {
     if (args.n) hipLaunchKernelGGL(accumulate_kernel, dim3((args.n + 255u) / 256u), dim3(256), 0, stream, args);
 }
 
-void launch_untile(const UntileArgs& args, hipStream_t stream) {
+void launch_untile(const UntileArgs& args, uint32_t n_frames, hipStream_t stream) {
     const uint32_t n = args.frame_w * args.frame_h;
-    if (args.elem_bytes == 16) hipLaunchKernelGGL(untile_kernel<uint4>, dim3((n + 255u) / 256u), dim3(256), 0, stream, args);
-    else hipLaunchKernelGGL(untile_kernel<uint32_t>, dim3((n + 255u) / 256u), dim3(256), 0, stream, args);
+    if (!n || !n_frames) return;
+    if (args.elem_bytes == 16) hipLaunchKernelGGL(untile_kernel<uint4>, dim3((n + 255u) / 256u, n_frames), dim3(256), 0, stream, args);
+    else hipLaunchKernelGGL(untile_kernel<uint32_t>, dim3((n + 255u) / 256u, n_frames), dim3(256), 0, stream, args);
 }
 
 }  // namespace blok

@@ -113,6 +113,28 @@ class HipBackend:
     def untile(self, gathered, elem_bytes, tile, n_ranks, per_rank, out, stream):
         self.tracer.untile_device(gathered.data_ptr(), elem_bytes, tile, n_ranks, per_rank, out.data_ptr(), stream=stream)
 
+    # several frames per call (blok_hip.h: BLOK_MAX_TILE_FRAMES); a view is what one frame is traced from: here, its camera
+    max_frames = 8
+
+    def view(self):
+        return self.cam
+
+    def trace_tile_frames(self, views, tile, rank, n_ranks, stride_tiles, hits, rgba, stream):
+        import numpy as np
+        cams = views[0] if len(views) == 1 else np.concatenate([np.asarray(v).reshape(-1) for v in views])
+        self.tracer.draw_tile_frames_device(cams, tile, rank, n_ranks, stride_tiles, hits.data_ptr() if hits is not None else 0,
+                                            rgba.data_ptr() if rgba is not None else 0, stream=stream)
+
+    def untile_frames(self, gathered, elem_bytes, tile, n_ranks, per_rank, n_frames, stride_tiles, out, stream):
+        self.tracer.untile_frames_device(gathered.data_ptr(), elem_bytes, tile, n_ranks, per_rank, n_frames, stride_tiles, out.data_ptr(), stream=stream)
+
+    def compact_frames(self, rgba, tile, n_tiles, n_frames, stride_tiles, out, out_stride_words, stream):
+        self.tracer.compact_tile_frames_device(rgba.data_ptr(), tile, n_tiles, n_frames, stride_tiles, out.data_ptr(), out_stride_words, stream=stream)
+
+    def scatter_frames(self, gathered, n_ranks, rank_stride, tile, max_records, n_frames, frame_stride_words, out, stream):
+        self.tracer.scatter_tile_frames_device(gathered.data_ptr(), n_ranks, rank_stride, tile, max_records, n_frames, frame_stride_words,
+                                               out.data_ptr(), stream=stream)
+
     def compact(self, rgba, tile, n_tiles, out, stream):
         self.tracer.compact_tiles_device(rgba.data_ptr(), tile, n_tiles, out.data_ptr(), stream=stream)
 
@@ -121,44 +143,59 @@ class HipBackend:
 
 
 class FramePipeline:
+    """`depth` slots in flight, each a BATCH of `batch` consecutive frames that are traced by ONE launch pair and share ONE exchange.
+    At N = 8 a rank's share of a frame is 1/8 of a launch pair whose duration is mostly latency (~130 us alone for 26 us of work),
+    and every call and collective costs host time (scripts/host_cost_probe.py on one GPU with a one-rank RCCL group: 76 us of host
+    time per frame for trace + dense gather + un-permute, 145 us for the sparse exchange), so frame by frame the host is the bound.
+    A batch of 8 frames of a rank's eighth is a launch of the single-GPU size.  A step is still one frame (its view — the camera —
+    is taken when step() is called); the launches and the exchange of a batch are issued with its last frame."""
+
     def __init__(self, backend, width: int, height: int, rank: int = 0, world_size: int = 1, dist=None,
-                 tile: int = 32, device="cuda", depth: int = 3, sparse: bool = False):
+                 tile: int = 32, device="cuda", depth: int = 3, sparse: bool = False, partition=None, batch: int = 1):
         import torch
         self.torch = torch
         self.backend, self.width, self.height = backend, width, height
         self.rank, self.world_size, self.dist, self.tile, self.depth = rank, world_size, dist, tile, depth
-        self.sparse = bool(sparse) and world_size > 1
+        # partition=True with world_size 1 and a process group: the whole distributed path (tiles, collectives, assembly) on one rank —
+        # how the RCCL calls get exercised on a one-GPU box (scripts/rccl_smoke.py)
+        self.partitioned = world_size > 1 if partition is None else bool(partition) and dist is not None
+        self.sparse = bool(sparse) and self.partitioned
+        self.batch = min(max(1, int(batch)), getattr(backend, "max_frames", 1 << 30)) if self.partitioned else 1
         self.on_gpu = str(device).startswith("cuda")
         self.streams = [torch.cuda.Stream() for _ in range(depth)] if self.on_gpu else [None] * depth
         self.frames_submitted = 0
         self.frames_done = 0
-        self.in_flight: List[tuple] = []          # (slot, work or None)
-        self.records_gathered = 0                 # sparse: tile records per rank asked for so far (sum of S)
+        self.in_flight: List[tuple] = []          # (slot, frames in the batch, work or None)
+        self.filling = 0                          # frames traced into the batch that is being filled
+        self.records_gathered = 0                 # sparse: tile records per rank asked for so far (sum of S over the frames)
         n_px = width * height
-        # the newest completed frame: frame_rgba (rank 0) and hits (this rank's pixels) point at its slot
+        # the newest completed frame: frame_rgba (rank 0) and hits (this rank's pixels); last_frames: all frames of the batch retired last
         self.frame_rgba = None
         self.hits = None
-        if world_size == 1:
-            self._hits = [torch.zeros((n_px, 4), dtype=torch.int32, device=device) for _ in range(depth)]
-            self._frame = [torch.zeros(n_px, dtype=torch.int32, device=device) for _ in range(depth)]
+        self.last_frames = []
+        F = self.batch
+        if not self.partitioned:
+            self._hits = [torch.zeros((1, n_px, 4), dtype=torch.int32, device=device) for _ in range(depth)]
+            self._frame = [torch.zeros((1, n_px), dtype=torch.int32, device=device) for _ in range(depth)]
             return
         self.per_rank = backend.tiles_for_rank(tile, 0, world_size)          # rank 0 owns the most tiles
         self.mine = backend.tiles_for_rank(tile, rank, world_size)
-        n_tile_px = self.per_rank * tile * tile
+        self.n_tile_px = n_tile_px = self.per_rank * tile * tile
         # zero-initialised: the tile slots a rank does not own (rank counts that do not divide the tiles) are never written
-        self._hits = [torch.zeros((n_tile_px, 4), dtype=torch.int32, device=device) for _ in range(depth)]
-        self.rgba = [torch.zeros(n_tile_px, dtype=torch.int32, device=device) for _ in range(depth)]
+        self._hits = [torch.zeros((F, n_tile_px, 4), dtype=torch.int32, device=device) for _ in range(depth)]
+        self.rgba = [torch.zeros((F, n_tile_px), dtype=torch.int32, device=device) for _ in range(depth)]
         if self.sparse:
             self.words = 1 + self.per_rank * (1 + tile * tile)               # blok_hip_compact_words
-            self.compacted = [torch.zeros(self.words, dtype=torch.int32, device=device) for _ in range(depth)]
-            self.smax = [torch.zeros(1, dtype=torch.int32, device=device) for _ in range(depth)]
-            self.smax_host = [torch.zeros(1, dtype=torch.int32).pin_memory() if self.on_gpu else torch.zeros(1, dtype=torch.int32)
+            self.compacted = [torch.zeros((F, self.words), dtype=torch.int32, device=device) for _ in range(depth)]
+            self.staged = [torch.zeros(F * self.words, dtype=torch.int32, device=device) for _ in range(depth)] if F > 1 else None
+            self.smax = [torch.zeros(F, dtype=torch.int32, device=device) for _ in range(depth)]
+            self.smax_host = [torch.zeros(F, dtype=torch.int32).pin_memory() if self.on_gpu else torch.zeros(F, dtype=torch.int32)
                               for _ in range(depth)]
             self.smax_event = [torch.cuda.Event() if self.on_gpu else None for _ in range(depth)]
         if rank == 0:
-            width_words = self.words if self.sparse else n_tile_px
+            width_words = F * (self.words if self.sparse else n_tile_px)
             self.gathered = [torch.zeros((world_size, width_words), dtype=torch.int32, device=device) for _ in range(depth)]
-            self._frame = [torch.zeros(n_px, dtype=torch.int32, device=device) for _ in range(depth)]
+            self._frame = [torch.zeros((F, n_px), dtype=torch.int32, device=device) for _ in range(depth)]
 
     def _on(self, slot):
         return self.torch.cuda.stream(self.streams[slot]) if self.on_gpu else contextlib.nullcontext()
@@ -166,59 +203,83 @@ class FramePipeline:
     def _handle(self, slot):
         return self.streams[slot].cuda_stream if self.on_gpu else 0
 
-    # one frame: enqueue its trace on the slot's stream, start its exchange, retire frames beyond the depth
+    # one frame: its view joins the batch that is being filled; the last frame of a batch issues the batch
     def step(self):
-        while len(self.in_flight) >= self.depth:
-            self._retire()
-        slot = self.frames_submitted % self.depth
-        with self._on(slot):
-            if self.world_size == 1:
-                self.backend.trace_full(self._hits[slot], self._frame[slot], self._handle(slot))
-                work = None
-            else:
-                self.backend.trace_tiles(self.tile, self.rank, self.world_size, self._hits[slot], self.rgba[slot],
-                                         self._handle(slot))
+        if self.filling == 0:
+            while len(self.in_flight) >= self.depth:
+                self._retire()
+            self._cur = (self.frames_submitted // self.batch) % self.depth
+            self._views = []
+        if not self.partitioned:
+            slot = self._cur
+            with self._on(slot):
+                self.backend.trace_full(self._hits[slot][0], self._frame[slot][0], self._handle(slot))
+        else:
+            self._views.append(self.backend.view())
+        self.filling += 1
+        self.frames_submitted += 1
+        if self.filling == self.batch:
+            self._issue()
+
+    # trace the batch that is being filled (all `filling` frames of it) and start its exchange
+    def _issue(self):
+        slot, n_frames = self._cur, self.filling
+        work = None
+        if self.partitioned:
+            with self._on(slot):
+                h = self._handle(slot)
+                self.backend.trace_tile_frames(self._views, self.tile, self.rank, self.world_size, self.per_rank, self._hits[slot],
+                                               self.rgba[slot], h)
                 if self.sparse:
-                    # compact on the device; the largest record count over the ranks starts its way to every host now
-                    self.backend.compact(self.rgba[slot], self.tile, self.mine, self.compacted[slot], self._handle(slot))
-                    self.smax[slot].copy_(self.compacted[slot][:1])
+                    # compact on the device; the largest record count over the ranks, per frame of the batch, starts its way to every host now
+                    self.backend.compact_frames(self.rgba[slot], self.tile, self.mine, n_frames, self.per_rank, self.compacted[slot], self.words, h)
+                    self.smax[slot][:n_frames].copy_(self.compacted[slot][:n_frames, 0])
                     w = self.dist.all_reduce(self.smax[slot], op=self.dist.ReduceOp.MAX, async_op=True)
                     w.wait()                       # the slot's stream (or the host, on gloo) waits for that reduction only
                     self.smax_host[slot].copy_(self.smax[slot], non_blocking=True)
                     if self.on_gpu:
                         self.smax_event[slot].record()
-                    work = None
                 else:
-                    gather_list = [self.gathered[slot][r] for r in range(self.world_size)] if self.rank == 0 else None
-                    work = self.dist.gather(self.rgba[slot], gather_list=gather_list, dst=0, async_op=True)
-        self.in_flight.append((slot, work))
-        self.frames_submitted += 1
+                    n = n_frames * self.n_tile_px
+                    gather_list = [self.gathered[slot][r][:n] for r in range(self.world_size)] if self.rank == 0 else None
+                    work = self.dist.gather(self.rgba[slot].view(-1)[:n], gather_list=gather_list, dst=0, async_op=True)
+        self.in_flight.append((slot, n_frames, work))
+        self.filling = 0
 
     def _retire(self):
-        slot, work = self.in_flight.pop(0)
+        slot, n_frames, work = self.in_flight.pop(0)
         with self._on(slot):
             if self.sparse:
                 if self.on_gpu:
-                    self.smax_event[slot].synchronize()        # enqueued `depth` frames ago
-                records = int(self.smax_host[slot][0])
-                n = 1 + records * (1 + self.tile * self.tile)  # words: the count and the first `records` records
-                self.records_gathered += records
-                gather_list = [self.gathered[slot][r][:n] for r in range(self.world_size)] if self.rank == 0 else None
-                self.dist.gather(self.compacted[slot][:n], gather_list=gather_list, dst=0)
+                    self.smax_event[slot].synchronize()        # enqueued `depth` batches ago
+                records = int(self.smax_host[slot][:n_frames].max())    # one prefix length for the batch: the exchange is one block
+                n = 1 + records * (1 + self.tile * self.tile)  # words per frame: the count and the first `records` records
+                self.records_gathered += records * n_frames
+                if self.batch == 1:
+                    send = self.compacted[slot][0][:n]
+                else:                                          # the frames' prefixes side by side
+                    send = self.staged[slot][:n_frames * n]
+                    send.view(n_frames, n).copy_(self.compacted[slot][:n_frames, :n])
+                gather_list = [self.gathered[slot][r][:n_frames * n] for r in range(self.world_size)] if self.rank == 0 else None
+                self.dist.gather(send, gather_list=gather_list, dst=0)
                 if self.rank == 0:
-                    self.backend.scatter(self.gathered[slot], self.world_size, self.words, self.tile, records,
-                                         self._frame[slot], self._handle(slot))
+                    self.backend.scatter_frames(self.gathered[slot], self.world_size, self.gathered[slot].shape[1], self.tile, records,
+                                                n_frames, n, self._frame[slot], self._handle(slot))
             elif work is not None:
                 work.wait()                        # the slot's stream (or the host, on gloo) waits for that gather only
                 if self.rank == 0:
-                    self.backend.untile(self.gathered[slot], 4, self.tile, self.world_size, self.per_rank,
-                                        self._frame[slot], self._handle(slot))
-        self.hits = self._hits[slot]
+                    stride_tiles = self.gathered[slot].shape[1] // (self.tile * self.tile)
+                    self.backend.untile_frames(self.gathered[slot], 4, self.tile, self.world_size, stride_tiles, n_frames, self.per_rank,
+                                               self._frame[slot], self._handle(slot))
+        self.hits = self._hits[slot][n_frames - 1]
         if self.rank == 0:
-            self.frame_rgba = self._frame[slot]
-        self.frames_done += 1
+            self.frame_rgba = self._frame[slot][n_frames - 1]
+            self.last_frames = [self._frame[slot][f] for f in range(n_frames)]
+        self.frames_done += n_frames
 
     def flush(self):
+        if self.filling:
+            self._issue()                       # a partial batch at the end
         while self.in_flight:
             self._retire()
         if self.on_gpu:

@@ -284,6 +284,28 @@ class HipTracer:
         self._check(self._lib.blok_hip_scatter_tiles_device(self._ctx, C.c_void_p(gathered_ptr), n_ranks, rank_stride_words, tile, max_records,
                                                             C.c_void_p(out_ptr), C.c_void_p(stream)))
 
+    # several frames per call (blok_hip.h: BLOK_MAX_TILE_FRAMES): cams is an array of 1..8 cameras
+    def draw_tile_frames_device(self, cams: np.ndarray, tile: int, rank: int, n_ranks: int, frame_stride_tiles: int, hits_ptr: int = 0,
+                                rgba_ptr: int = 0, stream: int = 0):
+        cams = np.ascontiguousarray(cams, dtype=CAMERA).reshape(-1)
+        self._check(self._lib.blok_hip_trace_tile_frames_device(self._ctx, _ffi.ptr(cams), len(cams), tile, rank, n_ranks, frame_stride_tiles,
+                                                                C.c_void_p(hits_ptr), C.c_void_p(rgba_ptr), C.c_void_p(stream)))
+
+    def untile_frames_device(self, gathered_ptr: int, elem_bytes: int, tile: int, n_ranks: int, tiles_per_rank_max: int, n_frames: int,
+                             frame_stride_tiles: int, out_ptr: int, stream: int = 0):
+        self._check(self._lib.blok_hip_untile_frames_device(self._ctx, C.c_void_p(gathered_ptr), elem_bytes, tile, n_ranks, tiles_per_rank_max,
+                                                            n_frames, frame_stride_tiles, C.c_void_p(out_ptr), C.c_void_p(stream)))
+
+    def compact_tile_frames_device(self, rgba_tiles_ptr: int, tile: int, n_tiles: int, n_frames: int, frame_stride_tiles: int, out_ptr: int,
+                                   out_frame_stride_words: int, stream: int = 0):
+        self._check(self._lib.blok_hip_compact_tile_frames_device(self._ctx, C.c_void_p(rgba_tiles_ptr), tile, n_tiles, n_frames, frame_stride_tiles,
+                                                                  C.c_void_p(out_ptr), out_frame_stride_words, C.c_void_p(stream)))
+
+    def scatter_tile_frames_device(self, gathered_ptr: int, n_ranks: int, rank_stride_words: int, tile: int, max_records: int, n_frames: int,
+                                   frame_stride_words: int, out_ptr: int, stream: int = 0):
+        self._check(self._lib.blok_hip_scatter_tile_frames_device(self._ctx, C.c_void_p(gathered_ptr), n_ranks, rank_stride_words, tile, max_records,
+                                                                  n_frames, frame_stride_words, C.c_void_p(out_ptr), C.c_void_p(stream)))
+
     def trace_rays(self, rays: np.ndarray) -> np.ndarray:
         rays = np.ascontiguousarray(rays, dtype=RAY)
         hits = np.zeros(len(rays), dtype=HIT)

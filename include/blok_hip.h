@@ -239,6 +239,29 @@ int blok_hip_compact_tiles_device(blok_hip_ctx* ctx, const void* rgba_tiles_dev,
 int blok_hip_scatter_tiles_device(blok_hip_ctx* ctx, const void* gathered_dev, uint32_t n_ranks, size_t rank_stride_words,
                                   uint32_t tile, uint32_t max_records, void* out_frame_rgba_dev, void* hip_stream);
 
+/* Several frames per call (no reference counterpart: the reference issues one traceRaysKHR per frame,
+ * blok/src/renderer_raytracing.cpp:666-685, on one GPU).  At N ranks one frame's share of the tiles is 1/N of a launch whose
+ * duration is mostly latency, and every call and collective costs host time, so a rank traces up to BLOK_MAX_TILE_FRAMES
+ * consecutive frames — cams[0 .. n_frames), one camera each — in ONE beam + trace launch pair and exchanges them together.
+ * Frame f of a buffer starts `frame_stride_tiles` tiles (compact / scatter: `..._stride_words` words) behind frame f - 1;
+ * the root's output frames are contiguous (width*height elements each).  Each call equals n_frames calls of the one-frame
+ * entry above it, bit for bit. */
+#define BLOK_MAX_TILE_FRAMES 8
+int blok_hip_trace_tile_frames_device(blok_hip_ctx* ctx, const blok_camera* cams, uint32_t n_frames,
+                                      uint32_t tile, uint32_t rank, uint32_t n_ranks, uint32_t frame_stride_tiles,
+                                      void* out_hits_dev, void* out_rgba_dev, void* hip_stream);
+/* gathered: rank r's block starts at tile r * tiles_per_rank_max, frame f inside it at tile f * frame_stride_tiles */
+int blok_hip_untile_frames_device(blok_hip_ctx* ctx, const void* gathered_dev, uint32_t elem_bytes, uint32_t tile,
+                                  uint32_t n_ranks, uint32_t tiles_per_rank_max, uint32_t n_frames, uint32_t frame_stride_tiles,
+                                  void* out_frames_dev, void* hip_stream);
+int blok_hip_compact_tile_frames_device(blok_hip_ctx* ctx, const void* rgba_tiles_dev, uint32_t tile, uint32_t n_tiles,
+                                        uint32_t n_frames, uint32_t frame_stride_tiles,
+                                        void* out_words_dev, size_t out_frame_stride_words, void* hip_stream);
+/* gathered: rank r's block starts at word r * rank_stride_words, frame f inside it at word f * frame_stride_words */
+int blok_hip_scatter_tile_frames_device(blok_hip_ctx* ctx, const void* gathered_dev, uint32_t n_ranks, size_t rank_stride_words,
+                                        uint32_t tile, uint32_t max_records, uint32_t n_frames, size_t frame_stride_words,
+                                        void* out_frames_rgba_dev, void* hip_stream);
+
 /* The reference's per-pixel sample / bounce loop and G-buffer: raygen.rgen:167-414 with hit.rchit, miss.rmiss
  * and shadow.rmiss (reference assets/shaders/).  Planes are float4 per pixel of the rectangle, row-major; any
  * pointer may be NULL.  color = (rgb, 1); world_pos = (first-hit position, depth); normal_roughness;

@@ -631,6 +631,75 @@ def test_sparse_tile_exchange_kernels(tracer_cls, scene1024):
     tr.shutdown()
 
 
+def test_several_frames_per_launch_equal_frame_by_frame(tracer_cls, scene1024):
+    """blok_hip_trace_tile_frames_device and the *_frames_device forms of compact / scatter / un-permute (one launch for up to 8
+    frames of a rank's tile share, each frame with its own camera): every frame bit-identical to what the one-frame entries
+    give for its camera — hit records and RGBA8, for rank counts that do and do not divide the tiles, with and without the
+    pre-pass — and the assembled frames equal the single-GPU frames."""
+    import torch
+    from blok_amd import tiles as T
+    cm, pw = scene1024
+    Wd, Ht = 1920, 1080
+    tr = tracer_cls(Wd, Ht).init()
+    tr.add_world(pw)
+    cams = [W.scene_camera(1024, pose, Wd, Ht, SEED) for pose in (0, 1, 2)]
+    centre = 512.0
+    cams += [W.camera_look_at((centre + 900.0 * np.cos(a), 300.0 + 40.0 * k, centre + 900.0 * np.sin(a)), (centre, 60.0, centre), 60.0, Wd, Ht)
+             for k, a in enumerate(np.linspace(0.3, 5.1, 5))]
+    assert len(cams) == 8
+    want = [tr.shade_rgba8(c).reshape(-1) for c in cams]
+    for beam in (32, 0):
+        tr.set_beam(beam)
+        for n_ranks, tile, n_frames in ((8, 32, 8), (3, 64, 5), (2, 32, 2)):
+            per = tr.tiles_for_rank(tile, 0, n_ranks)
+            px = tile * tile
+            words = T.compact_words(tile, per)
+            dense_g = torch.zeros((n_ranks, n_frames, per * px), dtype=torch.int32, device="cuda")
+            sparse_g = torch.zeros((n_ranks, n_frames, words), dtype=torch.int32, device="cuda")
+            most = 0
+            for r in range(n_ranks):
+                mine = tr.tiles_for_rank(tile, r, n_ranks)
+                hits = torch.zeros((n_frames, per * px, 4), dtype=torch.int32, device="cuda")
+                tr.draw_tile_frames_device(np.concatenate(cams[:n_frames]), tile, r, n_ranks, per, hits_ptr=hits.data_ptr(), rgba_ptr=dense_g[r].data_ptr())
+                tr.compact_tile_frames_device(dense_g[r].data_ptr(), tile, mine, n_frames, per, sparse_g[r].data_ptr(), words)
+                one_h = torch.zeros((per * px, 4), dtype=torch.int32, device="cuda")
+                one_c = torch.zeros(per * px, dtype=torch.int32, device="cuda")
+                one_s = torch.zeros(words, dtype=torch.int32, device="cuda")
+                for f in range(n_frames):
+                    tr.draw_tiles_device(cams[f], tile, r, n_ranks, hits_ptr=one_h.data_ptr(), rgba_ptr=one_c.data_ptr())
+                    tr.compact_tiles_device(one_c.data_ptr(), tile, mine, one_s.data_ptr())
+                    torch.cuda.synchronize()
+                    assert torch.equal(hits[f][:mine * px], one_h[:mine * px]), (beam, n_ranks, r, f)
+                    assert torch.equal(dense_g[r, f][:mine * px], one_c[:mine * px]), (beam, n_ranks, r, f)
+                    a, b = sparse_g[r, f].cpu().numpy().view(np.uint32), one_s.cpu().numpy().view(np.uint32)
+                    assert a[0] == b[0]
+                    ra, rb = a[1:1 + a[0] * (1 + px)].reshape(-1, 1 + px), b[1:1 + b[0] * (1 + px)].reshape(-1, 1 + px)
+                    assert (ra[np.argsort(ra[:, 0])] == rb[np.argsort(rb[:, 0])]).all()
+                    most = max(most, int(a[0]))
+            frames = torch.zeros((n_frames, Ht * Wd), dtype=torch.int32, device="cuda")
+            tr.untile_frames_device(dense_g.data_ptr(), 4, tile, n_ranks, n_frames * per, n_frames, per, frames.data_ptr())
+            torch.cuda.synchronize()
+            for f in range(n_frames):
+                assert (frames[f].cpu().numpy().view(np.uint32) == want[f]).all(), ("dense", beam, n_ranks, f)
+            # the sparse exchange: the first `most` records of every frame of every rank, side by side as the gather delivers them
+            n = 1 + most * (1 + px)
+            packed = torch.full((n_ranks, n_frames * words), -1, dtype=torch.int32, device="cuda")
+            packed[:, :n_frames * n].view(n_ranks, n_frames, n).copy_(sparse_g[:, :, :n])
+            frames.zero_()
+            tr.scatter_tile_frames_device(packed.data_ptr(), n_ranks, n_frames * words, tile, most, n_frames, n, frames.data_ptr())
+            torch.cuda.synchronize()
+            for f in range(n_frames):
+                assert (frames[f].cpu().numpy().view(np.uint32) == want[f]).all(), ("sparse", beam, n_ranks, f)
+    tr.set_beam(32)
+    # refused: more frames than one launch takes, a frame stride smaller than the rank's tiles
+    buf = torch.zeros(9 * tr.tiles_for_rank(32, 0, 2) * 1024, dtype=torch.int32, device="cuda")
+    with pytest.raises(Exception):
+        tr.draw_tile_frames_device(np.concatenate(cams + cams[:1]), 32, 0, 2, tr.tiles_for_rank(32, 0, 2), rgba_ptr=buf.data_ptr())
+    with pytest.raises(Exception):
+        tr.draw_tile_frames_device(np.concatenate(cams[:2]), 32, 0, 2, 5, rgba_ptr=buf.data_ptr())
+    tr.shutdown()
+
+
 @pytest.mark.parametrize("vs", [0.5, 2.0, 0.125])
 def test_power_of_two_voxel_sizes(tracer_cls, vs):
     """ChunkManager(chunkSize, voxelSize) with voxelSize != 1 (reference chunk_manager.cpp:19-25): for a power of two every box

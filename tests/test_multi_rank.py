@@ -87,11 +87,35 @@ class _FakeBackend:
         from blok_amd import tiles as T
         return T.tiles_for_rank(self.width, self.height, tile, rank, n)
 
+    def view(self):                      # what a frame is traced from: here, its index
+        self.k += 1
+        return self.k - 1
+
+    def trace_tile_frames(self, views, tile, rank, n, stride_tiles, hits, rgba, stream):
+        for f, v in enumerate(views):
+            self._trace_tiles(v, tile, rank, n, rgba[f])
+
+    def untile_frames(self, gathered, elem_bytes, tile, n, per, n_frames, stride_tiles, out, stream):
+        flat = gathered.view(-1)
+        for f in range(n_frames):
+            self.untile(flat[f * stride_tiles * tile * tile:], elem_bytes, tile, n, per, out[f], stream)
+
+    def compact_frames(self, rgba, tile, n_tiles, n_frames, stride_tiles, out, out_stride_words, stream):
+        for f in range(n_frames):
+            self.compact(rgba[f], tile, n_tiles, out[f], stream)
+
+    def scatter_frames(self, gathered, n, rank_stride, tile, max_records, n_frames, frame_stride_words, out, stream):
+        flat = gathered.view(-1)
+        for f in range(n_frames):
+            self.scatter(flat[f * frame_stride_words:], n, rank_stride, tile, max_records, out[f], stream)
+
     def trace_tiles(self, tile, rank, n, hits, rgba, stream):
+        self._trace_tiles(self.view(), tile, rank, n, rgba)
+
+    def _trace_tiles(self, k, tile, rank, n, rgba):
         import torch
         from blok_amd import tiles as T
-        frame = self.frames[self.k % len(self.frames)]
-        self.k += 1
+        frame = self.frames[k % len(self.frames)]
         out = np.full(len(rgba), -1, dtype=np.int32)
         for j, (x0, y0) in enumerate(T.rank_tile_origins(self.width, self.height, tile, rank, n)):
             block = out[j * tile * tile:(j + 1) * tile * tile].reshape(tile, tile)
@@ -118,7 +142,7 @@ class _FakeBackend:
         out.copy_(torch.from_numpy(frame.view(np.int32).reshape(-1)))
 
 
-def _pipeline_worker(rank, world_size, port, out_dir, sparse=False):
+def _pipeline_worker(rank, world_size, port, out_dir, sparse=False, batch=1):
     sys.path.insert(0, str(ROOT))
     import torch
     import torch.distributed as dist
@@ -146,15 +170,17 @@ def _pipeline_worker(rank, world_size, port, out_dir, sparse=False):
                         if rng.random() < 0.6:
                             f[ty:ty + tile, tx:tx + tile] = sky
     pipe = FramePipeline(_FakeBackend(width, height, frames), width, height, rank, world_size, dist, tile=tile,
-                         device="cpu", depth=2, sparse=sparse)
+                         device="cpu", depth=2, sparse=sparse, batch=batch)
     seen = []
 
     def collect():
-        if rank == 0 and pipe.frames_done > len(seen):        # frame (frames_done - 1) is complete on the root
-            seen.append(pipe.frame_rgba.numpy().reshape(height, width).copy())
+        if rank == 0 and pipe.frames_done > len(seen):        # the frames of the batch retired last are complete on the root
+            seen.extend(f.numpy().reshape(height, width).copy() for f in pipe.last_frames)
     for k in range(5):
         pipe.step()
         collect()
+    if pipe.filling:
+        pipe._issue()                                       # 5 frames in batches of 2: the last batch is partial
     while pipe.in_flight:
         pipe._retire()
         collect()
@@ -181,6 +207,14 @@ def test_frame_pipeline_sparse_gather_two_ranks(tmp_path):
     frame, in order, bit-identical on rank 0, with sky tiles that never travel."""
     import torch.multiprocessing as mp
     mp.spawn(_pipeline_worker, args=(2, _free_port(), str(tmp_path), True), nprocs=2, join=True)
+    assert (tmp_path / "pipe0.txt").read_text() == "1" and (tmp_path / "pipe1.txt").read_text() == "1"
+
+
+@pytest.mark.parametrize("sparse", [False, True])
+def test_frame_pipeline_batched_exchange_two_ranks(tmp_path, sparse):
+    """Two frames per exchange (and a partial last batch): the same frames, in order, bit-identical on rank 0."""
+    import torch.multiprocessing as mp
+    mp.spawn(_pipeline_worker, args=(2, _free_port(), str(tmp_path), sparse, 2), nprocs=2, join=True)
     assert (tmp_path / "pipe0.txt").read_text() == "1" and (tmp_path / "pipe1.txt").read_text() == "1"
 
 
