@@ -30,7 +30,12 @@ namespace blok {
 #define BLOK_BEAM_STOP_LEVEL 1      // finest cells examined = children of a node of this level (1: voxels, 2: 4^3 bricks)
 #endif
 constexpr float kBeamSlack = 0.05f;
-constexpr uint32_t kBeamMaxVisits = 8192u;   // typical searches take 10-60 visits; TraceArgs::beam_budget overrides (tests exhaust it on purpose)
+// Node visits one search may spend; TraceArgs::beam_budget overrides.  Searches average 35 visits on the benchmark frame, but the
+// pre-pass lasts as long as its LONGEST wave (all of them are resident at once): 77 us for a 13 us average.  A search that runs out
+// stops where it is with a valid, less tight answer (the end of beam_search), so the budget trades the pre-pass's tail against the
+// walk's start: measured at 4K over 1024^3 (scripts/beam_budget_sweep.py), launch pair alone / three frames in flight, pose A:
+// unlimited 0.282 / 0.191 ms, 256: 0.263 / 0.190, 128: 0.246 / 0.194, 64: 0.243 / 0.207 — 256 is free, below it the walk pays.
+constexpr uint32_t kBeamMaxVisits = 256u;
 
 struct BeamVec { float x, y, z; };
 
@@ -86,7 +91,7 @@ __device__ __forceinline__ float beam_search(const TraceArgs& A, BeamVec ref, Be
     bool fresh = true;
     uint64_t cand = 0;
     // every wave reaches the exit: the search is a finite tree walk, and a visit budget bounds it even for a frustum whose
-    // planes cull nothing (degenerate inputs): running out is answered with "start at the ray origin", never with "none"
+    // planes cull nothing (degenerate inputs): running out is answered with a lower bound over what is left, never with "none"
     uint32_t budget = A.beam_budget ? A.beam_budget : kBeamMaxVisits;
     for (; budget != 0u; --budget) {
         const uint4 rec = A.nodes[node];
@@ -144,7 +149,35 @@ __device__ __forceinline__ float beam_search(const TraceArgs& A, BeamVec ref, Be
         --level;
         fresh = true;
     }
-    if (budget == 0u) return kClampAtZero ? 0.0f : -kBeamNone;
+    if (budget == 0u) {
+        if constexpr (!kClampAtZero) return -kBeamNone;
+        // Out of visits.  Every filled voxel the search has not seen lies in a cell that is still pending: the node just entered
+        // (fresh), or the candidates left at this level and at every level on the stack.  A cell's `depth` is a lower bound for
+        // everything inside it, so min(best, depth of every pending cell) is a valid — only less tight — answer: the search stops
+        // where it is instead of giving up, which bounds the pre-pass's longest wave (its duration) by the budget.
+        float lb = best;
+        auto take = [&](float d) { lb = d >= 0.0f ? fminf(lb, d) : 0.0f; };          // negative or NaN: start at the ray origin
+        uint32_t l = level;
+        if (fresh) {
+            take(__builtin_fmaf(static_cast<float>(1u << (2u * level)), near4, p4));   // the whole node: its nearest corner
+            l = level + 1u;                                                            // its parent's entry is on the stack
+        }
+        for (; l <= root_level; ++l) {
+            uint64_t pending; float q4;
+            if (l == level) { pending = cand; q4 = p4; }                               // revisited node: what is left of its candidates
+            else {
+                pending = static_cast<uint64_t>(__builtin_amdgcn_readlane(stk_lo, l)) | (static_cast<uint64_t>(__builtin_amdgcn_readlane(stk_hi, l)) << 32);
+                q4 = beam_lane(stk_p4, l);
+            }
+            const float sl = static_cast<float>(1u << (2u * (l - 1u)));
+            const float dl = __builtin_fmaf(sl, near4, __builtin_fmaf(sl, a4, q4));    // this lane's child of that node
+            while (pending) {
+                take(beam_lane(dl, static_cast<uint32_t>(__builtin_ctzll(pending))));
+                pending &= pending - 1u;
+            }
+        }
+        return lb;
+    }
     return best;
 }
 

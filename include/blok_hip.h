@@ -437,9 +437,10 @@ int blok_hip_set_beam(blok_hip_ctx* ctx, uint32_t beam_tile_pixels);
  * (renderer_raytracing.cpp:666-685 leaves scheduling to the driver).  0 = off; N > 0 = re-sort every N frames.
  * Measured (4K over 1024^3, one frame at a time): 0.295 -> 0.252 ms (poses A, C: -14 %; B: -3 %). */
 int blok_hip_set_tile_ordering(blok_hip_ctx* ctx, int resort_every_n_frames);
-/* Node visits one beam search may spend (0 = the default, 8192; typical searches take 10-60).  A search that runs out answers
- * "start at the ray origin", never "none", so the frame is the same whatever the budget (tests/test_gpu_parity.py runs with
- * budgets of 1-7 visits); the knob exists for that test and for worlds whose searches are pathological. */
+/* Node visits one beam search may spend (0 = the default, 256; searches average 35).  A search that runs out answers with the
+ * lower bound over the cells it has not visited yet — valid, only less tight — never "none", so the frame is the same whatever
+ * the budget (tests/test_gpu_parity.py runs with budgets of 1-64 visits against an unlimited search).  The pre-pass lasts as
+ * long as its longest search, so the budget bounds its duration; too small a budget is paid for by the walk (beam.h). */
 int blok_hip_set_beam_budget(blok_hip_ctx* ctx, uint32_t max_node_visits);
 /* TAA jitter of the primary rays of all following frames, in pixels (each within +-0.5; NULL or {0,0} = none, the default and
  * the parity / benchmark contract).  The reference applies its Halton(2,3) - 0.5 sequence through the projection matrix

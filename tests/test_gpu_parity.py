@@ -334,9 +334,10 @@ def test_one_launch_frame_queue_rearms_itself(tracer_cls, scene1024):
 
 
 def test_beam_visit_budget_exhaustion_is_conservative(tracer_cls, scene1024):
-    """A beam search that runs out of its visit budget answers "start at the ray origin" (beam.h), never "none": with budgets
-    of 1, 2, 3, 7 and 20 node visits (typical searches need 10-60, so nearly every tile runs out at the small ones) the 4K
-    frames of all three poses, a rectangle and a rank's tiles are the frames of the default budget, bit for bit."""
+    """A beam search that runs out of its visit budget answers with the lower bound over its pending cells (beam.h), never
+    "none": with the default budget (256) and budgets of 1, 2, 3, 7, 20 and 64 node visits (searches average 35, so nearly
+    every tile runs out at the small ones) the 4K frames of all three poses, a rectangle and a rank's tiles are the frames of
+    an unlimited search, bit for bit."""
     import torch
     cm, pw = scene1024
     Wd, Ht = 3840, 2160
@@ -344,11 +345,11 @@ def test_beam_visit_budget_exhaustion_is_conservative(tracer_cls, scene1024):
     tr.add_world(pw)
     for pose in (0, 1, 2):
         cam = W.scene_camera(1024, pose, Wd, Ht, SEED)
-        tr.set_beam_budget(0)
+        tr.set_beam_budget(1 << 20)
         want = tr.draw_frame(cam).reshape(-1)
         rect = (777, 333, 640, 480)
         want_rect = tr.draw_frame(cam, rect).reshape(-1)
-        for budget in (1, 2, 3, 7, 20):
+        for budget in (0, 1, 2, 3, 7, 20, 64):
             tr.set_beam_budget(budget)
             assert records_equal(tr.draw_frame(cam).reshape(-1), want).all(), (pose, budget)
             assert records_equal(tr.draw_frame(cam, rect).reshape(-1), want_rect).all(), (pose, budget)
@@ -356,7 +357,7 @@ def test_beam_visit_budget_exhaustion_is_conservative(tracer_cls, scene1024):
                 tr.set_fused(fused)
                 assert records_equal(tr.draw_frame(cam).reshape(-1), want).all(), (pose, budget, fused)
     cam = W.scene_camera(1024, 1, Wd, Ht, SEED)
-    tr.set_beam_budget(0)
+    tr.set_beam_budget(1 << 20)
     per = tr.tiles_for_rank(32, 3, 8)
     a = torch.zeros((per * 1024, 4), dtype=torch.int32, device="cuda"); b = torch.zeros_like(a)
     tr.draw_tiles_device(cam, 32, 3, 8, hits_ptr=a.data_ptr())
