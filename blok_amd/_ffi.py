@@ -194,9 +194,9 @@ HIP_SYMBOLS = {
     "blok_hip_untile_frames_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                                 C.c_void_p, C.c_void_p]),
     "blok_hip_compact_tile_frames_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
-                                                      C.c_size_t, C.c_void_p]),
+                                                      C.c_void_p]),
     "blok_hip_scatter_tile_frames_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
-                                                      C.c_size_t, C.c_void_p, C.c_void_p]),
+                                                      C.c_void_p, C.c_void_p, C.c_void_p]),
     "blok_hip_compact_tiles_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "blok_hip_scatter_tiles_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "blok_hip_frame_queue_stalls": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),

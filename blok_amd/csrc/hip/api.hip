@@ -404,7 +404,7 @@ void blok_hip_destroy(blok_hip_ctx* ctx) {
     free_post(ctx);
     if (ctx->has_volume) blok::gpu_volume_destroy(&ctx->volume);
     for (auto& kv : ctx->beam_buffers)
-        for (void* p : {static_cast<void*>(kv.second.beam), static_cast<void*>(kv.second.ctl), static_cast<void*>(kv.second.entries)})
+        for (void* p : {static_cast<void*>(kv.second.beam), static_cast<void*>(kv.second.ctl), static_cast<void*>(kv.second.entries), static_cast<void*>(kv.second.tile_map)})
             if (p) (void)hipFree(p);
     if (ctx->order_done) (void)hipEventDestroy(ctx->order_done);
     for (auto& kv : ctx->order_last_use) if (kv.second) (void)hipEventDestroy(kv.second);
@@ -720,48 +720,56 @@ int blok_hip_untile_device(blok_hip_ctx* ctx, const void* gathered_dev, uint32_t
 size_t blok_hip_compact_words(uint32_t tile, uint32_t n_tiles) { return 1u + static_cast<size_t>(n_tiles) * (1u + static_cast<size_t>(tile) * tile); }
 
 int blok_hip_compact_tile_frames_device(blok_hip_ctx* ctx, const void* rgba_tiles_dev, uint32_t tile, uint32_t n_tiles, uint32_t n_frames,
-                                        uint32_t frame_stride_tiles, void* out_words_dev, size_t out_frame_stride_words, void* hip_stream) {
+                                        uint32_t frame_stride_tiles, void* out_words_dev, void* hip_stream) {
     if (!ctx) return BLOK_ERR_INVALID_ARG;
-    if (!rgba_tiles_dev || !out_words_dev || !tile || !n_frames || (n_frames > 1 && (frame_stride_tiles < n_tiles || out_frame_stride_words < blok_hip_compact_words(tile, n_tiles))))
+    if (!rgba_tiles_dev || !out_words_dev || !tile || !n_frames || (n_frames > 1 && frame_stride_tiles < n_tiles))
         return set_error(ctx, BLOK_ERR_INVALID_ARG, "bad compact arguments");
     BLOK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-    // the count words, one per frame
-    if (n_frames == 1) BLOK_HIP_TRY(ctx, hipMemsetAsync(out_words_dev, 0, sizeof(uint32_t), stream));
-    else BLOK_HIP_TRY(ctx, hipMemset2DAsync(out_words_dev, out_frame_stride_words * sizeof(uint32_t), 0, sizeof(uint32_t), n_frames, stream));
-    blok::CompactArgs a{static_cast<const uint32_t*>(rgba_tiles_dev), static_cast<uint32_t*>(out_words_dev), tile, n_tiles,
-                        static_cast<size_t>(frame_stride_tiles) * tile * tile, out_frame_stride_words};
-    blok::launch_compact_tiles(a, n_frames, stream);
+    BLOK_HIP_TRY(ctx, hipMemsetAsync(out_words_dev, 0, n_frames * sizeof(uint32_t), stream));          // the count words
+    blok::CompactArgs a{static_cast<const uint32_t*>(rgba_tiles_dev), static_cast<uint32_t*>(out_words_dev), tile, n_tiles, n_frames,
+                        static_cast<size_t>(frame_stride_tiles) * tile * tile};
+    blok::launch_compact_tiles(a, stream);
     BLOK_HIP_TRY(ctx, hipGetLastError());
     return BLOK_OK;
 }
 
 int blok_hip_compact_tiles_device(blok_hip_ctx* ctx, const void* rgba_tiles_dev, uint32_t tile, uint32_t n_tiles,
                                   void* out_words_dev, void* hip_stream) {
-    return blok_hip_compact_tile_frames_device(ctx, rgba_tiles_dev, tile, n_tiles, 1, 0, out_words_dev, 0, hip_stream);
+    return blok_hip_compact_tile_frames_device(ctx, rgba_tiles_dev, tile, n_tiles, 1, 0, out_words_dev, hip_stream);
 }
 
 int blok_hip_scatter_tile_frames_device(blok_hip_ctx* ctx, const void* gathered_dev, uint32_t n_ranks, size_t rank_stride_words, uint32_t tile,
-                                        uint32_t max_records, uint32_t n_frames, size_t frame_stride_words, void* out_frames_rgba_dev, void* hip_stream) {
+                                        uint32_t max_records, uint32_t n_frames, void* out_frames_rgba_dev, void* tile_state_dev, void* hip_stream) {
     if (!ctx) return BLOK_ERR_INVALID_ARG;
     if (!gathered_dev || !out_frames_rgba_dev || !tile || !n_ranks || !n_frames) return set_error(ctx, BLOK_ERR_INVALID_ARG, "bad scatter arguments");
     BLOK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-    const size_t n_px = static_cast<size_t>(ctx->width) * ctx->height;
-    BLOK_HIP_TRY(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(out_frames_rgba_dev), static_cast<int>(blok::sky_rgba()), n_px * n_frames, stream));   // every tile nobody sent is sky
     blok::ScatterArgs a{};
     a.gathered = static_cast<const uint32_t*>(gathered_dev); a.frame = static_cast<uint32_t*>(out_frames_rgba_dev);
+    a.tile_state = static_cast<uint8_t*>(tile_state_dev);
     a.frame_w = ctx->width; a.frame_h = ctx->height; a.tile = tile; a.n_ranks = n_ranks;
-    a.tiles_x = (ctx->width + tile - 1) / tile; a.max_records = max_records; a.rank_stride = rank_stride_words;
-    a.gathered_frame_stride = frame_stride_words;
-    blok::launch_scatter_tiles(a, n_frames, stream);
+    a.tiles_x = (ctx->width + tile - 1) / tile; a.tiles_total = a.tiles_x * ((ctx->height + tile - 1) / tile);
+    a.max_records = max_records; a.n_frames = n_frames; a.rank_stride = rank_stride_words;
+    // the stream's tile map: zero when a launch begins and when it ends (the tile kernel puts back what the map kernel set)
+    auto& slot = ctx->beam_buffers[stream];
+    const size_t need = static_cast<size_t>(a.tiles_total) * n_frames;
+    if (slot.n_tile_map < need) {
+        if (slot.tile_map) { BLOK_HIP_TRY(ctx, hipStreamSynchronize(stream)); (void)hipFree(slot.tile_map); }
+        slot.tile_map = nullptr; slot.n_tile_map = 0;
+        BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&slot.tile_map), need * sizeof(uint32_t)));
+        BLOK_HIP_TRY(ctx, hipMemsetAsync(slot.tile_map, 0, need * sizeof(uint32_t), stream));
+        slot.n_tile_map = need;
+    }
+    a.tile_map = slot.tile_map;
+    blok::launch_scatter_tiles(a, stream);
     BLOK_HIP_TRY(ctx, hipGetLastError());
     return BLOK_OK;
 }
 
 int blok_hip_scatter_tiles_device(blok_hip_ctx* ctx, const void* gathered_dev, uint32_t n_ranks, size_t rank_stride_words,
                                   uint32_t tile, uint32_t max_records, void* out_frame_rgba_dev, void* hip_stream) {
-    return blok_hip_scatter_tile_frames_device(ctx, gathered_dev, n_ranks, rank_stride_words, tile, max_records, 1, 0, out_frame_rgba_dev, hip_stream);
+    return blok_hip_scatter_tile_frames_device(ctx, gathered_dev, n_ranks, rank_stride_words, tile, max_records, 1, out_frame_rgba_dev, nullptr, hip_stream);
 }
 
 int blok_hip_trace_rays(blok_hip_ctx* ctx, const blok_ray* rays_host, size_t n, blok_hit* out_hits_host) {

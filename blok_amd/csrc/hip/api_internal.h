@@ -112,6 +112,7 @@ struct blok_hip_ctx {
     struct StreamScratch {             // per launch stream
         float* beam = nullptr; size_t n_beam = 0;                       // two-launch form: start parameters per beam tile
         uint32_t* ctl = nullptr; unsigned long long* entries = nullptr; size_t capacity = 0;   // one-launch form: work queue (trace_kernels.h: FrameQueue)
+        uint32_t* tile_map = nullptr; size_t n_tile_map = 0;            // sparse exchange, root: frame tile -> record (zero between launches)
     };
     std::unordered_map<hipStream_t, StreamScratch> beam_buffers;
     // one-launch frame (frame_kernel): pre-pass and walk in one persistent grid; off (default, faster as measured) = beam_kernel, then trace_kernel

@@ -140,21 +140,25 @@ struct UntileArgs {
     size_t gathered_frame_stride;          // elements between consecutive frames (grid y) inside the gathered buffer; output frames are contiguous
 };
 
-struct CompactArgs {                       // rank's dense RGBA8 tiles -> {count, records {local tile index, tile^2 pixels}}
+// Sparse exchange buffers, for n_frames frames at once: n_frames count words, then the records INTERLEAVED by frame — slot j of
+// frame f at word n_frames + (j * n_frames + f) * (1 + tile^2) — so that the first S slots of every frame are ONE contiguous
+// prefix (what travels); one frame: the count word, then its records.
+struct CompactArgs {                       // rank's dense RGBA8 tiles -> {counts, records {local tile index, tile^2 pixels}}
     const uint32_t* tiles;
-    uint32_t* out;                         // word 0 = count (zero before the launch)
-    uint32_t tile, n_tiles;
-    size_t tiles_frame_stride, out_frame_stride;   // words between consecutive frames (grid y)
+    uint32_t* out;                         // count words zero before the launch
+    uint32_t tile, n_tiles, n_frames;
+    size_t tiles_frame_stride;             // words between consecutive frames (grid y) of the dense tiles
 };
-struct ScatterArgs {                       // gathered compact buffers of all ranks -> row-major frame (pre-filled with sky)
+struct ScatterArgs {                       // gathered compact buffers of all ranks -> row-major frames
     const uint32_t* gathered;
-    uint32_t* frame;
-    uint32_t frame_w, frame_h, tile, n_ranks, tiles_x, max_records;
+    uint32_t* frame;                       // n_frames contiguous frames
+    uint32_t* tile_map;                    // n_frames * tiles_total words, zero before and after: 1 + (rank * max_records + slot) of the record that holds a tile
+    uint8_t* tile_state;                   // optional, n_frames * tiles_total: does the frame buffer's tile hold anything but sky?  Lets sky tiles that stay sky go unwritten
+    uint32_t frame_w, frame_h, tile, n_ranks, tiles_x, tiles_total, max_records, n_frames;
     size_t rank_stride;                    // words between the ranks' buffers
-    size_t gathered_frame_stride;          // words between consecutive frames (grid y) inside a rank's buffer; output frames are contiguous
 };
-void launch_compact_tiles(const CompactArgs& args, uint32_t n_frames, hipStream_t stream);
-void launch_scatter_tiles(const ScatterArgs& args, uint32_t n_frames, hipStream_t stream);
+void launch_compact_tiles(const CompactArgs& args, hipStream_t stream);
+void launch_scatter_tiles(const ScatterArgs& args, hipStream_t stream);      // map kernel, then one wave per frame tile
 uint32_t sky_rgba();                       // the RGBA8 a miss is shaded with (trace_core.h: kSkyRgba)
 
 struct SunMapArgs {                        // beam.h: prism_far, one wave per texel

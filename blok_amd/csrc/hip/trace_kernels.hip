@@ -447,36 +447,57 @@ __global__ __launch_bounds__(256) void untile_kernel(const UntileArgs U) {
 }
 
 // ---- sparse framebuffer exchange (multi-GPU): only the tiles with at least one pixel that is not sky travel --------------
-// No reference counterpart (blok is single-GPU).  compact: one wave per tile of the rank's dense RGBA8 tile
-// buffer; a tile with a non-sky pixel takes the next record {local tile index, tile^2 pixels} behind the count word.
-// scatter (root): one wave per (rank, record slot); records beyond the rank's count exit; the frame was filled with sky before.
+// No reference counterpart (blok is single-GPU).  compact: one wave per (tile of the rank's dense RGBA8 tile
+// buffer, frame); a tile with a non-sky pixel takes the next record slot {local tile index, tile^2 pixels} of its frame
+// (trace_kernels.h: CompactArgs for the layout).  scatter (root): a map kernel notes which record holds which frame tile, then one
+// wave per (frame tile, frame) writes the tile — its record, or sky — so that no pixel is written twice and, with a tile-state
+// array, a sky tile that stays sky is not written at all (the root's assembly is on the critical path of every frame at N ranks).
 __global__ __launch_bounds__(64) void compact_tiles_kernel(const CompactArgs a) {
-    const uint32_t b = blockIdx.x, lane = threadIdx.x, px = a.tile * a.tile;
+    const uint32_t b = blockIdx.x, f = blockIdx.y, lane = threadIdx.x, px = a.tile * a.tile;
     if (b >= a.n_tiles) return;
-    const uint32_t* src = a.tiles + blockIdx.y * a.tiles_frame_stride + static_cast<size_t>(b) * px;
-    uint32_t* out = a.out + blockIdx.y * a.out_frame_stride;
+    const uint32_t* src = a.tiles + f * a.tiles_frame_stride + static_cast<size_t>(b) * px;
     bool live = false;
     for (uint32_t i = lane; i < px; i += 64u) live |= src[i] != kSkyRgba;
     if (__ballot(live) == 0ull) return;
     uint32_t slot = 0;
-    if (lane == 0) slot = atomicAdd(out, 1u);
+    if (lane == 0) slot = atomicAdd(a.out + f, 1u);
     slot = __builtin_amdgcn_readfirstlane(slot);
-    uint32_t* rec = out + 1u + static_cast<size_t>(slot) * (1u + px);
+    uint32_t* rec = a.out + a.n_frames + (static_cast<size_t>(slot) * a.n_frames + f) * (1u + px);
     if (lane == 0) rec[0] = b;
     for (uint32_t i = lane; i < px; i += 64u) rec[1u + i] = src[i];
 }
 
+// root, step 1: one thread per (rank, record slot, frame): which record holds which frame tile
+__global__ __launch_bounds__(64) void scatter_map_kernel(const ScatterArgs a) {
+    const uint32_t i = blockIdx.x * 64u + threadIdx.x, f = blockIdx.y;
+    if (i >= a.n_ranks * a.max_records) return;
+    const uint32_t r = i / a.max_records, j = i % a.max_records;
+    const uint32_t* base = a.gathered + static_cast<size_t>(r) * a.rank_stride;
+    if (j >= base[f]) return;
+    const uint32_t* rec = base + a.n_frames + (static_cast<size_t>(j) * a.n_frames + f) * (1u + a.tile * a.tile);
+    const uint64_t g = r + static_cast<uint64_t>(rec[0]) * a.n_ranks;
+    if (g < a.tiles_total) a.tile_map[static_cast<size_t>(f) * a.tiles_total + g] = i + 1u;
+}
+
+// root, step 2: one wave per (frame tile, frame): the tile's record, or sky; every pixel of the frame is written at most once
 __global__ __launch_bounds__(64) void scatter_tiles_kernel(const ScatterArgs a) {
-    const uint32_t r = blockIdx.x / a.max_records, j = blockIdx.x % a.max_records, lane = threadIdx.x, px = a.tile * a.tile;
-    const uint32_t* base = a.gathered + static_cast<size_t>(r) * a.rank_stride + blockIdx.y * a.gathered_frame_stride;
-    uint32_t* frame = a.frame + static_cast<size_t>(blockIdx.y) * a.frame_w * a.frame_h;
-    if (j >= base[0]) return;
-    const uint32_t* rec = base + 1u + static_cast<size_t>(j) * (1u + px);
-    const uint32_t g = r + rec[0] * a.n_ranks;
+    const uint32_t g = blockIdx.x, f = blockIdx.y, lane = threadIdx.x, px = a.tile * a.tile;
+    const size_t slot = static_cast<size_t>(f) * a.tiles_total + g;
+    const uint32_t m = a.tile_map[slot];                       // all lanes read it before lane 0 puts the word back to 0
+    uint8_t* state = a.tile_state ? a.tile_state + slot : nullptr;
+    const bool was_live = state ? *state != 0 : true;
+    if (m == 0u && !was_live) return;                          // sky before, sky now
+    if (lane == 0) { if (m) a.tile_map[slot] = 0u; if (state) *state = m ? 1 : 0; }
+    uint32_t* frame = a.frame + static_cast<size_t>(f) * a.frame_w * a.frame_h;
     const uint32_t x0 = (g % a.tiles_x) * a.tile, y0 = (g / a.tiles_x) * a.tile;
+    const uint32_t* rec = nullptr;
+    if (m) {
+        const uint32_t r = (m - 1u) / a.max_records, j = (m - 1u) % a.max_records;
+        rec = a.gathered + static_cast<size_t>(r) * a.rank_stride + a.n_frames + (static_cast<size_t>(j) * a.n_frames + f) * (1u + px);
+    }
     for (uint32_t i = lane; i < px; i += 64u) {
         const uint32_t x = x0 + i % a.tile, y = y0 + i / a.tile;
-        if (x < a.frame_w && y < a.frame_h) frame[static_cast<size_t>(y) * a.frame_w + x] = rec[1u + i];
+        if (x < a.frame_w && y < a.frame_h) frame[static_cast<size_t>(y) * a.frame_w + x] = rec ? rec[1u + i] : kSkyRgba;
     }
 }
 
@@ -484,13 +505,15 @@ __global__ __launch_bounds__(64) void scatter_tiles_kernel(const ScatterArgs a) 
 
 uint32_t sky_rgba() { return kSkyRgba; }
 
-void launch_compact_tiles(const CompactArgs& args, uint32_t n_frames, hipStream_t stream) {
-    if (args.n_tiles && n_frames) hipLaunchKernelGGL(compact_tiles_kernel, dim3(args.n_tiles, n_frames), dim3(64), 0, stream, args);
+void launch_compact_tiles(const CompactArgs& args, hipStream_t stream) {
+    if (args.n_tiles && args.n_frames) hipLaunchKernelGGL(compact_tiles_kernel, dim3(args.n_tiles, args.n_frames), dim3(64), 0, stream, args);
 }
 
-void launch_scatter_tiles(const ScatterArgs& args, uint32_t n_frames, hipStream_t stream) {
+void launch_scatter_tiles(const ScatterArgs& args, hipStream_t stream) {
+    if (!args.n_frames || !args.tiles_total) return;
     const uint32_t n = args.n_ranks * args.max_records;
-    if (n && n_frames) hipLaunchKernelGGL(scatter_tiles_kernel, dim3(n, n_frames), dim3(64), 0, stream, args);
+    if (n) hipLaunchKernelGGL(scatter_map_kernel, dim3((n + 63u) / 64u, args.n_frames), dim3(64), 0, stream, args);
+    hipLaunchKernelGGL(scatter_tiles_kernel, dim3(args.tiles_total, args.n_frames), dim3(64), 0, stream, args);
 }
 
 void launch_tile_frames(const TraceArgs& args, const TileFrames& frames, hipStream_t stream) {

@@ -128,12 +128,12 @@ class HipBackend:
     def untile_frames(self, gathered, elem_bytes, tile, n_ranks, per_rank, n_frames, stride_tiles, out, stream):
         self.tracer.untile_frames_device(gathered.data_ptr(), elem_bytes, tile, n_ranks, per_rank, n_frames, stride_tiles, out.data_ptr(), stream=stream)
 
-    def compact_frames(self, rgba, tile, n_tiles, n_frames, stride_tiles, out, out_stride_words, stream):
-        self.tracer.compact_tile_frames_device(rgba.data_ptr(), tile, n_tiles, n_frames, stride_tiles, out.data_ptr(), out_stride_words, stream=stream)
+    def compact_frames(self, rgba, tile, n_tiles, n_frames, stride_tiles, out, stream):
+        self.tracer.compact_tile_frames_device(rgba.data_ptr(), tile, n_tiles, n_frames, stride_tiles, out.data_ptr(), stream=stream)
 
-    def scatter_frames(self, gathered, n_ranks, rank_stride, tile, max_records, n_frames, frame_stride_words, out, stream):
-        self.tracer.scatter_tile_frames_device(gathered.data_ptr(), n_ranks, rank_stride, tile, max_records, n_frames, frame_stride_words,
-                                               out.data_ptr(), stream=stream)
+    def scatter_frames(self, gathered, n_ranks, rank_stride, tile, max_records, n_frames, out, tile_state, stream):
+        self.tracer.scatter_tile_frames_device(gathered.data_ptr(), n_ranks, rank_stride, tile, max_records, n_frames, out.data_ptr(),
+                                               tile_state.data_ptr() if tile_state is not None else 0, stream=stream)
 
     def compact(self, rgba, tile, n_tiles, out, stream):
         self.tracer.compact_tiles_device(rgba.data_ptr(), tile, n_tiles, out.data_ptr(), stream=stream)
@@ -186,8 +186,8 @@ class FramePipeline:
         self.rgba = [torch.zeros((F, n_tile_px), dtype=torch.int32, device=device) for _ in range(depth)]
         if self.sparse:
             self.words = 1 + self.per_rank * (1 + tile * tile)               # blok_hip_compact_words
-            self.compacted = [torch.zeros((F, self.words), dtype=torch.int32, device=device) for _ in range(depth)]
-            self.staged = [torch.zeros(F * self.words, dtype=torch.int32, device=device) for _ in range(depth)] if F > 1 else None
+            # a batch's counts, then its records interleaved by frame, so that what travels is one prefix (blok_hip.h)
+            self.compacted = [torch.zeros(F * self.words, dtype=torch.int32, device=device) for _ in range(depth)]
             self.smax = [torch.zeros(F, dtype=torch.int32, device=device) for _ in range(depth)]
             self.smax_host = [torch.zeros(F, dtype=torch.int32).pin_memory() if self.on_gpu else torch.zeros(F, dtype=torch.int32)
                               for _ in range(depth)]
@@ -195,7 +195,13 @@ class FramePipeline:
         if rank == 0:
             width_words = F * (self.words if self.sparse else n_tile_px)
             self.gathered = [torch.zeros((world_size, width_words), dtype=torch.int32, device=device) for _ in range(depth)]
-            self._frame = [torch.zeros((F, n_px), dtype=torch.int32, device=device) for _ in range(depth)]
+            if self.sparse:
+                # frames start as sky, with an all-zero tile state: the root then writes only tiles that hold, or held, something else
+                from .tiles import SKY_RGBA
+                self._frame = [torch.full((F, n_px), int(SKY_RGBA) - (1 << 32), dtype=torch.int32, device=device) for _ in range(depth)]
+                self.tile_state = [torch.zeros((F, backend.tiles_for_rank(tile, 0, 1)), dtype=torch.uint8, device=device) for _ in range(depth)]
+            else:
+                self._frame = [torch.zeros((F, n_px), dtype=torch.int32, device=device) for _ in range(depth)]
 
     def _on(self, slot):
         return self.torch.cuda.stream(self.streams[slot]) if self.on_gpu else contextlib.nullcontext()
@@ -232,8 +238,8 @@ class FramePipeline:
                                                self.rgba[slot], h)
                 if self.sparse:
                     # compact on the device; the largest record count over the ranks, per frame of the batch, starts its way to every host now
-                    self.backend.compact_frames(self.rgba[slot], self.tile, self.mine, n_frames, self.per_rank, self.compacted[slot], self.words, h)
-                    self.smax[slot][:n_frames].copy_(self.compacted[slot][:n_frames, 0])
+                    self.backend.compact_frames(self.rgba[slot], self.tile, self.mine, n_frames, self.per_rank, self.compacted[slot], h)
+                    self.smax[slot][:n_frames].copy_(self.compacted[slot][:n_frames])
                     w = self.dist.all_reduce(self.smax[slot], op=self.dist.ReduceOp.MAX, async_op=True)
                     w.wait()                       # the slot's stream (or the host, on gloo) waits for that reduction only
                     self.smax_host[slot].copy_(self.smax[slot], non_blocking=True)
@@ -253,18 +259,13 @@ class FramePipeline:
                 if self.on_gpu:
                     self.smax_event[slot].synchronize()        # enqueued `depth` batches ago
                 records = int(self.smax_host[slot][:n_frames].max())    # one prefix length for the batch: the exchange is one block
-                n = 1 + records * (1 + self.tile * self.tile)  # words per frame: the count and the first `records` records
+                n = n_frames * (1 + records * (1 + self.tile * self.tile))   # the counts and the first `records` record slots of every frame
                 self.records_gathered += records * n_frames
-                if self.batch == 1:
-                    send = self.compacted[slot][0][:n]
-                else:                                          # the frames' prefixes side by side
-                    send = self.staged[slot][:n_frames * n]
-                    send.view(n_frames, n).copy_(self.compacted[slot][:n_frames, :n])
-                gather_list = [self.gathered[slot][r][:n_frames * n] for r in range(self.world_size)] if self.rank == 0 else None
-                self.dist.gather(send, gather_list=gather_list, dst=0)
+                gather_list = [self.gathered[slot][r][:n] for r in range(self.world_size)] if self.rank == 0 else None
+                self.dist.gather(self.compacted[slot][:n], gather_list=gather_list, dst=0)
                 if self.rank == 0:
                     self.backend.scatter_frames(self.gathered[slot], self.world_size, self.gathered[slot].shape[1], self.tile, records,
-                                                n_frames, n, self._frame[slot], self._handle(slot))
+                                                n_frames, self._frame[slot], self.tile_state[slot], self._handle(slot))
             elif work is not None:
                 work.wait()                        # the slot's stream (or the host, on gloo) waits for that gather only
                 if self.rank == 0:

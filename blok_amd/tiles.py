@@ -68,3 +68,38 @@ def scatter_tiles(gathered: np.ndarray, n_ranks: int, rank_stride: int, tile: in
             h, w = min(tile, height - y0), min(tile, width - x0)
             frame[y0:y0 + h, x0:x0 + w] = rec[1:].reshape(tile, tile)[:h, :w]
     return frame
+
+
+def compact_tile_frames(rgba_frames: np.ndarray, tile: int, n_tiles: int) -> np.ndarray:
+    """Reference of blok_hip_compact_tile_frames_device: rgba_frames (F, >= n_tiles * tile*tile).  F count words, then the records
+    interleaved by frame: slot j of frame f at word F + (j*F + f) * (1 + tile*tile) (ascending tiles here; the kernel's order is arbitrary)."""
+    frames = np.asarray(rgba_frames).view(np.uint32)
+    F, px = frames.shape[0], tile * tile
+    out = np.zeros(F * compact_words(tile, n_tiles), dtype=np.uint32)
+    for f in range(F):
+        one = compact_tiles(frames[f], tile, n_tiles)
+        out[f] = one[0]
+        for j in range(int(one[0])):
+            at = F + (j * F + f) * (1 + px)
+            out[at:at + 1 + px] = one[1 + j * (1 + px):1 + (j + 1) * (1 + px)]
+    return out
+
+
+def scatter_tile_frames(gathered: np.ndarray, n_ranks: int, rank_stride: int, tile: int, max_records: int, n_frames: int, width: int,
+                        height: int) -> np.ndarray:
+    """Reference of blok_hip_scatter_tile_frames_device: (n_frames, height, width) uint32 frames."""
+    px = tile * tile
+    g = np.asarray(gathered).view(np.uint32).reshape(-1)
+    frames = np.full((n_frames, height, width), SKY_RGBA, dtype=np.uint32)
+    tiles_x = (width + tile - 1) // tile
+    for r in range(n_ranks):
+        base = g[r * rank_stride:]
+        for f in range(n_frames):
+            for j in range(min(int(base[f]), max_records)):
+                at = n_frames + (j * n_frames + f) * (1 + px)
+                rec = base[at:at + 1 + px]
+                gt = r + int(rec[0]) * n_ranks
+                x0, y0 = (gt % tiles_x) * tile, (gt // tiles_x) * tile
+                h, w = min(tile, height - y0), min(tile, width - x0)
+                frames[f, y0:y0 + h, x0:x0 + w] = rec[1:].reshape(tile, tile)[:h, :w]
+    return frames

@@ -297,14 +297,15 @@ class HipTracer:
                                                             n_frames, frame_stride_tiles, C.c_void_p(out_ptr), C.c_void_p(stream)))
 
     def compact_tile_frames_device(self, rgba_tiles_ptr: int, tile: int, n_tiles: int, n_frames: int, frame_stride_tiles: int, out_ptr: int,
-                                   out_frame_stride_words: int, stream: int = 0):
+                                   stream: int = 0):
+        """n_frames frames of dense RGBA8 tiles -> counts + records interleaved by frame (blok_hip.h)."""
         self._check(self._lib.blok_hip_compact_tile_frames_device(self._ctx, C.c_void_p(rgba_tiles_ptr), tile, n_tiles, n_frames, frame_stride_tiles,
-                                                                  C.c_void_p(out_ptr), out_frame_stride_words, C.c_void_p(stream)))
+                                                                  C.c_void_p(out_ptr), C.c_void_p(stream)))
 
     def scatter_tile_frames_device(self, gathered_ptr: int, n_ranks: int, rank_stride_words: int, tile: int, max_records: int, n_frames: int,
-                                   frame_stride_words: int, out_ptr: int, stream: int = 0):
+                                   out_ptr: int, tile_state_ptr: int = 0, stream: int = 0):
         self._check(self._lib.blok_hip_scatter_tile_frames_device(self._ctx, C.c_void_p(gathered_ptr), n_ranks, rank_stride_words, tile, max_records,
-                                                                  n_frames, frame_stride_words, C.c_void_p(out_ptr), C.c_void_p(stream)))
+                                                                  n_frames, C.c_void_p(out_ptr), C.c_void_p(tile_state_ptr), C.c_void_p(stream)))
 
     def trace_rays(self, rays: np.ndarray) -> np.ndarray:
         rays = np.ascontiguousarray(rays, dtype=RAY)

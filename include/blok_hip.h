@@ -230,9 +230,9 @@ int blok_hip_untile_device(blok_hip_ctx* ctx, const void* gathered_dev, uint32_t
  * blok_hip_trace_tiles_device writes it) to  word 0 = number of tiles with at least one non-sky pixel, then one record
  * {local tile index, tile*tile pixels} per such tile, in no particular order; `out_words_dev` holds
  * blok_hip_compact_words(tile, n_tiles) 32-bit words.  A prefix of 1 + S * (1 + tile*tile) words carries the first S records.
- * scatter (on the root): fills the context's width x height RGBA8 frame with the sky colour, then writes the records of every
- * rank's buffer (rank r's buffer starts at word r * rank_stride_words; at most max_records records each are looked at;
- * local tile index j of rank r is frame tile r + j * n_ranks).  Both asynchronous on `hip_stream`. */
+ * scatter (on the root): writes the context's width x height RGBA8 frame: the tiles the ranks' records hold (rank r's buffer
+ * starts at word r * rank_stride_words; at most max_records records each are looked at; local tile index j of rank r is frame
+ * tile r + j * n_ranks) and the sky colour everywhere else.  Both asynchronous on `hip_stream`. */
 size_t blok_hip_compact_words(uint32_t tile, uint32_t n_tiles);
 int blok_hip_compact_tiles_device(blok_hip_ctx* ctx, const void* rgba_tiles_dev, uint32_t tile, uint32_t n_tiles,
                                   void* out_words_dev, void* hip_stream);
@@ -243,8 +243,8 @@ int blok_hip_scatter_tiles_device(blok_hip_ctx* ctx, const void* gathered_dev, u
  * blok/src/renderer_raytracing.cpp:666-685, on one GPU).  At N ranks one frame's share of the tiles is 1/N of a launch whose
  * duration is mostly latency, and every call and collective costs host time, so a rank traces up to BLOK_MAX_TILE_FRAMES
  * consecutive frames — cams[0 .. n_frames), one camera each — in ONE beam + trace launch pair and exchanges them together.
- * Frame f of a buffer starts `frame_stride_tiles` tiles (compact / scatter: `..._stride_words` words) behind frame f - 1;
- * the root's output frames are contiguous (width*height elements each).  Each call equals n_frames calls of the one-frame
+ * Frame f of a dense tile buffer starts `frame_stride_tiles` tiles behind frame f - 1; the root's output frames are contiguous
+ * (width*height elements each).  Each call equals n_frames calls of the one-frame
  * entry above it, bit for bit. */
 #define BLOK_MAX_TILE_FRAMES 8
 int blok_hip_trace_tile_frames_device(blok_hip_ctx* ctx, const blok_camera* cams, uint32_t n_frames,
@@ -254,13 +254,20 @@ int blok_hip_trace_tile_frames_device(blok_hip_ctx* ctx, const blok_camera* cams
 int blok_hip_untile_frames_device(blok_hip_ctx* ctx, const void* gathered_dev, uint32_t elem_bytes, uint32_t tile,
                                   uint32_t n_ranks, uint32_t tiles_per_rank_max, uint32_t n_frames, uint32_t frame_stride_tiles,
                                   void* out_frames_dev, void* hip_stream);
+/* Sparse exchange of n_frames frames.  compact: `out_words_dev` holds n_frames * blok_hip_compact_words(tile, n_tiles) words:
+ * n_frames count words, then the records INTERLEAVED by frame — record slot j of frame f at word
+ * n_frames + (j * n_frames + f) * (1 + tile*tile) — so that the first S slots of all frames are one contiguous prefix of
+ * n_frames * (1 + S * (1 + tile*tile)) words: what travels (n_frames = 1 is the one-frame layout above).
+ * scatter (root): rank r's prefix starts at word r * rank_stride_words; writes n_frames contiguous width*height RGBA8 frames: a
+ * tile some record holds gets its pixels, every other tile the sky colour, no pixel is written twice.  tile_state_dev (optional):
+ * n_frames * ceil(width/tile) * ceil(height/tile) bytes that belong to `out_frames_rgba_dev` — zero while the buffer is all sky —
+ * in which the call keeps "this tile of this frame buffer holds something other than sky"; with it a sky tile that stays sky is
+ * not written at all (the root's assembly is on every frame's critical path).  NULL: every tile is written. */
 int blok_hip_compact_tile_frames_device(blok_hip_ctx* ctx, const void* rgba_tiles_dev, uint32_t tile, uint32_t n_tiles,
-                                        uint32_t n_frames, uint32_t frame_stride_tiles,
-                                        void* out_words_dev, size_t out_frame_stride_words, void* hip_stream);
-/* gathered: rank r's block starts at word r * rank_stride_words, frame f inside it at word f * frame_stride_words */
+                                        uint32_t n_frames, uint32_t frame_stride_tiles, void* out_words_dev, void* hip_stream);
 int blok_hip_scatter_tile_frames_device(blok_hip_ctx* ctx, const void* gathered_dev, uint32_t n_ranks, size_t rank_stride_words,
-                                        uint32_t tile, uint32_t max_records, uint32_t n_frames, size_t frame_stride_words,
-                                        void* out_frames_rgba_dev, void* hip_stream);
+                                        uint32_t tile, uint32_t max_records, uint32_t n_frames,
+                                        void* out_frames_rgba_dev, void* tile_state_dev, void* hip_stream);
 
 /* The reference's per-pixel sample / bounce loop and G-buffer: raygen.rgen:167-414 with hit.rchit, miss.rmiss
  * and shadow.rmiss (reference assets/shaders/).  Planes are float4 per pixel of the rectangle, row-major; any

@@ -34,7 +34,7 @@ def timed(name, fn, sync_every=30):
 h = s.cuda_stream
 timed("trace_tiles (beam + trace launches)", lambda: b.trace_tiles(32, 0, 1, pipe._hits[0][0], pipe.rgba[0][0], h))
 timed("trace_full", lambda: b.trace_full(pipe._hits[0][0], pipe.rgba[0][0], h))
-timed("compact", lambda: b.compact(pipe.rgba[0][0], 32, pipe.mine, pipe.compacted[0][0], h))
+timed("compact", lambda: b.compact(pipe.rgba[0][0], 32, pipe.mine, pipe.compacted[0], h))
 def ctx():
     with torch.cuda.stream(s):
         pass
@@ -51,7 +51,7 @@ def allred():
 timed("dist.all_reduce MAX of one int", allred)
 def smax_copy():
     with torch.cuda.stream(s):
-        pipe.smax[0].zero_(); pipe.smax[0][:1].copy_(pipe.compacted[0][:1, 0]); pipe.smax_host[0].copy_(pipe.smax[0], non_blocking=True); pipe.smax_event[0].record()
+        pipe.smax[0][:1].copy_(pipe.compacted[0][:1]); pipe.smax_host[0].copy_(pipe.smax[0], non_blocking=True); pipe.smax_event[0].record()
 timed("smax zero + copy + D2H + event", smax_copy)
 timed("untile", lambda: b.untile(pipe.gathered[0].view(-1), 4, 32, 1, pipe.per_rank, pipe._frame[0][0], h))
 timed("scatter", lambda: b.scatter(pipe.gathered[0].view(-1), 1, pipe.gathered[0].shape[1], 32, 409, pipe._frame[0][0], h))

@@ -656,41 +656,65 @@ def test_several_frames_per_launch_equal_frame_by_frame(tracer_cls, scene1024):
             px = tile * tile
             words = T.compact_words(tile, per)
             dense_g = torch.zeros((n_ranks, n_frames, per * px), dtype=torch.int32, device="cuda")
-            sparse_g = torch.zeros((n_ranks, n_frames, words), dtype=torch.int32, device="cuda")
+            sparse_g = torch.zeros((n_ranks, n_frames * words), dtype=torch.int32, device="cuda")
             most = 0
             for r in range(n_ranks):
                 mine = tr.tiles_for_rank(tile, r, n_ranks)
                 hits = torch.zeros((n_frames, per * px, 4), dtype=torch.int32, device="cuda")
                 tr.draw_tile_frames_device(np.concatenate(cams[:n_frames]), tile, r, n_ranks, per, hits_ptr=hits.data_ptr(), rgba_ptr=dense_g[r].data_ptr())
-                tr.compact_tile_frames_device(dense_g[r].data_ptr(), tile, mine, n_frames, per, sparse_g[r].data_ptr(), words)
+                tr.compact_tile_frames_device(dense_g[r].data_ptr(), tile, mine, n_frames, per, sparse_g[r].data_ptr())
                 one_h = torch.zeros((per * px, 4), dtype=torch.int32, device="cuda")
                 one_c = torch.zeros(per * px, dtype=torch.int32, device="cuda")
                 one_s = torch.zeros(words, dtype=torch.int32, device="cuda")
+                torch.cuda.synchronize()
+                a = sparse_g[r].cpu().numpy().view(np.uint32)
+                ref = T.compact_tile_frames(dense_g[r].cpu().numpy(), tile, mine)
+                assert (a[:n_frames] == ref[:n_frames]).all()
                 for f in range(n_frames):
                     tr.draw_tiles_device(cams[f], tile, r, n_ranks, hits_ptr=one_h.data_ptr(), rgba_ptr=one_c.data_ptr())
                     tr.compact_tiles_device(one_c.data_ptr(), tile, mine, one_s.data_ptr())
                     torch.cuda.synchronize()
                     assert torch.equal(hits[f][:mine * px], one_h[:mine * px]), (beam, n_ranks, r, f)
                     assert torch.equal(dense_g[r, f][:mine * px], one_c[:mine * px]), (beam, n_ranks, r, f)
-                    a, b = sparse_g[r, f].cpu().numpy().view(np.uint32), one_s.cpu().numpy().view(np.uint32)
-                    assert a[0] == b[0]
-                    ra, rb = a[1:1 + a[0] * (1 + px)].reshape(-1, 1 + px), b[1:1 + b[0] * (1 + px)].reshape(-1, 1 + px)
+                    b = one_s.cpu().numpy().view(np.uint32)
+                    assert a[f] == b[0]
+                    # frame f's records sit at slots j * n_frames + f of the interleaved buffer
+                    ra = a[n_frames:n_frames + int(a[:n_frames].max()) * n_frames * (1 + px)].reshape(-1, n_frames, 1 + px)[:a[f], f]
+                    rb = b[1:1 + b[0] * (1 + px)].reshape(-1, 1 + px)
                     assert (ra[np.argsort(ra[:, 0])] == rb[np.argsort(rb[:, 0])]).all()
-                    most = max(most, int(a[0]))
+                    most = max(most, int(a[f]))
             frames = torch.zeros((n_frames, Ht * Wd), dtype=torch.int32, device="cuda")
             tr.untile_frames_device(dense_g.data_ptr(), 4, tile, n_ranks, n_frames * per, n_frames, per, frames.data_ptr())
             torch.cuda.synchronize()
             for f in range(n_frames):
                 assert (frames[f].cpu().numpy().view(np.uint32) == want[f]).all(), ("dense", beam, n_ranks, f)
-            # the sparse exchange: the first `most` records of every frame of every rank, side by side as the gather delivers them
-            n = 1 + most * (1 + px)
+            # the sparse exchange: the first `most` record slots of every frame of every rank = ONE prefix per rank, as the gather delivers it
+            n = n_frames * (1 + most * (1 + px))
             packed = torch.full((n_ranks, n_frames * words), -1, dtype=torch.int32, device="cuda")
-            packed[:, :n_frames * n].view(n_ranks, n_frames, n).copy_(sparse_g[:, :, :n])
-            frames.zero_()
-            tr.scatter_tile_frames_device(packed.data_ptr(), n_ranks, n_frames * words, tile, most, n_frames, n, frames.data_ptr())
+            packed[:, :n].copy_(sparse_g[:, :n])
+            frames.fill_(12345)                          # without a tile state every pixel is written
+            tr.scatter_tile_frames_device(packed.data_ptr(), n_ranks, n_frames * words, tile, most, n_frames, frames.data_ptr())
             torch.cuda.synchronize()
             for f in range(n_frames):
                 assert (frames[f].cpu().numpy().view(np.uint32) == want[f]).all(), ("sparse", beam, n_ranks, f)
+                assert (T.scatter_tile_frames(packed.cpu().numpy(), n_ranks, n_frames * words, tile, most, n_frames, Wd, Ht)[f].reshape(-1) == want[f]).all()
+            # with a tile state (buffer all sky, state all zero to begin with): the frames, then no records at all (every live tile
+            # goes back to sky), then the frames again, then the frames in another order (live <-> sky per tile)
+            sky = int(T.SKY_RGBA) - (1 << 32)
+            frames.fill_(sky)
+            state = torch.zeros((n_frames, T.tiles_total(Wd, Ht, tile)), dtype=torch.uint8, device="cuda")
+            empty = torch.zeros_like(packed)
+            back = torch.full_like(packed, -1)           # frame f <- frame n_frames - 1 - f
+            bw = back[:, :n]; sw = sparse_g[:, :n]
+            bw[:, :n_frames] = sw[:, :n_frames].flip(1)
+            bw[:, n_frames:].view(n_ranks, most, n_frames, 1 + px).copy_(sw[:, n_frames:].view(n_ranks, most, n_frames, 1 + px).flip(2))
+            for step, (buf, order) in enumerate(((packed, 1), (empty, 0), (packed, 1), (back, -1), (packed, 1))):
+                tr.scatter_tile_frames_device(buf.data_ptr(), n_ranks, n_frames * words, tile, most, n_frames, frames.data_ptr(), state.data_ptr())
+                torch.cuda.synchronize()
+                for f in range(n_frames):
+                    got = frames[f].cpu().numpy().view(np.uint32)
+                    expect = want[f] if order == 1 else want[n_frames - 1 - f] if order == -1 else np.uint32(T.SKY_RGBA)
+                    assert (got == expect).all(), ("state", step, beam, n_ranks, f)
     tr.set_beam(32)
     # refused: more frames than one launch takes, a frame stride smaller than the rank's tiles
     buf = torch.zeros(9 * tr.tiles_for_rank(32, 0, 2) * 1024, dtype=torch.int32, device="cuda")

@@ -100,14 +100,17 @@ class _FakeBackend:
         for f in range(n_frames):
             self.untile(flat[f * stride_tiles * tile * tile:], elem_bytes, tile, n, per, out[f], stream)
 
-    def compact_frames(self, rgba, tile, n_tiles, n_frames, stride_tiles, out, out_stride_words, stream):
-        for f in range(n_frames):
-            self.compact(rgba[f], tile, n_tiles, out[f], stream)
+    def compact_frames(self, rgba, tile, n_tiles, n_frames, stride_tiles, out, stream):
+        import torch
+        from blok_amd import tiles as T
+        words = T.compact_tile_frames(rgba[:n_frames].numpy(), tile, n_tiles)
+        out[:len(words)].copy_(torch.from_numpy(words.view(np.int32)))
 
-    def scatter_frames(self, gathered, n, rank_stride, tile, max_records, n_frames, frame_stride_words, out, stream):
-        flat = gathered.view(-1)
-        for f in range(n_frames):
-            self.scatter(flat[f * frame_stride_words:], n, rank_stride, tile, max_records, out[f], stream)
+    def scatter_frames(self, gathered, n, rank_stride, tile, max_records, n_frames, out, tile_state, stream):
+        import torch
+        from blok_amd import tiles as T
+        frames = T.scatter_tile_frames(gathered.numpy().reshape(-1), n, rank_stride, tile, max_records, n_frames, self.width, self.height)
+        out[:n_frames].copy_(torch.from_numpy(frames.view(np.int32).reshape(n_frames, -1)))
 
     def trace_tiles(self, tile, rank, n, hits, rgba, stream):
         self._trace_tiles(self.view(), tile, rank, n, rgba)
