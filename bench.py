@@ -64,7 +64,8 @@ def parse():
     ap.add_argument("--no-paths", action="store_true", help="skip the 64-spp path-tracing side measurement")
     ap.add_argument("--no-poses", action="store_true", help="skip the per-pose side measurements (poses A, B, C)")
     ap.add_argument("--gather-frames", type=int, default=0, help="N > 1: consecutive frames a rank traces in one launch pair and exchanges in one collective (0 = N, at most 8: every launch pair then has the size of a single-GPU frame)")
-    ap.add_argument("--sparse-gather", type=int, default=1, help="N > 1: gather only the tiles the pre-pass did not mark as sky")
+    ap.add_argument("--sparse-gather", type=int, default=2, help="N > 1: 0 = dense RGBA8 gather + un-permute; 1 = only the tiles with a non-sky pixel travel, as RGBA8; "
+                    "2 = those tiles as 16-bit (material, face) codes that the root expands with the material table (half the bytes; falls back to 1 for very large tables)")
     return ap.parse_args()
 
 
@@ -206,7 +207,7 @@ def main():
     from blok_amd.multi_gpu import FramePipeline, HipBackend
     stream = torch.cuda.current_stream()
     pipe = FramePipeline(HipBackend(tracer, cam), W_, H_, rank, world_size, dist, tile=args.tile, depth=args.frames_in_flight,
-                         sparse=bool(args.sparse_gather), batch=args.gather_frames or min(8, world_size))
+                         sparse=args.sparse_gather, batch=args.gather_frames or min(8, world_size))
 
     def fence():
         if dist is not None:
@@ -356,7 +357,7 @@ def main():
                                    f"{stats.n_voxels} voxels, {stats.n_ref_nodes} reference SvoNodes, "
                                    f"{stats.n_sub_chunks} sub-chunks), {W_}x{H_} primary rays, camera pose "
                                    f"{'ABC'[args.pose]}, first-hit records 16 B/ray",
-                       "parallelism": f"single GPU, {launch}, {args.frames_in_flight} frame(s) in flight" if world_size == 1 else f"{args.tile}x{args.tile} screen tiles round-robin over {world_size} GPUs, {'RCCL' if args.backend == 'nccl' else args.backend} gather of {'the live ' if args.sparse_gather else ''}RGBA8 tiles to rank 0, {pipe.batch} frame(s) per launch pair and exchange, {args.frames_in_flight} batches in flight",
+                       "parallelism": f"single GPU, {launch}, {args.frames_in_flight} frame(s) in flight" if world_size == 1 else f"{args.tile}x{args.tile} screen tiles round-robin over {world_size} GPUs, {'RCCL' if args.backend == 'nccl' else args.backend} gather of {'the live tiles as 16-bit material/face codes' if pipe.codes else 'the live RGBA8 tiles' if args.sparse_gather else 'RGBA8 tiles'} to rank 0, {pipe.batch} frame(s) per launch pair and exchange, {args.frames_in_flight} batches in flight",
                        "hits_per_frame": hits, "framebuffer_pixels_hit": lit_pixels,
                        "outputs": "16-B first-hit records (kept on the tracing GPU) + RGBA8 framebuffer on rank 0",
                        "tile_records_gathered_per_frame_and_rank": (pipe.records_gathered / max(1, pipe.frames_done)) if world_size > 1 and args.sparse_gather else None,

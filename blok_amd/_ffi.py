@@ -197,6 +197,12 @@ HIP_SYMBOLS = {
                                                       C.c_void_p]),
     "blok_hip_scatter_tile_frames_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
                                                       C.c_void_p, C.c_void_p, C.c_void_p]),
+    "blok_hip_exchange_code_bits": (C.c_uint32, [C.c_void_p]),
+    "blok_hip_compact_code_words": (C.c_size_t, [C.c_uint32, C.c_uint32]),
+    "blok_hip_compact_hit_tile_frames_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
+                                                          C.c_void_p]),
+    "blok_hip_scatter_code_tile_frames_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                           C.c_void_p, C.c_void_p, C.c_void_p]),
     "blok_hip_compact_tiles_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "blok_hip_scatter_tiles_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "blok_hip_frame_queue_stalls": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),

@@ -739,10 +739,11 @@ int blok_hip_compact_tiles_device(blok_hip_ctx* ctx, const void* rgba_tiles_dev,
     return blok_hip_compact_tile_frames_device(ctx, rgba_tiles_dev, tile, n_tiles, 1, 0, out_words_dev, hip_stream);
 }
 
-int blok_hip_scatter_tile_frames_device(blok_hip_ctx* ctx, const void* gathered_dev, uint32_t n_ranks, size_t rank_stride_words, uint32_t tile,
-                                        uint32_t max_records, uint32_t n_frames, void* out_frames_rgba_dev, void* tile_state_dev, void* hip_stream) {
+static int scatter_frames(blok_hip_ctx* ctx, bool codes, const void* gathered_dev, uint32_t n_ranks, size_t rank_stride_words, uint32_t tile,
+                          uint32_t max_records, uint32_t n_frames, void* out_frames_rgba_dev, void* tile_state_dev, void* hip_stream) {
     if (!ctx) return BLOK_ERR_INVALID_ARG;
-    if (!gathered_dev || !out_frames_rgba_dev || !tile || !n_ranks || !n_frames) return set_error(ctx, BLOK_ERR_INVALID_ARG, "bad scatter arguments");
+    if (!gathered_dev || !out_frames_rgba_dev || !tile || (tile & 1u) || !n_ranks || !n_frames) return set_error(ctx, BLOK_ERR_INVALID_ARG, "bad scatter arguments");
+    if (codes && !blok_hip_exchange_code_bits(ctx)) return set_error(ctx, BLOK_ERR_UNSUPPORTED, "the material table is too large for 16-bit pixel codes");
     BLOK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     blok::ScatterArgs a{};
@@ -751,6 +752,8 @@ int blok_hip_scatter_tile_frames_device(blok_hip_ctx* ctx, const void* gathered_
     a.frame_w = ctx->width; a.frame_h = ctx->height; a.tile = tile; a.n_ranks = n_ranks;
     a.tiles_x = (ctx->width + tile - 1) / tile; a.tiles_total = a.tiles_x * ((ctx->height + tile - 1) / tile);
     a.max_records = max_records; a.n_frames = n_frames; a.rank_stride = rank_stride_words;
+    a.record_words = 1u + (codes ? tile * tile / 2u : tile * tile);
+    a.mat_table = ctx->d_materials; a.n_materials = static_cast<uint32_t>(ctx->n_materials);
     // the stream's tile map: zero when a launch begins and when it ends (the tile kernel puts back what the map kernel set)
     auto& slot = ctx->beam_buffers[stream];
     const size_t need = static_cast<size_t>(a.tiles_total) * n_frames;
@@ -762,9 +765,41 @@ int blok_hip_scatter_tile_frames_device(blok_hip_ctx* ctx, const void* gathered_
         slot.n_tile_map = need;
     }
     a.tile_map = slot.tile_map;
-    blok::launch_scatter_tiles(a, stream);
+    blok::launch_scatter_tiles(a, codes, stream);
     BLOK_HIP_TRY(ctx, hipGetLastError());
     return BLOK_OK;
+}
+
+int blok_hip_scatter_tile_frames_device(blok_hip_ctx* ctx, const void* gathered_dev, uint32_t n_ranks, size_t rank_stride_words, uint32_t tile,
+                                        uint32_t max_records, uint32_t n_frames, void* out_frames_rgba_dev, void* tile_state_dev, void* hip_stream) {
+    return scatter_frames(ctx, false, gathered_dev, n_ranks, rank_stride_words, tile, max_records, n_frames, out_frames_rgba_dev, tile_state_dev, hip_stream);
+}
+
+uint32_t blok_hip_exchange_code_bits(const blok_hip_ctx* ctx) {
+    return ctx && ctx->has_world && ctx->d_materials && (ctx->n_materials + 1u) * 8u <= 0xFFFFu ? 16u : 0u;
+}
+
+size_t blok_hip_compact_code_words(uint32_t tile, uint32_t n_tiles) { return 1u + static_cast<size_t>(n_tiles) * (1u + static_cast<size_t>(tile) * tile / 2u); }
+
+int blok_hip_compact_hit_tile_frames_device(blok_hip_ctx* ctx, const void* hit_tiles_dev, uint32_t tile, uint32_t n_tiles, uint32_t n_frames,
+                                            uint32_t frame_stride_tiles, void* out_words_dev, void* hip_stream) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    if (!hit_tiles_dev || !out_words_dev || !tile || (tile & 1u) || !n_frames || (n_frames > 1 && frame_stride_tiles < n_tiles))
+        return set_error(ctx, BLOK_ERR_INVALID_ARG, "bad compact arguments");
+    if (!blok_hip_exchange_code_bits(ctx)) return set_error(ctx, BLOK_ERR_UNSUPPORTED, "the material table is too large for 16-bit pixel codes");
+    BLOK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    BLOK_HIP_TRY(ctx, hipMemsetAsync(out_words_dev, 0, n_frames * sizeof(uint32_t), stream));          // the count words
+    blok::CompactHitArgs a{static_cast<const blok_hit*>(hit_tiles_dev), static_cast<uint32_t*>(out_words_dev), tile, n_tiles, n_frames,
+                           static_cast<uint32_t>(ctx->n_materials), static_cast<size_t>(frame_stride_tiles) * tile * tile};
+    blok::launch_compact_hit_tiles(a, stream);
+    BLOK_HIP_TRY(ctx, hipGetLastError());
+    return BLOK_OK;
+}
+
+int blok_hip_scatter_code_tile_frames_device(blok_hip_ctx* ctx, const void* gathered_dev, uint32_t n_ranks, size_t rank_stride_words, uint32_t tile,
+                                             uint32_t max_records, uint32_t n_frames, void* out_frames_rgba_dev, void* tile_state_dev, void* hip_stream) {
+    return scatter_frames(ctx, true, gathered_dev, n_ranks, rank_stride_words, tile, max_records, n_frames, out_frames_rgba_dev, tile_state_dev, hip_stream);
 }
 
 int blok_hip_scatter_tiles_device(blok_hip_ctx* ctx, const void* gathered_dev, uint32_t n_ranks, size_t rank_stride_words,

@@ -149,6 +149,17 @@ struct CompactArgs {                       // rank's dense RGBA8 tiles -> {count
     uint32_t tile, n_tiles, n_frames;
     size_t tiles_frame_stride;             // words between consecutive frames (grid y) of the dense tiles
 };
+// The same exchange with 16 bits per pixel instead of 32: a shaded pixel is a function of (material id, face) — shade_rgba,
+// trace_core.h — or the sky, and every rank holds the material table, so a pixel travels as
+//   code = min(material id, n_materials) * 8 + face,  0xFFFF = sky        (needs (n_materials + 1) * 8 <= 0xFFFF)
+// made from the rank's first-hit records and expanded by the root through the very function the trace kernels shade with: the
+// assembled frame is bit-identical, the bytes on the wire are half (kCodeSky / pixel_code / code_rgba in trace_kernels.hip).
+struct CompactHitArgs {                    // rank's dense first-hit tiles -> {counts, records {local tile index, tile^2 16-bit codes}}
+    const blok_hit* hits;
+    uint32_t* out;
+    uint32_t tile, n_tiles, n_frames, n_materials;
+    size_t hits_frame_stride;              // records between consecutive frames (grid y)
+};
 struct ScatterArgs {                       // gathered compact buffers of all ranks -> row-major frames
     const uint32_t* gathered;
     uint32_t* frame;                       // n_frames contiguous frames
@@ -156,9 +167,13 @@ struct ScatterArgs {                       // gathered compact buffers of all ra
     uint8_t* tile_state;                   // optional, n_frames * tiles_total: does the frame buffer's tile hold anything but sky?  Lets sky tiles that stay sky go unwritten
     uint32_t frame_w, frame_h, tile, n_ranks, tiles_x, tiles_total, max_records, n_frames;
     size_t rank_stride;                    // words between the ranks' buffers
+    uint32_t record_words;                 // 1 + tile^2 (RGBA8 pixels) or 1 + tile^2 / 2 (16-bit codes)
+    const blok_material* mat_table;        // codes only
+    uint32_t n_materials;
 };
+void launch_compact_hit_tiles(const CompactHitArgs& args, hipStream_t stream);
 void launch_compact_tiles(const CompactArgs& args, hipStream_t stream);
-void launch_scatter_tiles(const ScatterArgs& args, hipStream_t stream);      // map kernel, then one wave per frame tile
+void launch_scatter_tiles(const ScatterArgs& args, bool codes, hipStream_t stream);      // map kernel, then one wave per frame tile
 uint32_t sky_rgba();                       // the RGBA8 a miss is shaded with (trace_core.h: kSkyRgba)
 
 struct SunMapArgs {                        // beam.h: prism_far, one wave per texel

@@ -467,6 +467,31 @@ __global__ __launch_bounds__(64) void compact_tiles_kernel(const CompactArgs a) 
     for (uint32_t i = lane; i < px; i += 64u) rec[1u + i] = src[i];
 }
 
+constexpr uint32_t kCodeSky = 0xFFFFu;
+__device__ __forceinline__ uint32_t pixel_code(const uint4 hit, uint32_t n_materials) {          // hit: one blok_hit as four words
+    if ((hit.w >> 24) == 0u) return kCodeSky;
+    return (hit.y < n_materials ? hit.y : n_materials) * 8u + ((hit.w >> 16) & 7u);                 // ids beyond the table share its "out of table" colour
+}
+__device__ __forceinline__ uint32_t code_rgba(uint32_t code, const blok_material* table, uint32_t n_materials) {
+    return code == kCodeSky ? kSkyRgba : shade_rgba(table, n_materials, code >> 3, code & 7u);
+}
+
+__global__ __launch_bounds__(64) void compact_hit_tiles_kernel(const CompactHitArgs a) {
+    const uint32_t b = blockIdx.x, f = blockIdx.y, lane = threadIdx.x, px = a.tile * a.tile;
+    if (b >= a.n_tiles) return;
+    const uint4* src = reinterpret_cast<const uint4*>(a.hits) + f * a.hits_frame_stride + static_cast<size_t>(b) * px;
+    bool live = false;
+    for (uint32_t i = lane; i < px; i += 64u) live |= (src[i].w >> 24) != 0u;
+    if (__ballot(live) == 0ull) return;
+    uint32_t slot = 0;
+    if (lane == 0) slot = atomicAdd(a.out + f, 1u);
+    slot = __builtin_amdgcn_readfirstlane(slot);
+    uint32_t* rec = a.out + a.n_frames + (static_cast<size_t>(slot) * a.n_frames + f) * (1u + px / 2u);
+    if (lane == 0) rec[0] = b;
+    for (uint32_t i = lane; i < px / 2u; i += 64u)                      // two pixels per word, the even one in the low half
+        rec[1u + i] = pixel_code(src[2u * i], a.n_materials) | (pixel_code(src[2u * i + 1u], a.n_materials) << 16);
+}
+
 // root, step 1: one thread per (rank, record slot, frame): which record holds which frame tile
 __global__ __launch_bounds__(64) void scatter_map_kernel(const ScatterArgs a) {
     const uint32_t i = blockIdx.x * 64u + threadIdx.x, f = blockIdx.y;
@@ -474,12 +499,13 @@ __global__ __launch_bounds__(64) void scatter_map_kernel(const ScatterArgs a) {
     const uint32_t r = i / a.max_records, j = i % a.max_records;
     const uint32_t* base = a.gathered + static_cast<size_t>(r) * a.rank_stride;
     if (j >= base[f]) return;
-    const uint32_t* rec = base + a.n_frames + (static_cast<size_t>(j) * a.n_frames + f) * (1u + a.tile * a.tile);
+    const uint32_t* rec = base + a.n_frames + (static_cast<size_t>(j) * a.n_frames + f) * a.record_words;
     const uint64_t g = r + static_cast<uint64_t>(rec[0]) * a.n_ranks;
     if (g < a.tiles_total) a.tile_map[static_cast<size_t>(f) * a.tiles_total + g] = i + 1u;
 }
 
 // root, step 2: one wave per (frame tile, frame): the tile's record, or sky; every pixel of the frame is written at most once
+template <bool kCodes>
 __global__ __launch_bounds__(64) void scatter_tiles_kernel(const ScatterArgs a) {
     const uint32_t g = blockIdx.x, f = blockIdx.y, lane = threadIdx.x, px = a.tile * a.tile;
     const size_t slot = static_cast<size_t>(f) * a.tiles_total + g;
@@ -493,11 +519,16 @@ __global__ __launch_bounds__(64) void scatter_tiles_kernel(const ScatterArgs a) 
     const uint32_t* rec = nullptr;
     if (m) {
         const uint32_t r = (m - 1u) / a.max_records, j = (m - 1u) % a.max_records;
-        rec = a.gathered + static_cast<size_t>(r) * a.rank_stride + a.n_frames + (static_cast<size_t>(j) * a.n_frames + f) * (1u + px);
+        rec = a.gathered + static_cast<size_t>(r) * a.rank_stride + a.n_frames + (static_cast<size_t>(j) * a.n_frames + f) * a.record_words;
     }
     for (uint32_t i = lane; i < px; i += 64u) {
         const uint32_t x = x0 + i % a.tile, y = y0 + i / a.tile;
-        if (x < a.frame_w && y < a.frame_h) frame[static_cast<size_t>(y) * a.frame_w + x] = rec ? rec[1u + i] : kSkyRgba;
+        uint32_t v = kSkyRgba;
+        if (rec) {
+            if constexpr (kCodes) v = code_rgba((rec[1u + i / 2u] >> ((i & 1u) * 16u)) & 0xFFFFu, a.mat_table, a.n_materials);
+            else v = rec[1u + i];
+        }
+        if (x < a.frame_w && y < a.frame_h) frame[static_cast<size_t>(y) * a.frame_w + x] = v;
     }
 }
 
@@ -509,11 +540,16 @@ void launch_compact_tiles(const CompactArgs& args, hipStream_t stream) {
     if (args.n_tiles && args.n_frames) hipLaunchKernelGGL(compact_tiles_kernel, dim3(args.n_tiles, args.n_frames), dim3(64), 0, stream, args);
 }
 
-void launch_scatter_tiles(const ScatterArgs& args, hipStream_t stream) {
+void launch_compact_hit_tiles(const CompactHitArgs& args, hipStream_t stream) {
+    if (args.n_tiles && args.n_frames) hipLaunchKernelGGL(compact_hit_tiles_kernel, dim3(args.n_tiles, args.n_frames), dim3(64), 0, stream, args);
+}
+
+void launch_scatter_tiles(const ScatterArgs& args, bool codes, hipStream_t stream) {
     if (!args.n_frames || !args.tiles_total) return;
     const uint32_t n = args.n_ranks * args.max_records;
     if (n) hipLaunchKernelGGL(scatter_map_kernel, dim3((n + 63u) / 64u, args.n_frames), dim3(64), 0, stream, args);
-    hipLaunchKernelGGL(scatter_tiles_kernel, dim3(args.tiles_total, args.n_frames), dim3(64), 0, stream, args);
+    if (codes) hipLaunchKernelGGL(scatter_tiles_kernel<true>, dim3(args.tiles_total, args.n_frames), dim3(64), 0, stream, args);
+    else hipLaunchKernelGGL(scatter_tiles_kernel<false>, dim3(args.tiles_total, args.n_frames), dim3(64), 0, stream, args);
 }
 
 void launch_tile_frames(const TraceArgs& args, const TileFrames& frames, hipStream_t stream) {

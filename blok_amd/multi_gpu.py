@@ -135,6 +135,17 @@ class HipBackend:
         self.tracer.scatter_tile_frames_device(gathered.data_ptr(), n_ranks, rank_stride, tile, max_records, n_frames, out.data_ptr(),
                                                tile_state.data_ptr() if tile_state is not None else 0, stream=stream)
 
+    # the same exchange with 16-bit (material, face) codes made from the first-hit tiles (blok_hip.h): half the bytes on the wire
+    def code_bits(self):
+        return self.tracer.exchange_code_bits()
+
+    def compact_hit_frames(self, hits, tile, n_tiles, n_frames, stride_tiles, out, stream):
+        self.tracer.compact_hit_tile_frames_device(hits.data_ptr(), tile, n_tiles, n_frames, stride_tiles, out.data_ptr(), stream=stream)
+
+    def scatter_code_frames(self, gathered, n_ranks, rank_stride, tile, max_records, n_frames, out, tile_state, stream):
+        self.tracer.scatter_code_tile_frames_device(gathered.data_ptr(), n_ranks, rank_stride, tile, max_records, n_frames, out.data_ptr(),
+                                                    tile_state.data_ptr() if tile_state is not None else 0, stream=stream)
+
     def compact(self, rgba, tile, n_tiles, out, stream):
         self.tracer.compact_tiles_device(rgba.data_ptr(), tile, n_tiles, out.data_ptr(), stream=stream)
 
@@ -151,7 +162,7 @@ class FramePipeline:
     is taken when step() is called); the launches and the exchange of a batch are issued with its last frame."""
 
     def __init__(self, backend, width: int, height: int, rank: int = 0, world_size: int = 1, dist=None,
-                 tile: int = 32, device="cuda", depth: int = 3, sparse: bool = False, partition=None, batch: int = 1):
+                 tile: int = 32, device="cuda", depth: int = 3, sparse=False, partition=None, batch: int = 1):
         import torch
         self.torch = torch
         self.backend, self.width, self.height = backend, width, height
@@ -160,6 +171,8 @@ class FramePipeline:
         # how the RCCL calls get exercised on a one-GPU box (scripts/rccl_smoke.py)
         self.partitioned = world_size > 1 if partition is None else bool(partition) and dist is not None
         self.sparse = bool(sparse) and self.partitioned
+        # sparse = 2: pixels travel as 16-bit (material, face) codes when the backend's material table allows it (else as RGBA8)
+        self.codes = self.sparse and int(sparse) == 2 and getattr(backend, "code_bits", lambda: 0)() == 16
         self.batch = min(max(1, int(batch)), getattr(backend, "max_frames", 1 << 30)) if self.partitioned else 1
         self.on_gpu = str(device).startswith("cuda")
         self.streams = [torch.cuda.Stream() for _ in range(depth)] if self.on_gpu else [None] * depth
@@ -185,7 +198,8 @@ class FramePipeline:
         self._hits = [torch.zeros((F, n_tile_px, 4), dtype=torch.int32, device=device) for _ in range(depth)]
         self.rgba = [torch.zeros((F, n_tile_px), dtype=torch.int32, device=device) for _ in range(depth)]
         if self.sparse:
-            self.words = 1 + self.per_rank * (1 + tile * tile)               # blok_hip_compact_words
+            self.record_words = 1 + (tile * tile // 2 if self.codes else tile * tile)
+            self.words = 1 + self.per_rank * self.record_words               # blok_hip_compact_words / blok_hip_compact_code_words
             # a batch's counts, then its records interleaved by frame, so that what travels is one prefix (blok_hip.h)
             self.compacted = [torch.zeros(F * self.words, dtype=torch.int32, device=device) for _ in range(depth)]
             self.smax = [torch.zeros(F, dtype=torch.int32, device=device) for _ in range(depth)]
@@ -238,7 +252,10 @@ class FramePipeline:
                                                self.rgba[slot], h)
                 if self.sparse:
                     # compact on the device; the largest record count over the ranks, per frame of the batch, starts its way to every host now
-                    self.backend.compact_frames(self.rgba[slot], self.tile, self.mine, n_frames, self.per_rank, self.compacted[slot], h)
+                    if self.codes:
+                        self.backend.compact_hit_frames(self._hits[slot], self.tile, self.mine, n_frames, self.per_rank, self.compacted[slot], h)
+                    else:
+                        self.backend.compact_frames(self.rgba[slot], self.tile, self.mine, n_frames, self.per_rank, self.compacted[slot], h)
                     self.smax[slot][:n_frames].copy_(self.compacted[slot][:n_frames])
                     w = self.dist.all_reduce(self.smax[slot], op=self.dist.ReduceOp.MAX, async_op=True)
                     w.wait()                       # the slot's stream (or the host, on gloo) waits for that reduction only
@@ -259,13 +276,14 @@ class FramePipeline:
                 if self.on_gpu:
                     self.smax_event[slot].synchronize()        # enqueued `depth` batches ago
                 records = int(self.smax_host[slot][:n_frames].max())    # one prefix length for the batch: the exchange is one block
-                n = n_frames * (1 + records * (1 + self.tile * self.tile))   # the counts and the first `records` record slots of every frame
+                n = n_frames * (1 + records * self.record_words)        # the counts and the first `records` record slots of every frame
                 self.records_gathered += records * n_frames
                 gather_list = [self.gathered[slot][r][:n] for r in range(self.world_size)] if self.rank == 0 else None
                 self.dist.gather(self.compacted[slot][:n], gather_list=gather_list, dst=0)
                 if self.rank == 0:
-                    self.backend.scatter_frames(self.gathered[slot], self.world_size, self.gathered[slot].shape[1], self.tile, records,
-                                                n_frames, self._frame[slot], self.tile_state[slot], self._handle(slot))
+                    scatter = self.backend.scatter_code_frames if self.codes else self.backend.scatter_frames
+                    scatter(self.gathered[slot], self.world_size, self.gathered[slot].shape[1], self.tile, records,
+                            n_frames, self._frame[slot], self.tile_state[slot], self._handle(slot))
             elif work is not None:
                 work.wait()                        # the slot's stream (or the host, on gloo) waits for that gather only
                 if self.rank == 0:

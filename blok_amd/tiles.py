@@ -103,3 +103,67 @@ def scatter_tile_frames(gathered: np.ndarray, n_ranks: int, rank_stride: int, ti
                 h, w = min(tile, height - y0), min(tile, width - x0)
                 frames[f, y0:y0 + h, x0:x0 + w] = rec[1:].reshape(tile, tile)[:h, :w]
     return frames
+
+
+# ---- 16-bit coded exchange (blok_hip.h: blok_hip_compact_hit_tile_frames_device / blok_hip_scatter_code_tile_frames_device) ----------
+CODE_SKY = 0xFFFF
+
+
+def compact_code_words(tile: int, n_tiles: int) -> int:
+    return 1 + n_tiles * (1 + tile * tile // 2)
+
+
+def shade_rgba8(albedo: np.ndarray, material_id: np.ndarray, face: np.ndarray) -> np.ndarray:
+    """trace_core.h: shade_rgba — albedo (n_materials, 3) float32; ids beyond the table show magenta."""
+    albedo = np.asarray(albedo, dtype=np.float32)
+    mid = np.asarray(material_id).astype(np.int64)
+    rgb = np.where((mid < len(albedo))[..., None], albedo[np.minimum(mid, len(albedo) - 1)], np.array([1.0, 0.0, 1.0], dtype=np.float32))
+    k = np.array([0.8, 0.8, 1.0, 0.4, 0.6, 0.6, 0.6, 0.6], dtype=np.float32)[np.asarray(face) & 7]
+    q = (np.minimum(rgb * k[..., None], np.float32(1.0)) * np.float32(255.0) + np.float32(0.5)).astype(np.uint32)
+    return (0xFF000000 | (q[..., 2] << 16) | (q[..., 1] << 8) | q[..., 0]).astype(np.uint32)
+
+
+def pixel_codes(hits: np.ndarray, n_materials: int) -> np.ndarray:
+    """hits: structured first-hit records (fields material_id, face, hit) -> uint16 codes."""
+    code = np.minimum(hits["material_id"].astype(np.int64), n_materials) * 8 + (hits["face"] & 7)
+    return np.where(hits["hit"] != 0, code, CODE_SKY).astype(np.uint16)
+
+
+def compact_hit_tile_frames(hit_frames: np.ndarray, tile: int, n_tiles: int, n_materials: int) -> np.ndarray:
+    """Reference of blok_hip_compact_hit_tile_frames_device: hit_frames (F, >= n_tiles * tile*tile) first-hit records."""
+    F, px = hit_frames.shape[0], tile * tile
+    rw = 1 + px // 2
+    out = np.zeros(F * compact_code_words(tile, n_tiles), dtype=np.uint32)
+    for f in range(F):
+        codes = pixel_codes(hit_frames[f][:n_tiles * px], n_materials).reshape(n_tiles, px)
+        live = np.flatnonzero((codes != CODE_SKY).any(axis=1))
+        out[f] = len(live)
+        for j, t in enumerate(live):
+            at = F + (j * F + f) * rw
+            out[at] = t
+            out[at + 1:at + rw] = codes[t].astype(np.uint32)[0::2] | (codes[t].astype(np.uint32)[1::2] << 16)
+    return out
+
+
+def scatter_code_tile_frames(gathered: np.ndarray, n_ranks: int, rank_stride: int, tile: int, max_records: int, n_frames: int, width: int,
+                             height: int, albedo: np.ndarray) -> np.ndarray:
+    """Reference of blok_hip_scatter_code_tile_frames_device: (n_frames, height, width) uint32 frames."""
+    px = tile * tile
+    rw = 1 + px // 2
+    g = np.asarray(gathered).view(np.uint32).reshape(-1)
+    frames = np.full((n_frames, height, width), SKY_RGBA, dtype=np.uint32)
+    tiles_x = (width + tile - 1) // tile
+    for r in range(n_ranks):
+        base = g[r * rank_stride:]
+        for f in range(n_frames):
+            for j in range(min(int(base[f]), max_records)):
+                at = n_frames + (j * n_frames + f) * rw
+                words = base[at + 1:at + rw]
+                codes = np.empty(px, dtype=np.uint32)
+                codes[0::2] = words & 0xFFFF; codes[1::2] = words >> 16
+                rgba = np.where(codes == CODE_SKY, SKY_RGBA, shade_rgba8(albedo, codes >> 3, codes & 7)).astype(np.uint32)
+                gt = r + int(base[at]) * n_ranks
+                x0, y0 = (gt % tiles_x) * tile, (gt // tiles_x) * tile
+                h, w = min(tile, height - y0), min(tile, width - x0)
+                frames[f, y0:y0 + h, x0:x0 + w] = rgba.reshape(tile, tile)[:h, :w]
+    return frames

@@ -307,6 +307,20 @@ class HipTracer:
         self._check(self._lib.blok_hip_scatter_tile_frames_device(self._ctx, C.c_void_p(gathered_ptr), n_ranks, rank_stride_words, tile, max_records,
                                                                   n_frames, C.c_void_p(out_ptr), C.c_void_p(tile_state_ptr), C.c_void_p(stream)))
 
+    def exchange_code_bits(self) -> int:
+        """16 if pixels can travel as 16-bit (material, face) codes with this world's material table, else 0 (blok_hip.h)."""
+        return int(self._lib.blok_hip_exchange_code_bits(self._ctx))
+
+    def compact_hit_tile_frames_device(self, hit_tiles_ptr: int, tile: int, n_tiles: int, n_frames: int, frame_stride_tiles: int, out_ptr: int,
+                                       stream: int = 0):
+        self._check(self._lib.blok_hip_compact_hit_tile_frames_device(self._ctx, C.c_void_p(hit_tiles_ptr), tile, n_tiles, n_frames, frame_stride_tiles,
+                                                                      C.c_void_p(out_ptr), C.c_void_p(stream)))
+
+    def scatter_code_tile_frames_device(self, gathered_ptr: int, n_ranks: int, rank_stride_words: int, tile: int, max_records: int, n_frames: int,
+                                        out_ptr: int, tile_state_ptr: int = 0, stream: int = 0):
+        self._check(self._lib.blok_hip_scatter_code_tile_frames_device(self._ctx, C.c_void_p(gathered_ptr), n_ranks, rank_stride_words, tile, max_records,
+                                                                       n_frames, C.c_void_p(out_ptr), C.c_void_p(tile_state_ptr), C.c_void_p(stream)))
+
     def trace_rays(self, rays: np.ndarray) -> np.ndarray:
         rays = np.ascontiguousarray(rays, dtype=RAY)
         hits = np.zeros(len(rays), dtype=HIT)

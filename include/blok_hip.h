@@ -269,6 +269,20 @@ int blok_hip_scatter_tile_frames_device(blok_hip_ctx* ctx, const void* gathered_
                                         uint32_t tile, uint32_t max_records, uint32_t n_frames,
                                         void* out_frames_rgba_dev, void* tile_state_dev, void* hip_stream);
 
+/* The same exchange with 16 bits per pixel.  A shaded pixel is a function of (material id, face) or the sky, and every rank holds
+ * the material table, so a pixel can travel as  code = min(material id, n_materials) * 8 + face  (0xFFFF = sky), made from the
+ * rank's FIRST-HIT tiles (what blok_hip_trace_tile(_frame)s_device writes to out_hits_dev) and expanded on the root through the
+ * function the trace kernels shade with: the assembled RGBA8 frames are bit-identical, the bytes on the wire half.
+ * blok_hip_exchange_code_bits: 16 if the uploaded material table allows it ((n_materials + 1) * 8 <= 0xFFFF), else 0 (use the
+ * RGBA8 entries).  Buffers as above with records of 1 + tile*tile/2 words: blok_hip_compact_code_words(tile, n_tiles) words per frame. */
+uint32_t blok_hip_exchange_code_bits(const blok_hip_ctx* ctx);
+size_t blok_hip_compact_code_words(uint32_t tile, uint32_t n_tiles);
+int blok_hip_compact_hit_tile_frames_device(blok_hip_ctx* ctx, const void* hit_tiles_dev, uint32_t tile, uint32_t n_tiles,
+                                            uint32_t n_frames, uint32_t frame_stride_tiles, void* out_words_dev, void* hip_stream);
+int blok_hip_scatter_code_tile_frames_device(blok_hip_ctx* ctx, const void* gathered_dev, uint32_t n_ranks, size_t rank_stride_words,
+                                             uint32_t tile, uint32_t max_records, uint32_t n_frames,
+                                             void* out_frames_rgba_dev, void* tile_state_dev, void* hip_stream);
+
 /* The reference's per-pixel sample / bounce loop and G-buffer: raygen.rgen:167-414 with hit.rchit, miss.rmiss
  * and shadow.rmiss (reference assets/shaders/).  Planes are float4 per pixel of the rectangle, row-major; any
  * pointer may be NULL.  color = (rgb, 1); world_pos = (first-hit position, depth); normal_roughness;

@@ -20,7 +20,7 @@ for (Wd, Ht) in ((3840, 2160), (1344, 768)):
     tr = HipTracer(Wd, Ht).init(); tr.add_world(pw)
     cam = W.scene_camera(n, 0, Wd, Ht)
     want = torch.from_numpy(tr.shade_rgba8(cam).reshape(-1).view(np.int32)).cuda()
-    for sparse in (False, True):
+    for sparse in (0, 1, 2):
         for batch in (1, 2, 4, 8):
             pipe = FramePipeline(HipBackend(tr, cam), Wd, Ht, 0, 1, dist, tile=32, depth=3, sparse=sparse, partition=True, batch=batch)
             for _ in range(8):
@@ -34,7 +34,7 @@ for (Wd, Ht) in ((3840, 2160), (1344, 768)):
             dt = (time.perf_counter() - t) / frames * 1e3
             ok = all(bool(torch.equal(f, want)) for f in pipe.last_frames)
             extra = f", {pipe.records_gathered / pipe.frames_done:.0f} of {pipe.per_rank} tiles travel per frame" if sparse else ""
-            print(f"RCCL world_size 1, {Wd}x{Ht}, {'sparse exchange' if sparse else 'dense gather'}, {batch} frame(s) per exchange: "
+            print(f"RCCL world_size 1, {Wd}x{Ht}, {('dense gather', 'sparse exchange', 'sparse exchange, 16-bit codes')[sparse]}, {batch} frame(s) per exchange: "
                   f"frames equal the single-launch frame: {ok}; {dt:.3f} ms/frame incl. host{extra}", flush=True)
             assert ok
     tr.shutdown()

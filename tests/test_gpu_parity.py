@@ -657,12 +657,16 @@ def test_several_frames_per_launch_equal_frame_by_frame(tracer_cls, scene1024):
             words = T.compact_words(tile, per)
             dense_g = torch.zeros((n_ranks, n_frames, per * px), dtype=torch.int32, device="cuda")
             sparse_g = torch.zeros((n_ranks, n_frames * words), dtype=torch.int32, device="cuda")
+            cwords = T.compact_code_words(tile, per)
+            code_g = torch.zeros((n_ranks, n_frames * cwords), dtype=torch.int32, device="cuda")
+            assert tr.exchange_code_bits() == 16
             most = 0
             for r in range(n_ranks):
                 mine = tr.tiles_for_rank(tile, r, n_ranks)
                 hits = torch.zeros((n_frames, per * px, 4), dtype=torch.int32, device="cuda")
                 tr.draw_tile_frames_device(np.concatenate(cams[:n_frames]), tile, r, n_ranks, per, hits_ptr=hits.data_ptr(), rgba_ptr=dense_g[r].data_ptr())
                 tr.compact_tile_frames_device(dense_g[r].data_ptr(), tile, mine, n_frames, per, sparse_g[r].data_ptr())
+                tr.compact_hit_tile_frames_device(hits.data_ptr(), tile, mine, n_frames, per, code_g[r].data_ptr())
                 one_h = torch.zeros((per * px, 4), dtype=torch.int32, device="cuda")
                 one_c = torch.zeros(per * px, dtype=torch.int32, device="cuda")
                 one_s = torch.zeros(words, dtype=torch.int32, device="cuda")
@@ -670,6 +674,16 @@ def test_several_frames_per_launch_equal_frame_by_frame(tracer_cls, scene1024):
                 a = sparse_g[r].cpu().numpy().view(np.uint32)
                 ref = T.compact_tile_frames(dense_g[r].cpu().numpy(), tile, mine)
                 assert (a[:n_frames] == ref[:n_frames]).all()
+                # 16-bit codes from the first-hit tiles: same counts, and per frame the same records as the numpy reference
+                c = code_g[r].cpu().numpy().view(np.uint32)
+                cref = T.compact_hit_tile_frames(hits.cpu().numpy().view(O.HIT).reshape(n_frames, -1), tile, mine, len(pw.materials))
+                assert (c[:n_frames] == a[:n_frames]).all() and (cref[:n_frames] == a[:n_frames]).all()
+                top, rw = int(a[:n_frames].max()), 1 + px // 2
+                cg = c[n_frames:n_frames + top * n_frames * rw].reshape(-1, n_frames, rw)
+                cr = cref[n_frames:n_frames + top * n_frames * rw].reshape(-1, n_frames, rw)
+                for f in range(n_frames):
+                    x, y = cg[:a[f], f], cr[:a[f], f]
+                    assert (x[np.argsort(x[:, 0])] == y[np.argsort(y[:, 0])]).all(), ("codes", beam, n_ranks, r, f)
                 for f in range(n_frames):
                     tr.draw_tiles_device(cams[f], tile, r, n_ranks, hits_ptr=one_h.data_ptr(), rgba_ptr=one_c.data_ptr())
                     tr.compact_tiles_device(one_c.data_ptr(), tile, mine, one_s.data_ptr())
@@ -698,6 +712,18 @@ def test_several_frames_per_launch_equal_frame_by_frame(tracer_cls, scene1024):
             for f in range(n_frames):
                 assert (frames[f].cpu().numpy().view(np.uint32) == want[f]).all(), ("sparse", beam, n_ranks, f)
                 assert (T.scatter_tile_frames(packed.cpu().numpy(), n_ranks, n_frames * words, tile, most, n_frames, Wd, Ht)[f].reshape(-1) == want[f]).all()
+            # the same through 16-bit codes: half the words travel, the root expands them with the material table
+            cn = n_frames * (1 + most * (1 + px // 2))
+            cpacked = torch.full((n_ranks, n_frames * cwords), -1, dtype=torch.int32, device="cuda")
+            cpacked[:, :cn].copy_(code_g[:, :cn])
+            frames.fill_(54321)
+            tr.scatter_code_tile_frames_device(cpacked.data_ptr(), n_ranks, n_frames * cwords, tile, most, n_frames, frames.data_ptr())
+            torch.cuda.synchronize()
+            cpu_frames = T.scatter_code_tile_frames(cpacked.cpu().numpy(), n_ranks, n_frames * cwords, tile, most, n_frames, Wd, Ht, pw.materials["albedo"])
+            for f in range(n_frames):
+                assert (frames[f].cpu().numpy().view(np.uint32) == want[f]).all(), ("codes", beam, n_ranks, f)
+                assert (cpu_frames[f].reshape(-1) == want[f]).all()
+            assert cn * 2 < n * 1.01 + 2 * n_frames
             # with a tile state (buffer all sky, state all zero to begin with): the frames, then no records at all (every live tile
             # goes back to sky), then the frames again, then the frames in another order (live <-> sky per tile)
             sky = int(T.SKY_RGBA) - (1 << 32)

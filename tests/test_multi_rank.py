@@ -247,3 +247,44 @@ def test_compact_scatter_reference_round_trip():
             gathered[r * stride:r * stride + len(c)] = c
             most = max(most, int(c[0]))
         assert (T.scatter_tiles(gathered, n, stride, tile, most, w, h) == frame).all()
+
+
+def test_coded_exchange_reference_round_trip():
+    """tiles.compact_hit_tile_frames / scatter_code_tile_frames (the references of the 16-bit exchange kernels): first-hit records
+    cut into rank tiles, coded per rank (min(material, n) * 8 + face, 0xFFFF = sky), interleaved by frame, expanded on the root ==
+    the shading of the records (material ids beyond the table included), for ragged frames and uneven rank counts."""
+    from blok_amd import tiles as T
+    from tests import oracle_ffi as O
+    rng = np.random.default_rng(11)
+    n_mat = 37
+    albedo = rng.uniform(0, 1.2, (n_mat, 3)).astype(np.float32)
+    for (w, h, tile, n, F) in [(200, 136, 32, 2, 3), (100, 70, 16, 3, 1), (64, 64, 32, 8, 2)]:
+        hits = np.zeros((F, h, w), dtype=O.HIT)
+        hits["face"] = 0xFF
+        for f in range(F):
+            for ty in range(0, h, tile):
+                for tx in range(0, w, tile):
+                    if rng.random() < 0.5:
+                        blk = hits[f, ty:ty + tile, tx:tx + tile]
+                        blk["hit"] = rng.random(blk.shape) < 0.7
+                        blk["material_id"] = rng.integers(0, n_mat + 5, size=blk.shape)       # some beyond the table
+                        blk["face"] = rng.integers(0, 6, size=blk.shape)
+        want = np.where(hits["hit"] != 0, T.shade_rgba8(albedo, hits["material_id"], hits["face"]), T.SKY_RGBA).astype(np.uint32)
+        per = T.tiles_for_rank(w, h, tile, 0, n)
+        stride = F * T.compact_code_words(tile, per)
+        gathered = np.zeros(n * stride, dtype=np.uint32)
+        most = 0
+        for r in range(n):
+            mine = T.tiles_for_rank(w, h, tile, r, n)
+            dense = np.zeros((F, per * tile * tile), dtype=O.HIT)
+            dense["face"] = 0xFF
+            for f in range(F):
+                for k, (x0, y0) in enumerate(T.rank_tile_origins(w, h, tile, r, n)):
+                    block = dense[f, k * tile * tile:(k + 1) * tile * tile].reshape(tile, tile)
+                    hh, ww = min(tile, h - y0), min(tile, w - x0)
+                    block[:hh, :ww] = hits[f, y0:y0 + hh, x0:x0 + ww]
+            c = T.compact_hit_tile_frames(dense, tile, mine, n_mat)
+            gathered[r * stride:r * stride + len(c)] = c
+            most = max(most, int(c[:F].max()))
+        got = T.scatter_code_tile_frames(gathered, n, stride, tile, most, F, w, h, albedo)
+        assert (got == want).all()
