@@ -306,6 +306,7 @@ int launch_timed(blok_hip_ctx* ctx, blok::RayMode mode, blok::TraceArgs args, ui
     const bool one_launch = n_beams && ctx->fused;
     if (one_launch) { const int rc = prepare_queue(ctx, mode, args, stream, n_beams, &queue, &frame_blocks); if (rc != BLOK_OK) return rc; }
     if (ctx->timing) BLOK_HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, stream));
+    args.miss_in_walk = !one_launch && n_beams && ctx->miss_in_walk ? 1u : 0u;
     if (one_launch) {
         blok::launch_frame(mode, args, queue, frame_blocks, stream);
     } else {
@@ -676,6 +677,7 @@ static int trace_tile_frames(blok_hip_ctx* ctx, const blok_camera* cams, uint32_
     for (uint32_t f = 0; f < n_frames; ++f) frames.cam[f] = cams[f];
     frames.n_frames = n_frames; frames.blocks_per_frame = blocks; frames.beams_per_frame = n_beams;
     frames.frame_stride = static_cast<size_t>(frame_stride_tiles) * tile * tile;
+    a.miss_in_walk = n_beams && ctx->miss_in_walk ? 1u : 0u;
     if (ctx->timing) BLOK_HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, stream));
     blok::launch_tile_frames(a, frames, stream);
     BLOK_HIP_TRY(ctx, hipGetLastError());
@@ -1081,6 +1083,12 @@ int blok_hip_set_tile_ordering(blok_hip_ctx* ctx, int resort_every_n_frames) {
     if (resort_every_n_frames < 0) return set_error(ctx, BLOK_ERR_INVALID_ARG, "tile ordering: interval must be >= 0");
     ctx->tile_ordering = resort_every_n_frames != 0;
     if (resort_every_n_frames) ctx->order_interval = static_cast<uint32_t>(resort_every_n_frames);
+    return BLOK_OK;
+}
+
+int blok_hip_set_miss_writer(blok_hip_ctx* ctx, int in_walk) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    ctx->miss_in_walk = in_walk != 0;
     return BLOK_OK;
 }
 

@@ -88,6 +88,7 @@ struct blok_hip_ctx {
     // ordered, frames in flight on different streams must not share)
     uint32_t beam_tile = 32;
     uint32_t beam_budget = 0;           // 0 = beam.h's default visit budget
+    bool miss_in_walk = true;           // who writes the pixels of tiles the pre-pass found empty (blok_hip_set_miss_writer)
     // Longest-first scheduling of the walk (tile_order.h; Rect launches of the two-launch form): every wave leaves the clocks it
     // spent in d_tile_cost (one buffer per context, for the launch geometry in order_key).  Every order_interval frames — and only
     // while no other stream of the context has frames in flight — a radix sort of those costs follows the frame on its stream: it

@@ -102,6 +102,7 @@ struct TraceArgs {
     uint32_t beam_tile, beam_bx;           // beam_bx: beam tiles per row of the rectangle (Rect)
     const uint32_t* order;                 // Rect: workgroup b walks tile order[b] (null = b): longest-first scheduling
     uint32_t* cost_out;                    // Rect: per tile, the clocks its wave spent (null = not recorded)
+    uint32_t miss_in_walk;                 // two-launch form: 1 = the walk's waves write the miss pixels of tiles the pre-pass found empty (they are launched anyway), 0 = the pre-pass does
     uint32_t beam_budget;                  // node visits a search may spend (0 = kBeamMaxVisits); running out is answered conservatively
 };
 

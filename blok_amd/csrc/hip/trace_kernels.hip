@@ -72,7 +72,15 @@ __device__ __forceinline__ void trace_block(const TraceArgs& A, const uint32_t b
             cost_slot = A.cost_out ? A.cost_out + b : nullptr;
             if (A.beam) {
                 t0 = A.beam[((by * kTileH + wave_y) / A.beam_tile) * A.beam_bx + (bx * kTileW + wave_x) / A.beam_tile];
-                if (t0 >= kBeamNone) { if (cost_slot && tid == 0) *cost_slot = 0u; return; }
+                if (t0 >= kBeamNone) {
+                    if (cost_slot && tid == 0) *cost_slot = 0u;
+                    if (A.miss_in_walk) {
+                        const uint32_t mx = bx * kTileW + lx, my = by * kTileH + ly;
+                        const size_t at = static_cast<size_t>(my) * A.w + mx;
+                        if (mx < A.w && my < A.h) write_miss(Sink{A.out ? A.out + at : nullptr, A.out_rgba ? A.out_rgba + at : nullptr});
+                    }
+                    return;
+                }
             }
             const uint32_t rx = bx * kTileW + lx, ry = by * kTileH + ly;
             inside = rx < A.w && ry < A.h;
@@ -96,7 +104,10 @@ __device__ __forceinline__ void trace_block(const TraceArgs& A, const uint32_t b
                 const uint32_t beams_per_side = A.tile / A.beam_tile;
                 t0 = A.beam[(local_tile * beams_per_side + ((sub / per_side) * kTileH + wave_y) / A.beam_tile) * beams_per_side +
                             ((sub % per_side) * kTileW + wave_x) / A.beam_tile];
-                if (t0 >= kBeamNone) return;
+                if (t0 >= kBeamNone) {
+                    if (A.miss_in_walk) write_miss(Sink{A.out ? A.out + out_index : nullptr, A.out_rgba ? A.out_rgba + out_index : nullptr});   // the tile buffer is dense
+                    return;
+                }
             }
         }
         const Sink sink{A.out ? A.out + out_index : nullptr, A.out_rgba ? A.out_rgba + out_index : nullptr};
@@ -162,7 +173,7 @@ __device__ __forceinline__ void beam_block(const TraceArgs& A, const uint32_t b,
     }
     const float t0 = beam_start(A, static_cast<float>(px), static_cast<float>(py), static_cast<float>(px_end), static_cast<float>(py_end), lane);
     if (lane == 0) A.beam[b] = t0;
-    if (t0 >= kBeamNone && (A.out || A.out_rgba)) {
+    if (t0 >= kBeamNone && !A.miss_in_walk && (A.out || A.out_rgba)) {
         // no ray of this tile can hit anything: its pixels are written here, 64 at a time, and the tile's trace waves exit at once
         const uint32_t tw = px_end - px, n = tw * (py_end - py);
         for (uint32_t i = lane; i < n; i += 64u) {

@@ -173,6 +173,10 @@ class HipTracer:
         n = 8 if resort_every_n_frames is True else int(resort_every_n_frames or 0)
         self._check(self._lib.blok_hip_set_tile_ordering(self._ctx, n))
 
+    def set_miss_writer(self, in_walk: bool):
+        """Empty tiles' miss pixels: written by the walk launch's waves (True, default) or by the pre-pass (blok_hip.h)."""
+        self._check(self._lib.blok_hip_set_miss_writer(self._ctx, 1 if in_walk else 0))
+
     def set_beam_budget(self, max_node_visits: int):
         """Node visits a beam search may spend (0 = default); running out is answered conservatively, never changes a result."""
         self._check(self._lib.blok_hip_set_beam_budget(self._ctx, max_node_visits))

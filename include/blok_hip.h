@@ -458,6 +458,10 @@ int blok_hip_set_beam(blok_hip_ctx* ctx, uint32_t beam_tile_pixels);
  * (renderer_raytracing.cpp:666-685 leaves scheduling to the driver).  0 = off; N > 0 = re-sort every N frames.
  * Measured (4K over 1024^3, one frame at a time): 0.295 -> 0.252 ms (poses A, C: -14 %; B: -3 %). */
 int blok_hip_set_tile_ordering(blok_hip_ctx* ctx, int resort_every_n_frames);
+/* Who writes the miss pixels of the tiles the pre-pass found empty (two-launch form): 1 (default) = the walk launch's waves of
+ * those tiles — they are launched anyway and have nothing else to do — 0 = the pre-pass wave of the tile, 1 024 pixels each, which
+ * puts ~120 MB of stores on the pre-pass's critical path (4K, 73 % sky).  Never changes a result. */
+int blok_hip_set_miss_writer(blok_hip_ctx* ctx, int in_walk);
 /* Node visits one beam search may spend (0 = the default, 256; searches average 35).  A search that runs out answers with the
  * lower bound over the cells it has not visited yet — valid, only less tight — never "none", so the frame is the same whatever
  * the budget (tests/test_gpu_parity.py runs with budgets of 1-64 visits against an unlimited search).  The pre-pass lasts as
