@@ -31,11 +31,20 @@ namespace blok {
 #endif
 constexpr float kBeamSlack = 0.05f;
 // Node visits one search may spend; TraceArgs::beam_budget overrides.  Searches average 35 visits on the benchmark frame, but the
-// pre-pass lasts as long as its LONGEST wave (all of them are resident at once): 77 us for a 13 us average.  A search that runs out
-// stops where it is with a valid, less tight answer (the end of beam_search), so the budget trades the pre-pass's tail against the
-// walk's start: measured at 4K over 1024^3 (scripts/beam_budget_sweep.py), launch pair alone / three frames in flight, pose A:
-// unlimited 0.282 / 0.191 ms, 256: 0.263 / 0.190, 128: 0.246 / 0.194, 64: 0.243 / 0.207 — 256 is free, below it the walk pays.
+// pre-pass lasts as long as its LONGEST wave (all of them are resident at once; a visit is a chain of ~650 dependent cycles):
+// 77 us for a 13 us average.  A long search first coarsens (below), and one that runs out stops where it is with a valid, less
+// tight answer (the end of beam_search), so the budget trades the pre-pass's tail against the walk's start: measured at 4K over
+// 1024^3 (scripts/beam_budget_sweep.py, profiles/r02_beam_budget_sweep.txt), launch pair alone / three frames in flight, poses
+// A, B, C: unlimited 0.259 / 0.186, 0.308 / 0.245, 0.290 / 0.192 ms; 256: 0.251 / 0.186, 0.305 / 0.248, 0.269 / 0.192;
+// 128: 0.239 / 0.189, 0.317 / 0.275, 0.248 / 0.193 — below 256 the grazing pose pays more in the walk than the pre-pass saves.
 constexpr uint32_t kBeamMaxVisits = 256u;
+#ifndef BLOK_BEAM_COARSEN1
+#define BLOK_BEAM_COARSEN1 3      // eighths of the budget after which a search stops at bricks ...
+#endif
+#ifndef BLOK_BEAM_COARSEN2
+#define BLOK_BEAM_COARSEN2 5      // ... and at 16^3 cells (8 = never)
+#endif
+constexpr uint32_t kBeamCoarsen1 = BLOK_BEAM_COARSEN1, kBeamCoarsen2 = BLOK_BEAM_COARSEN2;
 
 struct BeamVec { float x, y, z; };
 
@@ -92,7 +101,12 @@ __device__ __forceinline__ float beam_search(const TraceArgs& A, BeamVec ref, Be
     uint64_t cand = 0;
     // every wave reaches the exit: the search is a finite tree walk, and a visit budget bounds it even for a frustum whose
     // planes cull nothing (degenerate inputs): running out is answered with a lower bound over what is left, never with "none"
-    uint32_t budget = A.beam_budget ? A.beam_budget : kBeamMaxVisits;
+    const uint32_t budget0 = A.beam_budget ? A.beam_budget : kBeamMaxVisits;
+    uint32_t budget = budget0;
+    // A long search coarsens before it is cut off: past kBeamCoarsen1/8 of its budget it stops at the 4^3 bricks (their nearest
+    // corners stand for their voxels), past kBeamCoarsen2/8 at the 16^3 cells — still a front-to-back search with a valid bound,
+    // with the brick visits (most of a search) gone.  Only kClampAtZero searches (the others want an exact answer).
+    const uint32_t coarse1 = kClampAtZero ? budget0 - budget0 * kBeamCoarsen1 / 8u : 0u, coarse2 = kClampAtZero ? budget0 - budget0 * kBeamCoarsen2 / 8u : 0u;
     for (; budget != 0u; --budget) {
         const uint4 rec = A.nodes[node];
         const uint32_t mlo = beam_uniform(rec.x), mhi = beam_uniform(rec.y), base = beam_uniform(rec.z);
@@ -104,11 +118,13 @@ __device__ __forceinline__ float beam_search(const TraceArgs& A, BeamVec ref, Be
         float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f, g3 = 0.0f;
         if (fresh) {
             g0 = __builtin_fmaf(s, a0, p0); g1 = __builtin_fmaf(s, a1, p1); g2 = __builtin_fmaf(s, a2, p2); g3 = __builtin_fmaf(s, a3, p3);
-            const bool outside = (__builtin_fmaf(s, far0, g0) < -kBeamSlack) | (__builtin_fmaf(s, far1, g1) < -kBeamSlack) |
-                                 (__builtin_fmaf(s, far2, g2) < -kBeamSlack) | (__builtin_fmaf(s, far3, g3) < -kBeamSlack);
+            // behind any side plane?  fminf drops NaNs, so a NaN never culls (as with four separate comparisons)
+            const bool outside = fminf(fminf(__builtin_fmaf(s, far0, g0), __builtin_fmaf(s, far1, g1)),
+                                       fminf(__builtin_fmaf(s, far2, g2), __builtin_fmaf(s, far3, g3))) < -kBeamSlack;
             const bool filled = ((child_hi ? mhi : mlo) & child_bit) != 0u;
             cand = __ballot(filled && !outside && nearer);
-            if (level <= BLOK_BEAM_STOP_LEVEL) {
+            const uint32_t stop_level = budget < coarse2 ? BLOK_BEAM_STOP_LEVEL + 2u : (budget < coarse1 ? BLOK_BEAM_STOP_LEVEL + 1u : BLOK_BEAM_STOP_LEVEL);
+            if (level <= stop_level) {
                 while (cand) {
                     const uint32_t j = static_cast<uint32_t>(__builtin_ctzll(cand));
                     const float dj = beam_lane(depth, j);
