@@ -183,6 +183,10 @@ HIP_SYMBOLS = {
     "blok_hip_multi_draw_frame_device": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "blok_hip_multi_synchronize": (C.c_int, [C.c_void_p]),
     "blok_hip_multi_draw_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "blok_hip_multi_set_exchange": (C.c_int, [C.c_void_p, C.c_int]),
+    "blok_hip_multi_exchange": (C.c_char_p, [C.c_void_p]),
+    "blok_hip_multi_draw_frames_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "blok_hip_multi_draw_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "blok_hip_multi_download_hits": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]),
     "blok_hip_set_beam_budget": (C.c_int, [C.c_void_p, C.c_uint32]),
     "blok_hip_set_miss_writer": (C.c_int, [C.c_void_p, C.c_int]),

@@ -741,15 +741,18 @@ int blok_hip_compact_tiles_device(blok_hip_ctx* ctx, const void* rgba_tiles_dev,
     return blok_hip_compact_tile_frames_device(ctx, rgba_tiles_dev, tile, n_tiles, 1, 0, out_words_dev, hip_stream);
 }
 
-static int scatter_frames(blok_hip_ctx* ctx, bool codes, const void* gathered_dev, uint32_t n_ranks, size_t rank_stride_words, uint32_t tile,
-                          uint32_t max_records, uint32_t n_frames, void* out_frames_rgba_dev, void* tile_state_dev, void* hip_stream) {
+}   // extern "C"
+namespace blok_api {
+int scatter_frames(blok_hip_ctx* ctx, bool codes, const void* gathered_dev, const void* const* rank_ptrs_dev, uint32_t n_ranks, size_t rank_stride_words,
+                   uint32_t tile, uint32_t max_records, uint32_t n_frames, void* out_frames_rgba_dev, void* tile_state_dev, void* hip_stream) {
     if (!ctx) return BLOK_ERR_INVALID_ARG;
-    if (!gathered_dev || !out_frames_rgba_dev || !tile || (tile & 1u) || !n_ranks || !n_frames) return set_error(ctx, BLOK_ERR_INVALID_ARG, "bad scatter arguments");
+    if ((!gathered_dev && !rank_ptrs_dev) || !out_frames_rgba_dev || !tile || (tile & 1u) || !n_ranks || !n_frames) return set_error(ctx, BLOK_ERR_INVALID_ARG, "bad scatter arguments");
     if (codes && !blok_hip_exchange_code_bits(ctx)) return set_error(ctx, BLOK_ERR_UNSUPPORTED, "the material table is too large for 16-bit pixel codes");
     BLOK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     blok::ScatterArgs a{};
     a.gathered = static_cast<const uint32_t*>(gathered_dev); a.frame = static_cast<uint32_t*>(out_frames_rgba_dev);
+    a.rank_ptrs = reinterpret_cast<const uint32_t* const*>(rank_ptrs_dev);
     a.tile_state = static_cast<uint8_t*>(tile_state_dev);
     a.frame_w = ctx->width; a.frame_h = ctx->height; a.tile = tile; a.n_ranks = n_ranks;
     a.tiles_x = (ctx->width + tile - 1) / tile; a.tiles_total = a.tiles_x * ((ctx->height + tile - 1) / tile);
@@ -771,10 +774,12 @@ static int scatter_frames(blok_hip_ctx* ctx, bool codes, const void* gathered_de
     BLOK_HIP_TRY(ctx, hipGetLastError());
     return BLOK_OK;
 }
+}   // namespace blok_api
+extern "C" {
 
 int blok_hip_scatter_tile_frames_device(blok_hip_ctx* ctx, const void* gathered_dev, uint32_t n_ranks, size_t rank_stride_words, uint32_t tile,
                                         uint32_t max_records, uint32_t n_frames, void* out_frames_rgba_dev, void* tile_state_dev, void* hip_stream) {
-    return scatter_frames(ctx, false, gathered_dev, n_ranks, rank_stride_words, tile, max_records, n_frames, out_frames_rgba_dev, tile_state_dev, hip_stream);
+    return scatter_frames(ctx, false, gathered_dev, nullptr, n_ranks, rank_stride_words, tile, max_records, n_frames, out_frames_rgba_dev, tile_state_dev, hip_stream);
 }
 
 uint32_t blok_hip_exchange_code_bits(const blok_hip_ctx* ctx) {
@@ -801,7 +806,7 @@ int blok_hip_compact_hit_tile_frames_device(blok_hip_ctx* ctx, const void* hit_t
 
 int blok_hip_scatter_code_tile_frames_device(blok_hip_ctx* ctx, const void* gathered_dev, uint32_t n_ranks, size_t rank_stride_words, uint32_t tile,
                                              uint32_t max_records, uint32_t n_frames, void* out_frames_rgba_dev, void* tile_state_dev, void* hip_stream) {
-    return scatter_frames(ctx, true, gathered_dev, n_ranks, rank_stride_words, tile, max_records, n_frames, out_frames_rgba_dev, tile_state_dev, hip_stream);
+    return scatter_frames(ctx, true, gathered_dev, nullptr, n_ranks, rank_stride_words, tile, max_records, n_frames, out_frames_rgba_dev, tile_state_dev, hip_stream);
 }
 
 int blok_hip_scatter_tiles_device(blok_hip_ctx* ctx, const void* gathered_dev, uint32_t n_ranks, size_t rank_stride_words,

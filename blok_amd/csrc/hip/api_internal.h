@@ -153,6 +153,10 @@ int prepare_beam(blok_hip_ctx* ctx, blok::RayMode mode, blok::TraceArgs& args, h
 int prepare_queue(blok_hip_ctx* ctx, blok::RayMode mode, const blok::TraceArgs& args, hipStream_t stream, uint32_t n_beams, blok::FrameQueue* queue, uint32_t* n_blocks);
 int check_trace(blok_hip_ctx* ctx, const blok_camera* cam);
 bool rect_inside(const blok_hip_ctx* ctx, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h);
+// The root's assembly of a sparse exchange (blok_hip_scatter_*_tile_frames_device): the ranks' buffers either side by side in
+// `gathered_dev` or, rank_ptrs_dev != null, wherever a device array of n_ranks pointers says (peer-mapped memory of other devices).
+int scatter_frames(blok_hip_ctx* ctx, bool codes, const void* gathered_dev, const void* const* rank_ptrs_dev, uint32_t n_ranks, size_t rank_stride_words,
+                   uint32_t tile, uint32_t max_records, uint32_t n_frames, void* out_frames_rgba_dev, void* tile_state_dev, void* hip_stream);
 
 }  // namespace blok_api
 #endif

@@ -3,6 +3,12 @@
 // replica of the world, the RGBA8 tiles travel to the root device (device 0 of the list) and are un-permuted there.  No reference
 // counterpart: blok is single-GPU.
 //
+// Exchange.  "sparse-pull" (the default when it can be had): every device compacts its tiles with at least one hit into 16-bit
+// (material, face) code records (blok_hip_compact_hit_tile_frames_device) in its OWN memory, and the root's assembly kernel reads the
+// counts and the records straight out of the peers' memory through peer mappings — fine-grained loads over each peer's own xGMI link —
+// and expands them (blok_hip.h: the coded exchange).  Nothing is staged, no size ever reaches the host, only live records cross a
+// link, and the frame is bit-identical.  Needs peer access from the root to every device and a material table that fits the codes.
+// "dense": every rank's RGBA8 tiles travel whole, then an un-permute kernel — over:
 // Transport.  RCCL (loaded at run time with dlopen, so the library has no link-time dependency on it): one communicator per
 // device from ncclCommInitAll, one ncclGroupStart/End per frame holding every peer's ncclSend and the root's matching ncclRecvs —
 // each peer's tiles cross its own xGMI link to the root.  Peer copy (hipMemcpyPeerAsync, same links, no RCCL): the fallback
@@ -52,15 +58,22 @@ struct blok_hip_multi {
         int device = 0;
         blok_hip_ctx* ctx = nullptr;
         hipStream_t stream = nullptr;
-        uint32_t* d_rgba = nullptr;          // this rank's dense RGBA8 tiles (rank 0: its slot of the gathered buffer)
-        blok_hit* d_hits = nullptr;          // this rank's first-hit records, tile order (stay on the device)
+        uint32_t* d_rgba = nullptr;          // dense exchange: this rank's RGBA8 tiles, frames x per_rank tiles (rank 0: its slot of the gathered buffer)
+        blok_hit* d_hits = nullptr;          // this rank's first-hit records, frames x per_rank tiles, tile order (stay on the device)
+        uint32_t* d_codes = nullptr;         // sparse-pull exchange: counts + code records of the batch (blok_hip_compact_hit_tile_frames_device)
         void* comm = nullptr;
         hipEvent_t traced = nullptr;
     };
     std::vector<Rank> ranks;
     uint32_t width = 0, height = 0, tile = 32, per_rank = 0;
-    uint32_t* d_gathered = nullptr;          // root: n_ranks x per_rank x tile^2
-    uint32_t* d_frame = nullptr;             // root: width x height
+    uint32_t frames_capacity = 0;            // frames per call the buffers are sized for
+    uint32_t* d_gathered = nullptr;          // root, dense: n_ranks x frames x per_rank x tile^2
+    uint32_t* d_frame = nullptr;             // root: frames x width x height
+    uint8_t* d_tile_state = nullptr;         // root, sparse-pull: which tiles of d_frame hold something other than sky
+    const uint32_t** d_rank_ptrs = nullptr;  // root, sparse-pull: every rank's d_codes
+    bool frame_is_sky = false;               // d_frame / d_tile_state are in the state sparse-pull assumes (all sky / all zero, or left by it)
+    bool peer_readable = false;              // the root can read every device's memory
+    int exchange = -1;                       // -1 = sparse-pull when possible, 0 = dense, 1 = sparse-pull (refused when impossible)
     Rccl rccl;
     bool use_rccl = false;
     std::string transport = "none";
@@ -95,6 +108,7 @@ void destroy(blok_hip_multi* m) {
         if (r.comm && m->rccl.CommDestroy) (void)m->rccl.CommDestroy(r.comm);
         if (r.traced) (void)hipEventDestroy(r.traced);
         if (r.d_hits) (void)hipFree(r.d_hits);
+        if (r.d_codes) (void)hipFree(r.d_codes);
         if (r.d_rgba && &r != &m->ranks[0]) (void)hipFree(r.d_rgba);
         if (r.stream) { (void)hipStreamSynchronize(r.stream); (void)hipStreamDestroy(r.stream); }
         if (r.ctx) blok_hip_destroy(r.ctx);
@@ -102,8 +116,49 @@ void destroy(blok_hip_multi* m) {
     if (!m->ranks.empty() && m->ranks[0].ctx) (void)hipSetDevice(m->ranks[0].device);
     if (m->d_gathered) (void)hipFree(m->d_gathered);
     if (m->d_frame) (void)hipFree(m->d_frame);
+    if (m->d_tile_state) (void)hipFree(m->d_tile_state);
+    if (m->d_rank_ptrs) (void)hipFree(m->d_rank_ptrs);
     if (m->rccl.lib) dlclose(m->rccl.lib);
     delete m;
+}
+
+// Buffers for `frames` frames per call (grown on demand; everything in flight is finished first).
+int ensure_frames(blok_hip_multi* m, uint32_t frames) {
+    if (frames <= m->frames_capacity) return BLOK_OK;
+    const uint32_t G = static_cast<uint32_t>(m->ranks.size());
+    const size_t tile_px = static_cast<size_t>(m->per_rank) * m->tile * m->tile;
+    const size_t n_px = static_cast<size_t>(m->width) * m->height;
+    const size_t tiles_total = static_cast<size_t>((m->width + m->tile - 1) / m->tile) * ((m->height + m->tile - 1) / m->tile);
+    for (auto& r : m->ranks) { MULTI_TRY(m, hipSetDevice(r.device)); MULTI_TRY(m, hipStreamSynchronize(r.stream)); }
+    for (uint32_t i = 0; i < G; ++i) {
+        auto& r = m->ranks[i];
+        MULTI_TRY(m, hipSetDevice(r.device));
+        if (r.d_hits) (void)hipFree(r.d_hits);
+        if (r.d_codes) (void)hipFree(r.d_codes);
+        if (r.d_rgba && i != 0) (void)hipFree(r.d_rgba);
+        r.d_hits = nullptr; r.d_codes = nullptr; r.d_rgba = nullptr;
+        MULTI_TRY(m, hipMalloc(reinterpret_cast<void**>(&r.d_hits), frames * tile_px * sizeof(blok_hit)));
+        MULTI_TRY(m, hipMalloc(reinterpret_cast<void**>(&r.d_codes), frames * blok_hip_compact_code_words(m->tile, m->per_rank) * sizeof(uint32_t)));
+        if (i == 0) {
+            for (void* p : {static_cast<void*>(m->d_gathered), static_cast<void*>(m->d_frame), static_cast<void*>(m->d_tile_state), static_cast<void*>(m->d_rank_ptrs)})
+                if (p) (void)hipFree(p);
+            m->d_gathered = nullptr; m->d_frame = nullptr; m->d_tile_state = nullptr; m->d_rank_ptrs = nullptr;
+            MULTI_TRY(m, hipMalloc(reinterpret_cast<void**>(&m->d_gathered), static_cast<size_t>(G) * frames * tile_px * sizeof(uint32_t)));
+            MULTI_TRY(m, hipMalloc(reinterpret_cast<void**>(&m->d_frame), frames * n_px * sizeof(uint32_t)));
+            MULTI_TRY(m, hipMalloc(reinterpret_cast<void**>(&m->d_tile_state), frames * tiles_total));
+            MULTI_TRY(m, hipMalloc(reinterpret_cast<void**>(&m->d_rank_ptrs), G * sizeof(uint32_t*)));
+            r.d_rgba = m->d_gathered;                                              // the root traces straight into its slot
+        } else {
+            MULTI_TRY(m, hipMalloc(reinterpret_cast<void**>(&r.d_rgba), frames * tile_px * sizeof(uint32_t)));
+        }
+    }
+    std::vector<const uint32_t*> ptrs(G);
+    for (uint32_t i = 0; i < G; ++i) ptrs[i] = m->ranks[i].d_codes;
+    MULTI_TRY(m, hipSetDevice(m->ranks[0].device));
+    MULTI_TRY(m, hipMemcpy(m->d_rank_ptrs, ptrs.data(), G * sizeof(uint32_t*), hipMemcpyHostToDevice));
+    m->frames_capacity = frames;
+    m->frame_is_sky = false;
+    return BLOK_OK;
 }
 
 }  // namespace
@@ -126,7 +181,6 @@ int blok_hip_multi_create(blok_hip_multi** out, const int* device_ordinals, uint
     bool distinct = true;
     for (uint32_t i = 0; i < n_devices; ++i)
         for (uint32_t j = 0; j < i; ++j) distinct = distinct && device_ordinals[i] != device_ordinals[j];
-    const size_t tile_px = static_cast<size_t>(m->per_rank) * tile * tile;
     int rc = BLOK_OK;
     for (uint32_t i = 0; i < n_devices && rc == BLOK_OK; ++i) {
         auto& r = m->ranks[i];
@@ -136,14 +190,6 @@ int blok_hip_multi_create(blok_hip_multi** out, const int* device_ordinals, uint
         hipError_t e = hipSetDevice(r.device);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&r.traced, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r.d_hits), tile_px * sizeof(blok_hit));
-        if (e == hipSuccess && i == 0) {
-            e = hipMalloc(reinterpret_cast<void**>(&m->d_gathered), static_cast<size_t>(n_devices) * tile_px * sizeof(uint32_t));
-            if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&m->d_frame), static_cast<size_t>(width) * height * sizeof(uint32_t));
-            r.d_rgba = m->d_gathered;                                              // the root traces straight into its slot
-        } else if (e == hipSuccess) {
-            e = hipMalloc(reinterpret_cast<void**>(&r.d_rgba), tile_px * sizeof(uint32_t));
-        }
         if (e != hipSuccess) { rc = fail(nullptr, e == hipErrorOutOfMemory ? BLOK_ERR_OOM : BLOK_ERR_HIP, std::string("multi: device ") + std::to_string(r.device) + ": " + hipGetErrorString(e)); break; }
     }
     if (rc == BLOK_OK && n_devices > 1) {
@@ -167,7 +213,20 @@ int blok_hip_multi_create(blok_hip_multi** out, const int* device_ordinals, uint
             }
         }
     }
-    if (rc != BLOK_OK) { const std::string msg = g_multi_create_error; destroy(m); g_multi_create_error = msg; return rc; }
+    if (rc == BLOK_OK) {
+        // can the root read every device's memory (sparse-pull)?  A device listed twice is trivially readable.
+        m->peer_readable = true;
+        (void)hipSetDevice(m->ranks[0].device);
+        for (uint32_t i = 1; i < n_devices; ++i) {
+            if (m->ranks[i].device == m->ranks[0].device) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, m->ranks[0].device, m->ranks[i].device) != hipSuccess || !can) { m->peer_readable = false; (void)hipGetLastError(); continue; }
+            const hipError_t e = hipDeviceEnablePeerAccess(m->ranks[i].device, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { m->peer_readable = false; (void)hipGetLastError(); }
+        }
+        rc = ensure_frames(m, 1);
+    }
+    if (rc != BLOK_OK) { const std::string msg = m->error.empty() ? g_multi_create_error : m->error; destroy(m); g_multi_create_error = msg; return rc; }
     *out = m;
     return BLOK_OK;
 }
@@ -188,43 +247,89 @@ int blok_hip_multi_upload_world(blok_hip_multi* m, const blok_svo_node* nodes, s
     return BLOK_OK;
 }
 
-int blok_hip_multi_draw_frame_device(blok_hip_multi* m, const blok_camera* cam, const uint32_t** out_rgba8_dev_on_root) {
+// Will this call use the sparse-pull exchange?  (Decided per call: the material table arrives with the world.)
+static bool sparse_pull(const blok_hip_multi* m) {
+    return m->exchange != 0 && m->peer_readable && blok_hip_exchange_code_bits(m->ranks[0].ctx) == 16u;
+}
+
+int blok_hip_multi_set_exchange(blok_hip_multi* m, int mode) {
+    if (!m || mode < -1 || mode > 1) return BLOK_ERR_INVALID_ARG;
+    if (mode == 1 && !m->peer_readable) return fail(m, BLOK_ERR_UNSUPPORTED, "multi: the root device cannot read every device's memory (no peer access)");
+    m->exchange = mode;
+    return BLOK_OK;
+}
+
+const char* blok_hip_multi_exchange(const blok_hip_multi* m) { return !m ? "" : sparse_pull(m) ? "sparse-pull" : "dense"; }
+
+int blok_hip_multi_draw_frames_device(blok_hip_multi* m, const blok_camera* cams, uint32_t n_frames, const uint32_t** out_rgba8_dev_on_root) {
     if (!m) return BLOK_ERR_INVALID_ARG;
+    if (!cams || !n_frames || n_frames > BLOK_MAX_TILE_FRAMES) return fail(m, BLOK_ERR_INVALID_ARG, "multi: 1 to 8 cameras per call");
+    int rc = ensure_frames(m, n_frames);
+    if (rc != BLOK_OK) return rc;
     const uint32_t G = static_cast<uint32_t>(m->ranks.size());
     const size_t tile_px = static_cast<size_t>(m->per_rank) * m->tile * m->tile;
-    // every device traces its tiles
+    const size_t n_px = static_cast<size_t>(m->width) * m->height;
+    auto& root = m->ranks[0];
+    const bool pull = sparse_pull(m);
+    // every device traces its tiles of all the frames in one launch pair (and, sparse-pull, compacts them where they are)
     for (uint32_t i = 0; i < G; ++i) {
         auto& r = m->ranks[i];
-        const int rc = blok_hip_trace_tiles_device(r.ctx, cam, m->tile, i, G, r.d_hits, r.d_rgba, r.stream);
+        rc = blok_hip_trace_tile_frames_device(r.ctx, cams, n_frames, m->tile, i, G, m->per_rank, r.d_hits, pull ? nullptr : r.d_rgba, r.stream);
+        if (rc == BLOK_OK && pull)
+            rc = blok_hip_compact_hit_tile_frames_device(r.ctx, r.d_hits, m->tile, blok_hip_tiles_for_rank(m->width, m->height, m->tile, i, G), n_frames,
+                                                         m->per_rank, r.d_codes, r.stream);
         if (rc != BLOK_OK) return rank_error(m, i, rc);
+        if (pull && i != 0) { MULTI_TRY(m, hipSetDevice(r.device)); MULTI_TRY(m, hipEventRecord(r.traced, r.stream)); }
     }
-    auto& root = m->ranks[0];
-    if (G > 1 && m->use_rccl) {
+    if (pull) {
+        MULTI_TRY(m, hipSetDevice(root.device));
+        if (!m->frame_is_sky) {            // the state the assembly kernel builds on: every tile sky, no tile marked
+            MULTI_TRY(m, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(m->d_frame), static_cast<int>(0xFF000000u | (230u << 16) | (200u << 8) | 160u),
+                                           m->frames_capacity * n_px, root.stream));
+            const size_t tiles_total = static_cast<size_t>((m->width + m->tile - 1) / m->tile) * ((m->height + m->tile - 1) / m->tile);
+            MULTI_TRY(m, hipMemsetAsync(m->d_tile_state, 0, m->frames_capacity * tiles_total, root.stream));
+            m->frame_is_sky = true;
+        }
+        for (uint32_t i = 1; i < G; ++i) MULTI_TRY(m, hipStreamWaitEvent(root.stream, m->ranks[i].traced, 0));
+        // the root reads every rank's counts and live records where they lie (its own, and the peers' over xGMI) and expands them
+        rc = blok_api::scatter_frames(root.ctx, true, nullptr, reinterpret_cast<const void* const*>(m->d_rank_ptrs), G, 0, m->tile, m->per_rank, n_frames,
+                                      m->d_frame, m->d_tile_state, root.stream);
+        if (rc != BLOK_OK) return rank_error(m, 0, rc);
+        if (out_rgba8_dev_on_root) *out_rgba8_dev_on_root = m->d_frame;
+        return BLOK_OK;
+    }
+    m->frame_is_sky = false;
+    const size_t block = n_frames * tile_px;                       // a rank's tiles of all the frames: what travels, and the stride of the gathered buffer
+    if (m->use_rccl) {
         // one group: every peer sends on its own stream (ordered behind its trace), the root posts the matching receives
         int st = m->rccl.GroupStart();
         for (uint32_t i = 1; i < G && st == 0; ++i) {
             auto& r = m->ranks[i];
-            st = m->rccl.Send(r.d_rgba, tile_px, kNcclUint32, 0, r.comm, r.stream);
-            if (st == 0) st = m->rccl.Recv(m->d_gathered + i * tile_px, tile_px, kNcclUint32, static_cast<int>(i), root.comm, root.stream);
+            st = m->rccl.Send(r.d_rgba, block, kNcclUint32, 0, r.comm, r.stream);
+            if (st == 0) st = m->rccl.Recv(m->d_gathered + i * block, block, kNcclUint32, static_cast<int>(i), root.comm, root.stream);
         }
         const int st_end = m->rccl.GroupEnd();
         if (st == 0) st = st_end;
         if (st != 0) return fail(m, BLOK_ERR_HIP, std::string("rccl: ") + (m->rccl.GetErrorString ? m->rccl.GetErrorString(st) : "error"));
-    } else if (G > 1) {
+    } else {
         // peer copies: each peer pushes its tiles into the root's buffer on its own stream; the root waits for all of them
         for (uint32_t i = 1; i < G; ++i) {
             auto& r = m->ranks[i];
             MULTI_TRY(m, hipSetDevice(r.device));
-            MULTI_TRY(m, hipMemcpyPeerAsync(m->d_gathered + i * tile_px, root.device, r.d_rgba, r.device, tile_px * sizeof(uint32_t), r.stream));
+            MULTI_TRY(m, hipMemcpyPeerAsync(m->d_gathered + i * block, root.device, r.d_rgba, r.device, block * sizeof(uint32_t), r.stream));
             MULTI_TRY(m, hipEventRecord(r.traced, r.stream));
         }
         MULTI_TRY(m, hipSetDevice(root.device));
         for (uint32_t i = 1; i < G; ++i) MULTI_TRY(m, hipStreamWaitEvent(root.stream, m->ranks[i].traced, 0));
     }
-    const int rc = blok_hip_untile_device(root.ctx, m->d_gathered, 4, m->tile, G, m->per_rank, m->d_frame, root.stream);
+    rc = blok_hip_untile_frames_device(root.ctx, m->d_gathered, 4, m->tile, G, n_frames * m->per_rank, n_frames, m->per_rank, m->d_frame, root.stream);
     if (rc != BLOK_OK) return rank_error(m, 0, rc);
     if (out_rgba8_dev_on_root) *out_rgba8_dev_on_root = m->d_frame;
     return BLOK_OK;
+}
+
+int blok_hip_multi_draw_frame_device(blok_hip_multi* m, const blok_camera* cam, const uint32_t** out_rgba8_dev_on_root) {
+    return blok_hip_multi_draw_frames_device(m, cam, 1, out_rgba8_dev_on_root);
 }
 
 int blok_hip_multi_synchronize(blok_hip_multi* m) {
@@ -233,21 +338,26 @@ int blok_hip_multi_synchronize(blok_hip_multi* m) {
     return BLOK_OK;
 }
 
-int blok_hip_multi_draw_frame(blok_hip_multi* m, const blok_camera* cam, uint32_t* out_rgba8_host) {
+int blok_hip_multi_draw_frames(blok_hip_multi* m, const blok_camera* cams, uint32_t n_frames, uint32_t* out_rgba8_host) {
     if (!m) return BLOK_ERR_INVALID_ARG;
-    const uint32_t* frame = nullptr;
-    int rc = blok_hip_multi_draw_frame_device(m, cam, &frame);
+    const uint32_t* frames = nullptr;
+    int rc = blok_hip_multi_draw_frames_device(m, cams, n_frames, &frames);
     if (rc != BLOK_OK) return rc;
     rc = blok_hip_multi_synchronize(m);
     if (rc != BLOK_OK) return rc;
     if (out_rgba8_host) {
         MULTI_TRY(m, hipSetDevice(m->ranks[0].device));
-        MULTI_TRY(m, hipMemcpy(out_rgba8_host, frame, static_cast<size_t>(m->width) * m->height * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        MULTI_TRY(m, hipMemcpy(out_rgba8_host, frames, static_cast<size_t>(n_frames) * m->width * m->height * sizeof(uint32_t), hipMemcpyDeviceToHost));
     }
     return BLOK_OK;
 }
 
-// This rank's first-hit records, tile order (blok_hip_tiles_for_rank(...) x tile^2 records), after a synchronised frame.
+int blok_hip_multi_draw_frame(blok_hip_multi* m, const blok_camera* cam, uint32_t* out_rgba8_host) {
+    return blok_hip_multi_draw_frames(m, cam, 1, out_rgba8_host);
+}
+
+// This rank's first-hit records of the FIRST frame of the last call, tile order (blok_hip_tiles_for_rank(...) x tile^2 records), after a
+// synchronised call.
 int blok_hip_multi_download_hits(blok_hip_multi* m, uint32_t rank, blok_hit* out_host, size_t capacity_records) {
     if (!m || rank >= m->ranks.size() || !out_host) return BLOK_ERR_INVALID_ARG;
     const size_t n = static_cast<size_t>(blok_hip_tiles_for_rank(m->width, m->height, m->tile, rank, static_cast<uint32_t>(m->ranks.size()))) * m->tile * m->tile;

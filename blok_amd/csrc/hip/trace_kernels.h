@@ -163,6 +163,8 @@ struct CompactHitArgs {                    // rank's dense first-hit tiles -> {c
 };
 struct ScatterArgs {                       // gathered compact buffers of all ranks -> row-major frames
     const uint32_t* gathered;
+    const uint32_t* const* rank_ptrs;      // optional (device array of n_ranks pointers): rank r's buffer is rank_ptrs[r] instead of gathered + r * rank_stride —
+                                           // buffers that live on OTHER devices, read over xGMI through peer mappings (single-process entry, api_multi.hip)
     uint32_t* frame;                       // n_frames contiguous frames
     uint32_t* tile_map;                    // n_frames * tiles_total words, zero before and after: 1 + (rank * max_records + slot) of the record that holds a tile
     uint8_t* tile_state;                   // optional, n_frames * tiles_total: does the frame buffer's tile hold anything but sky?  Lets sky tiles that stay sky go unwritten

@@ -508,7 +508,7 @@ __global__ __launch_bounds__(64) void scatter_map_kernel(const ScatterArgs a) {
     const uint32_t i = blockIdx.x * 64u + threadIdx.x, f = blockIdx.y;
     if (i >= a.n_ranks * a.max_records) return;
     const uint32_t r = i / a.max_records, j = i % a.max_records;
-    const uint32_t* base = a.gathered + static_cast<size_t>(r) * a.rank_stride;
+    const uint32_t* base = a.rank_ptrs ? a.rank_ptrs[r] : a.gathered + static_cast<size_t>(r) * a.rank_stride;
     if (j >= base[f]) return;
     const uint32_t* rec = base + a.n_frames + (static_cast<size_t>(j) * a.n_frames + f) * a.record_words;
     const uint64_t g = r + static_cast<uint64_t>(rec[0]) * a.n_ranks;
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(64) void scatter_tiles_kernel(const ScatterArgs a) 
     const uint32_t* rec = nullptr;
     if (m) {
         const uint32_t r = (m - 1u) / a.max_records, j = (m - 1u) % a.max_records;
-        rec = a.gathered + static_cast<size_t>(r) * a.rank_stride + a.n_frames + (static_cast<size_t>(j) * a.n_frames + f) * a.record_words;
+        rec = (a.rank_ptrs ? a.rank_ptrs[r] : a.gathered + static_cast<size_t>(r) * a.rank_stride) + a.n_frames + (static_cast<size_t>(j) * a.n_frames + f) * a.record_words;
     }
     for (uint32_t i = lane; i < px; i += 64u) {
         const uint32_t x = x0 + i % a.tile, y = y0 + i / a.tile;

@@ -74,6 +74,22 @@ class HipMultiTracer:
         self._check(self._lib.blok_hip_multi_draw_frame(self._m, self._ffi.ptr(cam), self._ffi.ptr(out)))
         return out
 
+    def draw_frames(self, cams):
+        """1..8 cameras, one launch pair per device: (n, height, width) RGBA8 frames."""
+        import numpy as np
+        cams = np.ascontiguousarray(np.concatenate([np.asarray(c).reshape(-1) for c in cams]), dtype=self._ffi.CAMERA)
+        out = np.zeros((len(cams), self.height, self.width), dtype=np.uint32)
+        self._check(self._lib.blok_hip_multi_draw_frames(self._m, self._ffi.ptr(cams), len(cams), self._ffi.ptr(out)))
+        return out
+
+    def set_exchange(self, mode: int):
+        """-1 = sparse-pull when possible (default), 0 = dense, 1 = sparse-pull or an error (blok_hip.h)."""
+        self._check(self._lib.blok_hip_multi_set_exchange(self._m, mode))
+
+    @property
+    def exchange(self) -> str:
+        return (self._lib.blok_hip_multi_exchange(self._m) or b"").decode()
+
     def rank_hits(self, rank: int):
         import numpy as np
         n = int(self._lib.blok_hip_tiles_for_rank(self.width, self.height, self.tile, rank, self.n)) * self.tile * self.tile

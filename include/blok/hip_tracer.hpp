@@ -306,6 +306,16 @@ public:
         return frame;
     }
     void synchronize() { check(blok_hip_multi_synchronize(m_multi)); }
+    // Several frames per call (1..BLOK_MAX_TILE_FRAMES cameras, one launch pair per device); the frames follow one another in rgba8.
+    void drawFrames(const std::vector<Camera>& cams, std::vector<uint32_t>& rgba8) {
+        std::vector<blok_camera> basis;
+        for (const Camera& c : cams) basis.push_back(c.basis(m_width, m_height));
+        rgba8.resize(cams.size() * static_cast<size_t>(m_width) * m_height);
+        check(blok_hip_multi_draw_frames(m_multi, basis.data(), static_cast<uint32_t>(basis.size()), rgba8.data()));
+    }
+    // How the tiles reach the root: -1 = sparse-pull when possible (default), 0 = dense, 1 = sparse-pull or an exception (blok_hip.h).
+    void setExchange(int mode) { check(blok_hip_multi_set_exchange(m_multi, mode)); }
+    std::string exchange() const { return blok_hip_multi_exchange(m_multi); }
 
 private:
     void check(int rc) const { if (rc != BLOK_OK) throw std::runtime_error(std::string("HipMultiTracer: ") + blok_hip_multi_last_error(m_multi)); }

@@ -522,6 +522,19 @@ int  blok_hip_multi_draw_frame_device(blok_hip_multi* m, const blok_camera* cam,
 int  blok_hip_multi_synchronize(blok_hip_multi* m);
 int  blok_hip_multi_draw_frame(blok_hip_multi* m, const blok_camera* cam, uint32_t* out_rgba8_host);
 /* Rank `rank`'s first-hit records of the last synchronised frame, in its tile order (blok_hip_tiles_for_rank x tile^2). */
+/* Several frames per call (1..BLOK_MAX_TILE_FRAMES cameras, one launch pair per device; the frames lie one after the other in
+ * the root's buffer / in out_rgba8_host), and how the tiles reach the root:
+ *   "sparse-pull" (mode 1; the default, mode -1, whenever it can be had): every device compacts its tiles with a hit into 16-bit
+ *       (material, face) code records in its own memory and the root's assembly kernel reads counts and records straight out of
+ *       the peers' memory through peer mappings and expands them — nothing staged, no size on the host, only live records cross
+ *       a link, bit-identical frames.  Needs peer access from the root to every device (refused with BLOK_ERR_UNSUPPORTED
+ *       otherwise) and a material table that fits the codes (else the call uses "dense").
+ *   "dense" (mode 0): the RGBA8 tiles of every rank travel whole (blok_hip_multi_transport), then an un-permute kernel. */
+int  blok_hip_multi_set_exchange(blok_hip_multi* m, int mode);
+const char* blok_hip_multi_exchange(const blok_hip_multi* m);        /* what the next call will use: "sparse-pull" or "dense" */
+int  blok_hip_multi_draw_frames_device(blok_hip_multi* m, const blok_camera* cams, uint32_t n_frames, const uint32_t** out_rgba8_dev_on_root);
+int  blok_hip_multi_draw_frames(blok_hip_multi* m, const blok_camera* cams, uint32_t n_frames, uint32_t* out_rgba8_host);
+/* first-hit records of the first frame of the last call */
 int  blok_hip_multi_download_hits(blok_hip_multi* m, uint32_t rank, blok_hit* out_host, size_t capacity_records);
 
 #ifdef __cplusplus

@@ -741,6 +741,10 @@ def test_several_frames_per_launch_equal_frame_by_frame(tracer_cls, scene1024):
                     got = frames[f].cpu().numpy().view(np.uint32)
                     expect = want[f] if order == 1 else want[n_frames - 1 - f] if order == -1 else np.uint32(T.SKY_RGBA)
                     assert (got == expect).all(), ("state", step, beam, n_ranks, f)
+            # no record slots at all (every rank's count is zero: an all-sky batch): the buffer goes back to sky
+            tr.scatter_tile_frames_device(packed.data_ptr(), n_ranks, n_frames * words, tile, 0, n_frames, frames.data_ptr(), state.data_ptr())
+            torch.cuda.synchronize()
+            assert (frames.cpu().numpy().view(np.uint32) == np.uint32(T.SKY_RGBA)).all() and not state.any().item()
     tr.set_beam(32)
     # refused: more frames than one launch takes, a frame stride smaller than the rank's tiles
     buf = torch.zeros(9 * tr.tiles_for_rank(32, 0, 2) * 1024, dtype=torch.int32, device="cuda")
@@ -814,8 +818,9 @@ def test_power_of_two_voxel_sizes(tracer_cls, vs):
 
 def test_multi_device_entry_one_process(tracer_cls, scene1024):
     """blok_hip_multi_* (C ABI; one process, one context and stream per rank): 1, 3 and 8 ranks on device 0 — transport "none" /
-    "peer-copy" — give the single-device RGBA8 frame, and each rank's first-hit records are its tiles of the single-device
-    records; creation with RCCL allowed but a repeated device falls back to peer copies; bad arguments are refused."""
+    "peer-copy" — give the single-device RGBA8 frame with either exchange (sparse-pull / dense), one and several frames per call,
+    and each rank's first-hit records are its tiles of the single-device records; creation with RCCL allowed but a repeated
+    device falls back to peer copies; bad arguments are refused."""
     from blok_amd.multi_gpu import HipMultiTracer
     from blok_amd._ffi import BlokError
     from blok_amd import tiles as T
@@ -830,15 +835,29 @@ def test_multi_device_entry_one_process(tracer_cls, scene1024):
         mt = HipMultiTracer(devices, Wd, Ht, tile=tile, allow_rccl=True)
         assert mt.transport == transport
         mt.add_world(pw)
-        for _ in range(2):
-            assert (mt.draw_frame(cam) == want).all(), devices
         n = len(devices)
-        for r in (0, n - 1):
-            got = mt.rank_hits(r)
-            for k, (x0, y0) in enumerate(T.rank_tile_origins(Wd, Ht, tile, r, n)):
-                h, w = min(tile, Ht - y0), min(tile, Wd - x0)
-                block = got[k * tile * tile:(k + 1) * tile * tile].reshape(tile, tile)[:h, :w]
-                assert records_equal(block.reshape(-1), hits[y0:y0 + h, x0:x0 + w].reshape(-1)).all(), (devices, r, k)
+        cams = [cam] + [W.scene_camera(1024, p, Wd, Ht, SEED) for p in (1, 2)]
+        wants = [want] + [tr.shade_rgba8(c) for c in cams[1:]]
+        # both exchanges — the default "sparse-pull" (the root reads the ranks' 16-bit code records where they lie) and "dense"
+        # (whole RGBA8 tiles travel, then an un-permute) — one frame and three frames per call, back and forth
+        for mode, name in ((-1, "sparse-pull"), (0, "dense"), (1, "sparse-pull"), (0, "dense")):
+            mt.set_exchange(mode)
+            assert mt.exchange == name
+            for _ in range(2):
+                assert (mt.draw_frame(cam) == want).all(), (devices, name)
+            got3 = mt.draw_frames(cams)
+            for f in range(3):
+                assert (got3[f] == wants[f]).all(), (devices, name, f)
+            assert (mt.draw_frame(cams[2]) == wants[2]).all(), (devices, name)       # live <-> sky per tile between calls
+            assert (mt.draw_frame(cam) == want).all(), (devices, name)
+            for r in (0, n - 1):
+                got = mt.rank_hits(r)
+                for k, (x0, y0) in enumerate(T.rank_tile_origins(Wd, Ht, tile, r, n)):
+                    h, w = min(tile, Ht - y0), min(tile, Wd - x0)
+                    block = got[k * tile * tile:(k + 1) * tile * tile].reshape(tile, tile)[:h, :w]
+                    assert records_equal(block.reshape(-1), hits[y0:y0 + h, x0:x0 + w].reshape(-1)).all(), (devices, name, r, k)
+        with pytest.raises(BlokError):
+            mt.draw_frames([cam] * 9)
         mt.shutdown()
     with pytest.raises(BlokError):
         HipMultiTracer([0, 99], Wd, Ht)

@@ -49,10 +49,12 @@ def test_driver_full_ray_tracing_path(tmp_path):
 @pytest.mark.gpu
 def test_driver_multi_device_tile_partition(tmp_path):
     """blok::HipMultiTracer (one process, several ranks): three ranks rehearsed on device 0 (peer-copy transport; RCCL refuses a
-    repeated device) — the driver itself compares the partitioned frame with the single-device one."""
+    repeated device), with the sparse-pull and the dense exchange — the driver itself compares the partitioned frame with the
+    single-device one."""
     exe = b.build_tools()
     out = tmp_path / "multi.ppm"
-    proc = subprocess.run([str(exe), "--n", "64", "--size", "328x200", "--frames", "3", "--devices", "0,0,0", "--out", str(out)],
-                          capture_output=True, text=True, timeout=300)
-    assert proc.returncode == 0, proc.stderr + proc.stdout
-    assert "3 ranks, transport peer-copy" in proc.stdout and "0 pixels differ" in proc.stdout
+    for extra, exchange in (([], "sparse-pull"), (["--dense-exchange"], "dense")):
+        proc = subprocess.run([str(exe), "--n", "64", "--size", "328x200", "--frames", "3", "--devices", "0,0,0", "--out", str(out)] + extra,
+                              capture_output=True, text=True, timeout=300)
+        assert proc.returncode == 0, proc.stderr + proc.stdout
+        assert f"3 ranks, exchange {exchange}, transport peer-copy" in proc.stdout and "0 pixels differ" in proc.stdout

@@ -6,6 +6,7 @@
 //   --devices 0,1,2,...: the frame is tile-partitioned over these devices of the node by ONE process (blok::HipMultiTracer:
 //                        RCCL send / receive group or peer copies to the first device); an ordinal may repeat (rehearsal on one GPU)
 //   --no-rccl: peer copies even when RCCL is there
+//   --dense-exchange: whole RGBA8 tiles travel (RCCL / peer copies) instead of the root reading the ranks' sparse code records
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -26,6 +27,7 @@ struct Options {
     uint32_t spp = 8;                     // samples per pixel and frame in --rt mode (the reference forces 8)
     std::string vox;                      // optional .vox model instead of the synthetic scene (app.cpp:105-113)
     std::vector<int> devices;             // more than one entry: the multi-device tracer
+    bool dense_exchange = false;
     bool rccl = true;
 };
 
@@ -62,7 +64,8 @@ private:
                 if (m_opt.devices.size() > 1) {
                     m_multi = std::make_unique<blok::HipMultiTracer>(m_opt.devices, m_opt.width, m_opt.height, 32, m_opt.rccl);
                     m_multi->addWorld(m_world);
-                    std::cout << "multi-device: " << m_multi->deviceCount() << " ranks, transport " << m_multi->transport() << "\n";
+                    if (m_opt.dense_exchange) m_multi->setExchange(0);
+                    std::cout << "multi-device: " << m_multi->deviceCount() << " ranks, exchange " << m_multi->exchange() << ", transport " << m_multi->transport() << "\n";
                 }
                 const blok_world_stats s = m_tracer->worldStats();
                 std::cout << "world: " << s.n_voxels << " voxels, " << s.n_ref_nodes << " SVO nodes, " << s.n_sub_chunks
@@ -137,6 +140,7 @@ int main(int argc, char** argv) {
         else if (!std::strcmp(argv[i], "--rt")) opt.rt = true;
         else if (!std::strcmp(argv[i], "--spp")) opt.spp = std::strtoul(next(), nullptr, 10);
         else if (!std::strcmp(argv[i], "--no-rccl")) opt.rccl = false;
+        else if (!std::strcmp(argv[i], "--dense-exchange")) opt.dense_exchange = true;
         else if (!std::strcmp(argv[i], "--devices")) { for (const char* p = next(); *p;) { opt.devices.push_back(std::atoi(p)); while (*p && *p != ',') ++p; if (*p == ',') ++p; } }
         else { std::fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
     }
