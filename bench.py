@@ -180,10 +180,12 @@ def main():
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
+        limit = datetime.timedelta(seconds=300)      # a collective that never completes ends the run with an error instead of hanging the node
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index), timeout=limit)
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, timeout=limit)
 
     from blok_amd import world as W
     from blok_amd.tracer import HipTracer
