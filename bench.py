@@ -56,7 +56,8 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for "
                     "rehearsing the N > 1 code path with several ranks on one GPU, which RCCL refuses)")
     ap.add_argument("--beam", type=int, default=32, help="beam pre-pass tile in pixels (0 = off)")
-    ap.add_argument("--fused", type=int, default=0, help="1 = one persistent launch per frame (pre-pass + walk; measured slower), 0 = beam kernel then trace kernel")
+    ap.add_argument("--fused", type=int, default=3, help="launch form of a frame (blok_hip_set_fused): 0 = beam kernel then trace kernel, 1 = one persistent launch with work queues (measured slower), "
+                    "2 = joint launch (searches and walk waves in one grid), 3 = automatic: 2 when a launch has the chip to itself, else 0")
     ap.add_argument("--tile-ordering", type=int, default=8, help="longest-first scheduling of the walk from earlier frames' per-wave clocks, re-sorted every N frames (0 = off)")
     ap.add_argument("--orbit", type=float, default=0.0, help="degrees the camera turns around the world's centre per frame (0 = static camera)")
     ap.add_argument("--dense-dda", action="store_true", help="BASELINE configs[1]: upload the scene as a dense id grid and trace with the dense-grid kernel (N = 1, --n <= 512)")
@@ -201,7 +202,7 @@ def main():
     else:
         stats = tracer.add_world(packed)                  # world resident in HBM from here on
     tracer.set_beam(args.beam)
-    tracer.set_fused(bool(args.fused))
+    tracer.set_fused(args.fused)
     tracer.set_tile_ordering(args.tile_ordering)
 
     if args.frames_in_flight <= 0:
@@ -266,7 +267,7 @@ def main():
     def solitary_ms(backend, reps):
         tracer.set_timing(True)
         ms = []
-        for k in range(reps):
+        for k in range(-12, reps):          # 12 unmeasured launches first: the steady state of one frame at a time (the tile order is sorted behind the second and adopted a few launches later)
             if orbit_cams is not None:
                 backend.cam = orbit_cams[k % len(orbit_cams)]
             if world_size == 1:
@@ -274,7 +275,8 @@ def main():
             else:
                 backend.trace_tiles(args.tile, rank, world_size, pipe.hits, pipe.rgba[0], stream.cuda_stream)
             torch.cuda.synchronize()
-            ms.append(tracer.last_kernel_ms())
+            if k >= 0:
+                ms.append(tracer.last_kernel_ms())
         tracer.set_timing(False)
         return float(np.mean(ms))
 
@@ -321,7 +323,8 @@ def main():
         for f in range(3):
             tracer.trace_paths_device(cam, color.data_ptr(), spp=64, max_bounces=2, frame_index=f, stream=stream.cuda_stream)
             torch.cuda.synchronize()
-            ms.append(tracer.last_kernel_ms())
+            if k >= 0:
+                ms.append(tracer.last_kernel_ms())
         tracer.set_timing(False)
         path_ms = float(np.mean(ms[1:]))
         paths = {"config": "3840x2160 x 64 spp, 2 bounces + sun shadow ray (raygen.rgen loop)", "ms_per_frame": path_ms,
@@ -347,9 +350,19 @@ def main():
     if rank == 0:
         rays_per_step = W_ * H_
         value = rays_per_step * args.steps / elapsed / 1e6
-        launch = "dense_kernel per frame (id grid in 8^3 tiles, tile bits in LDS, two-level DDA)" if args.dense_dda else \
-                 "one persistent launch per frame (frame_kernel: beam pre-pass + walk)" if args.fused and args.beam else \
-                 ("beam_kernel + trace_kernel per frame" if args.beam else "trace_kernel per frame")
+        if args.dense_dda:
+            launch = "dense_kernel per frame (id grid in 8^3 tiles, tile bits in LDS, two-level DDA)"
+        elif not args.beam:
+            launch = "trace_kernel per frame"
+        elif args.fused == 1:
+            launch = "one persistent launch per frame (frame_kernel: beam pre-pass + walk, work queues)"
+        elif args.fused == 2:
+            launch = "joint_kernel per frame (searches and walk waves in one grid)"
+        elif args.fused == 3 and args.tile_ordering:
+            launch = ("joint_kernel per frame when the launch has the chip to itself (searches and walk waves in one grid; walk waves only for the "
+                      "tiles that walked when the order was made), beam_kernel + trace_kernel per frame with frames in flight")
+        else:
+            launch = "beam_kernel + trace_kernel per frame"
         out = {
             "metric": "Mrays/sec, primary first-hit rays at 4K over a 1024^3 SVO",
             "value": value, "unit": "Mrays/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
@@ -387,9 +400,9 @@ def main():
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                "kernel": launch, "kernel_ms": kernel_ms_avg,
-                               "timing": "HIP events around single launches, one at a time on an otherwise idle chip (longest-first tile "
-                                         "ordering active there, incl. its radix sort every 8th frame; it switches itself off in the timed "
-                                         "region, where other streams have frames in flight)" if args.tile_ordering and not args.fused and not args.dense_dda else
+                               "timing": "HIP events around single launches, one at a time on an otherwise idle chip (the joint launch and longest-first "
+                                         "tile ordering are active there, incl. the order's radix sort every 8th to 64th frame; with frames in flight on "
+                                         "other streams — the timed region — a frame is the two-launch form in natural order)" if args.tile_ordering and args.fused in (0, 3) and not args.dense_dda else
                                          "HIP events around single launches, one at a time on an otherwise idle chip",
                                "frac_overlapped": achieved_overlapped / HBM_PEAK_GBS, "achieved_overlapped": achieved_overlapped,
                                "kernel_ms_overlapped": overlapped_ms, "frames_in_flight": args.frames_in_flight,

@@ -95,9 +95,13 @@ struct blok_hip_ctx {
     // writes the order buffer that is NOT in use, and a later launch adopts it once hipEventQuery says it is complete.
     bool tile_ordering = true;
     uint32_t order_interval = 8;
+    uint32_t order_interval_now = 8;                  // grows while the view rests (api.hip: order_after_launch)
     uint32_t* d_tile_cost = nullptr;
     uint32_t* d_tile_iota = nullptr;
     uint32_t* d_order[2] = {nullptr, nullptr};
+    uint32_t* d_rank_of[2] = {nullptr, nullptr};      // inverse of d_order[k]
+    uint32_t* h_order_live = nullptr;                 // pinned, two words: how many leading entries of d_order[k] walked last time (written by the device)
+    uint32_t order_live[2] = {0, 0};                  // ... as read when the order was adopted
     uint32_t* d_order_keys = nullptr;
     void* d_order_temp = nullptr;
     size_t order_temp_bytes = 0, tile_cost_capacity = 0;
@@ -113,11 +117,15 @@ struct blok_hip_ctx {
     struct StreamScratch {             // per launch stream
         float* beam = nullptr; size_t n_beam = 0;                       // two-launch form: start parameters per beam tile
         uint32_t* ctl = nullptr; unsigned long long* entries = nullptr; size_t capacity = 0;   // one-launch form: work queue (trace_kernels.h: FrameQueue)
+        unsigned long long* slots = nullptr; size_t n_slots = 0; uint32_t serial = 0; uint32_t* gave_up = nullptr;   // joint launch: published beam results
         uint32_t* tile_map = nullptr; size_t n_tile_map = 0;            // sparse exchange, root: frame tile -> record (zero between launches)
     };
     std::unordered_map<hipStream_t, StreamScratch> beam_buffers;
     // one-launch frame (frame_kernel): pre-pass and walk in one persistent grid; off (default, faster as measured) = beam_kernel, then trace_kernel
     bool fused = false;
+    bool joint = false;                 // joint launch (joint_kernel): searches and walk waves in one grid, statically
+    uint32_t joint_prefix_limit = 0;    // tests: cap on the walk waves a joint launch dispatches (0 = none)
+    bool joint_auto = true;             // ... whenever a launch has the chip to itself (and the two-launch form when other streams have frames in flight)
     uint32_t frame_parts = 32, frame_chunk = 1;      // FrameQueue::n_parts / chunk (BLOK_FRAME_PARTS / BLOK_FRAME_CHUNK override, for experiments)
     int cu_count = 0;
     int frame_blocks_per_cu[2][16] = {};   // [mode][levels], 0 = not asked yet

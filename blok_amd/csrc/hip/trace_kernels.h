@@ -102,6 +102,16 @@ struct TraceArgs {
     uint32_t beam_tile, beam_bx;           // beam_bx: beam tiles per row of the rectangle (Rect)
     const uint32_t* order;                 // Rect: workgroup b walks tile order[b] (null = b): longest-first scheduling
     uint32_t* cost_out;                    // Rect: per tile, the clocks its wave spent (null = not recorded)
+    // joint launch (joint_kernel): the pre-pass waves and the walk waves are ONE grid; a beam tile's result is published as
+    // (serial << 32 | start parameter bits) and a walk wave waits for its tile's word to carry this launch's serial
+    unsigned long long* beam_slots;        // null = the two-launch form (TraceArgs::beam holds plain floats)
+    uint32_t beam_serial;
+    // joint launch over a PREFIX of the order: walk waves are dispatched only for the first `launched` tiles of `order` (the tiles that
+    // walked last time); rank_of[tile] >= launched = no walk wave exists for that tile, and the search wave of a live beam tile walks
+    // such tiles itself (a view that has changed; exact either way).  null = every tile has its walk wave.
+    const uint32_t* rank_of;
+    uint32_t launched;
+    uint32_t* joint_gave_up;               // waves that stopped waiting and started at the ray origin instead (0 in a working system)
     uint32_t miss_in_walk;                 // two-launch form: 1 = the walk's waves write the miss pixels of tiles the pre-pass found empty (they are launched anyway), 0 = the pre-pass does
     uint32_t beam_budget;                  // node visits a search may spend (0 = kBeamMaxVisits); running out is answered conservatively
 };
@@ -195,6 +205,9 @@ void launch_accumulate(const AccumArgs& args, hipStream_t stream);
 void launch_tonemap(const TonemapArgs& args, hipStream_t stream);
 void launch_paths(const PathArgs& args, uint32_t n_blocks, hipStream_t stream);
 void launch_trace(RayMode mode, const TraceArgs& args, uint32_t n_blocks, hipStream_t stream);
+// Pre-pass and walk in one grid, statically: workgroups [0, n_beam_tiles) search, the others walk (Rect and Tiles).
+void launch_joint(RayMode mode, const TraceArgs& args, uint32_t n_beam_tiles, uint32_t n_blocks, hipStream_t stream);
+constexpr uint32_t kJointPollBudget = 1u << 16;   // polls (a few hundred ns apart) before a walk wave stops waiting for its tile's search
 // Number of beam tiles of a launch (= floats of TraceArgs::beam) and the pre-pass itself; Rect and Tiles only.
 uint32_t beam_tiles(RayMode mode, const TraceArgs& args, uint32_t tiles_of_rank);
 void launch_beam(RayMode mode, const TraceArgs& args, uint32_t n_beam_tiles, hipStream_t stream);

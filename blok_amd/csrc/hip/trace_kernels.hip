@@ -35,6 +35,26 @@ __device__ __forceinline__ bool block_to_tile(uint32_t b, uint32_t grid, uint32_
 #endif
 }
 
+// joint launch: a beam tile's published word (trace_kernels.h).  Relaxed agent-scope atomics on the word itself — it validates
+// itself — as in the one-launch frame below (sc1 loads see another XCD's publication: scripts/microbench/xcd_poll.hip).
+__device__ __forceinline__ void publish_beam(unsigned long long* slot, uint32_t serial, float t0) {
+    (void)__hip_atomic_exchange(slot, (static_cast<unsigned long long>(serial) << 32) | __float_as_uint(t0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// All 64 lanes call this with the same slot; the result is wave-uniform.  A wave that has waited kJointPollBudget polls starts
+// at the ray origin instead (always a valid start parameter), so every wave reaches its exit whatever the dispatch order.
+__device__ __forceinline__ float await_beam(unsigned long long* slot, uint32_t serial, uint32_t* gave_up) {
+    uint32_t lo = 0u, hi = 0u, budget = kJointPollBudget;
+    for (;;) {
+        const unsigned long long v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v)); hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32));
+        if (hi == serial) return __uint_as_float(lo);
+        if (--budget == 0u) break;
+        __builtin_amdgcn_s_sleep(4);
+    }
+    if (gave_up && threadIdx.x == 0) (void)__hip_atomic_fetch_add(gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return 0.0f;
+}
+
 // Workgroup `block` of a launch of `grid` workgroups (the kernels below differ in where the arguments come from).
 template <RayMode MODE>
 __device__ __forceinline__ void trace_block(const TraceArgs& A, const uint32_t block, const uint32_t grid, uint4* lds_stack) {
@@ -68,10 +88,10 @@ __device__ __forceinline__ void trace_block(const TraceArgs& A, const uint32_t b
             // same launch geometry, api.hip); any permutation gives the same frame
             const uint32_t b = A.order ? A.order[block] : block;
             if (!block_to_tile(b, grid, bx_count, by_count, bx, by)) return;
-            if (A.cost_out && tid == 0) clock0 = __builtin_amdgcn_s_memtime();
             cost_slot = A.cost_out ? A.cost_out + b : nullptr;
             if (A.beam) {
-                t0 = A.beam[((by * kTileH + wave_y) / A.beam_tile) * A.beam_bx + (bx * kTileW + wave_x) / A.beam_tile];
+                const uint32_t beam_index = ((by * kTileH + wave_y) / A.beam_tile) * A.beam_bx + (bx * kTileW + wave_x) / A.beam_tile;
+                t0 = A.beam_slots ? await_beam(A.beam_slots + beam_index, A.beam_serial, A.joint_gave_up) : A.beam[beam_index];
                 if (t0 >= kBeamNone) {
                     if (cost_slot && tid == 0) *cost_slot = 0u;
                     if (A.miss_in_walk) {
@@ -82,6 +102,7 @@ __device__ __forceinline__ void trace_block(const TraceArgs& A, const uint32_t b
                     return;
                 }
             }
+            if (A.cost_out && tid == 0) clock0 = __builtin_amdgcn_s_memtime();      // the walk's cost: any wait for the tile's search is not part of it
             const uint32_t rx = bx * kTileW + lx, ry = by * kTileH + ly;
             inside = rx < A.w && ry < A.h;
             x = A.x0 + rx; y = A.y0 + ry;
@@ -102,8 +123,9 @@ __device__ __forceinline__ void trace_block(const TraceArgs& A, const uint32_t b
             }
             if (A.beam) {
                 const uint32_t beams_per_side = A.tile / A.beam_tile;
-                t0 = A.beam[(local_tile * beams_per_side + ((sub / per_side) * kTileH + wave_y) / A.beam_tile) * beams_per_side +
-                            ((sub % per_side) * kTileW + wave_x) / A.beam_tile];
+                const uint32_t beam_index = (local_tile * beams_per_side + ((sub / per_side) * kTileH + wave_y) / A.beam_tile) * beams_per_side +
+                                            ((sub % per_side) * kTileW + wave_x) / A.beam_tile;
+                t0 = A.beam_slots ? await_beam(A.beam_slots + beam_index, A.beam_serial, A.joint_gave_up) : A.beam[beam_index];
                 if (t0 >= kBeamNone) {
                     if (A.miss_in_walk) write_miss(Sink{A.out ? A.out + out_index : nullptr, A.out_rgba ? A.out_rgba + out_index : nullptr});   // the tile buffer is dense
                     return;
@@ -151,7 +173,7 @@ __global__ __launch_bounds__(kBlock) void trace_frames_kernel(const TraceArgs A,
 
 // One wave per beam tile: TraceArgs::beam[tile] = conservative start parameter of the tile's rays, or kBeamNone.
 template <RayMode MODE>
-__device__ __forceinline__ void beam_block(const TraceArgs& A, const uint32_t b, const uint32_t n_beam_tiles) {
+__device__ __forceinline__ void beam_block(const TraceArgs& A, const uint32_t b, const uint32_t n_beam_tiles, uint4* lds_stack = nullptr) {
     const uint32_t lane = threadIdx.x;
     if (b >= n_beam_tiles) return;
     const uint32_t B = A.beam_tile;
@@ -165,14 +187,14 @@ __device__ __forceinline__ void beam_block(const TraceArgs& A, const uint32_t b,
         const uint32_t per_side = A.tile / B, per_tile = per_side * per_side;
         const uint32_t local_tile = b / per_tile, sub = b % per_tile;
         const uint32_t global_tile = A.rank + local_tile * A.n_ranks;
-        if (global_tile >= A.tiles_total) { if (lane == 0) A.beam[b] = kBeamNone; return; }
+        if (global_tile >= A.tiles_total) { if (lane == 0) { if (A.beam_slots) publish_beam(A.beam_slots + b, A.beam_serial, kBeamNone); else A.beam[b] = kBeamNone; } return; }
         tile_x0 = (global_tile % A.tiles_x) * A.tile; tile_y0 = (global_tile / A.tiles_x) * A.tile;
         tile_base = static_cast<size_t>(local_tile) * A.tile * A.tile;
         px = tile_x0 + (sub % per_side) * B; py = tile_y0 + (sub / per_side) * B;
         px_end = px + B; py_end = py + B;
     }
     const float t0 = beam_start(A, static_cast<float>(px), static_cast<float>(py), static_cast<float>(px_end), static_cast<float>(py_end), lane);
-    if (lane == 0) A.beam[b] = t0;
+    if (lane == 0) { if (A.beam_slots) publish_beam(A.beam_slots + b, A.beam_serial, t0); else A.beam[b] = t0; }
     if (t0 >= kBeamNone && !A.miss_in_walk && (A.out || A.out_rgba)) {
         // no ray of this tile can hit anything: its pixels are written here, 64 at a time, and the tile's trace waves exit at once
         const uint32_t tw = px_end - px, n = tw * (py_end - py);
@@ -184,11 +206,52 @@ __device__ __forceinline__ void beam_block(const TraceArgs& A, const uint32_t b,
             write_miss(Sink{A.out ? A.out + out_index : nullptr, A.out_rgba ? A.out_rgba + out_index : nullptr});
         }
     }
+    if constexpr (MODE == RayMode::Rect && kBlock == 64) {
+        // joint launch over a prefix of the order: the wave-sized tiles of this (live) beam tile that no walk wave was dispatched for —
+        // the view has changed since the order was made — are walked here, one after the other
+        if (A.rank_of && lds_stack && t0 < kBeamNone) {
+            const uint32_t bx_count = (A.w + kTileW - 1u) / kTileW;
+            const uint32_t bx0 = (px - A.x0) / kTileW, bx1 = (px_end - A.x0 + kTileW - 1u) / kTileW;
+            const uint32_t by0 = (py - A.y0) / kTileH, by1 = (py_end - A.y0 + kTileH - 1u) / kTileH;
+            for (uint32_t by = by0; by < by1; ++by)
+                for (uint32_t bx = bx0; bx < bx1; ++bx) {
+                    const uint32_t tile = by * bx_count + bx;
+                    if (__builtin_amdgcn_readfirstlane(A.rank_of[tile]) < A.launched) continue;
+                    const uint64_t clock0 = __builtin_amdgcn_s_memtime();
+                    const uint32_t rx = bx * kTileW + lane % kWaveW, ry = by * kTileH + lane / kWaveW;
+                    if (rx < A.w && ry < A.h) {
+                        const size_t at = static_cast<size_t>(ry) * A.w + rx;
+                        RayIn r = primary_ray(A, A.x0 + rx, A.y0 + ry);
+                        r.tmin = fmaxf(r.tmin, t0);
+                        trace_one(A, r, lds_stack + lane, Sink{A.out ? A.out + at : nullptr, A.out_rgba ? A.out_rgba + at : nullptr});
+                    }
+                    // it walked: the next sort puts it into the prefix (any key >= 256 clocks counts as live)
+                    if (A.cost_out && lane == 0) A.cost_out[tile] = max(static_cast<uint32_t>(__builtin_amdgcn_s_memtime() - clock0), 256u);
+                }
+        }
+    }
 }
 
 template <RayMode MODE>
 __global__ __launch_bounds__(64) void beam_kernel(const TraceArgs A, const uint32_t n_beam_tiles) {
     beam_block<MODE>(A, blockIdx.x, n_beam_tiles);
+}
+
+// ---- joint launch: the pre-pass waves and the walk waves in ONE grid, statically ------------------------------------------
+// Workgroups [0, n_beam) are the searches, the others the walk's waves in their usual order.  Workgroups are dispatched in index
+// order, so all searches are resident before the first walk wave starts; a walk wave takes the slot of a search that has ended and
+// waits (a bounded spin on one word) only if its own tile's search is still running.  The chip therefore starts walking when the
+// FIRST searches end instead of when the LAST one does — the pre-pass is a 77 us tail of a 13 us average — without a queue, a
+// ticket or any atomic read-modify-write on a shared address (what the one-launch frame below pays for), and without the gap
+// between two dependent launches.  No reference counterpart (one traceRaysKHR per frame, renderer_raytracing.cpp:666-685).
+template <RayMode MODE>
+__global__ __launch_bounds__(kBlock) void joint_kernel(const TraceArgs A, const uint32_t n_beam_tiles) {
+    extern __shared__ uint4 lds_stack[];
+    if (blockIdx.x < n_beam_tiles) {
+        if (threadIdx.x < 64u) beam_block<MODE>(A, blockIdx.x, n_beam_tiles, lds_stack);
+        return;
+    }
+    trace_block<MODE>(A, blockIdx.x - n_beam_tiles, gridDim.x - n_beam_tiles, lds_stack);
 }
 
 __global__ __launch_bounds__(64) void beam_frames_kernel(const TraceArgs A, const TileFrames F) {
@@ -579,6 +642,13 @@ void launch_trace(RayMode mode, const TraceArgs& args, uint32_t n_blocks, hipStr
         case RayMode::Tiles: hipLaunchKernelGGL(trace_kernel<RayMode::Tiles>, dim3(n_blocks), dim3(kBlock), lds, stream, args); break;
         case RayMode::Rays:  hipLaunchKernelGGL(trace_kernel<RayMode::Rays>,  dim3(n_blocks), dim3(kBlock), lds, stream, args); break;
     }
+}
+
+void launch_joint(RayMode mode, const TraceArgs& args, uint32_t n_beam_tiles, uint32_t n_blocks, hipStream_t stream) {
+    if (n_beam_tiles + n_blocks == 0 || mode == RayMode::Rays) return;
+    const size_t lds = static_cast<size_t>(args.levels > 1 ? args.levels - 1 : 1) * kBlock * sizeof(uint4);
+    if (mode == RayMode::Rect) hipLaunchKernelGGL(joint_kernel<RayMode::Rect>, dim3(n_beam_tiles + n_blocks), dim3(kBlock), lds, stream, args, n_beam_tiles);
+    else hipLaunchKernelGGL(joint_kernel<RayMode::Tiles>, dim3(n_beam_tiles + n_blocks), dim3(kBlock), lds, stream, args, n_beam_tiles);
 }
 
 uint32_t beam_tiles(RayMode mode, const TraceArgs& a, uint32_t tiles_of_rank) {

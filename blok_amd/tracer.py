@@ -173,6 +173,10 @@ class HipTracer:
         n = 8 if resort_every_n_frames is True else int(resort_every_n_frames or 0)
         self._check(self._lib.blok_hip_set_tile_ordering(self._ctx, n))
 
+    def set_joint_prefix_limit(self, max_walk_waves: int):
+        """Diagnostic: cap on the walk waves of a joint launch; the rest is walked by the search waves (same frame)."""
+        self._check(self._lib.blok_hip_set_joint_prefix_limit(self._ctx, max_walk_waves))
+
     def set_miss_writer(self, in_walk: bool):
         """Empty tiles' miss pixels: written by the walk launch's waves (True, default) or by the pre-pass (blok_hip.h)."""
         self._check(self._lib.blok_hip_set_miss_writer(self._ctx, 1 if in_walk else 0))
@@ -191,8 +195,8 @@ class HipTracer:
         self._check(self._lib.blok_hip_set_dense_dda(self._ctx, 1 if enabled else 0))
 
     def set_fused(self, enabled: bool):
-        """One-launch frame (pre-pass + walk in one persistent grid; opt-in) or the two-launch form (default); never changes a result."""
-        self._check(self._lib.blok_hip_set_fused(self._ctx, 1 if enabled else 0))
+        """Launch form (blok_hip.h): 0 two launches, 1 persistent grid with queues, 2 joint launch, 3 automatic (default); never changes a result."""
+        self._check(self._lib.blok_hip_set_fused(self._ctx, int(enabled)))      # False/0, True/1 or 2 (joint launch, blok_hip.h)
 
     def frame_queue_stalls(self) -> int:
         """Waves of one-launch frames that ever gave up waiting for a queue entry (0 in a working system); synchronises."""

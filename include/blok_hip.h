@@ -458,6 +458,9 @@ int blok_hip_set_beam(blok_hip_ctx* ctx, uint32_t beam_tile_pixels);
  * (renderer_raytracing.cpp:666-685 leaves scheduling to the driver).  0 = off; N > 0 = re-sort every N frames.
  * Measured (4K over 1024^3, one frame at a time): 0.295 -> 0.252 ms (poses A, C: -14 %; B: -3 %). */
 int blok_hip_set_tile_ordering(blok_hip_ctx* ctx, int resort_every_n_frames);
+/* Diagnostic: the most walk waves a joint launch dispatches (0 = no limit).  Whatever is cut off is walked by the search waves;
+ * the frame is the same (the tests use it to exercise that path). */
+int blok_hip_set_joint_prefix_limit(blok_hip_ctx* ctx, uint32_t max_walk_waves);
 /* Who writes the miss pixels of the tiles the pre-pass found empty (two-launch form): 1 (default) = the walk launch's waves of
  * those tiles — they are launched anyway and have nothing else to do — 0 = the pre-pass wave of the tile, 1 024 pixels each, which
  * puts ~120 MB of stores on the pre-pass's critical path (4K, 73 % sky).  Never changes a result. */
@@ -475,17 +478,23 @@ int blok_hip_set_beam_budget(blok_hip_ctx* ctx, uint32_t max_node_visits);
  * (frame mod 16) by itself (blok_hip_set_rt_taa_jitter(ctx, 0) = PostProcess::Settings::enableTAA false for the jitter). */
 int blok_hip_set_taa_jitter(blok_hip_ctx* ctx, const float jitter_px[2]);
 int blok_hip_set_rt_taa_jitter(blok_hip_ctx* ctx, int enabled);
-/* One-launch frame (opt-in; default off): the pre-pass and the walk of a rectangle / tile launch run in ONE persistent grid
- * — resident waves first take beam tiles, append the wave-sized sub-tiles of the live ones to per-part queues with an atomic
- * reservation, then take walk tasks from those queues — so the walk starts while long searches are still running and no wave
- * is launched for a tile the pre-pass has written (no reference counterpart: blok/src/renderer_raytracing.cpp:666-685 issues
- * one traceRaysKHR per frame).  0 (default) = the two-launch form (beam kernel, then one walk wave per 8x8 pixels), which
- * measures faster on MI355X (0.30 vs 0.32 ms per 4K frame alone; same-address atomics run at 88 M/s).  Results
- * are identical (tests/test_gpu_parity.py). */
+/* Launch form of a rectangle / tile frame (no reference counterpart: blok/src/renderer_raytracing.cpp:666-685 issues one
+ * traceRaysKHR per frame); results are identical in every form (tests/test_gpu_parity.py):
+ *   0  two launches: the beam kernel, then one walk wave per 8x8 pixels;
+ *   1  one persistent launch with work queues: resident waves first take beam tiles, append the wave-sized sub-tiles of the live
+ *      ones to per-part queues with an atomic reservation, then take walk tasks from those queues (measures slower on MI355X:
+ *      same-address atomics run at 88 M/s);
+ *   2  joint launch: the search waves and the walk waves are ONE grid, statically — workgroups are dispatched in index order, the
+ *      searches first; a walk wave waits (bounded) only while its own tile's search is still running, so the chip starts walking
+ *      when the first searches end, not when the last one does.  With a longest-first order in force (blok_hip_set_tile_ordering)
+ *      walk waves are dispatched only for the tiles that walked when the order was made; a tile that has become live since is
+ *      walked by its search wave.  Alone on the chip: 0.26 -> 0.205 ms per 4K frame; with frames in flight on other streams the
+ *      waiting waves cost more than they save (0.187 -> 0.201 ms per frame);
+ *   3  (default) automatic: 2 for a launch that has the chip to itself (ordered, no other stream of the context busy), else 0. */
 int blok_hip_set_fused(blok_hip_ctx* ctx, int enabled);
-/* Health check of the one-launch frame's work queue: synchronises the device and returns how many waves ever gave up waiting
- * for a queue entry (a bounded wait, ~0.5 s; 0 in a working system — anything else means frames since context creation may
- * be incomplete). */
+/* Health check of forms 1 and 2: synchronises the device and returns how many waves ever gave up a bounded wait (0 in a working
+ * system).  Form 1: for a queue entry (~0.5 s; frames since context creation may then be incomplete).  Form 2: for their tile's
+ * search (such a wave starts at the ray origin instead: the frame is still exact). */
 int blok_hip_frame_queue_stalls(blok_hip_ctx* ctx, uint32_t* out_stalled_waves);
 /* Enable/disable the per-launch HIP event pair (default off: nothing but the kernel is
  * enqueued by the *_device entries). */

@@ -222,14 +222,14 @@ def test_beam_prepass_never_changes_a_record(tracer_cls, scene64, scene1024):
         plain_rect = tr.draw_frame(cam, rect)
         for beam in (8, 16, 32, 64):
             tr.set_beam(beam)
-            for fused in (True, False):                 # one persistent launch (pre-pass + walk) / beam kernel, then trace kernel
+            for fused in (1, 0, 2, 3):                  # persistent launch with queues / beam kernel, then trace kernel / joint launch / automatic
                 tr.set_fused(fused)
                 assert records_equal(tr.draw_frame(cam).reshape(-1), plain.reshape(-1)).all(), (beam, fused)
                 assert records_equal(tr.draw_frame(cam, rect).reshape(-1), plain_rect.reshape(-1)).all(), (beam, fused)
     cam = cams[1]
     tr.set_beam(0)
     plain = tr.draw_frame(cam)
-    for beam, tile, n_ranks, fused in [(32, 32, 8, True), (32, 48, 3, True), (16, 64, 2, True), (64, 64, 5, True), (32, 32, 8, False), (16, 64, 2, False)]:
+    for beam, tile, n_ranks, fused in [(32, 32, 8, 1), (32, 48, 3, 1), (16, 64, 2, 1), (64, 64, 5, 1), (32, 32, 8, 0), (16, 64, 2, 0), (32, 32, 8, 2), (16, 64, 3, 2)]:
         tr.set_beam(beam)
         tr.set_fused(fused)
         per = tr.tiles_for_rank(tile, 0, n_ranks)
@@ -254,7 +254,7 @@ def test_beam_prepass_never_changes_a_record(tracer_cls, scene64, scene1024):
         plain = tr.draw_frame(cam)
         for beam in (8, 32):
             tr.set_beam(beam)
-            for fused in (True, False):
+            for fused in (1, 0, 2):
                 tr.set_fused(fused)
                 assert records_equal(tr.draw_frame(cam).reshape(-1), plain.reshape(-1)).all(), (k, beam, fused)
     with pytest.raises(Exception):
@@ -291,7 +291,7 @@ def test_beam_prepass_random_cameras_and_odd_worlds(tracer_cls):
         plain = tr.draw_frame(cam).reshape(-1)
         for beam in (8, 32):
             tr.set_beam(beam)
-            for fused in (True, False):
+            for fused in (1, 0, 2):
                 tr.set_fused(fused)
                 assert records_equal(tr.draw_frame(cam).reshape(-1), plain).all(), (k, beam, fused)
         if k % 10 == 0:
@@ -353,7 +353,7 @@ def test_beam_visit_budget_exhaustion_is_conservative(tracer_cls, scene1024):
             tr.set_beam_budget(budget)
             assert records_equal(tr.draw_frame(cam).reshape(-1), want).all(), (pose, budget)
             assert records_equal(tr.draw_frame(cam, rect).reshape(-1), want_rect).all(), (pose, budget)
-            for fused in (True, False):
+            for fused in (1, 0, 2):
                 tr.set_fused(fused)
                 assert records_equal(tr.draw_frame(cam).reshape(-1), want).all(), (pose, budget, fused)
     cam = W.scene_camera(1024, 1, Wd, Ht, SEED)
@@ -366,6 +366,70 @@ def test_beam_visit_budget_exhaustion_is_conservative(tracer_cls, scene1024):
     torch.cuda.synchronize()
     assert torch.equal(a, b)
     tr.shutdown()
+
+
+def test_joint_launch_prefix_and_search_wave_fallback(tracer_cls, scene1024):
+    """Joint launch (blok_hip_set_fused 2 and the automatic default 3): searches and walk waves in one grid; with an order in force
+    walk waves exist only for the tiles that walked when the order was made, and a tile that is live now without one is walked by
+    its search wave.  4K over 1024^3: a static camera long enough for the order to be adopted; a camera creeping by 0.05 degrees per
+    frame (inside the order's 0.25-degree window, so tiles at the silhouettes change sides); a cap on the walk waves that leaves
+    most of the frame to the search waves; a jump to another pose and back — every frame equals the two-launch form's, records and
+    RGBA8, and no wave ever gave up waiting."""
+    import torch
+    cm, pw = scene1024
+    Wd, Ht = 3840, 2160
+    ref = tracer_cls(Wd, Ht).init(); ref.add_world(pw); ref.set_fused(0); ref.set_tile_ordering(0)
+    tr = tracer_cls(Wd, Ht).init(); tr.add_world(pw)
+    hits = torch.zeros((Wd * Ht, 4), dtype=torch.int32, device="cuda"); rgba = torch.zeros(Wd * Ht, dtype=torch.int32, device="cuda")
+    want_h = torch.zeros_like(hits); want_c = torch.zeros_like(rgba)
+
+    def same(cam, tag):
+        hits.fill_(5); rgba.fill_(5)
+        tr.draw_frame_device(cam, hits.data_ptr(), rgba.data_ptr())
+        ref.draw_frame_device(cam, want_h.data_ptr(), want_c.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(hits, want_h) and torch.equal(rgba, want_c), tag
+
+    centre = np.array([512.0, 60.0, 512.0])
+    for form in (3, 2):
+        tr.set_fused(form)
+        for pose in (0, 2):
+            cam = W.scene_camera(1024, pose, Wd, Ht, SEED)
+            for k in range(24):                      # the order is sorted behind frame 1-2 and adopted a few frames later
+                same(cam, (form, pose, "static", k))
+            pos = np.array(cam["pos"][0], dtype=np.float64) - centre
+            for k in range(1, 13):                   # creep around the world's centre: 0.05 degrees per frame
+                a = np.radians(0.05 * k)
+                p = centre + np.array([pos[0] * np.cos(a) - pos[2] * np.sin(a), pos[1], pos[0] * np.sin(a) + pos[2] * np.cos(a)])
+                same(W.camera_look_at(tuple(p), tuple(centre), 60.0, Wd, Ht), (form, pose, "creep", k))
+            for k in range(12):
+                same(cam, (form, pose, "back", k))
+            for limit in (20000, 1000, 1):           # most of the frame is walked by the search waves
+                tr.set_joint_prefix_limit(limit)
+                for k in range(3):
+                    same(cam, (form, pose, "limit", limit, k))
+            tr.set_joint_prefix_limit(0)
+            same(W.scene_camera(1024, 1, Wd, Ht, SEED), (form, pose, "jump"))
+            same(cam, (form, pose, "return"))
+    assert tr.frame_queue_stalls() == 0
+    # a rectangle of the frame, and frames in flight on three streams (the automatic form falls back to two launches there)
+    cam = W.scene_camera(1024, 0, Wd, Ht, SEED)
+    tr.set_fused(3)
+    rect = (640, 360, 2560, 1440)
+    for k in range(12):
+        assert records_equal(tr.draw_frame(cam, rect).reshape(-1), ref.draw_frame(cam, rect).reshape(-1)).all(), ("rect", k)
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    bufs = [(torch.zeros_like(hits), torch.zeros_like(rgba)) for _ in streams]
+    ref.draw_frame_device(cam, want_h.data_ptr(), want_c.data_ptr())
+    for form in (3, 2):
+        tr.set_fused(form)
+        for k in range(30):
+            tr.draw_frame_device(cam, bufs[k % 3][0].data_ptr(), bufs[k % 3][1].data_ptr(), stream=streams[k % 3].cuda_stream)
+        torch.cuda.synchronize()
+        for b in bufs:
+            assert torch.equal(b[0], want_h) and torch.equal(b[1], want_c), ("in flight", form)
+    assert tr.frame_queue_stalls() == 0
+    tr.shutdown(); ref.shutdown()
 
 
 def test_tile_ordering_is_pure_scheduling(tracer_cls, scene1024):
@@ -792,10 +856,10 @@ def test_power_of_two_voxel_sizes(tracer_cls, vs):
         assert ctr["hits"] > 50
         for beam in (32, 0, 8):
             tr.set_beam(beam)
-            for fused in (False, True):
+            for fused in (0, 1, 2):
                 tr.set_fused(fused)
                 assert records_equal(tr.draw_frame(cam).reshape(-1), ref).all(), (k, beam, fused)
-        tr.set_beam(32); tr.set_fused(False)
+        tr.set_beam(32); tr.set_fused(3)
         hit = ref[ref["hit"] == 1]
         assert np.isin(hit["voxel"].astype(np.int32).view([("", np.int32)] * 3), np.ascontiguousarray(xyz).view([("", np.int32)] * 3)).all()   # lattice coordinates
     rays = random_rays(int(160 * vs) + 8, 6000, 3)
