@@ -34,7 +34,7 @@ for f in sorted(src.glob("pmc*/**/*counter_collection.csv")):
         pmc[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
 summary = {}
 for kernel, counters in pmc.items():
-    if not any(name in kernel for name in ("trace_kernel", "beam_kernel", "frame_kernel")):
+    if not any(name in kernel for name in ("trace_kernel", "beam_kernel", "frame_kernel", "joint_kernel")):
         continue
     summary[kernel] = {c: {"mean": sum(v) / len(v), "n": len(v)} for c, v in counters.items()}
     d = durations.get(kernel)
@@ -44,7 +44,8 @@ for kernel, counters in pmc.items():
 (dst / f"{tag}_pmc.json").write_text(json.dumps(summary, indent=1))
 print(json.dumps(summary, indent=1))
 # HBM traffic per FRAME: FETCH_SIZE + WRITE_SIZE of every kernel of the frame's launch sequence (beam_kernel + trace_kernel of the
-# Rect mode, or frame_kernel in the one-launch form), per launch.  rocprofv3 reports both in KiB.
+# Rect mode, frame_kernel in the one-launch form, or joint_kernel — whichever the profiled run launched), per launch.  rocprofv3 reports
+# both in KiB.
 frame_kernels = {k: s for k, s in summary.items() if ("RayModeE0" in k or "(blok::RayMode)0" in k) and "FETCH_SIZE" in s and "WRITE_SIZE" in s}
 if frame_kernels:
     fetch_kb = sum(s["FETCH_SIZE"]["mean"] for s in frame_kernels.values())
