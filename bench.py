@@ -40,7 +40,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=40, help="untimed frames first (the tile order of a view at rest is sorted behind the second frame and adopted a few frames later)")
     ap.add_argument("--n", type=int, default=1024, help="world edge in voxels")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
@@ -295,7 +295,7 @@ def main():
             pcam = W.scene_camera(args.n, pose, W_, H_, args.seed)
             pb = HipBackend(tracer, pcam)
             pipe.backend = pb
-            for _ in range(5):
+            for _ in range(24):
                 pipe.step()
             pipe.flush(); torch.cuda.synchronize()
             k = max(10, min(args.steps, 60))

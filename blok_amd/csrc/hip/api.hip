@@ -272,7 +272,10 @@ int order_before_launch(blok_hip_ctx* ctx, blok::TraceArgs& args, uint32_t block
     for (auto& kv : ctx->order_last_use)
         if (kv.first != stream && hipEventQuery(kv.second) == hipErrorNotReady) { ctx->order_busy = true; break; }
     (void)hipGetLastError();                               // hipErrorNotReady is an answer, not a failure
-    if (ctx->order_busy) args.order = nullptr;             // (and no sort is started behind this launch: its kernels would only compete)
+    // ... in the two-launch form.  A joint launch over the order's live prefix gains from the order with frames in flight too (three in
+    // flight: 0.186 -> 0.180 ms per frame), so the forms that may launch jointly keep it (and keep re-sorting).
+    ctx->order_kept_busy = ctx->order_busy && (ctx->joint || ctx->joint_auto) && !ctx->fused;
+    if (ctx->order_busy && !ctx->order_kept_busy) args.order = nullptr;      // (and no sort is started behind this launch: its kernels would only compete)
     if (args.order) { args.rank_of = ctx->d_rank_of[ctx->order_current]; args.launched = ctx->order_live[ctx->order_current]; }   // used by a joint launch only
     return BLOK_OK;
 }
@@ -288,7 +291,7 @@ int order_after_launch(blok_hip_ctx* ctx, const blok::TraceArgs& args, uint32_t 
     // a view at rest is re-sorted ever less often (its costs do not change): the interval doubles with every re-sort of the same view, up to 64
     if (!have) ctx->order_interval_now = ctx->order_interval;
     const bool due = !have || ctx->frames_since_sort >= std::max(ctx->order_interval_now, ctx->order_interval);
-    if (!ctx->order_pending && !ctx->order_busy && ctx->order_interval && ctx->order_still_frames >= 1u && args.cost_out && due) {
+    if (!ctx->order_pending && (!ctx->order_busy || ctx->order_kept_busy) && ctx->order_interval && ctx->order_still_frames >= 1u && args.cost_out && due) {
         const int target = ctx->order_current == 0 ? 1 : 0;
         // The sort runs on the LAUNCH stream, behind the frame (a stream of its own would be one HIP stream more than the hardware
         // queues the three frame streams and the null stream already occupy: measured, that alone costs 18 % of the pipelined
@@ -353,10 +356,11 @@ int launch_timed(blok_hip_ctx* ctx, blok::RayMode mode, blok::TraceArgs args, ui
             else ctx->order_streak = same ? ctx->order_streak + 1u : 0u;
         }
         if (ordered) { const int rc = order_before_launch(ctx, args, blocks, stream); if (rc != BLOK_OK) return rc; }
-        // auto: a launch that has the chip to itself (it is ordered and no other stream of the context has frames in flight) goes as
-        // ONE joint launch; with frames in flight elsewhere the two-launch form measures faster (waiting walk waves hold slots that
-        // the other frames' waves would use: 0.187 vs 0.201 ms per frame with three in flight)
-        const bool go_joint = joint || (n_beams && ctx->joint_auto && !ctx->fused && ordered && !ctx->order_busy && blok::kBlock == 64);
+        // auto: ONE joint launch when the launch has the chip to itself or an order is in force (walk waves for the live prefix only:
+        // alone 0.26 -> 0.20 ms, three frames in flight 0.186 -> 0.180 ms per frame); with frames in flight elsewhere and no order
+        // (a camera in motion) the two-launch form measures faster (waiting walk waves hold slots the other frames' waves would
+        // use: 0.186 vs 0.201 ms per frame)
+        const bool go_joint = joint || (n_beams && ctx->joint_auto && !ctx->fused && ordered && (args.order || !ctx->order_busy) && blok::kBlock == 64);
         if (go_joint) {
             if (!joint) { const int rc = joint_slots(ctx, args, stream, n_beams); if (rc != BLOK_OK) return rc; }
             uint32_t launch_blocks = blocks;

@@ -107,6 +107,7 @@ struct blok_hip_ctx {
     size_t order_temp_bytes = 0, tile_cost_capacity = 0;
     uint32_t order_key[6] = {};
     int order_current = -1, order_target = 0;     // -1: no order yet (natural)
+    bool order_kept_busy = false;                     // ... and the order stays in use all the same (a form that may launch jointly)
     bool order_pending = false, order_busy = false;   // busy: another stream of the context had frames in flight at the last launch
     uint32_t frames_since_sort = 0;
     blok_camera order_cam[2] = {}, order_last_cam{};     // camera whose frame's costs each order buffer was sorted from; camera of the last launch
