@@ -359,8 +359,8 @@ def main():
         elif args.fused == 2:
             launch = "joint_kernel per frame (searches and walk waves in one grid)"
         elif args.fused == 3 and args.tile_ordering:
-            launch = ("joint_kernel per frame when the launch has the chip to itself (searches and walk waves in one grid; walk waves only for the "
-                      "tiles that walked when the order was made), beam_kernel + trace_kernel per frame with frames in flight")
+            launch = ("joint_kernel per frame (searches and walk waves in one grid; walk waves only for the tiles that walked when the order was "
+                      "made); beam_kernel + trace_kernel per frame only for a camera in motion with frames in flight")
         else:
             launch = "beam_kernel + trace_kernel per frame"
         out = {
@@ -400,9 +400,8 @@ def main():
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                "kernel": launch, "kernel_ms": kernel_ms_avg,
-                               "timing": "HIP events around single launches, one at a time on an otherwise idle chip (the joint launch and longest-first "
-                                         "tile ordering are active there, incl. the order's radix sort every 8th to 64th frame; with frames in flight on "
-                                         "other streams — the timed region — a frame is the two-launch form in natural order)" if args.tile_ordering and args.fused in (0, 3) and not args.dense_dda else
+                               "timing": "HIP events around single launches, one at a time on an otherwise idle chip (incl. the tile order's radix sort "
+                                         "every 8th to 64th frame)" if args.tile_ordering and args.fused in (0, 3) and not args.dense_dda else
                                          "HIP events around single launches, one at a time on an otherwise idle chip",
                                "frac_overlapped": achieved_overlapped / HBM_PEAK_GBS, "achieved_overlapped": achieved_overlapped,
                                "kernel_ms_overlapped": overlapped_ms, "frames_in_flight": args.frames_in_flight,
