@@ -450,9 +450,11 @@ int blok_hip_set_beam(blok_hip_ctx* ctx, uint32_t beam_tile_pixels);
 /* Longest-first scheduling of the walk (default: on, re-sorted every 8 frames; rectangle launches of at least 4096 wave tiles
  * behind the pre-pass): every wave of the walk leaves the clocks it spent; every N-th frame a 16-bit radix sort of those costs
  * (129 600 keys at 4K) follows the frame on its stream, a later launch adopts the finished order, and the walk's workgroups take
- * their tiles in it, so the long grazing-ray waves start first instead of forming the launch's tail.  Applied (and re-sorted) only
- * while the launch has the chip to itself: when another stream of the context still has frames in flight the tail is already
- * filled by their waves, front-loading every frame's heavy tiles measures slower, and the launch keeps the natural order.
+ * their tiles in it, so the long grazing-ray waves start first instead of forming the launch's tail.  A view at rest is re-sorted
+ * ever less often (the interval doubles up to 64 frames).  The order is also what tells a joint launch (blok_hip_set_fused)
+ * which tiles need a walk wave at all.  In the two-launch form it is applied (and re-sorted) only while the launch has the chip
+ * to itself: when another stream of the context still has frames in flight the tail is already filled by their waves and
+ * front-loading every frame's heavy tiles measures slower.
  * Pure scheduling: any order gives the same frame (tests/test_gpu_parity.py); the first frame of a geometry runs in natural
  * order, a camera that moves more than a fraction of a degree per frame gains nothing.  No reference counterpart
  * (renderer_raytracing.cpp:666-685 leaves scheduling to the driver).  0 = off; N > 0 = re-sort every N frames.
@@ -488,9 +490,10 @@ int blok_hip_set_rt_taa_jitter(blok_hip_ctx* ctx, int enabled);
  *      searches first; a walk wave waits (bounded) only while its own tile's search is still running, so the chip starts walking
  *      when the first searches end, not when the last one does.  With a longest-first order in force (blok_hip_set_tile_ordering)
  *      walk waves are dispatched only for the tiles that walked when the order was made; a tile that has become live since is
- *      walked by its search wave.  Alone on the chip: 0.26 -> 0.205 ms per 4K frame; with frames in flight on other streams the
- *      waiting waves cost more than they save (0.187 -> 0.201 ms per frame);
- *   3  (default) automatic: 2 for a launch that has the chip to itself (ordered, no other stream of the context busy), else 0. */
+ *      walked by its search wave.  Alone on the chip: 0.26 -> 0.20 ms per 4K frame; with frames in flight on other streams
+ *      0.186 -> 0.180 ms per frame over an order's live prefix, but 0.201 without an order (the waiting waves hold slots);
+ *   3  (default) automatic: 2 whenever an order is in force or the launch has the chip to itself, 0 for a camera in motion with
+ *      frames in flight on other streams (and for launches too small to be ordered). */
 int blok_hip_set_fused(blok_hip_ctx* ctx, int enabled);
 /* Health check of forms 1 and 2: synchronises the device and returns how many waves ever gave up a bounded wait (0 in a working
  * system).  Form 1: for a queue entry (~0.5 s; frames since context creation may then be incomplete).  Form 2: for their tile's
