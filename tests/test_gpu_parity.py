@@ -640,6 +640,12 @@ def test_config4_2048_svo_4k_tiles(tracer_cls):
         tr.set_beam(0)
         assert records_equal(tr.draw_frame(cam_x).reshape(-1), got.reshape(-1)).all()
         tr.set_beam(32)
+        # every launch form, each long enough on one view for the tile order (and the joint launch's live prefix) to come into force
+        for form in (0, 2, 3):
+            tr.set_fused(form)
+            for k in range(14):
+                assert records_equal(tr.draw_frame(cam_x).reshape(-1), got.reshape(-1)).all(), (form, k)
+    assert tr.frame_queue_stalls() == 0
     n_ranks, tile = 8, 32
     per = tr.tiles_for_rank(tile, 0, n_ranks)
     gathered = torch.zeros((n_ranks * per * tile * tile, 4), dtype=torch.int32, device="cuda")
