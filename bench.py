@@ -40,12 +40,14 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=40, help="untimed frames first (the tile order of a view at rest is sorted behind the second frame and adopted a few frames later)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--n", type=int, default=1024, help="world edge in voxels")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--pose", type=int, default=0, help="camera pose A/B/C = 0/1/2 (SURVEY.md §8(d))")
     ap.add_argument("--tile", type=int, default=32)
+    ap.add_argument("--settle", type=int, default=32, help="untimed frames before the warmup steps: the tile order of a view at rest is per-view state "
+                    "(sorted behind the second frame, adopted a few frames later), prepared like the world upload; reported in config.settle_frames")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0xB10C0001)
     ap.add_argument("--cpu-stride", type=int, default=1, help="CPU baseline traces every stride-th pixel in x and y")
     ap.add_argument("--frames-in-flight", type=int, default=0,
@@ -237,7 +239,7 @@ def main():
             frame_no[0] += 1
         pipe.step()
 
-    for _ in range(args.warmup):
+    for _ in range(args.settle + args.warmup):
         next_frame()
     pipe.flush()
     fence()
@@ -378,7 +380,7 @@ def main():
                        "tile_records_gathered_per_frame_and_rank": (pipe.records_gathered / max(1, pipe.frames_done)) if world_size > 1 and args.sparse_gather else None,
                        "tiles_per_rank": pipe.per_rank if world_size > 1 else None,
                        "camera_orbit_deg_per_frame": args.orbit, "tile_ordering_resort_every_n_frames": args.tile_ordering,
-                       "frames_in_flight": args.frames_in_flight, "device_ms_per_step": device_ms / args.steps, "kernel_ms_alone": kernel_ms_avg, "beam_tile": args.beam,
+                       "frames_in_flight": args.frames_in_flight, "settle_frames": args.settle, "device_ms_per_step": device_ms / args.steps, "kernel_ms_alone": kernel_ms_avg, "beam_tile": args.beam,
                        "poses": poses, "also_measured_paths": paths},
         }
         alg = None
