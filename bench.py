@@ -282,6 +282,7 @@ def main():
         tracer.set_timing(False)
         return float(np.mean(ms))
 
+    gave_up = tracer.frame_queue_stalls()        # joint launches: walk waves that stopped waiting for their tile's search (they start at the ray origin: same frame, more work)
     kernel_ms_avg = solitary_ms(pipe.backend, min(args.steps, 20))
     local_hits = (pipe.hits[:, 3] >> 24).sum()
     if dist is not None:
@@ -380,7 +381,7 @@ def main():
                        "tile_records_gathered_per_frame_and_rank": (pipe.records_gathered / max(1, pipe.frames_done)) if world_size > 1 and args.sparse_gather else None,
                        "tiles_per_rank": pipe.per_rank if world_size > 1 else None,
                        "camera_orbit_deg_per_frame": args.orbit, "tile_ordering_resort_every_n_frames": args.tile_ordering,
-                       "frames_in_flight": args.frames_in_flight, "settle_frames": args.settle, "device_ms_per_step": device_ms / args.steps, "kernel_ms_alone": kernel_ms_avg, "beam_tile": args.beam,
+                       "frames_in_flight": args.frames_in_flight, "settle_frames": args.settle, "walk_waves_that_gave_up_waiting": gave_up, "device_ms_per_step": device_ms / args.steps, "kernel_ms_alone": kernel_ms_avg, "beam_tile": args.beam,
                        "poses": poses, "also_measured_paths": paths},
         }
         alg = None

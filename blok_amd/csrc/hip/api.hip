@@ -356,25 +356,29 @@ int launch_timed(blok_hip_ctx* ctx, blok::RayMode mode, blok::TraceArgs args, ui
             else ctx->order_streak = same ? ctx->order_streak + 1u : 0u;
         }
         if (ordered) { const int rc = order_before_launch(ctx, args, blocks, stream); if (rc != BLOK_OK) return rc; }
-        // auto: ONE joint launch when the launch has the chip to itself or an order is in force (walk waves for the live prefix only:
-        // alone 0.26 -> 0.20 ms, three frames in flight 0.186 -> 0.180 ms per frame); with frames in flight elsewhere and no order
-        // (a camera in motion) the two-launch form measures faster (waiting walk waves hold slots the other frames' waves would
-        // use: 0.186 vs 0.201 ms per frame)
-        const bool go_joint = joint || (n_beams && ctx->joint_auto && !ctx->fused && ordered && (args.order || !ctx->order_busy) && blok::kBlock == 64);
+        // auto (form 3): with an order in force the walk gets waves for the order's live prefix only, and the searches and that walk
+        // are ONE joint launch when the launch has the chip to itself (alone: 0.26 -> 0.20 ms), two launches when other streams of the
+        // context have frames in flight (three in flight: 0.186 -> ~0.18 ms per frame either way; see below why not jointly)
+        const bool prefix = args.order && args.rank_of && args.launched <= blocks && blok::kBlock == 64;     // walk waves for the order's live prefix only
+        const bool go_joint = joint || (n_beams && ctx->joint_auto && !ctx->fused && ordered && !ctx->order_busy && blok::kBlock == 64);
+        uint32_t launch_blocks = blocks;
+        if (prefix && (go_joint || ctx->joint_auto)) {
+            // walk waves only for the tiles that walked when the order was made; the search wave of a beam tile that is live now walks
+            // any other tile of its own (a changed view), and writes the miss pixels of the empty ones
+            if (ctx->joint_prefix_limit && args.launched > ctx->joint_prefix_limit) args.launched = ctx->joint_prefix_limit;      // tests: more work for the search waves
+            launch_blocks = args.launched; args.miss_in_walk = 0u;
+        } else { args.rank_of = nullptr; args.launched = 0u; }
         if (go_joint) {
+            // ONE launch: searches and walk waves in one grid (a launch that has the chip to itself: 0.26 -> 0.20 ms)
             if (!joint) { const int rc = joint_slots(ctx, args, stream, n_beams); if (rc != BLOK_OK) return rc; }
-            uint32_t launch_blocks = blocks;
-            if (args.order && args.rank_of && args.launched <= blocks) {
-                // walk waves only for the tiles that walked when the order was made; the search wave of a beam tile that is live now
-                // walks any other tile of its own (a changed view), and writes the miss pixels of the empty ones
-                if (ctx->joint_prefix_limit && args.launched > ctx->joint_prefix_limit) args.launched = ctx->joint_prefix_limit;      // tests: more work for the search waves
-                launch_blocks = args.launched; args.miss_in_walk = 0u;
-            } else { args.rank_of = nullptr; args.launched = 0u; }
             blok::launch_joint(mode, args, n_beams, launch_blocks, stream);
         } else {
-            args.beam_slots = nullptr; args.rank_of = nullptr;
+            // two launches; with frames in flight on other streams a joint launch's waiting waves hold slots the other frames' waves
+            // would use — and several joint launches in flight can even wait for each other's searches in a circle until they give up
+            // (trace_kernels.h: kJointPollBudget) — so there the searches and the walk stay separate launches, over the prefix all the same
+            args.beam_slots = nullptr;
             if (n_beams) blok::launch_beam(mode, args, n_beams, stream);
-            blok::launch_trace(mode, args, blocks, stream);
+            blok::launch_trace(mode, args, launch_blocks, stream);
         }
         if (ordered) { const int rc = order_after_launch(ctx, args, blocks, stream); if (rc != BLOK_OK) return rc; }
     }

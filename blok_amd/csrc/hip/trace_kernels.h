@@ -207,7 +207,13 @@ void launch_paths(const PathArgs& args, uint32_t n_blocks, hipStream_t stream);
 void launch_trace(RayMode mode, const TraceArgs& args, uint32_t n_blocks, hipStream_t stream);
 // Pre-pass and walk in one grid, statically: workgroups [0, n_beam_tiles) search, the others walk (Rect and Tiles).
 void launch_joint(RayMode mode, const TraceArgs& args, uint32_t n_beam_tiles, uint32_t n_blocks, hipStream_t stream);
-constexpr uint32_t kJointPollBudget = 1u << 16;   // polls (a few hundred ns apart) before a walk wave stops waiting for its tile's search
+// Polls (>= 0.5 us apart: s_sleep 16 + the load) before a walk wave stops waiting for its tile's search and starts at the ray origin instead.  A search ends
+// within ~80 us of its launch's start, so a longer wait means the search has not been DISPATCHED yet — possible with several joint
+// launches in flight: workgroup i goes to XCD i mod 8 and each XCD works through its share on its own, so walk waves of launch A can
+// fill an XCD on which launch B's searches are still pending while B's walk waves do the same to A elsewhere.  Such a circle ends
+// when the waiting waves give up, so the budget is what it may cost: >= 0.25 ms (three times the longest search), not the seconds a
+// "never happens" budget would.  The automatic form never has two joint launches in flight (api.hip).
+constexpr uint32_t kJointPollBudget = 512u;
 // Number of beam tiles of a launch (= floats of TraceArgs::beam) and the pre-pass itself; Rect and Tiles only.
 uint32_t beam_tiles(RayMode mode, const TraceArgs& args, uint32_t tiles_of_rank);
 void launch_beam(RayMode mode, const TraceArgs& args, uint32_t n_beam_tiles, hipStream_t stream);

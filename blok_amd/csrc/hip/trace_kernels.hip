@@ -49,7 +49,7 @@ __device__ __forceinline__ float await_beam(unsigned long long* slot, uint32_t s
         lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v)); hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32));
         if (hi == serial) return __uint_as_float(lo);
         if (--budget == 0u) break;
-        __builtin_amdgcn_s_sleep(4);
+        __builtin_amdgcn_s_sleep(16);
     }
     if (gave_up && threadIdx.x == 0) (void)__hip_atomic_fetch_add(gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return 0.0f;
@@ -234,7 +234,8 @@ __device__ __forceinline__ void beam_block(const TraceArgs& A, const uint32_t b,
 
 template <RayMode MODE>
 __global__ __launch_bounds__(64) void beam_kernel(const TraceArgs A, const uint32_t n_beam_tiles) {
-    beam_block<MODE>(A, blockIdx.x, n_beam_tiles);
+    extern __shared__ uint4 lds_stack[];       // only when the walk launch covers a prefix of the order (TraceArgs::rank_of): the walk's stack, for the tiles walked here
+    beam_block<MODE>(A, blockIdx.x, n_beam_tiles, A.rank_of ? lds_stack : nullptr);
 }
 
 // ---- joint launch: the pre-pass waves and the walk waves in ONE grid, statically ------------------------------------------
@@ -658,8 +659,9 @@ uint32_t beam_tiles(RayMode mode, const TraceArgs& a, uint32_t tiles_of_rank) {
 
 void launch_beam(RayMode mode, const TraceArgs& args, uint32_t n_beam_tiles, hipStream_t stream) {
     if (n_beam_tiles == 0 || mode == RayMode::Rays) return;
-    if (mode == RayMode::Rect) hipLaunchKernelGGL(beam_kernel<RayMode::Rect>, dim3(n_beam_tiles), dim3(64), 0, stream, args, n_beam_tiles);
-    else hipLaunchKernelGGL(beam_kernel<RayMode::Tiles>, dim3(n_beam_tiles), dim3(64), 0, stream, args, n_beam_tiles);
+    const size_t lds = args.rank_of ? static_cast<size_t>(args.levels > 1 ? args.levels - 1 : 1) * kBlock * sizeof(uint4) : 0;
+    if (mode == RayMode::Rect) hipLaunchKernelGGL(beam_kernel<RayMode::Rect>, dim3(n_beam_tiles), dim3(64), lds, stream, args, n_beam_tiles);
+    else hipLaunchKernelGGL(beam_kernel<RayMode::Tiles>, dim3(n_beam_tiles), dim3(64), lds, stream, args, n_beam_tiles);
 }
 
 size_t frame_lds_bytes(const TraceArgs& args) { return static_cast<size_t>(args.levels > 1 ? args.levels - 1 : 1) * kBlock * sizeof(uint4); }

@@ -428,7 +428,10 @@ def test_joint_launch_prefix_and_search_wave_fallback(tracer_cls, scene1024):
         torch.cuda.synchronize()
         for b in bufs:
             assert torch.equal(b[0], want_h) and torch.equal(b[1], want_c), ("in flight", form)
-    assert tr.frame_queue_stalls() == 0
+        # the automatic form never has two joint launches in flight; FORCED joint launches in flight may wait for each other's
+        # searches in a circle until some waves give up and start at the ray origin (same frame, as just checked)
+        if form == 3:
+            assert tr.frame_queue_stalls() == 0
     tr.shutdown(); ref.shutdown()
 
 
