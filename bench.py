@@ -362,8 +362,8 @@ def main():
         elif args.fused == 2:
             launch = "joint_kernel per frame (searches and walk waves in one grid)"
         elif args.fused == 3 and args.tile_ordering:
-            launch = ("joint_kernel per frame (searches and walk waves in one grid; walk waves only for the tiles that walked when the order was "
-                      "made); beam_kernel + trace_kernel per frame only for a camera in motion with frames in flight")
+            launch = ("joint_kernel per frame when the launch has the chip to itself (searches and walk waves in one grid), beam_kernel + trace_kernel "
+                      "with frames in flight; walk waves only for the tiles that walked when the tile order was made")
         else:
             launch = "beam_kernel + trace_kernel per frame"
         out = {

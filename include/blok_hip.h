@@ -490,10 +490,11 @@ int blok_hip_set_rt_taa_jitter(blok_hip_ctx* ctx, int enabled);
  *      searches first; a walk wave waits (bounded) only while its own tile's search is still running, so the chip starts walking
  *      when the first searches end, not when the last one does.  With a longest-first order in force (blok_hip_set_tile_ordering)
  *      walk waves are dispatched only for the tiles that walked when the order was made; a tile that has become live since is
- *      walked by its search wave.  Alone on the chip: 0.26 -> 0.20 ms per 4K frame; with frames in flight on other streams
- *      0.186 -> 0.180 ms per frame over an order's live prefix, but 0.201 without an order (the waiting waves hold slots);
- *   3  (default) automatic: 2 whenever an order is in force or the launch has the chip to itself, 0 for a camera in motion with
- *      frames in flight on other streams (and for launches too small to be ordered). */
+ *      walked by its search wave.  Alone on the chip: 0.26 -> 0.20 ms per 4K frame.  Not for frames in flight on several
+ *      streams: the waiting waves hold slots other frames' waves would use, and several joint launches in flight can wait for
+ *      each other's searches in a circle until they give up (bounded; the frame stays exact);
+ *   3  (default) automatic: 2 for a launch that has the chip to itself; with frames in flight on other streams form 0, over the
+ *      order's live prefix when an order is in force (three in flight: 0.186 -> 0.177 ms per frame), over all tiles otherwise. */
 int blok_hip_set_fused(blok_hip_ctx* ctx, int enabled);
 /* Health check of forms 1 and 2: synchronises the device and returns how many waves ever gave up a bounded wait (0 in a working
  * system).  Form 1: for a queue entry (~0.5 s; frames since context creation may then be incomplete).  Form 2: for their tile's
