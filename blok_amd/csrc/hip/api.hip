@@ -925,7 +925,7 @@ static int launch_path_frame(blok_hip_ctx* ctx, const blok_camera* cam, uint32_t
     p.trace = base_args(ctx, cam);
     p.trace.x0 = x0; p.trace.y0 = y0; p.trace.w = w; p.trace.h = h;
     p.spp = spp; p.max_bounces = max_bounces; p.frame_count = frame_index;
-    p.batch_kinds = ctx->ray_batching ? 1u : 0u;
+    p.batch_kinds = ctx->ray_batching;
     if (ctx->sun_map_enabled && ctx->has_sun_map) {         // shadow rays stop at the last occluder of their column
         const blok::SunMapArgs& m = ctx->sun;
         p.sun_map = ctx->d_sun_map;
@@ -1088,7 +1088,8 @@ int blok_hip_accum_download(blok_hip_ctx* ctx, float* out_rgba32f_host) {
 
 int blok_hip_set_ray_batching(blok_hip_ctx* ctx, int enabled) {
     if (!ctx) return BLOK_ERR_INVALID_ARG;
-    ctx->ray_batching = enabled != 0;
+    if (enabled < 0 || enabled > 2) return set_error(ctx, BLOK_ERR_INVALID_ARG, "ray batching: 0 off, 1 by kind, 2 by sample and kind");
+    ctx->ray_batching = static_cast<uint32_t>(enabled);
     return BLOK_OK;
 }
 

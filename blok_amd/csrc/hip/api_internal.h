@@ -82,7 +82,8 @@ struct blok_hip_ctx {
     bool has_volume = false;
     // "last occluder" map of the shadow rays (beam.h: prism_far), rebuilt with every world
     float* d_sun_map = nullptr;
-    bool sun_map_enabled = true, has_sun_map = false, ray_batching = true;
+    bool sun_map_enabled = true, has_sun_map = false;
+    uint32_t ray_batching = 2;          // PathArgs::batch_kinds (blok_hip_set_ray_batching)
     blok::SunMapArgs sun{};
     // beam pre-pass (beam.h): start parameters per beam tile, one buffer per stream (launches on one stream are
     // ordered, frames in flight on different streams must not share)

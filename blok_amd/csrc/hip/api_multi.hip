@@ -71,6 +71,8 @@ struct blok_hip_multi {
     uint32_t* d_frame = nullptr;             // root: frames x width x height
     uint8_t* d_tile_state = nullptr;         // root, sparse-pull: which tiles of d_frame hold something other than sky
     const uint32_t** d_rank_ptrs = nullptr;  // root, sparse-pull: every rank's d_codes
+    hipEvent_t assembled = nullptr;          // root stream: behind the assembly (scatter / un-permute) of the previous call — the last reader of every rank's d_codes / d_gathered
+    bool has_assembled = false;
     bool frame_is_sky = false;               // d_frame / d_tile_state are in the state sparse-pull assumes (all sky / all zero, or left by it)
     bool peer_readable = false;              // the root can read every device's memory
     int exchange = -1;                       // -1 = sparse-pull when possible, 0 = dense, 1 = sparse-pull (refused when impossible)
@@ -114,6 +116,7 @@ void destroy(blok_hip_multi* m) {
         if (r.ctx) blok_hip_destroy(r.ctx);
     }
     if (!m->ranks.empty() && m->ranks[0].ctx) (void)hipSetDevice(m->ranks[0].device);
+    if (m->assembled) (void)hipEventDestroy(m->assembled);
     if (m->d_gathered) (void)hipFree(m->d_gathered);
     if (m->d_frame) (void)hipFree(m->d_frame);
     if (m->d_tile_state) (void)hipFree(m->d_tile_state);
@@ -271,6 +274,21 @@ int blok_hip_multi_draw_frames_device(blok_hip_multi* m, const blok_camera* cams
     const size_t n_px = static_cast<size_t>(m->width) * m->height;
     auto& root = m->ranks[0];
     const bool pull = sparse_pull(m);
+    // The calls are asynchronous: the root's assembly of the PREVIOUS call may still be reading every rank's code records (through the
+    // peer mappings) or the gathered buffer a peer copy is about to overwrite.  Each peer stream therefore waits for that assembly before
+    // it traces, compacts or copies again (the root's own work is ordered by its stream).
+    if (m->has_assembled)
+        for (uint32_t i = 1; i < G; ++i) {
+            MULTI_TRY(m, hipSetDevice(m->ranks[i].device));
+            MULTI_TRY(m, hipStreamWaitEvent(m->ranks[i].stream, m->assembled, 0));
+        }
+    auto note_assembled = [&]() -> int {
+        MULTI_TRY(m, hipSetDevice(root.device));
+        if (!m->assembled) MULTI_TRY(m, hipEventCreateWithFlags(&m->assembled, hipEventDisableTiming));
+        MULTI_TRY(m, hipEventRecord(m->assembled, root.stream));
+        m->has_assembled = true;
+        return BLOK_OK;
+    };
     // every device traces its tiles of all the frames in one launch pair (and, sparse-pull, compacts them where they are)
     for (uint32_t i = 0; i < G; ++i) {
         auto& r = m->ranks[i];
@@ -295,6 +313,8 @@ int blok_hip_multi_draw_frames_device(blok_hip_multi* m, const blok_camera* cams
         rc = blok_api::scatter_frames(root.ctx, true, nullptr, reinterpret_cast<const void* const*>(m->d_rank_ptrs), G, 0, m->tile, m->per_rank, n_frames,
                                       m->d_frame, m->d_tile_state, root.stream);
         if (rc != BLOK_OK) return rank_error(m, 0, rc);
+        rc = note_assembled();
+        if (rc != BLOK_OK) return rc;
         if (out_rgba8_dev_on_root) *out_rgba8_dev_on_root = m->d_frame;
         return BLOK_OK;
     }
@@ -324,6 +344,8 @@ int blok_hip_multi_draw_frames_device(blok_hip_multi* m, const blok_camera* cams
     }
     rc = blok_hip_untile_frames_device(root.ctx, m->d_gathered, 4, m->tile, G, n_frames * m->per_rank, n_frames, m->per_rank, m->d_frame, root.stream);
     if (rc != BLOK_OK) return rank_error(m, 0, rc);
+    rc = note_assembled();
+    if (rc != BLOK_OK) return rc;
     if (out_rgba8_dev_on_root) *out_rgba8_dev_on_root = m->d_frame;
     return BLOK_OK;
 }

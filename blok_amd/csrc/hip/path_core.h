@@ -23,6 +23,11 @@
 #pragma clang fp contract(off)
 #endif
 
+// Optional hook of the host harness' statistics build: the kind of the ray about to be walked (0 primary, 1 shadow, 2 bounce).
+#ifndef BLOK_PATH_KIND
+#define BLOK_PATH_KIND(kind)
+#endif
+
 namespace blok {
 
 struct PathArgs {
@@ -38,7 +43,7 @@ struct PathArgs {
     float sun_u[3], sun_v[3];
     float sun_u0, sun_v0, sun_inv_texel;
     uint32_t sun_nu, sun_nv;
-    uint32_t batch_kinds;            // 1: the wave walks one kind of ray at a time (see shade_pixel)
+    uint32_t batch_kinds;            // 1: the wave walks one kind of ray at a time; 2: and the oldest sample first (see shade_pixel)
     // The same G-buffer in the reference's own image formats (raygen.rgen:55-59; renderer_denoising.cpp:110-170), each optional:
     // normal + roughness RGBA16F, albedo + metallic RGBA8 (unorm), motion vectors RG16F (raygen.rgen:150-155, 409-413; needs
     // prev_view_proj = FrameUBO::prevViewProj, column-major).  48 B/pixel with the two float4 planes instead of 64.
@@ -230,8 +235,23 @@ BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t in
             // bounce there are only short rays and taking turns costs (3.8 -> 5.3 ms), so it is not done there.
             if (P.batch_kinds != 0u && P.max_bounces > 1u) {
                 const uint32_t kind = shadow_phase ? 1u : (bounce == 0u ? 0u : 2u);
-                const bool any_primary = __ballot(kind == 0u) != 0ull, any_shadow = __ballot(kind == 1u) != 0ull;
-                if (kind != (any_primary ? 0u : (any_shadow ? 1u : 2u))) continue;
+                if (P.batch_kinds >= 2u) {
+                    // ... and sample by sample: the OLDEST pending (sample, kind) of the wave goes first.  With "primary rays first" the
+                    // pixels whose primary rays miss race through all their samples in rounds of their own while the others still owe
+                    // the shadow and bounce rays of sample 0 — twice the primary rounds, each at partial occupancy; in step, every
+                    // sample is one full primary round, one shadow round, one bounce round.
+                    const uint32_t key = s * 4u + kind;
+                    uint32_t oldest = __builtin_amdgcn_readfirstlane(key);
+                    for (;;) {                                   // min over the active lanes: each turn strictly lowers it
+                        const unsigned long long lower = __ballot(key < oldest);
+                        if (lower == 0ull) break;
+                        oldest = __builtin_amdgcn_readlane(key, static_cast<uint32_t>(__builtin_ctzll(lower)));
+                    }
+                    if (key != oldest) continue;
+                } else {
+                    const bool any_primary = __ballot(kind == 0u) != 0ull, any_shadow = __ballot(kind == 1u) != 0ull;
+                    if (kind != (any_primary ? 0u : (any_shadow ? 1u : 2u))) continue;
+                }
             }
         }
 #endif
@@ -262,6 +282,7 @@ BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t in
             r.tmin = fmaxf(r.tmin, t0);
             if (t0 >= kBeamNone) r.tmax = 0.0f;                   // the tile's frustum meets no voxel: empty interval, immediate miss
         }
+        BLOK_PATH_KIND(shadow_phase ? 1u : (bounce == 0u ? 0u : 2u));
         const HitInfo hit = walk(A, r, stk);
 
         bool end_sample = false, continue_path = false;

@@ -143,9 +143,10 @@ class HipTracer:
     def post_reset(self):
         self._check(self._lib.blok_hip_post_reset(self._ctx))
 
-    def set_ray_batching(self, enabled: bool):
-        """Path kernel: a wave walks one kind of ray at a time (never changes a result); default on."""
-        self._check(self._lib.blok_hip_set_ray_batching(self._ctx, int(bool(enabled))))
+    def set_ray_batching(self, mode):
+        """Path kernel scheduling (never changes a result): 0 / False = off, 1 = one kind of ray at a time, 2 / True (default) = one
+        kind at a time and the oldest sample first."""
+        self._check(self._lib.blok_hip_set_ray_batching(self._ctx, 2 if mode is True else int(mode)))
 
     def set_sun_map(self, enabled: bool):
         """Shadow rays stop at the last occluder of their sun-direction column (never changes a result); default on."""

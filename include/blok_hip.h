@@ -434,8 +434,9 @@ int blok_hip_volume_apply_brush(blok_hip_ctx* ctx, const float center[3], float 
  * density > 0 and their material ids, with the given material table. */
 int blok_hip_volume_rebuild(blok_hip_ctx* ctx, const blok_material* materials, size_t n_materials);
 
-/* Scheduling knob of the path kernel (no reference counterpart): a wave walks one kind of ray at a time (primary, shadow, bounce)
- * instead of whatever each lane has pending.  Per-lane work and results are identical either way (tests/test_paths.py). Default on. */
+/* Scheduling knob of the path kernel (no reference counterpart): 0 = every lane walks whatever ray it has pending; 1 = a wave walks
+ * one kind of ray at a time (primary, else shadow, else bounce); 2 (default) = one kind at a time and the oldest sample first, so the
+ * pixels of a wave stay in step sample by sample.  Per-lane work and results are identical in all three (tests/test_paths.py). */
 int blok_hip_set_ray_batching(blok_hip_ctx* ctx, int enabled);
 /* "Last occluder" map of the path kernel's shadow rays (no reference counterpart): all shadow rays share the shader's constant sun
  * direction (raygen.rgen:142,185), so with every world the backend records, per 4-voxel texel of the plane perpendicular to

@@ -6,8 +6,10 @@
 static thread_local uint64_t g_stat[5][8];
 static thread_local unsigned char* g_seq = nullptr;      // optional per-ray event log: 1 descend, 2 step (+level*4)
 static thread_local uint32_t g_seq_len = 0, g_seq_cap = 0;
+static thread_local uint32_t g_kind = 0;                 // kind of the ray being walked (path loop): 0 primary, 1 shadow, 2 bounce
+#define BLOK_PATH_KIND(kind) do { g_kind = (kind); } while (0)
 #define BLOK_STAT(event, level) do { ++g_stat[event][level]; \
-    if (g_seq && (event == 1 || event == 2 || event == 4) && g_seq_len < g_seq_cap) g_seq[g_seq_len++] = (unsigned char)(event | ((level) << 2)); } while (0)
+    if (g_seq && (event == 1 || event == 2 || event == 4) && g_seq_len < g_seq_cap) g_seq[g_seq_len++] = (unsigned char)(event | ((level) << 2) | (event == 4 ? g_kind << 3 : 0u)); } while (0)
 #include "trace_core.h"
 #include "path_core.h"
 #include "post_core.h"
@@ -146,6 +148,26 @@ void hh_render_paths_events(const void* h, const blok_camera* cam, const blok_ma
             shade_pixel(p, x0 + x, y0 + y, 0, stack.data());
         }
     g_seq = nullptr;
+}
+
+// As hh_render_paths_events with a per-pixel start parameter for the primary rays (what the beam pre-pass provides) and the kind of
+// every walk in its start marker: (byte & 3) == 0 starts a walk, kind = byte >> 3.
+void hh_render_paths_events2(const void* h, const blok_camera* cam, const blok_material* materials, uint32_t n_materials,
+                             uint32_t width, uint32_t height, uint32_t x0, uint32_t y0, uint32_t w, uint32_t hgt,
+                             uint32_t spp, uint32_t max_bounces, const float* tstart, uint32_t cap, unsigned char* events) {
+    const Harness* H = static_cast<const Harness*>(h);
+    PathArgs p{};
+    p.trace = make_args(H);
+    p.trace.cam = *cam; p.trace.frame_w = width; p.trace.frame_h = height;
+    p.trace.mat_table = materials; p.trace.n_materials = n_materials;
+    p.spp = spp; p.max_bounces = max_bounces; p.frame_count = 1;
+    std::vector<uint4> stack(size_t(kMaxLevels) * 2 * kBlock);
+    for (uint32_t y = 0; y < hgt; ++y)
+        for (uint32_t x = 0; x < w; ++x) {
+            g_seq = events + (size_t(y) * w + x) * cap; g_seq_len = 0; g_seq_cap = cap;
+            shade_pixel(p, x0 + x, y0 + y, 0, stack.data(), tstart ? tstart[size_t(y) * w + x] : 0.0f);
+        }
+    g_seq = nullptr; g_kind = 0;
 }
 
 // Per-ray iteration counts for a rectangle of a frame with an optional per-pixel start parameter (beam experiments).

@@ -274,8 +274,12 @@ def test_prepasses_random_cameras_path_frames():
         cam = W.camera_look_at(tuple(float(v) for v in eye), tuple(float(v) for v in target), float(rng.uniform(10.0, 140.0)), w, h)
         tr.set_beam(0); tr.set_sun_map(False); tr.set_ray_batching(False)
         plain = tr.trace_paths(cam, spp=2, max_bounces=3, frame_index=k)
-        tr.set_beam(32); tr.set_sun_map(True); tr.set_ray_batching(True)
-        got = tr.trace_paths(cam, spp=2, max_bounces=3, frame_index=k)
-        for name in plain:
-            assert got[name].tobytes() == plain[name].tobytes(), (k, name)
+        for mode in (1, 2):            # one kind of ray at a time; and the oldest sample first (the default)
+            tr.set_beam(32); tr.set_sun_map(True); tr.set_ray_batching(mode)
+            got = tr.trace_paths(cam, spp=3 if mode == 2 else 2, max_bounces=3, frame_index=k)
+            if mode == 2:
+                tr.set_beam(0); tr.set_sun_map(False); tr.set_ray_batching(False)
+                plain = tr.trace_paths(cam, spp=3, max_bounces=3, frame_index=k)
+            for name in plain:
+                assert got[name].tobytes() == plain[name].tobytes(), (k, mode, name)
     tr.shutdown()
