@@ -46,8 +46,8 @@ def parse():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--pose", type=int, default=0, help="camera pose A/B/C = 0/1/2 (SURVEY.md §8(d))")
     ap.add_argument("--tile", type=int, default=32)
-    ap.add_argument("--settle", type=int, default=32, help="untimed frames before the warmup steps: the tile order of a view at rest is per-view state "
-                    "(sorted behind the second frame, adopted a few frames later), prepared like the world upload; reported in config.settle_frames")
+    ap.add_argument("--settle", type=int, default=0, help="untimed frames before the warmup steps (none needed: a frame takes nothing from earlier frames but the size of its walk grid, "
+                    "which the first warmup frame provides); reported in config.settle_frames")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0xB10C0001)
     ap.add_argument("--cpu-stride", type=int, default=1, help="CPU baseline traces every stride-th pixel in x and y")
     ap.add_argument("--frames-in-flight", type=int, default=0,
@@ -59,8 +59,8 @@ def parse():
                     "rehearsing the N > 1 code path with several ranks on one GPU, which RCCL refuses)")
     ap.add_argument("--beam", type=int, default=32, help="beam pre-pass tile in pixels (0 = off)")
     ap.add_argument("--fused", type=int, default=3, help="launch form of a frame (blok_hip_set_fused): 0 = beam kernel then trace kernel, 1 = one persistent launch with work queues (measured slower), "
-                    "2 = joint launch (searches and walk waves in one grid), 3 = automatic: 2 when a launch has the chip to itself, else 0")
-    ap.add_argument("--tile-ordering", type=int, default=8, help="longest-first scheduling of the walk from earlier frames' per-wave clocks, re-sorted every N frames (0 = off)")
+                    "2 = joint launch (searches and one walk wave per wave tile in one grid), 4 = list-fed joint launch (walk waves take the live wave tiles from the list the frame's searches publish), "
+                    "5 = beam kernel, then list-fed walk, 3 = automatic: 4 when a launch has the device to itself, else 5")
     ap.add_argument("--orbit", type=float, default=0.0, help="degrees the camera turns around the world's centre per frame (0 = static camera)")
     ap.add_argument("--dense-dda", action="store_true", help="BASELINE configs[1]: upload the scene as a dense id grid and trace with the dense-grid kernel (N = 1, --n <= 512)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -205,7 +205,6 @@ def main():
         stats = tracer.add_world(packed)                  # world resident in HBM from here on
     tracer.set_beam(args.beam)
     tracer.set_fused(args.fused)
-    tracer.set_tile_ordering(args.tile_ordering)
 
     if args.frames_in_flight <= 0:
         args.frames_in_flight = 3 if world_size <= 2 else 4
@@ -269,7 +268,7 @@ def main():
     def solitary_ms(backend, reps):
         tracer.set_timing(True)
         ms = []
-        for k in range(-12, reps):          # 12 unmeasured launches first: the steady state of one frame at a time (the tile order is sorted behind the second and adopted a few launches later)
+        for k in range(-2, reps):           # two unmeasured launches first (the first sizes the second's walk grid)
             if orbit_cams is not None:
                 backend.cam = orbit_cams[k % len(orbit_cams)]
             if world_size == 1:
@@ -326,8 +325,7 @@ def main():
         for f in range(3):
             tracer.trace_paths_device(cam, color.data_ptr(), spp=64, max_bounces=2, frame_index=f, stream=stream.cuda_stream)
             torch.cuda.synchronize()
-            if k >= 0:
-                ms.append(tracer.last_kernel_ms())
+            ms.append(tracer.last_kernel_ms())
         tracer.set_timing(False)
         path_ms = float(np.mean(ms[1:]))
         paths = {"config": "3840x2160 x 64 spp, 2 bounces + sun shadow ray (raygen.rgen loop)", "ms_per_frame": path_ms,
@@ -361,9 +359,11 @@ def main():
             launch = "one persistent launch per frame (frame_kernel: beam pre-pass + walk, work queues)"
         elif args.fused == 2:
             launch = "joint_kernel per frame (searches and walk waves in one grid)"
-        elif args.fused == 3 and args.tile_ordering:
-            launch = ("joint_kernel per frame when the launch has the chip to itself (searches and walk waves in one grid), beam_kernel + trace_kernel "
-                      "with frames in flight; walk waves only for the tiles that walked when the tile order was made")
+        elif args.fused in (3, 4, 5):
+            launch = {3: "list_joint_kernel per frame when the launch has the device to itself (searches and list-fed walk waves in one grid), beam_kernel + list_walk_kernel with frames in flight",
+                      4: "list_joint_kernel per frame (searches and list-fed walk waves in one grid)", 5: "beam_kernel + list_walk_kernel per frame"}[args.fused] + \
+                     "; walk waves only for the wave tiles the frame's own searches found live"
+
         else:
             launch = "beam_kernel + trace_kernel per frame"
         out = {
@@ -380,7 +380,7 @@ def main():
                        "outputs": "16-B first-hit records (kept on the tracing GPU) + RGBA8 framebuffer on rank 0",
                        "tile_records_gathered_per_frame_and_rank": (pipe.records_gathered / max(1, pipe.frames_done)) if world_size > 1 and args.sparse_gather else None,
                        "tiles_per_rank": pipe.per_rank if world_size > 1 else None,
-                       "camera_orbit_deg_per_frame": args.orbit, "tile_ordering_resort_every_n_frames": args.tile_ordering,
+                       "camera_orbit_deg_per_frame": args.orbit,
                        "frames_in_flight": args.frames_in_flight, "settle_frames": args.settle, "walk_waves_that_gave_up_waiting": gave_up, "device_ms_per_step": device_ms / args.steps, "kernel_ms_alone": kernel_ms_avg, "beam_tile": args.beam,
                        "poses": poses, "also_measured_paths": paths},
         }
@@ -403,9 +403,7 @@ def main():
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                "kernel": launch, "kernel_ms": kernel_ms_avg,
-                               "timing": "HIP events around single launches, one at a time on an otherwise idle chip (incl. the tile order's radix sort "
-                                         "every 8th to 64th frame)" if args.tile_ordering and args.fused in (0, 3) and not args.dense_dda else
-                                         "HIP events around single launches, one at a time on an otherwise idle chip",
+                               "timing": f"HIP events around single launches, one at a time on an otherwise idle chip; {args.settle} settle + {args.warmup} warmup frames before the timed region, 2 unmeasured launches before the single ones",
                                "frac_overlapped": achieved_overlapped / HBM_PEAK_GBS, "achieved_overlapped": achieved_overlapped,
                                "kernel_ms_overlapped": overlapped_ms, "frames_in_flight": args.frames_in_flight,
                                "beam_tile": args.beam, "algorithmic_bytes_per_ray": alg["bytes_per_ray"],

@@ -140,6 +140,7 @@ blok::TraceArgs base_args(const blok_hip_ctx* ctx, const blok_camera* cam) {
     a.n_materials = static_cast<uint32_t>(ctx->n_materials);
     a.tmin = BLOK_RAY_TMIN; a.tmax = BLOK_RAY_TMAX;
     a.beam_budget = ctx->beam_budget;
+    a.debug_clocks = ctx->debug_clocks;
     return a;
 }
 
@@ -203,110 +204,58 @@ int prepare_beam(blok_hip_ctx* ctx, blok::RayMode mode, blok::TraceArgs& args, h
     return beam_buffer(ctx, stream, *n_beams, &args.beam);
 }
 
-// Has the view hardly changed?  An order sorted from another view is worse than the natural one (measured: a camera orbiting by
-// 1 degree per frame loses 5 % under an order up to 8 frames old), so an order is used only within ~0.25 degree of the view it
-// was measured in: direction, position as seen from the world's centre, and the same lens.
-static bool camera_near(const blok_hip_ctx* ctx, const blok_camera& a, const blok_camera& b) {
-    const float dot = a.fwd[0] * b.fwd[0] + a.fwd[1] * b.fwd[1] + a.fwd[2] * b.fwd[2];
-    const float half = 0.5f * std::ldexp(1.0f, 2 * static_cast<int>(ctx->stats.levels)) * ctx->world_voxel_size;
-    float d2 = 0.0f, r2 = 0.0f;
-    for (int k = 0; k < 3; ++k) {
-        const float centre = static_cast<float>(ctx->stats.origin[k]) * ctx->world_voxel_size + half;
-        d2 += (a.pos[k] - b.pos[k]) * (a.pos[k] - b.pos[k]);
-        r2 += (a.pos[k] - centre) * (a.pos[k] - centre);
-    }
-    return dot > 0.99999f && d2 <= 1.6e-5f * std::max(r2, 1.0f) && std::fabs(a.tan_half_fov - b.tan_half_fov) < 1e-6f && std::fabs(a.aspect - b.aspect) < 1e-6f;
+// ---- who else is using the device -----------------------------------------------------------------------------------------------
+// A joint launch only pays when it has the device to itself (launch_policy.h), and "itself" is a property of the DEVICE, not of a
+// context: two contexts on one device (two HipTracers; blok_hip_multi_* with an ordinal listed twice) must see each other's frames.
+// So every frame launch leaves an event behind on its stream in a process-wide table per device, and a launch asks whether any OTHER
+// (context, stream) of the device still has one pending.
+namespace {
+struct DeviceActivity {
+    std::mutex lock;
+    std::map<std::pair<const blok_hip_ctx*, hipStream_t>, hipEvent_t> last;      // latest frame launch of every (context, stream)
+};
+DeviceActivity& device_activity(int device) {
+    static std::mutex table_lock;
+    static std::map<int, DeviceActivity> table;
+    std::lock_guard<std::mutex> g(table_lock);
+    return table[device];
+}
+}  // namespace
+
+static bool device_busy_elsewhere(const blok_hip_ctx* ctx, hipStream_t stream) {
+    DeviceActivity& act = device_activity(ctx->device);
+    std::lock_guard<std::mutex> g(act.lock);
+    bool busy = false;
+    for (auto& kv : act.last)
+        if (!(kv.first.first == ctx && kv.first.second == stream) && hipEventQuery(kv.second) == hipErrorNotReady) { busy = true; break; }
+    (void)hipGetLastError();                               // hipErrorNotReady is an answer, not a failure
+    return busy;
 }
 
-// Longest-first order for a Rect launch of `blocks` wave tiles (api_internal.h: tile ordering).  Before the launch: buffers for
-// the launch geometry, adoption of a finished sort, args.order / args.cost_out.  After it (order_after_launch): the stream's
-// "last use" event and, every order_interval frames, the next sort on the auxiliary stream.
-int order_before_launch(blok_hip_ctx* ctx, blok::TraceArgs& args, uint32_t blocks, hipStream_t stream) {
-    const uint32_t key[6] = {args.x0, args.y0, args.w, args.h, ctx->width, ctx->height};
-    if (ctx->tile_cost_capacity < blocks || std::memcmp(key, ctx->order_key, sizeof(key)) != 0) {
-        BLOK_HIP_TRY(ctx, hipDeviceSynchronize());                     // frames in flight and a pending sort use the old buffers
-        if (ctx->tile_cost_capacity < blocks) {
-            for (void* p : {static_cast<void*>(ctx->d_tile_cost), static_cast<void*>(ctx->d_tile_iota), static_cast<void*>(ctx->d_order[0]),
-                            static_cast<void*>(ctx->d_order[1]), static_cast<void*>(ctx->d_rank_of[0]), static_cast<void*>(ctx->d_rank_of[1]),
-                            static_cast<void*>(ctx->d_order_keys), ctx->d_order_temp})
-                if (p) (void)hipFree(p);
-            ctx->d_tile_cost = ctx->d_tile_iota = ctx->d_order[0] = ctx->d_order[1] = ctx->d_rank_of[0] = ctx->d_rank_of[1] = ctx->d_order_keys = nullptr;
-            ctx->d_order_temp = nullptr;
-            ctx->tile_cost_capacity = 0;
-            const size_t bytes = static_cast<size_t>(blocks) * sizeof(uint32_t);
-            BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_tile_cost), bytes));
-            BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_tile_iota), bytes));
-            BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_order[0]), bytes));
-            BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_order[1]), bytes));
-            BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_rank_of[0]), bytes));
-            BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_rank_of[1]), bytes));
-            if (!ctx->h_order_live) BLOK_HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_order_live), 2 * sizeof(uint32_t), hipHostMallocDefault));
-            BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_order_keys), bytes));
-            ctx->order_temp_bytes = blok::tile_order_temp_bytes(blocks);
-            BLOK_HIP_TRY(ctx, hipMalloc(&ctx->d_order_temp, ctx->order_temp_bytes ? ctx->order_temp_bytes : 16));
-            ctx->tile_cost_capacity = blocks;
-        }
-        if (!ctx->order_done) BLOK_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->order_done, hipEventDisableTiming));
-        BLOK_HIP_TRY(ctx, blok::launch_iota(ctx->d_tile_iota, blocks, nullptr));
-        BLOK_HIP_TRY(ctx, hipMemset(ctx->d_tile_cost, 0, static_cast<size_t>(blocks) * sizeof(uint32_t)));
-        BLOK_HIP_TRY(ctx, hipDeviceSynchronize());
-        std::memcpy(ctx->order_key, key, sizeof(key));
-        ctx->order_current = -1; ctx->order_pending = false; ctx->frames_since_sort = 0;     // a new geometry starts in natural order
-        ctx->order_still_frames = 0;
-    }
-    if (ctx->order_pending && hipEventQuery(ctx->order_done) == hipSuccess) {              // the sort launched some frames ago has finished
-        ctx->order_current = ctx->order_target;
-        ctx->order_live[ctx->order_current] = ctx->h_order_live[ctx->order_current];      // written by the device before the event
-        ctx->order_pending = false;
-        ctx->frames_since_sort = 0;
-    }
-    args.order = ctx->order_current >= 0 && camera_near(ctx, args.cam, ctx->order_cam[ctx->order_current]) ? ctx->d_order[ctx->order_current] : nullptr;
-    ctx->order_still_frames = camera_near(ctx, args.cam, ctx->order_last_cam) ? ctx->order_still_frames + 1u : 0u;
-    ctx->order_last_cam = args.cam;
-    args.cost_out = ctx->order_still_frames >= 1u ? ctx->d_tile_cost : nullptr;     // a camera in motion is not measured (nor sorted for)
-
-    // Longest first pays when the launch has the chip to itself (its tail is then idle time: 0.295 -> 0.252 ms for the benchmark
-    // frame).  With frames in flight on other streams the tail is already filled by their waves, and front-loading every frame's
-    // heavy tiles measures 14 % SLOWER (43.9 -> 37.9 Grays/s): such a launch keeps the natural order.
-    ctx->order_busy = false;
-    for (auto& kv : ctx->order_last_use)
-        if (kv.first != stream && hipEventQuery(kv.second) == hipErrorNotReady) { ctx->order_busy = true; break; }
-    (void)hipGetLastError();                               // hipErrorNotReady is an answer, not a failure
-    // ... in the two-launch form.  A joint launch over the order's live prefix gains from the order with frames in flight too (three in
-    // flight: 0.186 -> 0.180 ms per frame), so the forms that may launch jointly keep it (and keep re-sorting).
-    ctx->order_kept_busy = ctx->order_busy && (ctx->joint || ctx->joint_auto) && !ctx->fused;
-    if (ctx->order_busy && !ctx->order_kept_busy) args.order = nullptr;      // (and no sort is started behind this launch: its kernels would only compete)
-    if (args.order) { args.rank_of = ctx->d_rank_of[ctx->order_current]; args.launched = ctx->order_live[ctx->order_current]; }   // used by a joint launch only
+static int note_frame_launch(blok_hip_ctx* ctx, hipStream_t stream) {
+    DeviceActivity& act = device_activity(ctx->device);
+    std::lock_guard<std::mutex> g(act.lock);
+    hipEvent_t& ev = act.last[{ctx, stream}];
+    if (!ev) BLOK_HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    BLOK_HIP_TRY(ctx, hipEventRecord(ev, stream));
     return BLOK_OK;
 }
 
-int order_after_launch(blok_hip_ctx* ctx, const blok::TraceArgs& args, uint32_t blocks, hipStream_t stream) {
-    hipEvent_t& last = ctx->order_last_use[stream];
-    if (!last) BLOK_HIP_TRY(ctx, hipEventCreateWithFlags(&last, hipEventDisableTiming));
-    BLOK_HIP_TRY(ctx, hipEventRecord(last, stream));
-    ctx->frames_since_sort += 1;
-    // sort when there is no order for this view yet (none at all, or the camera has come to rest somewhere else) or the current one
-    // is order_interval frames old — but never for a camera in motion: the order would be stale before it is adopted
-    const bool have = ctx->order_current >= 0 && camera_near(ctx, args.cam, ctx->order_cam[ctx->order_current]);
-    // a view at rest is re-sorted ever less often (its costs do not change): the interval doubles with every re-sort of the same view, up to 64
-    if (!have) ctx->order_interval_now = ctx->order_interval;
-    const bool due = !have || ctx->frames_since_sort >= std::max(ctx->order_interval_now, ctx->order_interval);
-    if (!ctx->order_pending && (!ctx->order_busy || ctx->order_kept_busy) && ctx->order_interval && ctx->order_still_frames >= 1u && args.cost_out && due) {
-        const int target = ctx->order_current == 0 ? 1 : 0;
-        // The sort runs on the LAUNCH stream, behind the frame (a stream of its own would be one HIP stream more than the hardware
-        // queues the three frame streams and the null stream already occupy: measured, that alone costs 18 % of the pipelined
-        // rate).  Nothing still running may read the target buffer: it was last current before the previous adoption, and every
-        // launch since then on every stream is behind that stream's last-use event (all complete: the context is not busy).
-        for (auto& kv : ctx->order_last_use) if (kv.first != stream) BLOK_HIP_TRY(ctx, hipStreamWaitEvent(stream, kv.second, 0));
-        BLOK_HIP_TRY(ctx, blok::launch_tile_order_sort(ctx->d_tile_cost, ctx->d_order_keys, ctx->d_tile_iota, ctx->d_order[target], ctx->d_order_temp,
-                                                       ctx->order_temp_bytes, blocks, stream));
-        BLOK_HIP_TRY(ctx, blok::launch_tile_order_finish(ctx->d_order[target], ctx->d_order_keys, blocks, ctx->d_rank_of[target], ctx->h_order_live + target, stream));
-        BLOK_HIP_TRY(ctx, hipEventRecord(ctx->order_done, stream));
-        ctx->order_target = target;
-        ctx->order_cam[target] = args.cam;
-        ctx->order_pending = true;
-        if (have) ctx->order_interval_now = std::min(std::max(ctx->order_interval_now, ctx->order_interval) * 2u, std::max(64u, ctx->order_interval));
+void forget_device_activity(const blok_hip_ctx* ctx) {
+    DeviceActivity& act = device_activity(ctx->device);
+    std::lock_guard<std::mutex> g(act.lock);
+    for (auto it = act.last.begin(); it != act.last.end();)
+        if (it->first.first == ctx) { (void)hipEventDestroy(it->second); it = act.last.erase(it); } else ++it;
+}
+
+// The stream's give-up counter (joint and list forms).
+static int gave_up_counter(blok_hip_ctx* ctx, hipStream_t stream, uint32_t** out) {
+    auto& slot = ctx->beam_buffers[stream];
+    if (!slot.gave_up) {
+        BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&slot.gave_up), sizeof(uint32_t)));
+        BLOK_HIP_TRY(ctx, hipMemsetAsync(slot.gave_up, 0, sizeof(uint32_t), stream));
     }
+    *out = slot.gave_up;
     return BLOK_OK;
 }
 
@@ -320,70 +269,105 @@ static int joint_slots(blok_hip_ctx* ctx, blok::TraceArgs& args, hipStream_t str
         BLOK_HIP_TRY(ctx, hipMemsetAsync(slot.slots, 0, n_beams * sizeof(unsigned long long), stream));
         slot.n_slots = n_beams; slot.serial = 0;
     }
-    if (!slot.gave_up) {
-        BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&slot.gave_up), sizeof(uint32_t)));
-        BLOK_HIP_TRY(ctx, hipMemsetAsync(slot.gave_up, 0, sizeof(uint32_t), stream));
-    }
     if (++slot.serial == 0u) slot.serial = 1u;
-    args.beam_slots = slot.slots; args.beam_serial = slot.serial; args.joint_gave_up = slot.gave_up;
-    return BLOK_OK;
+    args.beam_slots = slot.slots; args.beam_serial = slot.serial;
+    return gave_up_counter(ctx, stream, &args.joint_gave_up);
 }
 
-// Rect / Tiles launches run the beam pre-pass first, on the same stream (tiles_of_rank: Tiles only).
+// The stream's live list for a launch of n_searches search workgroups with per_search wave tiles each (trace_kernels.h: LiveList).
+static int live_list(blok_hip_ctx* ctx, blok::TraceArgs& args, hipStream_t stream, uint32_t n_searches, uint32_t per_search) {
+    auto& slot = ctx->beam_buffers[stream];
+    const size_t seg_capacity = static_cast<size_t>((n_searches + blok::kListSegments - 1u) / blok::kListSegments) * per_search;
+    if (!slot.list_ctl) {
+        BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&slot.list_ctl), blok::kListSegments * blok::kListCtlWords * sizeof(unsigned long long)));
+        BLOK_HIP_TRY(ctx, hipMemsetAsync(slot.list_ctl, 0, blok::kListSegments * blok::kListCtlWords * sizeof(unsigned long long), stream));
+        BLOK_HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&slot.list_hint), blok::kListSegments * sizeof(uint32_t), hipHostMallocDefault));
+        slot.list_hint_valid = false;
+    }
+    const bool wrapped = slot.list_serial + 1u >= (1u << blok::kListSerialBits);
+    if (slot.list_capacity < seg_capacity || wrapped) {
+        if (slot.list_capacity < seg_capacity) {
+            if (slot.list_entries) { BLOK_HIP_TRY(ctx, hipStreamSynchronize(stream)); (void)hipFree(slot.list_entries); }
+            slot.list_entries = nullptr; slot.list_capacity = 0;
+            BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&slot.list_entries), seg_capacity * blok::kListSegments * sizeof(unsigned long long)));
+            slot.list_capacity = seg_capacity;
+        }
+        // every entry empty; also when the 20-bit serial starts over, so that no entry of a million launches ago can pass for a new one
+        BLOK_HIP_TRY(ctx, hipMemsetAsync(slot.list_entries, 0, slot.list_capacity * blok::kListSegments * sizeof(unsigned long long), stream));
+        if (wrapped) slot.list_serial = 0;
+    }
+    slot.list_serial += 1u;
+    args.list.entries = slot.list_entries; args.list.ctl = slot.list_ctl; args.list.hint = slot.list_hint;
+    args.list.seg_capacity = static_cast<uint32_t>(slot.list_capacity);      // the buffer's stride (>= this launch's need)
+    args.list.serial = slot.list_serial; args.list.n_searches = n_searches;
+    return gave_up_counter(ctx, stream, &args.joint_gave_up);
+}
+
+// What the previous list launch on this stream left in pinned memory: its longest segment (a sizing hint, launch_policy.h).
+static bool list_hint(const blok_hip_ctx* ctx, hipStream_t stream, uint32_t geometry_key, uint32_t* per_segment) {
+    auto it = ctx->beam_buffers.find(stream);
+    if (it == ctx->beam_buffers.end() || !it->second.list_hint || !it->second.list_hint_valid || it->second.list_hint_key != geometry_key) return false;
+    uint32_t longest = 0;
+    for (uint32_t k = 0; k < blok::kListSegments; ++k) longest = std::max(longest, it->second.list_hint[k]);      // plain reads of words the device may be writing: a hint
+    *per_segment = longest;
+    return true;
+}
+
+// Rect / Tiles launches run the beam pre-pass first, on the same stream (tiles_of_rank: Tiles only; frames: several frames of a rank's
+// tiles in one launch, `blocks` and the beam tiles then count ONE frame).
 int launch_timed(blok_hip_ctx* ctx, blok::RayMode mode, blok::TraceArgs args, uint32_t blocks, hipStream_t stream,
-                 uint32_t tiles_of_rank = 0) {
+                 uint32_t tiles_of_rank, const blok::TileFrames* frames) {
     uint32_t n_beams = 0;
     if (blocks) { const int rc = prepare_beam(ctx, mode, args, stream, tiles_of_rank, &n_beams); if (rc != BLOK_OK) return rc; }
+    const uint32_t n_frames = frames ? frames->n_frames : 1u;
+    if (frames && n_beams) { const int rc = beam_buffer(ctx, stream, static_cast<size_t>(n_beams) * n_frames, &args.beam); if (rc != BLOK_OK) return rc; }
+    blok::LaunchFacts facts{};
+    facts.form = ctx->launch_form;
+    facts.has_beam = n_beams != 0;
+    facts.one_wave_blocks = blok::kBlock == 64;
+    facts.wave_tiles = blocks * n_frames;
+    const uint32_t geometry_key = blocks * 31u + n_beams * n_frames;
+    facts.have_hint = list_hint(ctx, stream, geometry_key, &facts.hint_per_segment);
+    facts.device_busy = facts.has_beam && ctx->launch_form == blok::kFormAuto && device_busy_elsewhere(ctx, stream);
+    blok::LaunchPlan plan = blok::plan_launch(facts);
+    if (frames && (plan.kind == blok::LaunchKind::Queues || plan.kind == blok::LaunchKind::Joint)) plan.kind = blok::LaunchKind::TwoLaunches;      // several frames per launch: the two-launch or the list forms
+    ctx->last_launch_kind = static_cast<int>(plan.kind);
+
     blok::FrameQueue queue{};
     uint32_t frame_blocks = 0;
-    const bool one_launch = n_beams && ctx->fused && !ctx->joint;
-    const bool joint = n_beams && ctx->joint;
-    if (joint) { const int rc = joint_slots(ctx, args, stream, n_beams); if (rc != BLOK_OK) return rc; }
-    if (one_launch) { const int rc = prepare_queue(ctx, mode, args, stream, n_beams, &queue, &frame_blocks); if (rc != BLOK_OK) return rc; }
+    blok::TileFrames fr{};
+    if (frames) { fr = *frames; fr.blocks_per_frame = blocks; fr.beams_per_frame = n_beams; }
+    if (plan.kind == blok::LaunchKind::Joint) { const int rc = joint_slots(ctx, args, stream, n_beams); if (rc != BLOK_OK) return rc; }
+    if (plan.kind == blok::LaunchKind::Queues) { const int rc = prepare_queue(ctx, mode, args, stream, n_beams, &queue, &frame_blocks); if (rc != BLOK_OK) return rc; }
+    if (plan.kind == blok::LaunchKind::ListJoint || plan.kind == blok::LaunchKind::ListTwoLaunches) {
+        const uint32_t per_search = (args.beam_tile / blok::kWaveW) * (args.beam_tile / blok::kWaveH);
+        const int rc = live_list(ctx, args, stream, n_beams * n_frames, per_search);
+        if (rc != BLOK_OK) return rc;
+        args.list.walkers_per_seg = plan.walkers / blok::kListSegments;
+        auto& slot = ctx->beam_buffers[stream];
+        slot.list_hint_valid = true; slot.list_hint_key = geometry_key;      // the searches of this launch write the hint
+    }
     if (ctx->timing) BLOK_HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, stream));
-    args.miss_in_walk = !one_launch && n_beams && ctx->miss_in_walk ? 1u : 0u;
-    if (one_launch) {
-        blok::launch_frame(mode, args, queue, frame_blocks, stream);
-    } else {
-        bool ordered = n_beams && ctx->tile_ordering && mode == blok::RayMode::Rect && blocks >= 4096u;     // small launches have no tail worth a sort
-        if (ordered) {
-            // a caller that alternates between rectangles would pay a device synchronisation per change of geometry: after two
-            // changes in quick succession ordering sits out the next 64 eligible launches
-            const uint32_t key[6] = {args.x0, args.y0, args.w, args.h, ctx->width, ctx->height};
-            const bool same = std::memcmp(key, ctx->order_key, sizeof(key)) == 0 && ctx->tile_cost_capacity >= blocks;
-            if (!same && ctx->tile_cost_capacity && ctx->order_streak < 8u) ctx->order_backoff = 64u;
-            if (ctx->order_backoff) { ctx->order_backoff -= 1u; ordered = false; }
-            else ctx->order_streak = same ? ctx->order_streak + 1u : 0u;
-        }
-        if (ordered) { const int rc = order_before_launch(ctx, args, blocks, stream); if (rc != BLOK_OK) return rc; }
-        // auto (form 3): with an order in force the walk gets waves for the order's live prefix only, and the searches and that walk
-        // are ONE joint launch when the launch has the chip to itself (alone: 0.26 -> 0.20 ms), two launches when other streams of the
-        // context have frames in flight (three in flight: 0.186 -> ~0.18 ms per frame either way; see below why not jointly)
-        const bool prefix = args.order && args.rank_of && args.launched <= blocks && blok::kBlock == 64;     // walk waves for the order's live prefix only
-        const bool go_joint = joint || (n_beams && ctx->joint_auto && !ctx->fused && ordered && !ctx->order_busy && blok::kBlock == 64);
-        uint32_t launch_blocks = blocks;
-        if (prefix && (go_joint || ctx->joint_auto)) {
-            // walk waves only for the tiles that walked when the order was made; the search wave of a beam tile that is live now walks
-            // any other tile of its own (a changed view), and writes the miss pixels of the empty ones
-            if (ctx->joint_prefix_limit && args.launched > ctx->joint_prefix_limit) args.launched = ctx->joint_prefix_limit;      // tests: more work for the search waves
-            launch_blocks = args.launched; args.miss_in_walk = 0u;
-        } else { args.rank_of = nullptr; args.launched = 0u; }
-        if (go_joint) {
-            // ONE launch: searches and walk waves in one grid (a launch that has the chip to itself: 0.26 -> 0.20 ms)
-            if (!joint) { const int rc = joint_slots(ctx, args, stream, n_beams); if (rc != BLOK_OK) return rc; }
-            blok::launch_joint(mode, args, n_beams, launch_blocks, stream);
-        } else {
-            // two launches; with frames in flight on other streams a joint launch's waiting waves hold slots the other frames' waves
-            // would use — and several joint launches in flight can even wait for each other's searches in a circle until they give up
-            // (trace_kernels.h: kJointPollBudget) — so there the searches and the walk stay separate launches, over the prefix all the same
-            args.beam_slots = nullptr;
-            if (n_beams) blok::launch_beam(mode, args, n_beams, stream);
-            blok::launch_trace(mode, args, launch_blocks, stream);
-        }
-        if (ordered) { const int rc = order_after_launch(ctx, args, blocks, stream); if (rc != BLOK_OK) return rc; }
+    args.miss_in_walk = (plan.kind == blok::LaunchKind::TwoLaunches || plan.kind == blok::LaunchKind::Joint) && ctx->miss_in_walk ? 1u : 0u;
+    switch (plan.kind) {
+        case blok::LaunchKind::Walk:
+            if (frames) blok::launch_tile_frames(args, fr, stream); else blok::launch_trace(mode, args, blocks, stream);
+            break;
+        case blok::LaunchKind::TwoLaunches:
+            if (frames) blok::launch_tile_frames(args, fr, stream);
+            else { blok::launch_beam(mode, args, n_beams, stream); blok::launch_trace(mode, args, blocks, stream); }
+            break;
+        case blok::LaunchKind::Queues: blok::launch_frame(mode, args, queue, frame_blocks, stream); break;
+        case blok::LaunchKind::Joint: blok::launch_joint(mode, args, n_beams, blocks, stream); break;
+        case blok::LaunchKind::ListJoint: blok::launch_list_joint(mode, args, frames ? &fr : nullptr, n_beams * n_frames, plan.walkers, stream); break;
+        case blok::LaunchKind::ListTwoLaunches:
+            if (frames) blok::launch_beam_frames(args, fr, stream); else blok::launch_beam(mode, args, n_beams, stream);
+            blok::launch_list_walk(mode, args, frames ? &fr : nullptr, plan.walkers, stream);
+            break;
     }
     BLOK_HIP_TRY(ctx, hipGetLastError());
     if (ctx->timing) { BLOK_HIP_TRY(ctx, hipEventRecord(ctx->ev_end, stream)); ctx->timed = true; }
+    if (facts.has_beam && ctx->launch_form == blok::kFormAuto) return note_frame_launch(ctx, stream);
     return BLOK_OK;
 }
 
@@ -461,18 +445,13 @@ void blok_hip_destroy(blok_hip_ctx* ctx) {
     if (ctx->d_frame) (void)hipFree(ctx->d_frame);
     free_post(ctx);
     if (ctx->has_volume) blok::gpu_volume_destroy(&ctx->volume);
-    for (auto& kv : ctx->beam_buffers)
+    forget_device_activity(ctx);
+    for (auto& kv : ctx->beam_buffers) {
         for (void* p : {static_cast<void*>(kv.second.beam), static_cast<void*>(kv.second.ctl), static_cast<void*>(kv.second.entries), static_cast<void*>(kv.second.tile_map),
-                        static_cast<void*>(kv.second.slots), static_cast<void*>(kv.second.gave_up)})
+                        static_cast<void*>(kv.second.slots), static_cast<void*>(kv.second.gave_up), static_cast<void*>(kv.second.list_entries), static_cast<void*>(kv.second.list_ctl)})
             if (p) (void)hipFree(p);
-    if (ctx->order_done) (void)hipEventDestroy(ctx->order_done);
-    for (auto& kv : ctx->order_last_use) if (kv.second) (void)hipEventDestroy(kv.second);
-    for (void* p : {static_cast<void*>(ctx->d_order[0]), static_cast<void*>(ctx->d_order[1]), static_cast<void*>(ctx->d_rank_of[0]), static_cast<void*>(ctx->d_rank_of[1]),
-                    static_cast<void*>(ctx->d_order_keys), ctx->d_order_temp})
-        if (p) (void)hipFree(p);
-    if (ctx->h_order_live) (void)hipHostFree(ctx->h_order_live);
-    if (ctx->d_tile_cost) (void)hipFree(ctx->d_tile_cost);
-    if (ctx->d_tile_iota) (void)hipFree(ctx->d_tile_iota);
+        if (kv.second.list_hint) (void)hipHostFree(kv.second.list_hint);
+    }
     if (ctx->d_accum) (void)hipFree(ctx->d_accum);
     if (ctx->d_color) (void)hipFree(ctx->d_color);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
@@ -687,6 +666,86 @@ int blok_hip_trace_primary_device(blok_hip_ctx* ctx, const blok_camera* cam, uin
     return launch_timed(ctx, blok::RayMode::Rect, a, blocks, static_cast<hipStream_t>(hip_stream));
 }
 
+// The pre-pass alone: start parameter (and node visits) per beam tile of the rectangle, to the host.
+int blok_hip_beam_prepass(blok_hip_ctx* ctx, const blok_camera* cam, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
+                          float* out_t0_host, uint32_t* out_visits_host, size_t capacity) {
+    int rc = check_trace(ctx, cam);
+    if (rc != BLOK_OK) return rc;
+    if (!out_t0_host || !rect_inside(ctx, x0, y0, w, h)) return set_error(ctx, BLOK_ERR_INVALID_ARG, "rectangle outside the frame or no output");
+    if (!ctx->beam_tile) return set_error(ctx, BLOK_ERR_INVALID_ARG, "the beam pre-pass is off (blok_hip_set_beam)");
+    blok::TraceArgs a = base_args(ctx, cam);
+    a.x0 = x0; a.y0 = y0; a.w = w; a.h = h;
+    uint32_t n_beams = 0;
+    rc = prepare_beam(ctx, blok::RayMode::Rect, a, nullptr, 0, &n_beams);
+    if (rc != BLOK_OK) return rc;
+    if (!n_beams || capacity < n_beams) return set_error(ctx, BLOK_ERR_INVALID_ARG, "output too small for the rectangle's beam tiles");
+    uint32_t* d_visits = nullptr;
+    if (out_visits_host) BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d_visits), n_beams * sizeof(uint32_t)));
+    a.debug_visits = d_visits;
+    a.miss_in_walk = 1u;                               // nothing is written but the start parameters
+    blok::launch_beam(blok::RayMode::Rect, a, n_beams, nullptr);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(out_t0_host, a.beam, n_beams * sizeof(float), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && d_visits) e = hipMemcpy(out_visits_host, d_visits, n_beams * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    if (d_visits) (void)hipFree(d_visits);
+    BLOK_HIP_TRY(ctx, e);
+    return BLOK_OK;
+}
+
+// Walks exactly the listed 8x8-pixel wave tiles of the rectangle, in list order (walk workgroup j takes entry j).
+int blok_hip_trace_wave_tiles_device(blok_hip_ctx* ctx, const blok_camera* cam, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
+                                     const uint32_t* tiles_host, const float* t0_host, size_t n_tiles, void* out_hits_dev, void* out_rgba_dev, void* hip_stream) {
+    int rc = check_trace(ctx, cam);
+    if (rc != BLOK_OK) return rc;
+    if ((!out_hits_dev && !out_rgba_dev) || !rect_inside(ctx, x0, y0, w, h)) return set_error(ctx, BLOK_ERR_INVALID_ARG, "rectangle outside the frame or no output");
+    if (blok::kBlock != 64) return set_error(ctx, BLOK_ERR_UNSUPPORTED, "wave-tile lists need the one-wave-per-workgroup build");
+    if (!n_tiles) return BLOK_OK;
+    if (!tiles_host) return set_error(ctx, BLOK_ERR_INVALID_ARG, "null tile list");
+    const uint32_t bx_count = (w + blok::kTileW - 1u) / blok::kTileW, by_count = (h + blok::kTileH - 1u) / blok::kTileH;
+    if (static_cast<uint64_t>(bx_count) * by_count >= (1u << blok::kListTaskBits) || n_tiles > 0x7FFFFFFFu) return set_error(ctx, BLOK_ERR_UNSUPPORTED, "rectangle too large for a wave-tile list");
+    for (size_t i = 0; i < n_tiles; ++i) {
+        if (tiles_host[i] >= bx_count * by_count) return set_error(ctx, BLOK_ERR_INVALID_ARG, "wave tile index outside the rectangle");
+        if (t0_host && !(t0_host[i] >= 0.0f && t0_host[i] < blok::kBeamNone)) return set_error(ctx, BLOK_ERR_INVALID_ARG, "start parameters must be finite and >= 0");
+    }
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    blok::TraceArgs a = base_args(ctx, cam);
+    a.x0 = x0; a.y0 = y0; a.w = w; a.h = h;
+    a.out = static_cast<blok_hit*>(out_hits_dev);
+    a.out_rgba = static_cast<uint32_t*>(out_rgba_dev);
+    a.beam_tile = blok::kWaveW;                          // one entry per "search": the list's capacity arithmetic
+    rc = live_list(ctx, a, stream, static_cast<uint32_t>(n_tiles), 1u);
+    if (rc != BLOK_OK) return rc;
+    const size_t cap = a.list.seg_capacity;
+    std::vector<unsigned long long> entries(cap * blok::kListSegments, 0ull), ctl(blok::kListSegments * blok::kListCtlWords, 0ull);
+    uint32_t count[blok::kListSegments] = {};
+    for (size_t i = 0; i < n_tiles; ++i) {                 // entry i -> segment i mod 8, slot i / 8: walk workgroup i takes it
+        const uint32_t seg = static_cast<uint32_t>(i % blok::kListSegments);
+        const float t0 = t0_host ? t0_host[i] : 0.0f;
+        uint32_t bits; std::memcpy(&bits, &t0, sizeof(bits));
+        entries[seg * cap + i / blok::kListSegments] = (static_cast<unsigned long long>(a.list.serial) << 44) | (static_cast<unsigned long long>(tiles_host[i]) << 23) | (bits >> 8);
+        count[seg] += 1u;
+    }
+    for (uint32_t seg = 0; seg < blok::kListSegments; ++seg) ctl[seg * blok::kListCtlWords + blok::kListFinal] = (static_cast<unsigned long long>(a.list.serial) << 32) | count[seg];
+    BLOK_HIP_TRY(ctx, hipStreamSynchronize(stream));     // the stream's list may still be in use by an earlier launch
+    BLOK_HIP_TRY(ctx, hipMemcpy(a.list.entries, entries.data(), entries.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+    BLOK_HIP_TRY(ctx, hipMemcpy(a.list.ctl, ctl.data(), ctl.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+    ctx->beam_buffers[stream].list_hint_valid = false;   // this list says nothing about the next frame's
+    a.list.hint = nullptr;
+    const uint32_t walkers = static_cast<uint32_t>((n_tiles + blok::kListSegments - 1u) / blok::kListSegments) * blok::kListSegments;
+    a.list.walkers_per_seg = walkers / blok::kListSegments;
+    if (ctx->timing) BLOK_HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, stream));
+    blok::launch_list_walk(blok::RayMode::Rect, a, nullptr, walkers, stream);
+    BLOK_HIP_TRY(ctx, hipGetLastError());
+    if (ctx->timing) { BLOK_HIP_TRY(ctx, hipEventRecord(ctx->ev_end, stream)); ctx->timed = true; }
+    return BLOK_OK;
+}
+
+int blok_hip_set_debug_wave_clocks(blok_hip_ctx* ctx, void* clocks_dev) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    ctx->debug_clocks = static_cast<uint32_t*>(clocks_dev);
+    return BLOK_OK;
+}
+
 int blok_hip_trace_primary(blok_hip_ctx* ctx, const blok_camera* cam, uint32_t x0, uint32_t y0,
                            uint32_t w, uint32_t h, blok_hit* out_hits_host) {
     if (!ctx) return BLOK_ERR_INVALID_ARG;
@@ -729,20 +788,11 @@ static int trace_tile_frames(blok_hip_ctx* ctx, const blok_camera* cams, uint32_
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     if (n_frames == 1) return launch_timed(ctx, blok::RayMode::Tiles, a, blocks, stream, mine);
     if (!blocks) return BLOK_OK;
-    uint32_t n_beams = 0;
-    int rc = prepare_beam(ctx, blok::RayMode::Tiles, a, stream, mine, &n_beams);
-    if (rc != BLOK_OK) return rc;
-    if (n_beams) { rc = beam_buffer(ctx, stream, static_cast<size_t>(n_beams) * n_frames, &a.beam); if (rc != BLOK_OK) return rc; }
     blok::TileFrames frames{};
     for (uint32_t f = 0; f < n_frames; ++f) frames.cam[f] = cams[f];
-    frames.n_frames = n_frames; frames.blocks_per_frame = blocks; frames.beams_per_frame = n_beams;
+    frames.n_frames = n_frames;
     frames.frame_stride = static_cast<size_t>(frame_stride_tiles) * tile * tile;
-    a.miss_in_walk = n_beams && ctx->miss_in_walk ? 1u : 0u;
-    if (ctx->timing) BLOK_HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, stream));
-    blok::launch_tile_frames(a, frames, stream);
-    BLOK_HIP_TRY(ctx, hipGetLastError());
-    if (ctx->timing) { BLOK_HIP_TRY(ctx, hipEventRecord(ctx->ev_end, stream)); ctx->timed = true; }
-    return BLOK_OK;
+    return launch_timed(ctx, blok::RayMode::Tiles, a, blocks, stream, mine, &frames);      // blocks / beam tiles per frame are filled in there
 }
 
 int blok_hip_trace_tiles_device(blok_hip_ctx* ctx, const blok_camera* cam, uint32_t tile, uint32_t rank,
@@ -1124,10 +1174,8 @@ int blok_hip_set_rt_taa_jitter(blok_hip_ctx* ctx, int enabled) {
 
 int blok_hip_set_fused(blok_hip_ctx* ctx, int enabled) {
     if (!ctx) return BLOK_ERR_INVALID_ARG;
-    if (enabled < 0 || enabled > 3) return set_error(ctx, BLOK_ERR_INVALID_ARG, "launch form: 0 (two launches), 1 (one persistent launch with queues), 2 (joint launch) or 3 (automatic)");
-    ctx->fused = enabled == 1;
-    ctx->joint = enabled == 2;
-    ctx->joint_auto = enabled == 3;
+    if (enabled < 0 || enabled > 5) return set_error(ctx, BLOK_ERR_INVALID_ARG, "launch form: 0 (two launches), 1 (one persistent launch with queues), 2 (joint launch), 3 (automatic), 4 (list-fed joint launch) or 5 (list-fed walk behind the beam launch)");
+    ctx->launch_form = enabled;
     return BLOK_OK;
 }
 
@@ -1152,19 +1200,7 @@ int blok_hip_frame_queue_stalls(blok_hip_ctx* ctx, uint32_t* out_stalled_waves) 
     return BLOK_OK;
 }
 
-int blok_hip_set_tile_ordering(blok_hip_ctx* ctx, int resort_every_n_frames) {
-    if (!ctx) return BLOK_ERR_INVALID_ARG;
-    if (resort_every_n_frames < 0) return set_error(ctx, BLOK_ERR_INVALID_ARG, "tile ordering: interval must be >= 0");
-    ctx->tile_ordering = resort_every_n_frames != 0;
-    if (resort_every_n_frames) ctx->order_interval = static_cast<uint32_t>(resort_every_n_frames);
-    return BLOK_OK;
-}
-
-int blok_hip_set_joint_prefix_limit(blok_hip_ctx* ctx, uint32_t max_walk_waves) {
-    if (!ctx) return BLOK_ERR_INVALID_ARG;
-    ctx->joint_prefix_limit = max_walk_waves;
-    return BLOK_OK;
-}
+int blok_hip_last_launch_kind(const blok_hip_ctx* ctx) { return ctx ? ctx->last_launch_kind : -1; }
 
 int blok_hip_set_miss_writer(blok_hip_ctx* ctx, int in_walk) {
     if (!ctx) return BLOK_ERR_INVALID_ARG;

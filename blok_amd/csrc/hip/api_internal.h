@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <map>
+#include <mutex>
 #include <unordered_map>
 #include <utility>
 #include <cstdio>
@@ -21,7 +23,7 @@
 #include "reference_world.h"
 #include "trace_kernels.h"
 #include "dense_kernels.h"
-#include "tile_order.h"
+#include "launch_policy.h"
 #include "path_args.h"
 #include "tree.h"
 
@@ -90,44 +92,22 @@ struct blok_hip_ctx {
     uint32_t beam_tile = 32;
     uint32_t beam_budget = 0;           // 0 = beam.h's default visit budget
     bool miss_in_walk = true;           // who writes the pixels of tiles the pre-pass found empty (blok_hip_set_miss_writer)
-    // Longest-first scheduling of the walk (tile_order.h; Rect launches of the two-launch form): every wave leaves the clocks it
-    // spent in d_tile_cost (one buffer per context, for the launch geometry in order_key).  Every order_interval frames — and only
-    // while no other stream of the context has frames in flight — a radix sort of those costs follows the frame on its stream: it
-    // writes the order buffer that is NOT in use, and a later launch adopts it once hipEventQuery says it is complete.
-    bool tile_ordering = true;
-    uint32_t order_interval = 8;
-    uint32_t order_interval_now = 8;                  // grows while the view rests (api.hip: order_after_launch)
-    uint32_t* d_tile_cost = nullptr;
-    uint32_t* d_tile_iota = nullptr;
-    uint32_t* d_order[2] = {nullptr, nullptr};
-    uint32_t* d_rank_of[2] = {nullptr, nullptr};      // inverse of d_order[k]
-    uint32_t* h_order_live = nullptr;                 // pinned, two words: how many leading entries of d_order[k] walked last time (written by the device)
-    uint32_t order_live[2] = {0, 0};                  // ... as read when the order was adopted
-    uint32_t* d_order_keys = nullptr;
-    void* d_order_temp = nullptr;
-    size_t order_temp_bytes = 0, tile_cost_capacity = 0;
-    uint32_t order_key[6] = {};
-    int order_current = -1, order_target = 0;     // -1: no order yet (natural)
-    bool order_kept_busy = false;                     // ... and the order stays in use all the same (a form that may launch jointly)
-    bool order_pending = false, order_busy = false;   // busy: another stream of the context had frames in flight at the last launch
-    uint32_t frames_since_sort = 0;
-    blok_camera order_cam[2] = {}, order_last_cam{};     // camera whose frame's costs each order buffer was sorted from; camera of the last launch
-    uint32_t order_still_frames = 0;                     // consecutive launches whose camera hardly moved
-    uint32_t order_streak = 0, order_backoff = 0;     // launches of the current geometry; launches to skip after geometries alternated
-    hipEvent_t order_done = nullptr;
-    std::unordered_map<hipStream_t, hipEvent_t> order_last_use;     // per launch stream: behind its latest walk
     struct StreamScratch {             // per launch stream
         float* beam = nullptr; size_t n_beam = 0;                       // two-launch form: start parameters per beam tile
         uint32_t* ctl = nullptr; unsigned long long* entries = nullptr; size_t capacity = 0;   // one-launch form: work queue (trace_kernels.h: FrameQueue)
-        unsigned long long* slots = nullptr; size_t n_slots = 0; uint32_t serial = 0; uint32_t* gave_up = nullptr;   // joint launch: published beam results
+        unsigned long long* slots = nullptr; size_t n_slots = 0; uint32_t serial = 0;   // joint launch: published beam results
+        uint32_t* gave_up = nullptr;                                      // joint and list launches: waves that gave up a bounded wait (sticky; blok_hip_frame_queue_stalls)
+        // list launches (trace_kernels.h: LiveList): entries, control words, serial, and the pinned words the searches leave the segments' lengths in
+        unsigned long long* list_entries = nullptr; size_t list_capacity = 0;   // entries per segment
+        unsigned long long* list_ctl = nullptr;
+        uint32_t list_serial = 0;
+        uint32_t* list_hint = nullptr; bool list_hint_valid = false; uint32_t list_hint_key = 0;
         uint32_t* tile_map = nullptr; size_t n_tile_map = 0;            // sparse exchange, root: frame tile -> record (zero between launches)
     };
     std::unordered_map<hipStream_t, StreamScratch> beam_buffers;
-    // one-launch frame (frame_kernel): pre-pass and walk in one persistent grid; off (default, faster as measured) = beam_kernel, then trace_kernel
-    bool fused = false;
-    bool joint = false;                 // joint launch (joint_kernel): searches and walk waves in one grid, statically
-    uint32_t joint_prefix_limit = 0;    // tests: cap on the walk waves a joint launch dispatches (0 = none)
-    bool joint_auto = true;             // ... whenever a launch has the chip to itself (and the two-launch form when other streams have frames in flight)
+    uint32_t* debug_clocks = nullptr;   // blok_hip_set_debug_wave_clocks (caller's device memory)
+    int launch_form = blok::kFormAuto;  // blok_hip_set_fused (launch_policy.h: LaunchForm)
+    int last_launch_kind = -1;          // launch_policy.h: LaunchKind of the latest rectangle / tile launch (blok_hip_last_launch_kind)
     uint32_t frame_parts = 32, frame_chunk = 1;      // FrameQueue::n_parts / chunk (BLOK_FRAME_PARTS / BLOK_FRAME_CHUNK override, for experiments)
     int cu_count = 0;
     int frame_blocks_per_cu[2][16] = {};   // [mode][levels], 0 = not asked yet
@@ -162,6 +142,9 @@ blok::TraceArgs base_args(const blok_hip_ctx* ctx, const blok_camera* cam);
 int prepare_beam(blok_hip_ctx* ctx, blok::RayMode mode, blok::TraceArgs& args, hipStream_t stream, uint32_t tiles_of_rank, uint32_t* n_beams);
 int prepare_queue(blok_hip_ctx* ctx, blok::RayMode mode, const blok::TraceArgs& args, hipStream_t stream, uint32_t n_beams, blok::FrameQueue* queue, uint32_t* n_blocks);
 int check_trace(blok_hip_ctx* ctx, const blok_camera* cam);
+int launch_timed(blok_hip_ctx* ctx, blok::RayMode mode, blok::TraceArgs args, uint32_t blocks, hipStream_t stream, uint32_t tiles_of_rank = 0,
+                 const blok::TileFrames* frames = nullptr);
+void forget_device_activity(const blok_hip_ctx* ctx);
 bool rect_inside(const blok_hip_ctx* ctx, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h);
 // The root's assembly of a sparse exchange (blok_hip_scatter_*_tile_frames_device): the ranks' buffers either side by side in
 // `gathered_dev` or, rank_ptrs_dev != null, wherever a device array of n_ranks pointers says (peer-mapped memory of other devices).

@@ -71,7 +71,8 @@ __device__ __forceinline__ BeamVec beam_lane(BeamVec v, uint32_t lane) { return 
 // or kBeamNone.  Must be called by all 64 lanes of the wave.
 template <bool kClampAtZero>
 __device__ __forceinline__ float beam_search(const TraceArgs& A, BeamVec ref, BeamVec n0, BeamVec n1, BeamVec n2, BeamVec n3,
-                                             float c0, float c1, float c2, float c3, BeamVec mid, uint32_t lane, float initial_best = kBeamNone) {
+                                             float c0, float c1, float c2, float c3, BeamVec mid, uint32_t lane, float initial_best = kBeamNone,
+                                             uint32_t* visits_out = nullptr) {
     // lanes are children in front-to-back order for the central direction: mirrored child index
     const uint32_t mirror = beam_uniform((mid.x < 0.0f ? 0x03u : 0u) | (mid.y < 0.0f ? 0x0Cu : 0u) | (mid.z < 0.0f ? 0x30u : 0u));
     const uint32_t child = lane ^ mirror;
@@ -165,6 +166,7 @@ __device__ __forceinline__ float beam_search(const TraceArgs& A, BeamVec ref, Be
         --level;
         fresh = true;
     }
+    if (visits_out) *visits_out = budget0 - budget;                                    // diagnostics: node visits this search spent
     if (budget == 0u) {
         if constexpr (!kClampAtZero) return -kBeamNone;
         // Out of visits.  Every filled voxel the search has not seen lies in a cell that is still pending: the node just entered
@@ -202,7 +204,7 @@ __device__ __forceinline__ float beam_search(const TraceArgs& A, BeamVec ref, Be
 // depth_limit: only voxels nearer than this (along the tile's central direction) are looked for; when none is found the
 // answer is the limit itself (everything the rays can report lies at or beyond it) instead of kBeamNone.
 __device__ __forceinline__ float beam_start(const TraceArgs& A, float px_lo, float py_lo, float px_hi, float py_hi, uint32_t lane,
-                                            float depth_limit = kBeamNone) {
+                                            float depth_limit = kBeamNone, uint32_t* visits_out = nullptr) {
     const float inv_w = __builtin_amdgcn_rcpf(static_cast<float>(A.frame_w)), inv_h = __builtin_amdgcn_rcpf(static_cast<float>(A.frame_h));
     const BeamVec mid = beam_unit(beam_dir(A.cam, 0.5f * (px_lo + px_hi), 0.5f * (py_lo + py_hi), inv_w, inv_h));
     // lane k < 4 builds side plane k through corners k and k+1 of the grown rectangle (corner i: x high for i = 1, 2;
@@ -218,7 +220,7 @@ __device__ __forceinline__ float beam_start(const TraceArgs& A, float px_lo, flo
     // directions are unit-free, and the depth found, less its margins, goes back to the rays' world parameter
     const float iv = A.inv_voxel_size;
     const float best = beam_search<true>(A, {A.cam.pos[0] * iv, A.cam.pos[1] * iv, A.cam.pos[2] * iv}, n0, n1, n2, n3, 0.0f, 0.0f, 0.0f, 0.0f, mid, lane,
-                                         depth_limit >= kBeamNone ? kBeamNone : depth_limit * iv);
+                                         depth_limit >= kBeamNone ? kBeamNone : depth_limit * iv, visits_out);
     if (best >= kBeamNone) return kBeamNone;
     return fmaxf(best * (1.0f - 1.0e-4f) - 2.0f * kBeamSlack, 0.0f) * A.voxel_size;
 }

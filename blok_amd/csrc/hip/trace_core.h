@@ -77,6 +77,7 @@ BLOK_DEV uint32_t mask_rank(const NodeRec& n, uint32_t bit) {
 
 struct RayIn { float ox, oy, oz, dx, dy, dz, tmin, tmax; };
 
+
 // Two-bit digit of a (non-negative) tree coordinate at bit offset `shift`: one v_bfe_u32.
 BLOK_DEV uint32_t digit2(uint32_t q, uint32_t shift) {
 #ifdef BLOK_TRACE_HOST_HARNESS
@@ -139,56 +140,99 @@ struct HitInfo {
     int vx, vy, vz;          // world voxel
 };
 
-// Walks one ray.  `stk` points at this lane's slot of the LDS node stack (stride kBlock entries between
-// levels; slot l-2 holds the node of level l on the current path).
-BLOK_DEV HitInfo walk(const TraceArgs& A, const RayIn& r, uint4* stk) {
-    BLOK_STAT(4, 0);                       // a walk begins
-    HitInfo out;
-    out.found = false; out.t = -1.0f; out.material = 0u; out.face = 0xFFu; out.vx = out.vy = out.vz = 0;
-    const uint32_t L = A.levels;
-    const int W = 1 << (2 * L);
+// What a walk needs of its ray: the three axes (origin, safe inverse direction, mirroring) and the child-bit constant.
+struct WalkRay {
     Axis ax, ay, az;
-    ax.o = r.ox; ay.o = r.oy; az.o = r.oz;
-    ax.inv = safe_inv(r.dx); ay.inv = safe_inv(r.dy); az.inv = safe_inv(r.dz);
-    const bool negx = !(ax.inv > 0.0f), negy = !(ay.inv > 0.0f), negz = !(az.inv > 0.0f);
+    uint32_t mirror;
+};
+// Where a walk is: the current cell (mirrored min corner, level, parent node), the T of its far planes, the ray parameter at which it
+// was entered, and — once `found` — the reported voxel (cell, node, bit, tCur).
+struct WalkState {
+    float fx, fy, fz, tFx, tFy, tFz, tCur, size;
+    uint32_t lvl, bit;
+    NodeRec node;
+    bool walking, found;     // walking: the loop still has work for this lane
+};
+
+// ox, oy, oz and the safe inverse direction (intersect.rint:79) -> the axes.
+BLOK_DEV WalkRay walk_ray(const TraceArgs& A, float ox, float oy, float oz, float ix, float iy, float iz) {
+    WalkRay R;
+    const int W = 1 << (2 * A.levels);
+    R.ax.o = ox; R.ay.o = oy; R.az.o = oz;
+    R.ax.inv = ix; R.ay.inv = iy; R.az.inv = iz;
+    const bool negx = !(ix > 0.0f), negy = !(iy > 0.0f), negz = !(iz > 0.0f);
     // world plane = (base + sgn q) * voxel_size with a power-of-two voxel_size: sgn and c carry the factor, every product exact
     const float vs = A.voxel_size;
-    ax.sgn = negx ? -vs : vs; ay.sgn = negy ? -vs : vs; az.sgn = negz ? -vs : vs;
+    R.ax.sgn = negx ? -vs : vs; R.ay.sgn = negy ? -vs : vs; R.az.sgn = negz ? -vs : vs;
     // c = (base -+ 2^23) * voxel_size: an integer below 2^24 in magnitude times a power of two, exact
-    ax.c = (static_cast<float>(A.origin[0] + (negx ? W : 0)) + (negx ? kCoordBias : -kCoordBias)) * vs;
-    ay.c = (static_cast<float>(A.origin[1] + (negy ? W : 0)) + (negy ? kCoordBias : -kCoordBias)) * vs;
-    az.c = (static_cast<float>(A.origin[2] + (negz ? W : 0)) + (negz ? kCoordBias : -kCoordBias)) * vs;
-    const uint32_t mirror = (negx ? 3u : 0u) | (negy ? 12u : 0u) | (negz ? 48u : 0u);
+    R.ax.c = (static_cast<float>(A.origin[0] + (negx ? W : 0)) + (negx ? kCoordBias : -kCoordBias)) * vs;
+    R.ay.c = (static_cast<float>(A.origin[1] + (negy ? W : 0)) + (negy ? kCoordBias : -kCoordBias)) * vs;
+    R.az.c = (static_cast<float>(A.origin[2] + (negz ? W : 0)) + (negz ? kCoordBias : -kCoordBias)) * vs;
+    R.mirror = (negx ? 3u : 0u) | (negy ? 12u : 0u) | (negz ? 48u : 0u);
+    return R;
+}
 
+// T of the far planes of the world box (the ray leaves the tree at their minimum).
+BLOK_DEV float world_exit(const TraceArgs& A, const WalkRay& R) {
+    const float fW = kCoordBias + static_cast<float>(1 << (2 * A.levels));
+    return fminf(fminf(plane_t(R.ax, fW), plane_t(R.ay, fW)), plane_t(R.az, fW));
+}
+
+// The walk's start for the interval [tmin, tmax): world box, then the root's start cell.  Not walking = the interval misses the box.
+BLOK_DEV void walk_enter(const TraceArgs& A, const WalkRay& R, float tmin, float tmax, WalkState& s) {
+    const uint32_t L = A.levels;
     // world box: near planes q = 0, far planes q = W (T is monotone in q, so no min/max is needed)
-    const float fW = kCoordBias + static_cast<float>(W);
-    float tFx = plane_t(ax, fW), tFy = plane_t(ay, fW), tFz = plane_t(az, fW);
-    float tCur = fmaxf(fmaxf(fmaxf(plane_t(ax, kCoordBias), plane_t(ay, kCoordBias)), plane_t(az, kCoordBias)), r.tmin);
-    if (!(tCur < fminf(fminf(fminf(tFx, tFy), tFz), r.tmax))) return out;
+    const float fW = kCoordBias + static_cast<float>(1 << (2 * L));
+    s.tFx = plane_t(R.ax, fW); s.tFy = plane_t(R.ay, fW); s.tFz = plane_t(R.az, fW);
+    s.tCur = fmaxf(fmaxf(fmaxf(plane_t(R.ax, kCoordBias), plane_t(R.ay, kCoordBias)), plane_t(R.az, kCoordBias)), tmin);
+    s.found = false; s.bit = 0u;
+    s.fx = kCoordBias; s.fy = kCoordBias; s.fz = kCoordBias;   // mirrored min corner of the current cell (2^23 + q)
+    s.lvl = L - 1;                        // current cells have size 4^lvl; `node` is their parent
+    s.size = cell_size(s.lvl);
+    s.node.lo = s.node.hi = s.node.base = 0u;
+    s.walking = s.tCur < fminf(fminf(fminf(s.tFx, s.tFy), s.tFz), tmax);
+    if (!s.walking) return;
+    const uint4 q = A.nodes[0];
+    s.node.lo = q.x; s.node.hi = q.y; s.node.base = q.z;
+    const float s2 = s.size + s.size, s3 = s2 + s.size;
+    enter_axis(R.ax, s.fx, s.tFx, s.size, s2, s3, s.tCur);
+    enter_axis(R.ay, s.fy, s.tFy, s.size, s2, s3, s.tCur);
+    enter_axis(R.az, s.fz, s.tFz, s.size, s2, s3, s.tCur);
+}
 
-    float fx = kCoordBias, fy = kCoordBias, fz = kCoordBias;   // mirrored min corner of the current cell (2^23 + q)
-    uint32_t lvl = L - 1;                // current cells have size 4^lvl; `node` is their parent
-    float size = cell_size(lvl);
-    NodeRec node;
-    {
-        const uint4 q = A.nodes[0];
-        node.lo = q.x; node.hi = q.y; node.base = q.z;
-        const float s2 = size + size, s3 = s2 + size;
-        enter_axis(ax, fx, tFx, size, s2, s3, tCur);
-        enter_axis(ay, fy, tFy, size, s2, s3, tCur);
-        enter_axis(az, fz, tFz, size, s2, s3, tCur);
-    }
+// Lanes that entered this walk (split_lanes) and loop trips between looks at who is still walking.
+#ifndef BLOK_SPLIT_FIRST
+#define BLOK_SPLIT_FIRST 24
+#endif
+constexpr uint32_t kSplitFirstTrip = BLOK_SPLIT_FIRST, kSplitCheckEvery = 4u, kSplitMaxStragglers = 8u, kSplitMaxSegments = 32u, kSplitMinSegments = 4u;
 
+// The loop.  kMaySplit: from trip kSplitFirstTrip on, every kSplitCheckEvery-th trip looks at how many of the `lanes` that entered are
+// still walking; when they are few enough for each to get >= kSplitMinSegments lanes, the loop stops (for the whole wave) and says so.
+template <bool kMaySplit>
+BLOK_DEV bool walk_loop(const TraceArgs& A, const WalkRay& R, const float tmax, WalkState& s, uint4* stk, [[maybe_unused]] const uint32_t lanes) {
+    const uint32_t L = A.levels;
     // Invariant: tCur starts at max(world entry, tmin) and never decreases — a cell's far planes are never
     // before the plane through which it was entered (T is monotone along each axis and the start cell of a
     // node only counts planes with T <= tCur as crossed) — so max(tCur, tmin) == tCur throughout and the
     // reported t of a voxel, max(entry, tmin), is tCur itself.
-    bool found = false;
-    uint32_t bit = 0;
-    for (;;) {
+    float fx = s.fx, fy = s.fy, fz = s.fz, tFx = s.tFx, tFy = s.tFy, tFz = s.tFz, tCur = s.tCur, size = s.size;
+    uint32_t lvl = s.lvl, bit = s.bit;
+    NodeRec node = s.node;
+    bool found = false, split = false, walking = s.walking;
+    [[maybe_unused]] uint32_t trips = 0;           // loop trips of the WAVE (the same in every lane still walking)
+    while (walking) {
         BLOK_STAT(0, lvl);
+#if !defined(BLOK_TRACE_HOST_HARNESS)
+        if constexpr (kMaySplit) {
+            trips += 1u;
+            if (trips >= kSplitFirstTrip && (trips & (kSplitCheckEvery - 1u)) == 0u) {
+                const uint32_t left = static_cast<uint32_t>(__builtin_popcountll(__ballot(true)));      // the lanes still in the loop
+                if (left <= kSplitMaxStragglers && left * kSplitMinSegments <= lanes) { split = true; break; }
+            }
+        }
+#endif
         const uint32_t shift = 2 * lvl;
-        bit = (digit2(__float_as_uint(fx), shift) | (digit2(__float_as_uint(fy), shift) << 2) | (digit2(__float_as_uint(fz), shift) << 4)) ^ mirror;
+        bit = (digit2(__float_as_uint(fx), shift) | (digit2(__float_as_uint(fy), shift) << 2) | (digit2(__float_as_uint(fz), shift) << 4)) ^ R.mirror;
         const bool occupied = mask_bit(node, bit);
         if (occupied && lvl != 0) {
             // descend: remember the node we are leaving, fetch the child, pick its start cell
@@ -199,20 +243,20 @@ BLOK_DEV HitInfo walk(const TraceArgs& A, const RayIn& r, uint4* stk) {
             lvl -= 1;
             size *= 0.25f;
             const float s2 = size + size, s3 = s2 + size;
-            enter_axis(ax, fx, tFx, size, s2, s3, tCur);     // tCur >= tmin always (see the invariant above the loop)
-            enter_axis(ay, fy, tFy, size, s2, s3, tCur);
-            enter_axis(az, fz, tFz, size, s2, s3, tCur);
+            enter_axis(R.ax, fx, tFx, size, s2, s3, tCur);     // tCur >= tmin always (see the invariant above the loop)
+            enter_axis(R.ay, fy, tFy, size, s2, s3, tCur);
+            enter_axis(R.az, fz, tFz, size, s2, s3, tCur);
             continue;
         }
         const float tExit = fminf(fminf(tFx, tFy), tFz);
         if (occupied) {
             // a filled voxel: reported iff its clipped interval is non-empty (intersect.rint:189-193)
-            if (tCur < fminf(tExit, r.tmax)) { found = true; break; }
+            if (tCur < fminf(tExit, tmax)) { found = true; break; }
         }
         // step: cross the nearest far plane (x, then y, then z on ties)
         BLOK_STAT(2, lvl);
         tCur = tExit;
-        if (!(tCur < r.tmax)) break;
+        if (!(tCur < tmax)) break;
         const bool sx = tFx == tExit;
         const bool sy = !sx && tFy == tExit;
         const bool sz = !sx && !sy;
@@ -230,15 +274,25 @@ BLOK_DEV HitInfo walk(const TraceArgs& A, const RayIn& r, uint4* stk) {
             const uint4 c = stk[(lvl - 1) * kBlock];               // node of level lvl+1
             node.lo = c.x; node.hi = c.y; node.base = c.z;
         }
-        tFx = plane_t(ax, fx + size); tFy = plane_t(ay, fy + size); tFz = plane_t(az, fz + size);
+        tFx = plane_t(R.ax, fx + size); tFy = plane_t(R.ay, fy + size); tFz = plane_t(R.az, fz + size);
     }
-    if (!found) return out;
+    s.fx = fx; s.fy = fy; s.fz = fz; s.tCur = tCur; s.bit = bit; s.node = node; s.found = found;
+    s.walking = split && walking && !found;        // still owes the rest of its interval (the loop stopped for a split)
+    // (a lane that broke out of the loop by itself — found, left the box, passed tmax — is done; `split` is wave-uniform only among
+    // the lanes that were still in the loop, so it is combined by the caller)
+    return split;
+}
 
-    // reported: intersect.rint:136-141, hit.rchit:58-74
-    const float tc = tCur;                                            // = max(entry, tmin), intersect.rint:189,141
-    const uint32_t material = A.materials[node.base + mask_rank(node, bit)];
+// The reported voxel of a finished walk: intersect.rint:136-141, hit.rchit:58-74.  r: the ray itself (origin, direction).
+BLOK_DEV HitInfo walk_hit(const TraceArgs& A, const RayIn& r, const WalkRay& R, const WalkState& s) {
+    HitInfo out;
+    const int W = 1 << (2 * A.levels);
+    const float vs = A.voxel_size;
+    const bool negx = !(R.ax.inv > 0.0f), negy = !(R.ay.inv > 0.0f), negz = !(R.az.inv > 0.0f);
+    const float tc = s.tCur;                                          // = max(entry, tmin), intersect.rint:189,141
+    const uint32_t material = A.materials[s.node.base + mask_rank(s.node, s.bit)];
     // world voxel = mirrored cell un-mirrored: base + sgn * q - (negative ? 1 : 0)
-    const int qx = static_cast<int>(__float_as_uint(fx) & 0x7FFFFFu), qy = static_cast<int>(__float_as_uint(fy) & 0x7FFFFFu), qz = static_cast<int>(__float_as_uint(fz) & 0x7FFFFFu);
+    const int qx = static_cast<int>(__float_as_uint(s.fx) & 0x7FFFFFu), qy = static_cast<int>(__float_as_uint(s.fy) & 0x7FFFFFu), qz = static_cast<int>(__float_as_uint(s.fz) & 0x7FFFFFu);
     const int vx = negx ? A.origin[0] + W - qx - 1 : A.origin[0] + qx;
     const int vy = negy ? A.origin[1] + W - qy - 1 : A.origin[1] + qy;
     const int vz = negz ? A.origin[2] + W - qz - 1 : A.origin[2] + qz;
@@ -257,6 +311,109 @@ BLOK_DEV HitInfo walk(const TraceArgs& A, const RayIn& r, uint4* stk) {
     out.found = true; out.t = tc; out.material = material; out.face = face;
     out.vx = vx; out.vy = vy; out.vz = vz;
     return out;
+}
+
+#if !defined(BLOK_TRACE_HOST_HARNESS)
+BLOK_DEV float lane_value(float v, uint32_t lane) { return __shfl(v, static_cast<int>(lane)); }
+BLOK_DEV uint32_t lane_value(uint32_t v, uint32_t lane) { return static_cast<uint32_t>(__shfl(static_cast<int>(v), static_cast<int>(lane))); }
+#endif
+
+// Walks one ray.  `stk` points at this lane's slot of the LDS node stack (stride kBlock entries between
+// levels; slot l-2 holds the node of level l on the current path).
+//
+// STRAGGLERS.  A wave lasts as long as its longest ray, and ray lengths have a heavy tail: behind the pre-pass the median wave of the
+// benchmark frame leaves the loop after ~25 trips, the longest (a few rays grazing the terrain across the world) after 250, each trip a
+// chain of dependent instructions that no priority shortens — such a wave takes 130 us of a 200 us launch with one or two lanes busy, and
+// wherever it starts late it IS the launch's tail.  So when only a few lanes of a wave are still walking, the loop stops and the rest
+// of each of those rays is CUT INTO SEGMENTS [b_j, b_j+1) of its remaining parameter interval, one per lane of the wave (the lanes that
+// are done have nothing else to do): every lane walks its segment from the root, and a ray's answer is the hit of its first segment
+// that reports one.  That is the same answer bit for bit: a voxel is reported iff max(entry, tmin) < min(exit, tmax) with
+// t = max(entry, tmin) (trace_kernels.h), so the true first hit V — entry e — is reported, with t = e, by the segment that contains e;
+// no earlier segment reports anything (it would be a reported voxel with a smaller entry), and neither does that segment before V
+// (the same, or a voxel straddling its start b_j, whose entry is smaller still).  A voxel straddling a later boundary is reported there
+// with t = b_j, but later segments are never looked at.  And a walk restarted at tmin = the parameter a ray had reached continues the
+// same sequence of cells (the restart counts exactly the planes with T <= tCur as crossed; cells skipped have empty intervals).
+// kSplit: whether this call site cuts stragglers into segments (the path loop's incoherent rays; primary rays are long or short
+// tile by tile, not ray by ray — scripts/r03/straggler_stats.py — so their kernels leave it out and keep their registers).
+template <bool kSplit = false>
+BLOK_DEV HitInfo walk(const TraceArgs& A, const RayIn& r, uint4* stk) {
+    BLOK_STAT(4, 0);                       // a walk begins
+    HitInfo out;
+    out.found = false; out.t = -1.0f; out.material = 0u; out.face = 0xFFu; out.vx = out.vy = out.vz = 0;
+    const WalkRay R = walk_ray(A, r.ox, r.oy, r.oz, safe_inv(r.dx), safe_inv(r.dy), safe_inv(r.dz));
+    WalkState s;
+    walk_enter(A, R, r.tmin, r.tmax, s);
+#if defined(BLOK_TRACE_HOST_HARNESS) || defined(BLOK_NO_SPLIT)
+    (void)walk_loop<false>(A, R, r.tmax, s, stk, 0u);
+    if (s.found) out = walk_hit(A, r, R, s);
+    return out;
+#else
+    if constexpr (!kSplit) {
+        (void)walk_loop<false>(A, R, r.tmax, s, stk, 0u);
+        if (s.found) out = walk_hit(A, r, R, s);
+        return out;
+    }
+    const unsigned long long entered = __ballot(true);                       // the lanes of this call
+    const uint32_t lanes = static_cast<uint32_t>(__builtin_popcountll(entered));
+    const bool split = __ballot(walk_loop<true>(A, R, r.tmax, s, stk, lanes)) != 0ull;      // wave-uniform (lanes that had left the loop say false)
+    if (s.found) out = walk_hit(A, r, R, s);
+    if (!split) return out;
+
+    // ---- the rest of the stragglers' rays, cut into segments
+    const unsigned long long owing = __ballot(s.walking);                    // the stragglers (1 .. kSplitMaxStragglers lanes)
+    const uint32_t n = static_cast<uint32_t>(__builtin_popcountll(owing));
+    if (n == 0u) return out;
+    uint32_t segs = kSplitMaxSegments;                                       // per straggler: the largest power of two <= lanes / n (>= kSplitMinSegments by the loop's test)
+    while (segs * n > lanes) segs >>= 1;
+    const uint32_t seg_shift = static_cast<uint32_t>(__builtin_ctz(segs));
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(entered >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(entered), 0u));   // among the lanes of this call
+    const uint32_t group = rank >> seg_shift, j = rank & (segs - 1u);
+    uint32_t src = 64u;                                                      // the straggler this lane helps (none: group >= n)
+    {
+        unsigned long long m = owing;
+        for (uint32_t g = 0; g < n; ++g) {                                   // wave-uniform: <= kSplitMaxStragglers turns
+            const uint32_t id = static_cast<uint32_t>(__builtin_ctzll(m));
+            m &= m - 1ull;
+            if (group == g) src = id;
+        }
+    }
+    const uint32_t from = src < 64u ? src : 0u;
+    // the straggler's ray and where it stands (every lane of the call fetches; the stragglers are among them, so the sources are active)
+    const float sox = lane_value(R.ax.o, from), soy = lane_value(R.ay.o, from), soz = lane_value(R.az.o, from);
+    const float six = lane_value(R.ax.inv, from), siy = lane_value(R.ay.inv, from), siz = lane_value(R.az.inv, from);
+    const float s_cur = lane_value(s.tCur, from), s_max = lane_value(r.tmax, from);
+    const WalkRay H = walk_ray(A, sox, soy, soz, six, siy, siz);
+    // boundaries b_k = cur + (end - cur) * k / segs, the same expression in the lane that ends at b_k and the lane that starts there;
+    // the first segment starts where the ray stands, the last ends at the ray's own tmax
+    const float s_end = fminf(s_max, world_exit(A, H));
+    const float span = s_end - s_cur, inv_segs = 1.0f / static_cast<float>(segs);
+    const float b_lo = s_cur + span * (static_cast<float>(j) * inv_segs), b_hi = s_cur + span * (static_cast<float>(j + 1u) * inv_segs);
+    const float h_min = j == 0u ? s_cur : b_lo;
+    float h_max = j + 1u == segs ? s_max : b_hi;
+    if (src >= 64u || !(span > 0.0f)) h_max = 0.0f;                           // nothing to help with (an empty interval enters nothing); span <= 0: the ray is at its end,
+    WalkState h;                                                             // and its first segment (h_min = cur, h_max = tmax) settles that
+    if (src < 64u && !(span > 0.0f) && j == 0u) h_max = s_max;
+    walk_enter(A, H, h_min, h_max, h);
+    (void)walk_loop<false>(A, H, h_max, h, stk, 0u);
+    // a straggler's answer: its lowest segment with a hit (helpers of one straggler are consecutive lanes of the call, so that is the
+    // lowest such lane); its state goes to the straggler, which finishes the record with its own ray
+    for (uint32_t g = 0; g < n; ++g) {
+        const unsigned long long hits = __ballot(h.found && group == g);
+        unsigned long long m = owing;
+        for (uint32_t k = 0; k < g; ++k) m &= m - 1ull;
+        const uint32_t owner = static_cast<uint32_t>(__builtin_ctzll(m));
+        if (hits == 0ull) continue;
+        const uint32_t w = static_cast<uint32_t>(__builtin_ctzll(hits));
+        WalkState got;
+        got.fx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(h.fx), w)); got.fy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(h.fy), w));
+        got.fz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(h.fz), w)); got.tCur = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(h.tCur), w));
+        got.node.lo = __builtin_amdgcn_readlane(h.node.lo, w); got.node.hi = __builtin_amdgcn_readlane(h.node.hi, w); got.node.base = __builtin_amdgcn_readlane(h.node.base, w);
+        got.bit = __builtin_amdgcn_readlane(h.bit, w);
+        if (threadIdx.x % 64u == owner) { s.fx = got.fx; s.fy = got.fy; s.fz = got.fz; s.tCur = got.tCur; s.node = got.node; s.bit = got.bit; s.found = true; }
+    }
+    if (s.walking && s.found) out = walk_hit(A, r, R, s);
+    return out;
+#endif
 }
 
 // Walks one ray and writes its 16-byte record and/or RGBA8 pixel.

@@ -75,6 +75,30 @@ enum class RayMode : int { Rect = 0, Tiles = 1, Rays = 2 };
 
 constexpr float kBeamNone = 3.0e38f;   // beam pre-pass result: "no cell of the tree meets the tile's frustum" (beam.h)
 
+// Live list of a frame (list launches: list_joint_kernel / list_walk_kernel, trace_kernels.hip).  The searches of THIS frame say which
+// wave tiles need a walk at all: a search that finds its beam tile live appends one 64-bit entry per wave tile of it — serial | task |
+// start parameter — to the list of its segment (beam tile b -> segment b mod 8: one 64-bit add on the segment's tally reserves the
+// slots and counts the search as done), and walk wave (segment x, j) takes entries j, j + walkers_per_seg, ... of segment x.  The walk
+// therefore has no wave for a dead tile, needs nothing from an earlier frame, and in the joint form starts when the first searches end.
+// Segments follow the round-robin dispatch of workgroups to the 8 XCDs (workgroup i -> XCD i mod 8), so a walk wave only ever waits for
+// searches that were dispatched to its own XCD before it; nothing depends on that for exactness (a wave that gives up a bounded wait
+// leaves its entries to list_cleanup_kernel).
+constexpr uint32_t kListSegments = 8;
+// 64-bit control words per segment, two 128-byte lines: the tally the searches add to (entries reserved | searches done << 32) on one,
+// what the walk waves poll on the other — final (serial << 32 | length) and the serial of the last launch in which a walk wave gave up
+constexpr uint32_t kListCtlWords = 32;
+constexpr uint32_t kListTally = 0, kListFinal = 16, kListGaveUp = 17;
+constexpr uint32_t kListTaskBits = 21, kListT0Bits = 23, kListSerialBits = 20;
+struct LiveList {
+    unsigned long long* entries;           // kListSegments x seg_capacity; null = not a list launch
+    unsigned long long* ctl;               // kListSegments x kListCtlWords
+    uint32_t* hint;                        // pinned host memory, kListSegments words: the segments' entry counts of the last launch (sizes the next walk grid)
+    uint32_t seg_capacity;                 // entries per segment (>= its beam tiles x wave tiles per beam tile)
+    uint32_t serial;                       // of this launch, 1 .. 2^20 - 1: an entry / a final word is valid when it carries it
+    uint32_t walkers_per_seg;              // walk workgroups per segment
+    uint32_t n_searches;                   // search workgroups of this launch (segment x has those with index = x mod 8)
+};
+
 struct TraceArgs {
     const uint4*    nodes;
     const uint32_t* materials;
@@ -100,20 +124,18 @@ struct TraceArgs {
     // beam_kernel and read by the Rect / Tiles trace kernels of the same stream; null = no pre-pass
     float* beam;
     uint32_t beam_tile, beam_bx;           // beam_bx: beam tiles per row of the rectangle (Rect)
-    const uint32_t* order;                 // Rect: workgroup b walks tile order[b] (null = b): longest-first scheduling
-    uint32_t* cost_out;                    // Rect: per tile, the clocks its wave spent (null = not recorded)
     // joint launch (joint_kernel): the pre-pass waves and the walk waves are ONE grid; a beam tile's result is published as
     // (serial << 32 | start parameter bits) and a walk wave waits for its tile's word to carry this launch's serial
     unsigned long long* beam_slots;        // null = the two-launch form (TraceArgs::beam holds plain floats)
     uint32_t beam_serial;
-    // joint launch over a PREFIX of the order: walk waves are dispatched only for the first `launched` tiles of `order` (the tiles that
-    // walked last time); rank_of[tile] >= launched = no walk wave exists for that tile, and the search wave of a live beam tile walks
-    // such tiles itself (a view that has changed; exact either way).  null = every tile has its walk wave.
-    const uint32_t* rank_of;
-    uint32_t launched;
-    uint32_t* joint_gave_up;               // waves that stopped waiting and started at the ray origin instead (0 in a working system)
+    uint32_t* joint_gave_up;               // waves that gave up a bounded wait: joint form, for their tile's search (they start at the ray origin instead); list forms, for an entry (walked by the clean-up).  0 in a working system
     uint32_t miss_in_walk;                 // two-launch form: 1 = the walk's waves write the miss pixels of tiles the pre-pass found empty (they are launched anyway), 0 = the pre-pass does
     uint32_t beam_budget;                  // node visits a search may spend (0 = kBeamMaxVisits); running out is answered conservatively
+    // diagnostics (null in production; blok_hip_beam_prepass / blok_hip_set_debug_wave_clocks): node visits of every beam search, clocks
+    // every listed walk wave spent (indexed by wave tile)
+    uint32_t* debug_visits;
+    uint32_t* debug_clocks;
+    LiveList list;                         // list launches (entries != null): the searches publish the live wave tiles, the walk takes them from the list
 };
 
 // Work queues of the one-launch frame (frame_kernel, trace_kernels.hip), per stream: n_parts independent parts, each with its
@@ -214,12 +236,18 @@ void launch_joint(RayMode mode, const TraceArgs& args, uint32_t n_beam_tiles, ui
 // when the waiting waves give up, so the budget is what it may cost: >= 0.25 ms (three times the longest search), not the seconds a
 // "never happens" budget would.  The automatic form never has two joint launches in flight (api.hip).
 constexpr uint32_t kJointPollBudget = 512u;
+// List launches (TraceArgs::list): joint = searches and list-fed walk waves in ONE grid (n_walkers a multiple of kListSegments), followed
+// by the clean-up of entries whose walk wave gave up waiting (none in a working system); otherwise launch_beam (which fills the list),
+// then launch_list_walk.  frames: several frames of a rank's tiles in one launch (Tiles), or null.
+void launch_list_joint(RayMode mode, const TraceArgs& args, const TileFrames* frames, uint32_t n_beam_tiles, uint32_t n_walkers, hipStream_t stream);
+void launch_list_walk(RayMode mode, const TraceArgs& args, const TileFrames* frames, uint32_t n_walkers, hipStream_t stream);
 // Number of beam tiles of a launch (= floats of TraceArgs::beam) and the pre-pass itself; Rect and Tiles only.
 uint32_t beam_tiles(RayMode mode, const TraceArgs& args, uint32_t tiles_of_rank);
 void launch_beam(RayMode mode, const TraceArgs& args, uint32_t n_beam_tiles, hipStream_t stream);
 void launch_untile(const UntileArgs& args, uint32_t n_frames, hipStream_t stream);
 // Beam pre-pass (if args.beam) and walk of frames.n_frames frames of the rank's tiles, one launch each (Tiles mode).
 void launch_tile_frames(const TraceArgs& args, const TileFrames& frames, hipStream_t stream);
+void launch_beam_frames(const TraceArgs& args, const TileFrames& frames, hipStream_t stream);      // the pre-pass alone (list launches: it fills the list)
 // One-launch frame: pre-pass and walk in one persistent grid of n_blocks waves (Rect and Tiles).
 void launch_frame(RayMode mode, const TraceArgs& args, const FrameQueue& queue, uint32_t n_blocks, hipStream_t stream);
 int frame_blocks_per_cu(RayMode mode, const TraceArgs& args);      // resident workgroups per CU for the launch's LDS size (0 on error)

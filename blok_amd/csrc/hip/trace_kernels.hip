@@ -55,9 +55,105 @@ __device__ __forceinline__ float await_beam(unsigned long long* slot, uint32_t s
     return 0.0f;
 }
 
-// Workgroup `block` of a launch of `grid` workgroups (the kernels below differ in where the arguments come from).
+
+// ---- live list (trace_kernels.h: LiveList) ---------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long list_ld(unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void list_st(unsigned long long* p, unsigned long long v) { (void)__hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// One 64-bit fetch-add per WAVE, performed by lane 0 inside one opaque instruction sequence (see wave_fetch_add below for why), result
+// wave-uniform.  Must be called with all 64 lanes active.
+__device__ __forceinline__ unsigned long long wave_fetch_add64(unsigned long long* counter, unsigned long long v) {
+    unsigned long long result, saved;
+    asm volatile(
+        "s_mov_b64 %[saved], exec\n\t"
+        "s_mov_b64 exec, 1\n\t"
+        "global_atomic_add_x2 %[res], %[zero], %[val], %[ptr] sc0\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "s_mov_b64 exec, %[saved]\n\t"
+        "s_nop 4"
+        : [res] "=&v"(result), [saved] "=&s"(saved)
+        : [val] "v"(v), [zero] "v"(0u), [ptr] "s"(counter)
+        : "memory");
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(result)), hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(result >> 32));
+    return (static_cast<unsigned long long>(hi) << 32) | lo;
+}
+// entry = serial (20 bits) | task (21 bits) | start parameter (the 23 bits 30..8 of a non-negative float: rounded DOWN, still a lower bound)
+__device__ __forceinline__ unsigned long long list_entry(uint32_t serial, uint32_t task, float t0) {
+    return (static_cast<unsigned long long>(serial) << 44) | (static_cast<unsigned long long>(task) << 23) | (__float_as_uint(t0) >> 8);
+}
+constexpr uint32_t kListPollBudget = 1024u;      // polls (~1 us apart) before a walk wave stops waiting for an entry: ~1 ms, ten times the longest search
+
+// The search wave of beam tile b (search workgroup `search` of the launch) has found start parameter t0: a live tile's wave tiles
+// go onto the list of the search's segment, and the search is counted as done.  All 64 lanes.
 template <RayMode MODE>
-__device__ __forceinline__ void trace_block(const TraceArgs& A, const uint32_t block, const uint32_t grid, uint4* lds_stack) {
+__device__ __forceinline__ void list_publish(const TraceArgs& A, const uint32_t search, const uint32_t task_base, const uint32_t b, const float t0, const uint32_t lane) {
+    const LiveList& Q = A.list;
+    const uint32_t seg = search & (kListSegments - 1u);
+    const uint32_t subs_x = A.beam_tile / kWaveW, subs_y = A.beam_tile / kWaveH;
+    bool valid = false;
+    uint32_t task = 0;
+    if (t0 < kBeamNone && lane < subs_x * subs_y) {
+        const uint32_t sx = lane % subs_x, sy = lane / subs_x;
+        if constexpr (MODE == RayMode::Rect) {
+            const uint32_t bx_count = (A.w + kTileW - 1u) / kTileW, by_count = (A.h + kTileH - 1u) / kTileH;
+            const uint32_t bx = (b % A.beam_bx) * subs_x + sx, by = (b / A.beam_bx) * subs_y + sy;
+            valid = bx < bx_count && by < by_count;                     // an edge tile of the rectangle may be cut
+            task = by * bx_count + bx;
+        } else {
+            const uint32_t per_side = A.tile / kTileW, bps = A.tile / A.beam_tile;
+            const uint32_t local_tile = b / (bps * bps), rem = b % (bps * bps);
+            task = local_tile * per_side * (A.tile / kTileH) + ((rem / bps) * subs_y + sy) * per_side + (rem % bps) * subs_x + sx;
+            valid = true;
+        }
+    }
+    const unsigned long long vmask = __ballot(valid);
+    const uint32_t n = static_cast<uint32_t>(__builtin_popcountll(vmask));
+    unsigned long long* const ctl = Q.ctl + seg * kListCtlWords;
+    const unsigned long long old = wave_fetch_add64(ctl + kListTally, (1ull << 32) | n);      // low word: entries reserved, high word: searches done
+    const uint32_t pos = static_cast<uint32_t>(old), done = static_cast<uint32_t>(old >> 32);
+    if (valid) {
+        const uint32_t slot = pos + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(vmask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(vmask), 0u));
+        if (slot < Q.seg_capacity) list_st(Q.entries + static_cast<size_t>(seg) * Q.seg_capacity + slot, list_entry(Q.serial, task_base + task, t0));
+    }
+    const uint32_t in_seg = (Q.n_searches + kListSegments - 1u - seg) / kListSegments;       // searches of this segment
+    if (done + 1u == in_seg && lane == 0) {
+        // the last search of the segment: every reservation has been made, so the length is final; the tally is ready for the next launch
+        const uint32_t total = min(pos + n, Q.seg_capacity);
+        list_st(ctl + kListFinal, (static_cast<unsigned long long>(Q.serial) << 32) | total);
+        list_st(ctl + kListTally, 0ull);
+        if (Q.hint) Q.hint[seg] = total;
+    }
+}
+
+// Entry k of a segment, for all 64 lanes (wave-uniform result): true with the entry, false when the list is final and shorter, or when
+// the wait ran out (counted: the entry, should it still come, is left to list_cleanup_kernel).
+__device__ __forceinline__ bool list_await(unsigned long long* slot, unsigned long long* ctl, const uint32_t serial, const uint32_t k, uint32_t* gave_up,
+                                           uint32_t& task, float& t0) {
+    // The entry has its own word; the segment's `final` word is shared by every waiting wave of the segment, so it is looked at only
+    // every 8th poll (it matters to the waves beyond the end of the list alone, and those have nothing to do anyway).
+    for (uint32_t polls = 0; polls < kListPollBudget; ++polls) {
+        const unsigned long long v = list_ld(slot);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v)), hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32));
+        if ((hi >> 12) == serial) {
+            task = ((hi & 0xFFFu) << 9) | (lo >> 23);
+            t0 = __uint_as_float((lo & 0x7FFFFFu) << 8);
+            return true;
+        }
+        if ((polls & 7u) == 0u) {
+            const unsigned long long f = list_ld(ctl + kListFinal);
+            const uint32_t flo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(f)), fhi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(f >> 32));
+            if (fhi == serial && k >= flo) return false;
+        }
+        __builtin_amdgcn_s_sleep(32);
+    }
+    list_st(ctl + kListGaveUp, serial);          // "a wave of launch `serial` gave up in this segment": what list_cleanup_kernel looks at (every lane, same word)
+    if (gave_up && threadIdx.x == 0) (void)__hip_atomic_fetch_add(gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return false;
+}
+
+// Workgroup `block` of a launch of `grid` workgroups (the kernels below differ in where the arguments come from).  kListed: the block
+// comes from the frame's live list together with its start parameter (list launches): no order, no beam lookup, no cost.
+template <RayMode MODE, bool kListed = false>
+__device__ __forceinline__ void trace_block(const TraceArgs& A, const uint32_t block, const uint32_t grid, uint4* lds_stack, const float listed_t0 = 0.0f) {
     const uint32_t tid = threadIdx.x;
     uint4* stk = lds_stack + tid;
 
@@ -76,24 +172,19 @@ __device__ __forceinline__ void trace_block(const TraceArgs& A, const uint32_t b
         // where this wave's 8x8 pixels start inside the block (wave-uniform)
         const uint32_t wave_x = __builtin_amdgcn_readfirstlane((wave & 1u) * kWaveW), wave_y = __builtin_amdgcn_readfirstlane((wave >> 1) * kWaveH);
         uint32_t x, y;
-        [[maybe_unused]] uint64_t clock0 = 0;      // Rect: the wave's cost (clocks from here to its last record) goes to cost_slot
-        [[maybe_unused]] uint32_t* cost_slot = nullptr;
         float t0 = 0.0f;                           // start parameter of this wave's beam tile (beam.h); kBeamNone: the pre-pass
         size_t out_index;                          // has already written the tile's pixels as misses, nothing left to do
         bool inside;
         if constexpr (MODE == RayMode::Rect) {
             const uint32_t bx_count = (A.w + kTileW - 1u) / kTileW, by_count = (A.h + kTileH - 1u) / kTileH;
             uint32_t bx, by;
-            // longest first: workgroup i walks tile order[i] (the tiles by descending cost of their wave in the previous frame of the
-            // same launch geometry, api.hip); any permutation gives the same frame
-            const uint32_t b = A.order ? A.order[block] : block;
-            if (!block_to_tile(b, grid, bx_count, by_count, bx, by)) return;
-            cost_slot = A.cost_out ? A.cost_out + b : nullptr;
-            if (A.beam) {
+            if constexpr (kListed) { bx = block % bx_count; by = block / bx_count; if (by >= by_count) return; }      // a list entry names the tile itself
+            else if (!block_to_tile(block, grid, bx_count, by_count, bx, by)) return;
+            if constexpr (kListed) t0 = listed_t0;
+            else if (A.beam) {
                 const uint32_t beam_index = ((by * kTileH + wave_y) / A.beam_tile) * A.beam_bx + (bx * kTileW + wave_x) / A.beam_tile;
                 t0 = A.beam_slots ? await_beam(A.beam_slots + beam_index, A.beam_serial, A.joint_gave_up) : A.beam[beam_index];
                 if (t0 >= kBeamNone) {
-                    if (cost_slot && tid == 0) *cost_slot = 0u;
                     if (A.miss_in_walk) {
                         const uint32_t mx = bx * kTileW + lx, my = by * kTileH + ly;
                         const size_t at = static_cast<size_t>(my) * A.w + mx;
@@ -102,7 +193,6 @@ __device__ __forceinline__ void trace_block(const TraceArgs& A, const uint32_t b
                     return;
                 }
             }
-            if (A.cost_out && tid == 0) clock0 = __builtin_amdgcn_s_memtime();      // the walk's cost: any wait for the tile's search is not part of it
             const uint32_t rx = bx * kTileW + lx, ry = by * kTileH + ly;
             inside = rx < A.w && ry < A.h;
             x = A.x0 + rx; y = A.y0 + ry;
@@ -121,7 +211,8 @@ __device__ __forceinline__ void trace_block(const TraceArgs& A, const uint32_t b
                 write_miss(Sink{A.out ? A.out + out_index : nullptr, A.out_rgba ? A.out_rgba + out_index : nullptr});
                 return;
             }
-            if (A.beam) {
+            if constexpr (kListed) t0 = listed_t0;
+            else if (A.beam) {
                 const uint32_t beams_per_side = A.tile / A.beam_tile;
                 const uint32_t beam_index = (local_tile * beams_per_side + ((sub / per_side) * kTileH + wave_y) / A.beam_tile) * beams_per_side +
                                             ((sub % per_side) * kTileW + wave_x) / A.beam_tile;
@@ -137,11 +228,13 @@ __device__ __forceinline__ void trace_block(const TraceArgs& A, const uint32_t b
             if constexpr (MODE == RayMode::Tiles) write_miss(sink);     // the tile buffer is dense
             return;
         }
+        [[maybe_unused]] uint64_t clock0 = 0;
+        if constexpr (kListed && MODE == RayMode::Rect) { if (A.debug_clocks) clock0 = __builtin_amdgcn_s_memtime(); }
         RayIn r = primary_ray(A, x, y);
         r.tmin = fmaxf(r.tmin, t0);
         trace_one(A, r, stk, sink);
-        if constexpr (MODE == RayMode::Rect) {
-            if (cost_slot && tid == 0) *cost_slot = static_cast<uint32_t>(__builtin_amdgcn_s_memtime() - clock0);
+        if constexpr (kListed && MODE == RayMode::Rect) {
+            if (A.debug_clocks && tid == 0) A.debug_clocks[block] = static_cast<uint32_t>(__builtin_amdgcn_s_memtime() - clock0);
         }
     }
 }
@@ -172,14 +265,17 @@ __global__ __launch_bounds__(kBlock) void trace_frames_kernel(const TraceArgs A,
 }
 
 // One wave per beam tile: TraceArgs::beam[tile] = conservative start parameter of the tile's rays, or kBeamNone.
+// list_search / list_task_base (list launches): this search's index in the launch and the first task id of its frame.
 template <RayMode MODE>
-__device__ __forceinline__ void beam_block(const TraceArgs& A, const uint32_t b, const uint32_t n_beam_tiles, uint4* lds_stack = nullptr) {
+__device__ __forceinline__ void beam_block(const TraceArgs& A, const uint32_t b, const uint32_t n_beam_tiles,
+                                           const uint32_t list_search = 0u, const uint32_t list_task_base = 0u) {
     const uint32_t lane = threadIdx.x;
     if (b >= n_beam_tiles) return;
     const uint32_t B = A.beam_tile;
     uint32_t px, py, px_end, py_end;                                   // frame pixels [px, px_end) x [py, py_end)
     [[maybe_unused]] uint32_t tile_x0 = 0, tile_y0 = 0;                // Tiles: frame origin of the screen tile and its slot
     [[maybe_unused]] size_t tile_base = 0;                             // in the rank's dense tile buffer
+    bool padding = false;
     if constexpr (MODE == RayMode::Rect) {
         px = A.x0 + (b % A.beam_bx) * B; py = A.y0 + (b / A.beam_bx) * B;
         px_end = min(px + B, A.x0 + A.w); py_end = min(py + B, A.y0 + A.h);
@@ -187,16 +283,22 @@ __device__ __forceinline__ void beam_block(const TraceArgs& A, const uint32_t b,
         const uint32_t per_side = A.tile / B, per_tile = per_side * per_side;
         const uint32_t local_tile = b / per_tile, sub = b % per_tile;
         const uint32_t global_tile = A.rank + local_tile * A.n_ranks;
-        if (global_tile >= A.tiles_total) { if (lane == 0) { if (A.beam_slots) publish_beam(A.beam_slots + b, A.beam_serial, kBeamNone); else A.beam[b] = kBeamNone; } return; }
+        padding = global_tile >= A.tiles_total;                        // a tile slot beyond the frame's last tile: all misses
+        if (padding && !A.list.entries) { if (lane == 0) { if (A.beam_slots) publish_beam(A.beam_slots + b, A.beam_serial, kBeamNone); else A.beam[b] = kBeamNone; } return; }
         tile_x0 = (global_tile % A.tiles_x) * A.tile; tile_y0 = (global_tile / A.tiles_x) * A.tile;
         tile_base = static_cast<size_t>(local_tile) * A.tile * A.tile;
         px = tile_x0 + (sub % per_side) * B; py = tile_y0 + (sub / per_side) * B;
         px_end = px + B; py_end = py + B;
     }
-    const float t0 = beam_start(A, static_cast<float>(px), static_cast<float>(py), static_cast<float>(px_end), static_cast<float>(py_end), lane);
-    if (lane == 0) { if (A.beam_slots) publish_beam(A.beam_slots + b, A.beam_serial, t0); else A.beam[b] = t0; }
-    if (t0 >= kBeamNone && !A.miss_in_walk && (A.out || A.out_rgba)) {
-        // no ray of this tile can hit anything: its pixels are written here, 64 at a time, and the tile's trace waves exit at once
+    uint32_t visits = 0;
+    const float t0 = padding ? kBeamNone : beam_start(A, static_cast<float>(px), static_cast<float>(py), static_cast<float>(px_end), static_cast<float>(py_end), lane, kBeamNone,
+                                                      A.debug_visits ? &visits : nullptr);
+    if (A.debug_visits && lane == 0) A.debug_visits[b] = visits;
+    if (A.list.entries) list_publish<MODE>(A, list_search, list_task_base, b, t0, lane);      // list launches: the live wave tiles go onto the frame's list
+    else if (lane == 0) { if (A.beam_slots) publish_beam(A.beam_slots + b, A.beam_serial, t0); else A.beam[b] = t0; }
+    if (t0 >= kBeamNone && (A.list.entries || !A.miss_in_walk) && (A.out || A.out_rgba)) {
+        // no ray of this tile can hit anything: its pixels are written here, 64 at a time (a list launch has no walk wave for the tile;
+        // in the other forms the tile's trace waves exit at once)
         const uint32_t tw = px_end - px, n = tw * (py_end - py);
         for (uint32_t i = lane; i < n; i += 64u) {
             const uint32_t x = px + i % tw, y = py + i / tw;
@@ -206,36 +308,11 @@ __device__ __forceinline__ void beam_block(const TraceArgs& A, const uint32_t b,
             write_miss(Sink{A.out ? A.out + out_index : nullptr, A.out_rgba ? A.out_rgba + out_index : nullptr});
         }
     }
-    if constexpr (MODE == RayMode::Rect && kBlock == 64) {
-        // joint launch over a prefix of the order: the wave-sized tiles of this (live) beam tile that no walk wave was dispatched for —
-        // the view has changed since the order was made — are walked here, one after the other
-        if (A.rank_of && lds_stack && t0 < kBeamNone) {
-            const uint32_t bx_count = (A.w + kTileW - 1u) / kTileW;
-            const uint32_t bx0 = (px - A.x0) / kTileW, bx1 = (px_end - A.x0 + kTileW - 1u) / kTileW;
-            const uint32_t by0 = (py - A.y0) / kTileH, by1 = (py_end - A.y0 + kTileH - 1u) / kTileH;
-            for (uint32_t by = by0; by < by1; ++by)
-                for (uint32_t bx = bx0; bx < bx1; ++bx) {
-                    const uint32_t tile = by * bx_count + bx;
-                    if (__builtin_amdgcn_readfirstlane(A.rank_of[tile]) < A.launched) continue;
-                    const uint64_t clock0 = __builtin_amdgcn_s_memtime();
-                    const uint32_t rx = bx * kTileW + lane % kWaveW, ry = by * kTileH + lane / kWaveW;
-                    if (rx < A.w && ry < A.h) {
-                        const size_t at = static_cast<size_t>(ry) * A.w + rx;
-                        RayIn r = primary_ray(A, A.x0 + rx, A.y0 + ry);
-                        r.tmin = fmaxf(r.tmin, t0);
-                        trace_one(A, r, lds_stack + lane, Sink{A.out ? A.out + at : nullptr, A.out_rgba ? A.out_rgba + at : nullptr});
-                    }
-                    // it walked: the next sort puts it into the prefix (any key >= 256 clocks counts as live)
-                    if (A.cost_out && lane == 0) A.cost_out[tile] = max(static_cast<uint32_t>(__builtin_amdgcn_s_memtime() - clock0), 256u);
-                }
-        }
-    }
 }
 
 template <RayMode MODE>
 __global__ __launch_bounds__(64) void beam_kernel(const TraceArgs A, const uint32_t n_beam_tiles) {
-    extern __shared__ uint4 lds_stack[];       // only when the walk launch covers a prefix of the order (TraceArgs::rank_of): the walk's stack, for the tiles walked here
-    beam_block<MODE>(A, blockIdx.x, n_beam_tiles, A.rank_of ? lds_stack : nullptr);
+    beam_block<MODE>(A, blockIdx.x, n_beam_tiles, blockIdx.x, 0u);
 }
 
 // ---- joint launch: the pre-pass waves and the walk waves in ONE grid, statically ------------------------------------------
@@ -249,7 +326,7 @@ template <RayMode MODE>
 __global__ __launch_bounds__(kBlock) void joint_kernel(const TraceArgs A, const uint32_t n_beam_tiles) {
     extern __shared__ uint4 lds_stack[];
     if (blockIdx.x < n_beam_tiles) {
-        if (threadIdx.x < 64u) beam_block<MODE>(A, blockIdx.x, n_beam_tiles, lds_stack);
+        if (threadIdx.x < 64u) beam_block<MODE>(A, blockIdx.x, n_beam_tiles);
         return;
     }
     trace_block<MODE>(A, blockIdx.x - n_beam_tiles, gridDim.x - n_beam_tiles, lds_stack);
@@ -259,7 +336,91 @@ __global__ __launch_bounds__(64) void beam_frames_kernel(const TraceArgs A, cons
     const uint32_t f = blockIdx.x / F.beams_per_frame;
     if (f >= F.n_frames) return;
     const TraceArgs L = frame_args(A, F, f);
-    beam_block<RayMode::Tiles>(L, blockIdx.x - f * F.beams_per_frame, F.beams_per_frame);
+    beam_block<RayMode::Tiles>(L, blockIdx.x - f * F.beams_per_frame, F.beams_per_frame, blockIdx.x, f * F.blocks_per_frame);
+}
+
+// ---- list launches: the walk takes its wave tiles from the frame's live list (trace_kernels.h: LiveList) -------------------------
+// No reference counterpart (one traceRaysKHR per frame, renderer_raytracing.cpp:666-685).  Walk workgroup `walker` of the launch (on
+// XCD `seg` if workgroups go round the XCDs in index order) takes entries walker / 8, + walkers_per_seg, ... of segment `seg`: normally
+// one entry — the grid is sized from the previous launch's list, with a margin — and more only when the view has changed a lot.
+template <RayMode MODE, bool kFrames>
+__device__ __forceinline__ void list_walk(const TraceArgs& A, const TileFrames& F, const uint32_t walker, const uint32_t seg, uint4* lds_stack) {
+    const LiveList& Q = A.list;
+    unsigned long long* const entries = Q.entries + static_cast<size_t>(seg) * Q.seg_capacity;
+    unsigned long long* const ctl = Q.ctl + seg * kListCtlWords;
+    for (uint32_t k = walker / kListSegments; k < Q.seg_capacity; k += Q.walkers_per_seg) {
+        uint32_t task; float t0;
+        if (!list_await(entries + k, ctl, Q.serial, k, A.joint_gave_up, task, t0)) return;
+        __hip_atomic_store(entries + k, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // taken (every lane, same word)
+        if constexpr (kFrames) {
+            const uint32_t f = task / F.blocks_per_frame;
+            if (f >= F.n_frames) continue;
+            const TraceArgs L = frame_args(A, F, f);
+            trace_block<MODE, true>(L, task - f * F.blocks_per_frame, F.blocks_per_frame, lds_stack, t0);
+        } else {
+            trace_block<MODE, true>(A, task, 0u, lds_stack, t0);
+        }
+    }
+}
+
+template <RayMode MODE, bool kFrames>
+__device__ __forceinline__ void list_search(const TraceArgs& A, const TileFrames& F, const uint32_t search) {
+    if constexpr (kFrames) {
+        const uint32_t f = search / F.beams_per_frame;
+        if (f >= F.n_frames) return;
+        const TraceArgs L = frame_args(A, F, f);
+        beam_block<MODE>(L, search - f * F.beams_per_frame, F.beams_per_frame, search, f * F.blocks_per_frame);
+    } else {
+        beam_block<MODE>(A, search, A.list.n_searches, search, 0u);
+    }
+}
+
+// Searches and list-fed walk waves in ONE grid: workgroups [0, n_searches) search, the others walk.  Workgroups are dispatched in index
+// order, so a walk wave finds every search of its segment resident or finished, and waits (bounded) only for entries they still owe.
+template <RayMode MODE, bool kFrames>
+__global__ __launch_bounds__(kBlock) void list_joint_kernel(const TraceArgs A, const TileFrames F) {
+    static_assert(kBlock == 64, "one wave per workgroup");
+    extern __shared__ uint4 lds_stack[];
+    const uint32_t n = A.list.n_searches;
+    if (blockIdx.x < n) { list_search<MODE, kFrames>(A, F, blockIdx.x); return; }
+    list_walk<MODE, kFrames>(A, F, blockIdx.x - n, blockIdx.x & (kListSegments - 1u), lds_stack);
+}
+
+// The walk alone, behind a beam launch that has filled the list (nothing to wait for).
+template <RayMode MODE, bool kFrames>
+__global__ __launch_bounds__(kBlock) void list_walk_kernel(const TraceArgs A, const TileFrames F) {
+    extern __shared__ uint4 lds_stack[];
+    list_walk<MODE, kFrames>(A, F, blockIdx.x, blockIdx.x & (kListSegments - 1u), lds_stack);
+}
+
+// Behind a joint list launch: entries whose walk wave gave up waiting (none unless workgroups were dispatched in an order nobody has
+// seen yet, or several joint launches starved each other's searches) are walked here, so the frame is complete whatever happened.
+template <RayMode MODE, bool kFrames>
+__global__ __launch_bounds__(kBlock) void list_cleanup_kernel(const TraceArgs A, const TileFrames F) {
+    extern __shared__ uint4 lds_stack[];
+    const LiveList& Q = A.list;
+    const uint32_t seg = blockIdx.x & (kListSegments - 1u), part = blockIdx.x / kListSegments, parts = gridDim.x / kListSegments;
+    unsigned long long* const ctl = Q.ctl + seg * kListCtlWords;
+    if (__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(list_ld(ctl + kListGaveUp))) != Q.serial) return;      // nobody gave up in this launch
+    const unsigned long long f = list_ld(ctl + kListFinal);
+    const uint32_t total = static_cast<uint32_t>(f >> 32) == Q.serial ? min(static_cast<uint32_t>(f), Q.seg_capacity) : Q.seg_capacity;
+    unsigned long long* const entries = Q.entries + static_cast<size_t>(seg) * Q.seg_capacity;
+    for (uint32_t k = part; k < total; k += parts) {
+        const unsigned long long v = list_ld(entries + k);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v)), hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32));
+        if ((hi >> 12) != Q.serial) continue;
+        __hip_atomic_store(entries + k, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t task = ((hi & 0xFFFu) << 9) | (lo >> 23);
+        const float t0 = __uint_as_float((lo & 0x7FFFFFu) << 8);
+        if constexpr (kFrames) {
+            const uint32_t fr = task / F.blocks_per_frame;
+            if (fr >= F.n_frames) continue;
+            const TraceArgs L = frame_args(A, F, fr);
+            trace_block<MODE, true>(L, task - fr * F.blocks_per_frame, F.blocks_per_frame, lds_stack, t0);
+        } else {
+            trace_block<MODE, true>(A, task, 0u, lds_stack, t0);
+        }
+    }
 }
 
 // ---- one-launch frame: pre-pass and walk in ONE persistent grid ------------------------------------------------------
@@ -635,6 +796,11 @@ void launch_tile_frames(const TraceArgs& args, const TileFrames& frames, hipStre
     hipLaunchKernelGGL(trace_frames_kernel, dim3(frames.n_frames * frames.blocks_per_frame), dim3(kBlock), lds, stream, args, frames);
 }
 
+void launch_beam_frames(const TraceArgs& args, const TileFrames& frames, hipStream_t stream) {
+    if (args.beam_tile && frames.n_frames && frames.beams_per_frame)
+        hipLaunchKernelGGL(beam_frames_kernel, dim3(frames.n_frames * frames.beams_per_frame), dim3(64), 0, stream, args, frames);
+}
+
 void launch_trace(RayMode mode, const TraceArgs& args, uint32_t n_blocks, hipStream_t stream) {
     if (n_blocks == 0) return;
     const size_t lds = static_cast<size_t>(args.levels > 1 ? args.levels - 1 : 1) * kBlock * sizeof(uint4);
@@ -652,6 +818,34 @@ void launch_joint(RayMode mode, const TraceArgs& args, uint32_t n_beam_tiles, ui
     else hipLaunchKernelGGL(joint_kernel<RayMode::Tiles>, dim3(n_beam_tiles + n_blocks), dim3(kBlock), lds, stream, args, n_beam_tiles);
 }
 
+size_t frame_lds_bytes(const TraceArgs& args);
+
+void launch_list_joint(RayMode mode, const TraceArgs& args, const TileFrames* frames, uint32_t n_beam_tiles, uint32_t n_walkers, hipStream_t stream) {
+    if (n_beam_tiles == 0 || mode == RayMode::Rays || !args.list.entries) return;
+    const size_t lds = frame_lds_bytes(args);
+    const dim3 grid(n_beam_tiles + n_walkers), clean(kListSegments * 8u);
+    const TileFrames none{};
+    if (mode == RayMode::Rect) {
+        hipLaunchKernelGGL((list_joint_kernel<RayMode::Rect, false>), grid, dim3(kBlock), lds, stream, args, none);
+        hipLaunchKernelGGL((list_cleanup_kernel<RayMode::Rect, false>), clean, dim3(kBlock), lds, stream, args, none);
+    } else if (!frames) {
+        hipLaunchKernelGGL((list_joint_kernel<RayMode::Tiles, false>), grid, dim3(kBlock), lds, stream, args, none);
+        hipLaunchKernelGGL((list_cleanup_kernel<RayMode::Tiles, false>), clean, dim3(kBlock), lds, stream, args, none);
+    } else {
+        hipLaunchKernelGGL((list_joint_kernel<RayMode::Tiles, true>), grid, dim3(kBlock), lds, stream, args, *frames);
+        hipLaunchKernelGGL((list_cleanup_kernel<RayMode::Tiles, true>), clean, dim3(kBlock), lds, stream, args, *frames);
+    }
+}
+
+void launch_list_walk(RayMode mode, const TraceArgs& args, const TileFrames* frames, uint32_t n_walkers, hipStream_t stream) {
+    if (n_walkers == 0 || mode == RayMode::Rays || !args.list.entries) return;
+    const size_t lds = frame_lds_bytes(args);
+    const TileFrames none{};
+    if (mode == RayMode::Rect) hipLaunchKernelGGL((list_walk_kernel<RayMode::Rect, false>), dim3(n_walkers), dim3(kBlock), lds, stream, args, none);
+    else if (!frames) hipLaunchKernelGGL((list_walk_kernel<RayMode::Tiles, false>), dim3(n_walkers), dim3(kBlock), lds, stream, args, none);
+    else hipLaunchKernelGGL((list_walk_kernel<RayMode::Tiles, true>), dim3(n_walkers), dim3(kBlock), lds, stream, args, *frames);
+}
+
 uint32_t beam_tiles(RayMode mode, const TraceArgs& a, uint32_t tiles_of_rank) {
     if (mode == RayMode::Rect) return ((a.w + a.beam_tile - 1u) / a.beam_tile) * ((a.h + a.beam_tile - 1u) / a.beam_tile);
     return tiles_of_rank * (a.tile / a.beam_tile) * (a.tile / a.beam_tile);
@@ -659,9 +853,9 @@ uint32_t beam_tiles(RayMode mode, const TraceArgs& a, uint32_t tiles_of_rank) {
 
 void launch_beam(RayMode mode, const TraceArgs& args, uint32_t n_beam_tiles, hipStream_t stream) {
     if (n_beam_tiles == 0 || mode == RayMode::Rays) return;
-    const size_t lds = args.rank_of ? static_cast<size_t>(args.levels > 1 ? args.levels - 1 : 1) * kBlock * sizeof(uint4) : 0;
-    if (mode == RayMode::Rect) hipLaunchKernelGGL(beam_kernel<RayMode::Rect>, dim3(n_beam_tiles), dim3(64), lds, stream, args, n_beam_tiles);
-    else hipLaunchKernelGGL(beam_kernel<RayMode::Tiles>, dim3(n_beam_tiles), dim3(64), lds, stream, args, n_beam_tiles);
+    // no dynamic LDS: the search keeps its stack in registers (beam.h), and the kernel declares none
+    if (mode == RayMode::Rect) hipLaunchKernelGGL(beam_kernel<RayMode::Rect>, dim3(n_beam_tiles), dim3(64), 0, stream, args, n_beam_tiles);
+    else hipLaunchKernelGGL(beam_kernel<RayMode::Tiles>, dim3(n_beam_tiles), dim3(64), 0, stream, args, n_beam_tiles);
 }
 
 size_t frame_lds_bytes(const TraceArgs& args) { return static_cast<size_t>(args.levels > 1 ? args.levels - 1 : 1) * kBlock * sizeof(uint4); }

@@ -22,6 +22,7 @@ class HipTracer:
         self.width, self.height, self.device = int(width), int(height), int(device)
         self._lib = None
         self._ctx = None
+        self._beam_tile = 32
 
     # -- lifecycle -------------------------------------------------------------------------
     def init(self) -> "HipTracer":
@@ -155,6 +156,7 @@ class HipTracer:
     def set_beam(self, beam_tile_pixels: int):
         """Beam pre-pass granularity of the frame kernels in pixels (0 = off, default 32); never changes a result."""
         self._check(self._lib.blok_hip_set_beam(self._ctx, beam_tile_pixels))
+        self._beam_tile = int(beam_tile_pixels)
 
     def set_taa_jitter(self, jitter_px=None):
         """Sub-pixel TAA jitter (pixels, each within +-0.5) of the primary rays of all following frames; None = off."""
@@ -168,15 +170,35 @@ class HipTracer:
         """draw_frame_rt applies jitter entry (frame mod 16) by itself (default on = PostProcess::Settings::enableTAA)."""
         self._check(self._lib.blok_hip_set_rt_taa_jitter(self._ctx, 1 if enabled else 0))
 
-    def set_tile_ordering(self, resort_every_n_frames):
-        """Longest-first scheduling of the walk from earlier frames' per-wave clocks, re-sorted asynchronously every N frames
-        (default 8; 0 / False = off; True = 8); applied only to launches that have the chip to themselves; never changes a result."""
-        n = 8 if resort_every_n_frames is True else int(resort_every_n_frames or 0)
-        self._check(self._lib.blok_hip_set_tile_ordering(self._ctx, n))
+    def beam_prepass(self, cam, rect=None, want_visits=False):
+        """The pre-pass alone: (t0, visits) per beam tile of the rectangle, row-major (blok_hip.h: blok_hip_beam_prepass)."""
+        x0, y0, w, h = rect or (0, 0, self.width, self.height)
+        tile = self._beam_tile
+        n = ((w + tile - 1) // tile) * ((h + tile - 1) // tile)
+        t0 = np.zeros(n, dtype=np.float32)
+        visits = np.zeros(n, dtype=np.uint32) if want_visits else None
+        cam = np.ascontiguousarray(cam)
+        self._check(self._lib.blok_hip_beam_prepass(self._ctx, C.c_void_p(cam.ctypes.data), x0, y0, w, h, C.c_void_p(t0.ctypes.data),
+                                                    C.c_void_p(visits.ctypes.data) if want_visits else None, n))
+        return t0, visits
 
-    def set_joint_prefix_limit(self, max_walk_waves: int):
-        """Diagnostic: cap on the walk waves of a joint launch; the rest is walked by the search waves (same frame)."""
-        self._check(self._lib.blok_hip_set_joint_prefix_limit(self._ctx, max_walk_waves))
+    def trace_wave_tiles_device(self, cam, tiles, t0, hits_ptr=0, rgba_ptr=0, rect=None, stream=0):
+        """Walks the listed 8x8-pixel wave tiles of the rectangle in list order (blok_hip.h: blok_hip_trace_wave_tiles_device)."""
+        x0, y0, w, h = rect or (0, 0, self.width, self.height)
+        tiles = np.ascontiguousarray(tiles, dtype=np.uint32)
+        t0 = None if t0 is None else np.ascontiguousarray(t0, dtype=np.float32)
+        cam = np.ascontiguousarray(cam)
+        self._check(self._lib.blok_hip_trace_wave_tiles_device(self._ctx, C.c_void_p(cam.ctypes.data), x0, y0, w, h, C.c_void_p(tiles.ctypes.data),
+                                                               C.c_void_p(t0.ctypes.data) if t0 is not None else None, len(tiles),
+                                                               C.c_void_p(hits_ptr) if hits_ptr else None, C.c_void_p(rgba_ptr) if rgba_ptr else None,
+                                                               C.c_void_p(stream) if stream else None))
+
+    def set_debug_wave_clocks(self, dev_ptr):
+        self._check(self._lib.blok_hip_set_debug_wave_clocks(self._ctx, C.c_void_p(dev_ptr) if dev_ptr else None))
+
+    def last_launch_kind(self) -> int:
+        """Which kernels the latest rectangle / tile launch was issued as (blok_hip.h: blok_hip_last_launch_kind)."""
+        return int(self._lib.blok_hip_last_launch_kind(self._ctx))
 
     def set_miss_writer(self, in_walk: bool):
         """Empty tiles' miss pixels: written by the walk launch's waves (True, default) or by the pre-pass (blok_hip.h)."""

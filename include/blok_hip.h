@@ -448,22 +448,6 @@ int blok_hip_set_sun_map(blok_hip_ctx* ctx, int enabled);
  * conservative start parameter for that tile's rays, and tiles whose frustum meets no voxel are written as misses without
  * a walk.  Results are identical with and without it (tests/test_gpu_parity.py).  0 turns it off; default 32. */
 int blok_hip_set_beam(blok_hip_ctx* ctx, uint32_t beam_tile_pixels);
-/* Longest-first scheduling of the walk (default: on, re-sorted every 8 frames; rectangle launches of at least 4096 wave tiles
- * behind the pre-pass): every wave of the walk leaves the clocks it spent; every N-th frame a 16-bit radix sort of those costs
- * (129 600 keys at 4K) follows the frame on its stream, a later launch adopts the finished order, and the walk's workgroups take
- * their tiles in it, so the long grazing-ray waves start first instead of forming the launch's tail.  A view at rest is re-sorted
- * ever less often (the interval doubles up to 64 frames).  The order is also what tells a joint launch (blok_hip_set_fused)
- * which tiles need a walk wave at all.  In the two-launch form it is applied (and re-sorted) only while the launch has the chip
- * to itself: when another stream of the context still has frames in flight the tail is already filled by their waves and
- * front-loading every frame's heavy tiles measures slower.
- * Pure scheduling: any order gives the same frame (tests/test_gpu_parity.py); the first frame of a geometry runs in natural
- * order, a camera that moves more than a fraction of a degree per frame gains nothing.  No reference counterpart
- * (renderer_raytracing.cpp:666-685 leaves scheduling to the driver).  0 = off; N > 0 = re-sort every N frames.
- * Measured (4K over 1024^3, one frame at a time): 0.295 -> 0.252 ms (poses A, C: -14 %; B: -3 %). */
-int blok_hip_set_tile_ordering(blok_hip_ctx* ctx, int resort_every_n_frames);
-/* Diagnostic: the most walk waves a joint launch dispatches (0 = no limit).  Whatever is cut off is walked by the search waves;
- * the frame is the same (the tests use it to exercise that path). */
-int blok_hip_set_joint_prefix_limit(blok_hip_ctx* ctx, uint32_t max_walk_waves);
 /* Who writes the miss pixels of the tiles the pre-pass found empty (two-launch form): 1 (default) = the walk launch's waves of
  * those tiles — they are launched anyway and have nothing else to do — 0 = the pre-pass wave of the tile, 1 024 pixels each, which
  * puts ~120 MB of stores on the pre-pass's critical path (4K, 73 % sky).  Never changes a result. */
@@ -485,22 +469,44 @@ int blok_hip_set_rt_taa_jitter(blok_hip_ctx* ctx, int enabled);
  * traceRaysKHR per frame); results are identical in every form (tests/test_gpu_parity.py):
  *   0  two launches: the beam kernel, then one walk wave per 8x8 pixels;
  *   1  one persistent launch with work queues: resident waves first take beam tiles, append the wave-sized sub-tiles of the live
- *      ones to per-part queues with an atomic reservation, then take walk tasks from those queues (measures slower on MI355X:
- *      same-address atomics run at 88 M/s);
- *   2  joint launch: the search waves and the walk waves are ONE grid, statically — workgroups are dispatched in index order, the
- *      searches first; a walk wave waits (bounded) only while its own tile's search is still running, so the chip starts walking
- *      when the first searches end, not when the last one does.  With a longest-first order in force (blok_hip_set_tile_ordering)
- *      walk waves are dispatched only for the tiles that walked when the order was made; a tile that has become live since is
- *      walked by its search wave.  Alone on the chip: 0.26 -> 0.20 ms per 4K frame.  Not for frames in flight on several
- *      streams: the waiting waves hold slots other frames' waves would use, and several joint launches in flight can wait for
- *      each other's searches in a circle until they give up (bounded; the frame stays exact);
- *   3  (default) automatic: 2 for a launch that has the chip to itself; with frames in flight on other streams form 0, over the
- *      order's live prefix when an order is in force (three in flight: 0.186 -> 0.177 ms per frame), over all tiles otherwise. */
+ *      ones to per-part queues with an atomic reservation, then take walk tasks from those queues with one ticket each (measures
+ *      slower on MI355X: same-address atomics run at 88 M/s);
+ *   2  joint launch: the search waves and one walk wave per 8x8 pixels are ONE grid, statically — workgroups are dispatched in index
+ *      order, the searches first; a walk wave waits (bounded) only while its own tile's search is still running, so the chip starts
+ *      walking when the first searches end, not when the last one does;
+ *   4  list-fed joint launch: as 2, but the walk waves take their 8x8-pixel tiles from the frame's LIVE LIST — a search that finds
+ *      its beam tile live appends the tile's wave tiles, with their start parameter, to one of eight lists (one 64-bit add per search
+ *      reserves the slots), walk wave j of a list takes its entries j, j + n, ... — so no wave is launched for a dead tile and nothing
+ *      is needed from an earlier frame: the walk grid is sized from the previous launch's list length (a hint only; any size walks
+ *      every entry).  A walk wave that waits in vain (bounded, ~1 ms) leaves its entries to a clean-up launch behind the frame;
+ *   5  the same lists in two launches: the beam kernel fills them, the walk waves take them (nothing waits);
+ *   3  (default) automatic: 4 for a launch that has the DEVICE to itself — no frame launch of another stream or context of this
+ *      process still pending on it — else 5: beside other launches the waiting walk waves of a joint launch would only take wave slots
+ *      from them, and two joint launches can starve each other's searches (bounded; the frame stays exact).
+ * Measured at 4K over 1024^3, a launch alone: form 0 0.26 ms, 2 0.22 ms, 4 see DESIGN.md §6. */
 int blok_hip_set_fused(blok_hip_ctx* ctx, int enabled);
-/* Health check of forms 1 and 2: synchronises the device and returns how many waves ever gave up a bounded wait (0 in a working
+/* Health check of forms 1, 2 and 4: synchronises the device and returns how many waves ever gave up a bounded wait (0 in a working
  * system).  Form 1: for a queue entry (~0.5 s; frames since context creation may then be incomplete).  Form 2: for their tile's
- * search (such a wave starts at the ray origin instead: the frame is still exact). */
+ * search (such a wave starts at the ray origin instead: the frame is still exact).  Form 4: for a list entry (walked by the clean-up
+ * launch: the frame is still exact). */
 int blok_hip_frame_queue_stalls(blok_hip_ctx* ctx, uint32_t* out_stalled_waves);
+/* Diagnostics of the pre-pass and the walk's scheduling (no reference counterpart).  blok_hip_beam_prepass: the pre-pass alone over a
+ * rectangle — per beam tile (row-major, blok_hip_set_beam pixels each) its start parameter (>= 3e38 = no ray of the tile can hit
+ * anything) and, optionally, the node visits its search spent — to host arrays of `capacity` elements.
+ * blok_hip_trace_wave_tiles_device: walks exactly the listed 8x8-pixel wave tiles of the rectangle (index = row * ceil(w / 8) + column),
+ * walk workgroup j taking entry j, each ray starting at its tile's t0 (NULL = at the ray origin; a value beyond the true first hit
+ * would lose it — use what blok_hip_beam_prepass returned for the tile's beam tile); pixels of tiles not listed are left as they are.
+ * A frame assembled from the two equals blok_hip_trace_primary_device's (tests/test_gpu_parity.py).
+ * blok_hip_set_debug_wave_clocks: device array of one word per wave tile that list-fed walk waves leave their clock count in (NULL = off). */
+int blok_hip_beam_prepass(blok_hip_ctx* ctx, const blok_camera* cam, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
+                          float* out_t0_host, uint32_t* out_visits_host_or_null, size_t capacity);
+int blok_hip_trace_wave_tiles_device(blok_hip_ctx* ctx, const blok_camera* cam, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
+                                     const uint32_t* tiles_host, const float* t0_host_or_null, size_t n_tiles,
+                                     void* out_hits_dev_or_null, void* out_rgba8_dev_or_null, void* hip_stream);
+int blok_hip_set_debug_wave_clocks(blok_hip_ctx* ctx, void* clocks_dev_or_null);
+/* Which kernels the latest rectangle / tile launch of the context was issued as: 0 walk alone (no pre-pass), 1 two launches, 2 queues,
+ * 3 joint, 4 list-fed joint, 5 beam launch + list-fed walk; -1 before the first launch (what form 3 chose; tests and diagnostics). */
+int blok_hip_last_launch_kind(const blok_hip_ctx* ctx);
 /* Enable/disable the per-launch HIP event pair (default off: nothing but the kernel is
  * enqueued by the *_device entries). */
 int blok_hip_set_timing(blok_hip_ctx* ctx, int enabled);

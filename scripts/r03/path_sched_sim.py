@@ -121,6 +121,95 @@ def sim_b(lanes, SH, TH):
             ray[fin] += 1; walking[fin] = False; waiting[fin] = True
     return dict(cost=cost, shades=shades, util=lane_iters / max(1, 64 * wave_iters), wave_iters=wave_iters)
 
+def sim_d(lanes, SH, TH, RF=120):
+    """Lockstep: one primary round per sample, then ONE secondary round in which every lane walks its shadow ray and then its bounce
+    ray (both known once the primary hit is shaded), going on to the second when >= TH lanes wait (RF VALU per refill event)."""
+    sidx = sample_index(lanes)
+    n_s = max((x[-1] + 1) if x else 0 for x in sidx)
+    cost = 0; rounds = 0; wave_iters = 0; lane_iters = 0
+    for sm in range(n_s):
+        rays = [r[1] for i in range(64) for j, r in enumerate(lanes[i]) if sidx[i][j] == sm and r[0] == 0]
+        if rays:
+            m = max(len(r) for r in rays)
+            arr = np.zeros((len(rays), m), dtype=np.uint8)
+            for j, r in enumerate(rays): arr[j, :len(r)] = r
+            cost += m * T + int((arr == 1).any(axis=0).sum()) * D + int((arr == 2).any(axis=0).sum()) * S + SH
+            rounds += 1; wave_iters += m; lane_iters += int((arr != 0).sum())
+        queue = [[r[1] for j, r in enumerate(lanes[i]) if sidx[i][j] == sm and r[0] != 0] for i in range(64)]
+        if not any(queue): continue
+        rounds += 1; cost += SH
+        ptr = [0] * 64; pos = [0] * 64
+        walking = [len(q) > 0 for q in queue]; waiting = [False] * 64
+        while True:
+            nk = sum(walking); nw = sum(waiting)
+            if nk == 0 and nw == 0: break
+            if nw and (nw >= TH or nk == 0):
+                cost += RF
+                for i in range(64):
+                    if waiting[i]: waiting[i] = False; walking[i] = True
+                continue
+            anyD = anyS = False
+            for i in range(64):
+                if not walking[i]: continue
+                r = queue[i][ptr[i]]
+                if pos[i] < len(r):
+                    if r[pos[i]] == 1: anyD = True
+                    else: anyS = True
+                    pos[i] += 1
+                if pos[i] >= len(r):
+                    ptr[i] += 1; pos[i] = 0; walking[i] = False
+                    if ptr[i] < len(queue[i]): waiting[i] = True
+            cost += T + 4 + D * anyD + S * anyS; wave_iters += 1; lane_iters += nk
+    return dict(cost=cost, rounds=rounds, util=lane_iters / max(1, 64 * wave_iters), wave_iters=wave_iters)
+
+def sim_c(lanes, SH, G, TH, RF=120):
+    """Lockstep primary / shadow rounds sample by sample; the bounce rays of G consecutive samples are walked in ONE round in which a
+    lane that finished a ray goes on to its next one (refill when >= TH lanes wait, RF VALU per refill event)."""
+    sidx = sample_index(lanes)
+    n_s = max((x[-1] + 1) if x else 0 for x in sidx)
+    cost = 0; rounds = 0; wave_iters = 0; lane_iters = 0
+    def round_cost(rays):
+        m = max(len(r) for r in rays)
+        arr = np.zeros((len(rays), m), dtype=np.uint8)
+        for j, r in enumerate(rays): arr[j, :len(r)] = r
+        return m * T + int((arr == 1).any(axis=0).sum()) * D + int((arr == 2).any(axis=0).sum()) * S, m, int((arr != 0).sum())
+    for g0 in range(0, n_s, G):
+        queue = [[] for _ in range(64)]
+        for sm in range(g0, min(g0 + G, n_s)):
+            for kind in (0, 1):
+                rays = [r[1] for i in range(64) for j, r in enumerate(lanes[i]) if sidx[i][j] == sm and r[0] == kind]
+                if rays:
+                    c, m, li = round_cost(rays); cost += c + SH; rounds += 1; wave_iters += m; lane_iters += li
+            for i in range(64):
+                for j, r in enumerate(lanes[i]):
+                    if sidx[i][j] == sm and r[0] == 2: queue[i].append(r[1])
+        if not any(queue): continue
+        rounds += 1; cost += SH
+        # refill simulation over the queued bounce rays
+        ptr = [0] * 64; pos = [0] * 64
+        walking = [len(q) > 0 for q in queue]; waiting = [False] * 64
+        while True:
+            nk = sum(walking); nw = sum(waiting)
+            if nk == 0 and nw == 0: break
+            if nw and (nw >= TH or nk == 0):
+                cost += RF
+                for i in range(64):
+                    if waiting[i]: waiting[i] = False; walking[i] = True
+                continue
+            anyD = anyS = False
+            for i in range(64):
+                if not walking[i]: continue
+                r = queue[i][ptr[i]]
+                if pos[i] < len(r):
+                    if r[pos[i]] == 1: anyD = True
+                    else: anyS = True
+                    pos[i] += 1
+                if pos[i] >= len(r):
+                    ptr[i] += 1; pos[i] = 0; walking[i] = False
+                    if ptr[i] < len(queue[i]): waiting[i] = True
+            cost += T + 4 + D * anyD + S * anyS; wave_iters += 1; lane_iters += nk
+    return dict(cost=cost, rounds=rounds, util=lane_iters / max(1, 64 * wave_iters), wave_iters=wave_iters)
+
 rows = {0: (60, 110, 150, 190, 230, 262), 1: (20, 80, 140, 200, 250), 2: (30, 90, 150, 210, 260)}[pose]
 tiles = [(tx, ty) for ty in rows for tx in (25, 100, 175, 250, 325, 400, 470)]
 logs = []
@@ -134,14 +223,21 @@ for l in logs:
     for lane in l:
         for k, e in lane: kinds[k] += 1; iters[k] += len(e)
 print("rays per pixel and sample by kind (primary, shadow, bounce):", np.round(kinds / (64 * len(logs) * spp), 3), " iterations per ray:", np.round(iters / np.maximum(kinds, 1), 1))
-for SH in (400, 700):
+for SH in (500,):
     a = [sim_a(l, SH) for l in logs]
     a0 = [sim_a(l, SH, False) for l in logs]
     al = [sim_a(l, SH, True, True) for l in logs]
-    print(f"    lockstep by sample: {np.mean([x['cost'] for x in al]) / np.mean([x['cost'] for x in a]):.2f}x  rounds {np.mean([x['rounds'] for x in al]):.0f}, walk by kind {np.round(np.mean([x['per_kind'] for x in al], axis=0))}, lane util {np.mean([x['util'] for x in al]):.2f}")
+    print(f"    lockstep by sample: {np.mean([x['cost'] for x in al]) / np.mean([x['cost'] for x in a]):.2f}x  wave iterations {np.mean([x['wave_iters'] for x in al]):.0f} rounds {np.mean([x['rounds'] for x in al]):.0f}, walk by kind {np.round(np.mean([x['per_kind'] for x in al], axis=0))}, lane util {np.mean([x['util'] for x in al]):.2f}")
     ca = np.mean([x['cost'] for x in a])
     print(f"SHADE={SH}: (A) {ca:9.0f} VALU/wave (walk {np.mean([x['walk'] for x in a]):.0f}, rounds {np.mean([x['rounds'] for x in a]):.0f}, lane util in walks {np.mean([x['util'] for x in a]):.2f}, "
           f"walk VALU by kind {np.round(np.mean([x['per_kind'] for x in a], axis=0))});  without kind batching {np.mean([x['cost'] for x in a0]) / ca:.2f}x")
-    for TH in (8, 16, 24, 32, 48):
+    for TH in (4, 8, 16):
+        d = [sim_d(l, SH, TH) for l in logs]
+        print(f"    (D, TH={TH:2d}) {np.mean([x['cost'] for x in d]) / ca:.2f}x  rounds {np.mean([x['rounds'] for x in d]):.0f}, lane util {np.mean([x['util'] for x in d]):.2f}, wave iterations {np.mean([x['wave_iters'] for x in d]):.0f}")
+    for G in (4,):
+        for TH in (8,):
+            c = [sim_c(l, SH, G, TH) for l in logs]
+            print(f"    (C, G={G}, TH={TH:2d}) {np.mean([x['cost'] for x in c]) / ca:.2f}x  rounds {np.mean([x['rounds'] for x in c]):.0f}, lane util {np.mean([x['util'] for x in c]):.2f}, wave iterations {np.mean([x['wave_iters'] for x in c]):.0f}")
+    for TH in (16, 32):
         b = [sim_b(l, SH, TH) for l in logs]
         print(f"    (B, TH={TH:2d}) {np.mean([x['cost'] for x in b]) / ca:.2f}x  shading rounds {np.mean([x['shades'] for x in b]):.0f}, lane util {np.mean([x['util'] for x in b]):.2f}, wave iterations {np.mean([x['wave_iters'] for x in b]):.0f} vs {np.mean([x['wave_iters'] for x in a]):.0f}")

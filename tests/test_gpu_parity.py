@@ -222,14 +222,14 @@ def test_beam_prepass_never_changes_a_record(tracer_cls, scene64, scene1024):
         plain_rect = tr.draw_frame(cam, rect)
         for beam in (8, 16, 32, 64):
             tr.set_beam(beam)
-            for fused in (1, 0, 2, 3):                  # persistent launch with queues / beam kernel, then trace kernel / joint launch / automatic
+            for fused in (1, 0, 2, 3, 4, 5):            # persistent launch with queues / beam kernel, then trace kernel / joint launch / automatic / list-fed joint / list-fed walk
                 tr.set_fused(fused)
                 assert records_equal(tr.draw_frame(cam).reshape(-1), plain.reshape(-1)).all(), (beam, fused)
                 assert records_equal(tr.draw_frame(cam, rect).reshape(-1), plain_rect.reshape(-1)).all(), (beam, fused)
     cam = cams[1]
     tr.set_beam(0)
     plain = tr.draw_frame(cam)
-    for beam, tile, n_ranks, fused in [(32, 32, 8, 1), (32, 48, 3, 1), (16, 64, 2, 1), (64, 64, 5, 1), (32, 32, 8, 0), (16, 64, 2, 0), (32, 32, 8, 2), (16, 64, 3, 2)]:
+    for beam, tile, n_ranks, fused in [(32, 32, 8, 1), (32, 48, 3, 1), (16, 64, 2, 1), (64, 64, 5, 1), (32, 32, 8, 0), (16, 64, 2, 0), (32, 32, 8, 2), (16, 64, 3, 2), (32, 32, 8, 4), (32, 48, 3, 4), (16, 64, 3, 5), (32, 32, 8, 3)]:
         tr.set_beam(beam)
         tr.set_fused(fused)
         per = tr.tiles_for_rank(tile, 0, n_ranks)
@@ -254,7 +254,7 @@ def test_beam_prepass_never_changes_a_record(tracer_cls, scene64, scene1024):
         plain = tr.draw_frame(cam)
         for beam in (8, 32):
             tr.set_beam(beam)
-            for fused in (1, 0, 2):
+            for fused in (1, 0, 2, 4, 5):
                 tr.set_fused(fused)
                 assert records_equal(tr.draw_frame(cam).reshape(-1), plain.reshape(-1)).all(), (k, beam, fused)
     with pytest.raises(Exception):
@@ -291,7 +291,7 @@ def test_beam_prepass_random_cameras_and_odd_worlds(tracer_cls):
         plain = tr.draw_frame(cam).reshape(-1)
         for beam in (8, 32):
             tr.set_beam(beam)
-            for fused in (1, 0, 2):
+            for fused in (1, 0, 2, 4, 5):
                 tr.set_fused(fused)
                 assert records_equal(tr.draw_frame(cam).reshape(-1), plain).all(), (k, beam, fused)
         if k % 10 == 0:
@@ -353,7 +353,7 @@ def test_beam_visit_budget_exhaustion_is_conservative(tracer_cls, scene1024):
             tr.set_beam_budget(budget)
             assert records_equal(tr.draw_frame(cam).reshape(-1), want).all(), (pose, budget)
             assert records_equal(tr.draw_frame(cam, rect).reshape(-1), want_rect).all(), (pose, budget)
-            for fused in (1, 0, 2):
+            for fused in (1, 0, 2, 4, 5):
                 tr.set_fused(fused)
                 assert records_equal(tr.draw_frame(cam).reshape(-1), want).all(), (pose, budget, fused)
     cam = W.scene_camera(1024, 1, Wd, Ht, SEED)
@@ -368,17 +368,17 @@ def test_beam_visit_budget_exhaustion_is_conservative(tracer_cls, scene1024):
     tr.shutdown()
 
 
-def test_joint_launch_prefix_and_search_wave_fallback(tracer_cls, scene1024):
-    """Joint launch (blok_hip_set_fused 2 and the automatic default 3): searches and walk waves in one grid; with an order in force
-    walk waves exist only for the tiles that walked when the order was made, and a tile that is live now without one is walked by
-    its search wave.  4K over 1024^3: a static camera long enough for the order to be adopted; a camera creeping by 0.05 degrees per
-    frame (inside the order's 0.25-degree window, so tiles at the silhouettes change sides); a cap on the walk waves that leaves
-    most of the frame to the search waves; a jump to another pose and back — every frame equals the two-launch form's, records and
-    RGBA8, and no wave ever gave up waiting."""
+def test_list_launches_equal_the_two_launch_form(tracer_cls, scene1024):
+    """List launches (blok_hip_set_fused 4, 5 and the automatic default 3): the walk waves take their wave tiles from the list the
+    frame's own searches publish, and the walk grid is sized from the previous launch's list — a hint.  4K over 1024^3: a static
+    camera; a camera creeping by 0.05 degrees per frame; jumps between poses; a view of nothing but sky followed by the top-down pose
+    (the hint says "empty", every walk wave strides over several entries); the plain joint form 2 — every frame equals the
+    two-launch form's, records and RGBA8, and no wave ever gave up waiting.  Then a rectangle, and frames in flight on three streams
+    and from two contexts (the automatic form keeps searches and walk apart there)."""
     import torch
     cm, pw = scene1024
     Wd, Ht = 3840, 2160
-    ref = tracer_cls(Wd, Ht).init(); ref.add_world(pw); ref.set_fused(0); ref.set_tile_ordering(0)
+    ref = tracer_cls(Wd, Ht).init(); ref.add_world(pw); ref.set_fused(0)
     tr = tracer_cls(Wd, Ht).init(); tr.add_world(pw)
     hits = torch.zeros((Wd * Ht, 4), dtype=torch.int32, device="cuda"); rgba = torch.zeros(Wd * Ht, dtype=torch.int32, device="cuda")
     want_h = torch.zeros_like(hits); want_c = torch.zeros_like(rgba)
@@ -391,84 +391,60 @@ def test_joint_launch_prefix_and_search_wave_fallback(tracer_cls, scene1024):
         assert torch.equal(hits, want_h) and torch.equal(rgba, want_c), tag
 
     centre = np.array([512.0, 60.0, 512.0])
-    for form in (3, 2):
+    sky = W.camera_look_at((512.0, 900.0, 512.0), (600.0, 2000.0, 700.0), 60.0, Wd, Ht)       # looks up and away: no ray hits anything
+    kinds = {3: 4, 4: 4, 5: 5, 2: 3}                 # what each form is launched as when the device is otherwise idle
+    for form in (3, 4, 5, 2):
         tr.set_fused(form)
         for pose in (0, 2):
             cam = W.scene_camera(1024, pose, Wd, Ht, SEED)
-            for k in range(24):                      # the order is sorted behind frame 1-2 and adopted a few frames later
+            for k in range(4):
                 same(cam, (form, pose, "static", k))
+            assert tr.last_launch_kind() == kinds[form], (form, tr.last_launch_kind())
             pos = np.array(cam["pos"][0], dtype=np.float64) - centre
-            for k in range(1, 13):                   # creep around the world's centre: 0.05 degrees per frame
+            for k in range(1, 7):                    # creep around the world's centre: 0.05 degrees per frame
                 a = np.radians(0.05 * k)
                 p = centre + np.array([pos[0] * np.cos(a) - pos[2] * np.sin(a), pos[1], pos[0] * np.sin(a) + pos[2] * np.cos(a)])
                 same(W.camera_look_at(tuple(p), tuple(centre), 60.0, Wd, Ht), (form, pose, "creep", k))
-            for k in range(12):
-                same(cam, (form, pose, "back", k))
-            for limit in (20000, 1000, 1):           # most of the frame is walked by the search waves
-                tr.set_joint_prefix_limit(limit)
-                for k in range(3):
-                    same(cam, (form, pose, "limit", limit, k))
-            tr.set_joint_prefix_limit(0)
             same(W.scene_camera(1024, 1, Wd, Ht, SEED), (form, pose, "jump"))
             same(cam, (form, pose, "return"))
+        for k in range(2):
+            same(sky, (form, "sky", k))
+            assert int((hits[:, 3] >> 24).sum().item()) == 0
+        same(W.scene_camera(1024, 2, Wd, Ht, SEED), (form, "after sky"))      # the smallest walk grid over the longest list
+        same(W.scene_camera(1024, 1, Wd, Ht, SEED), (form, "after sky, inside"))
     assert tr.frame_queue_stalls() == 0
-    # a rectangle of the frame, and frames in flight on three streams (the automatic form falls back to two launches there)
+    # a rectangle of the frame
     cam = W.scene_camera(1024, 0, Wd, Ht, SEED)
     tr.set_fused(3)
     rect = (640, 360, 2560, 1440)
-    for k in range(12):
+    for k in range(4):
         assert records_equal(tr.draw_frame(cam, rect).reshape(-1), ref.draw_frame(cam, rect).reshape(-1)).all(), ("rect", k)
+    odd = (333, 77, 1001, 515)                       # cut wave tiles and beam tiles on every side
+    assert records_equal(tr.draw_frame(cam, odd).reshape(-1), ref.draw_frame(cam, odd).reshape(-1)).all()
+    # frames in flight on three streams, and a second context rendering at the same time
     streams = [torch.cuda.Stream() for _ in range(3)]
     bufs = [(torch.zeros_like(hits), torch.zeros_like(rgba)) for _ in streams]
+    other = tracer_cls(Wd, Ht).init(); other.add_world(pw)
+    o_h = torch.zeros_like(hits); o_c = torch.zeros_like(rgba); o_stream = torch.cuda.Stream()
     ref.draw_frame_device(cam, want_h.data_ptr(), want_c.data_ptr())
-    for form in (3, 2):
-        tr.set_fused(form)
+    for form in (3, 4, 2):
+        tr.set_fused(form); other.set_fused(form)
+        seen = set()
         for k in range(30):
             tr.draw_frame_device(cam, bufs[k % 3][0].data_ptr(), bufs[k % 3][1].data_ptr(), stream=streams[k % 3].cuda_stream)
+            seen.add(tr.last_launch_kind())
+            if k % 5 == 0:
+                other.draw_frame_device(cam, o_h.data_ptr(), o_c.data_ptr(), stream=o_stream.cuda_stream)
         torch.cuda.synchronize()
-        for b in bufs:
+        for b in bufs + [(o_h, o_c)]:
             assert torch.equal(b[0], want_h) and torch.equal(b[1], want_c), ("in flight", form)
-        # the automatic form never has two joint launches in flight; FORCED joint launches in flight may wait for each other's
-        # searches in a circle until some waves give up and start at the ray origin (same frame, as just checked)
+        # the automatic form never has two joint launches in flight on a device; FORCED joint launches in flight may wait for each
+        # other's searches until some waves give up (same frame, as just checked)
         if form == 3:
-            assert tr.frame_queue_stalls() == 0
-    tr.shutdown(); ref.shutdown()
+            assert 5 in seen, seen
+            assert tr.frame_queue_stalls() == 0 and other.frame_queue_stalls() == 0
+    tr.shutdown(); ref.shutdown(); other.shutdown()
 
-
-def test_tile_ordering_is_pure_scheduling(tracer_cls, scene1024):
-    """Longest-first scheduling (tile_order.hip): the walk's workgroups take their tiles in descending order of the clocks the
-    tiles' waves spent in the previous frame.  Whatever the history — first frame, repeated camera, a camera that jumps between
-    poses (stale costs), rectangles in between (another geometry resets the history), three streams with frames in flight
-    sharing the cost buffer while sorts read it — every frame equals the frame of a context with ordering off."""
-    import torch
-    cm, pw = scene1024
-    Wd, Ht = 3840, 2160
-    a, b = tracer_cls(Wd, Ht).init(), tracer_cls(Wd, Ht).init()
-    b.set_tile_ordering(False)
-    a.add_world(pw); b.add_world(pw)
-    cams = [W.scene_camera(1024, p, Wd, Ht, SEED) for p in (0, 0, 0, 1, 2, 0, 1, 1)]
-    want = {}
-    for k, cam in enumerate(cams):
-        key = cam.tobytes()
-        if key not in want:
-            want[key] = b.draw_frame(cam).reshape(-1)
-        assert records_equal(a.draw_frame(cam).reshape(-1), want[key]).all(), k
-        if k in (2, 5):
-            rect = (512, 256, 2048, 1024)                       # 32768 wave tiles: ordered too, own geometry
-            for _ in range(2):
-                assert records_equal(a.draw_frame(cam, rect).reshape(-1), b.draw_frame(cam, rect).reshape(-1)).all(), k
-    streams = [torch.cuda.Stream() for _ in range(3)]
-    outs = [torch.zeros((Ht * Wd, 4), dtype=torch.int32, device="cuda") for _ in range(3)]
-    ref = {p: torch.from_numpy(want[W.scene_camera(1024, p, Wd, Ht, SEED).tobytes()].view(np.int32).reshape(-1, 4)).cuda() for p in (0, 1)}
-    for k in range(12):
-        pose = (k // 3) % 2
-        cam = W.scene_camera(1024, pose, Wd, Ht, SEED)
-        for j in range(3):
-            a.draw_frame_device(cam, outs[j].data_ptr(), 0, stream=streams[j].cuda_stream)
-        torch.cuda.synchronize()
-        for o in outs:
-            assert torch.equal(o, ref[pose]), k
-    a.shutdown(); b.shutdown()
 
 
 def test_degenerate_cameras_are_refused(tracer_cls, scene64):
@@ -643,10 +619,10 @@ def test_config4_2048_svo_4k_tiles(tracer_cls):
         tr.set_beam(0)
         assert records_equal(tr.draw_frame(cam_x).reshape(-1), got.reshape(-1)).all()
         tr.set_beam(32)
-        # every launch form, each long enough on one view for the tile order (and the joint launch's live prefix) to come into force
-        for form in (0, 2, 3):
+        # every launch form, a few frames each (the list forms size their second launch from the first one's list)
+        for form in (0, 2, 3, 4, 5):
             tr.set_fused(form)
-            for k in range(14):
+            for k in range(3):
                 assert records_equal(tr.draw_frame(cam_x).reshape(-1), got.reshape(-1)).all(), (form, k)
     assert tr.frame_queue_stalls() == 0
     n_ranks, tile = 8, 32
@@ -865,7 +841,7 @@ def test_power_of_two_voxel_sizes(tracer_cls, vs):
         assert ctr["hits"] > 50
         for beam in (32, 0, 8):
             tr.set_beam(beam)
-            for fused in (0, 1, 2):
+            for fused in (0, 1, 2, 4, 5):
                 tr.set_fused(fused)
                 assert records_equal(tr.draw_frame(cam).reshape(-1), ref).all(), (k, beam, fused)
         tr.set_beam(32); tr.set_fused(3)
