@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--fused", type=int, default=3, help="launch form of a frame (blok_hip_set_fused): 0 = beam kernel then trace kernel, 1 = one persistent launch with work queues (measured slower), "
                     "2 = joint launch (searches and one walk wave per wave tile in one grid), 4 = list-fed joint launch (walk waves take the live wave tiles from the list the frame's searches publish), "
                     "5 = beam kernel, then list-fed walk, 3 = automatic: 4 when a launch has the device to itself, else 5")
+    ap.add_argument("--tile-ordering", type=int, default=8, help="camera at rest: longest-first scheduling of the walk from earlier frames' per-wave clocks, re-sorted every N launches (0 = off)")
+    ap.add_argument("--list-classes", type=int, default=1, help="list launches: order the walk by the previous frame's measured cost in four classes (0 = the order the searches finish in)")
     ap.add_argument("--orbit", type=float, default=0.0, help="degrees the camera turns around the world's centre per frame (0 = static camera)")
     ap.add_argument("--dense-dda", action="store_true", help="BASELINE configs[1]: upload the scene as a dense id grid and trace with the dense-grid kernel (N = 1, --n <= 512)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -205,6 +207,8 @@ def main():
         stats = tracer.add_world(packed)                  # world resident in HBM from here on
     tracer.set_beam(args.beam)
     tracer.set_fused(args.fused)
+    tracer.set_list_classes(bool(args.list_classes))
+    tracer.set_tile_ordering(args.tile_ordering)
 
     if args.frames_in_flight <= 0:
         args.frames_in_flight = 3 if world_size <= 2 else 4

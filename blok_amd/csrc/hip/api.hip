@@ -248,6 +248,102 @@ void forget_device_activity(const blok_hip_ctx* ctx) {
         if (it->first.first == ctx) { (void)hipEventDestroy(it->second); it = act.last.erase(it); } else ++it;
 }
 
+// ---- longest-first order of a camera at rest (api_internal.h: TileOrder; decisions in launch_policy.h: plan_order) -------------------
+// Has the view hardly changed?  Within ~0.25 degree: direction, position as seen from the world's centre, and the same lens.
+static bool camera_near(const blok_hip_ctx* ctx, const blok_camera& a, const blok_camera& b) {
+    const float dot = a.fwd[0] * b.fwd[0] + a.fwd[1] * b.fwd[1] + a.fwd[2] * b.fwd[2];
+    const float half = 0.5f * std::ldexp(1.0f, 2 * static_cast<int>(ctx->stats.levels)) * ctx->world_voxel_size;
+    float d2 = 0.0f, r2 = 0.0f;
+    for (int k = 0; k < 3; ++k) {
+        const float centre = static_cast<float>(ctx->stats.origin[k]) * ctx->world_voxel_size + half;
+        d2 += (a.pos[k] - b.pos[k]) * (a.pos[k] - b.pos[k]);
+        r2 += (a.pos[k] - centre) * (a.pos[k] - centre);
+    }
+    return dot > 0.99999f && d2 <= 1.6e-5f * std::max(r2, 1.0f) && std::fabs(a.tan_half_fov - b.tan_half_fov) < 1e-6f && std::fabs(a.aspect - b.aspect) < 1e-6f;
+}
+
+static void free_order(blok_hip_ctx* ctx) {
+    auto& O = ctx->order;
+    for (void* p : {static_cast<void*>(O.d_cost), static_cast<void*>(O.d_iota), static_cast<void*>(O.d_order[0]), static_cast<void*>(O.d_order[1]), static_cast<void*>(O.d_rank_of[0]),
+                    static_cast<void*>(O.d_rank_of[1]), static_cast<void*>(O.d_keys_in), static_cast<void*>(O.d_keys), O.d_temp})
+        if (p) (void)hipFree(p);
+    O.d_cost = O.d_iota = O.d_order[0] = O.d_order[1] = O.d_rank_of[0] = O.d_rank_of[1] = O.d_keys_in = O.d_keys = nullptr;
+    O.d_temp = nullptr; O.capacity = 0;
+}
+
+// Before an orderable launch: buffers for the launch geometry, adoption of a finished sort, the plan; fills args.order / rank_of / launched / cost_out.
+static int order_before_launch(blok_hip_ctx* ctx, blok::TraceArgs& args, uint32_t blocks, hipStream_t stream, blok::OrderPlan* plan) {
+    auto& O = ctx->order;
+    const uint32_t key[6] = {args.x0, args.y0, args.w, args.h, ctx->width, ctx->height};
+    if (O.capacity < blocks) {
+        // (Re)grown for the largest rectangle seen — the full frame the first time a frame is drawn; the only device-wide wait of the
+        // ordering, and only because frames in flight and a pending sort may use the old buffers.
+        BLOK_HIP_TRY(ctx, hipDeviceSynchronize());
+        free_order(ctx);
+        const uint32_t want = std::max<uint32_t>(blocks, blok::rect_grid_blocks(ctx->width, ctx->height));
+        const size_t bytes = static_cast<size_t>(want) * sizeof(uint32_t);
+        for (uint32_t** p : {&O.d_cost, &O.d_iota, &O.d_order[0], &O.d_order[1], &O.d_rank_of[0], &O.d_rank_of[1], &O.d_keys_in, &O.d_keys})
+            BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(p), bytes));
+        if (!O.h_live) BLOK_HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&O.h_live), 2 * sizeof(uint32_t), hipHostMallocDefault));
+        O.temp_bytes = blok::tile_order_temp_bytes(want);
+        BLOK_HIP_TRY(ctx, hipMalloc(&O.d_temp, O.temp_bytes ? O.temp_bytes : 16));
+        if (!O.done) BLOK_HIP_TRY(ctx, hipEventCreateWithFlags(&O.done, hipEventDisableTiming));
+        BLOK_HIP_TRY(ctx, blok::launch_iota(O.d_iota, want, stream));          // the identity, whatever the geometry: written once
+        O.capacity = want;
+        std::memset(O.key, 0xFF, sizeof(O.key));
+    }
+    if (std::memcmp(key, O.key, sizeof(key)) != 0) {
+        // another launch geometry starts in natural order with no costs; in stream order, nothing waits (a sort still pending for the old
+        // geometry finishes into a buffer nobody will adopt: its event is simply never asked again)
+        BLOK_HIP_TRY(ctx, hipMemsetAsync(O.d_cost, 0, static_cast<size_t>(blocks) * sizeof(uint32_t), stream));
+        std::memcpy(O.key, key, sizeof(key));
+        O.current = -1; O.pending = false; O.frames_since_sort = 0; O.still_frames = 0; O.interval_now = O.interval;
+    }
+    if (O.pending && hipEventQuery(O.done) == hipSuccess) {              // the sort launched some frames ago has finished
+        O.current = O.target;
+        O.live[O.current] = O.h_live[O.current];                         // written by the device before the event
+        O.pending = false; O.frames_since_sort = 0;
+    }
+    (void)hipGetLastError();                                             // hipErrorNotReady is an answer, not a failure
+    blok::OrderFacts f{};
+    f.enabled = true; f.have_order = O.current >= 0;
+    f.near_order_view = f.have_order && camera_near(ctx, args.cam, O.cam[O.current]);
+    f.near_last_view = camera_near(ctx, args.cam, O.last_cam);
+    f.sort_pending = O.pending; f.still_frames = O.still_frames;
+    f.frames_since_sort = O.frames_since_sort; f.interval = O.interval; f.interval_now = O.interval_now;
+    *plan = blok::plan_order(f);
+    O.still_frames = plan->still_frames; O.last_cam = args.cam;
+    args.order = plan->use_order ? O.d_order[O.current] : nullptr;
+    args.cost_out = plan->measure ? O.d_cost : nullptr;                  // a camera in motion is not measured (nor sorted for)
+    if (args.order) { args.rank_of = O.d_rank_of[O.current]; args.launched = O.live[O.current]; }
+    return BLOK_OK;
+}
+
+// After it: the sort, if the plan says so — on the LAUNCH stream, behind the frame (a stream of its own would be one HIP stream more than
+// the hardware queues the frame streams and the null stream occupy: measured, that alone costs 18 % of the pipelined rate).
+static int order_after_launch(blok_hip_ctx* ctx, const blok::TraceArgs& args, uint32_t blocks, hipStream_t stream, const blok::OrderPlan& plan) {
+    auto& O = ctx->order;
+    O.frames_since_sort += 1;
+    O.interval_now = plan.next_interval_now;
+    if (!plan.start_sort) return BLOK_OK;
+    const int target = O.current == 0 ? 1 : 0;
+    // Nothing still running may read the target buffer: it was last current before the previous adoption, and every launch since then,
+    // on every stream of this context, is behind that stream's latest frame-launch event.
+    {
+        DeviceActivity& act = device_activity(ctx->device);
+        std::lock_guard<std::mutex> g(act.lock);
+        for (auto& kv : act.last) if (kv.first.first == ctx && kv.first.second != stream) BLOK_HIP_TRY(ctx, hipStreamWaitEvent(stream, kv.second, 0));
+    }
+    // the sort reads a SNAPSHOT of the costs: frames in flight on other streams keep writing the live buffer, and a radix sort that saw a
+    // key change between its histogram and its scatter would not produce a permutation
+    BLOK_HIP_TRY(ctx, hipMemcpyAsync(O.d_keys_in, O.d_cost, static_cast<size_t>(blocks) * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+    BLOK_HIP_TRY(ctx, blok::launch_tile_order_sort(O.d_keys_in, O.d_keys, O.d_iota, O.d_order[target], O.d_temp, O.temp_bytes, blocks, stream));
+    BLOK_HIP_TRY(ctx, blok::launch_tile_order_finish(O.d_order[target], O.d_keys, blocks, O.d_rank_of[target], O.h_live + target, stream));
+    BLOK_HIP_TRY(ctx, hipEventRecord(O.done, stream));
+    O.target = target; O.cam[target] = args.cam; O.pending = true;
+    return BLOK_OK;
+}
+
 // The stream's give-up counter (joint and list forms).
 static int gave_up_counter(blok_hip_ctx* ctx, hipStream_t stream, uint32_t** out) {
     auto& slot = ctx->beam_buffers[stream];
@@ -281,7 +377,7 @@ static int live_list(blok_hip_ctx* ctx, blok::TraceArgs& args, hipStream_t strea
     if (!slot.list_ctl) {
         BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&slot.list_ctl), blok::kListSegments * blok::kListCtlWords * sizeof(unsigned long long)));
         BLOK_HIP_TRY(ctx, hipMemsetAsync(slot.list_ctl, 0, blok::kListSegments * blok::kListCtlWords * sizeof(unsigned long long), stream));
-        BLOK_HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&slot.list_hint), blok::kListSegments * sizeof(uint32_t), hipHostMallocDefault));
+        BLOK_HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&slot.list_hint), blok::kListSegments * blok::kListClasses * sizeof(uint32_t), hipHostMallocDefault));
         slot.list_hint_valid = false;
     }
     const bool wrapped = slot.list_serial + 1u >= (1u << blok::kListSerialBits);
@@ -289,11 +385,11 @@ static int live_list(blok_hip_ctx* ctx, blok::TraceArgs& args, hipStream_t strea
         if (slot.list_capacity < seg_capacity) {
             if (slot.list_entries) { BLOK_HIP_TRY(ctx, hipStreamSynchronize(stream)); (void)hipFree(slot.list_entries); }
             slot.list_entries = nullptr; slot.list_capacity = 0;
-            BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&slot.list_entries), seg_capacity * blok::kListSegments * sizeof(unsigned long long)));
+            BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&slot.list_entries), seg_capacity * blok::kListSegments * blok::kListClasses * sizeof(unsigned long long)));
             slot.list_capacity = seg_capacity;
         }
         // every entry empty; also when the 20-bit serial starts over, so that no entry of a million launches ago can pass for a new one
-        BLOK_HIP_TRY(ctx, hipMemsetAsync(slot.list_entries, 0, slot.list_capacity * blok::kListSegments * sizeof(unsigned long long), stream));
+        BLOK_HIP_TRY(ctx, hipMemsetAsync(slot.list_entries, 0, slot.list_capacity * blok::kListSegments * blok::kListClasses * sizeof(unsigned long long), stream));
         if (wrapped) slot.list_serial = 0;
     }
     slot.list_serial += 1u;
@@ -303,14 +399,36 @@ static int live_list(blok_hip_ctx* ctx, blok::TraceArgs& args, hipStream_t strea
     return gave_up_counter(ctx, stream, &args.joint_gave_up);
 }
 
-// What the previous list launch on this stream left in pinned memory: its longest segment (a sizing hint, launch_policy.h).
-static bool list_hint(const blok_hip_ctx* ctx, hipStream_t stream, uint32_t geometry_key, uint32_t* per_segment) {
+// What the previous list launch on this stream left in pinned memory: per class its longest list (sizing hints, launch_policy.h).
+static bool list_hint(const blok_hip_ctx* ctx, hipStream_t stream, uint32_t geometry_key, uint32_t per_class[blok::kListClasses]) {
     auto it = ctx->beam_buffers.find(stream);
     if (it == ctx->beam_buffers.end() || !it->second.list_hint || !it->second.list_hint_valid || it->second.list_hint_key != geometry_key) return false;
-    uint32_t longest = 0;
-    for (uint32_t k = 0; k < blok::kListSegments; ++k) longest = std::max(longest, it->second.list_hint[k]);      // plain reads of words the device may be writing: a hint
-    *per_segment = longest;
+    for (uint32_t c = 0; c < blok::kListClasses; ++c) {
+        per_class[c] = 0;
+        for (uint32_t k = 0; k < blok::kListSegments; ++k) per_class[c] = std::max(per_class[c], it->second.list_hint[k * blok::kListClasses + c]);      // plain reads of words the device may be writing: hints
+    }
     return true;
+}
+
+// The context's cost buffer for a rectangle launch (trace_kernels.h: cost classes): one word per wave tile of the launch geometry.
+static int list_costs(blok_hip_ctx* ctx, blok::TraceArgs& args, uint32_t wave_tiles, hipStream_t stream) {
+    const uint32_t key[6] = {args.x0, args.y0, args.w, args.h, ctx->width, ctx->height};
+    if (ctx->list_cost_capacity < wave_tiles || std::memcmp(key, ctx->list_cost_key, sizeof(key)) != 0) {
+        if (ctx->list_cost_capacity < wave_tiles) {
+            if (ctx->d_list_cost) { BLOK_HIP_TRY(ctx, hipDeviceSynchronize()); (void)hipFree(ctx->d_list_cost); }      // frames in flight on other streams still write it
+            ctx->d_list_cost = nullptr; ctx->list_cost_capacity = 0;
+            BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_list_cost), static_cast<size_t>(wave_tiles) * sizeof(uint32_t)));
+            ctx->list_cost_capacity = wave_tiles;
+        }
+        BLOK_HIP_TRY(ctx, hipMemsetAsync(ctx->d_list_cost, 0, ctx->list_cost_capacity * sizeof(uint32_t), stream));      // another geometry: nothing is known
+        std::memcpy(ctx->list_cost_key, key, sizeof(key));
+        ctx->list_has_prev_cam = false;
+    }
+    args.list.cost = ctx->d_list_cost;
+    args.list.has_prev = ctx->list_has_prev_cam ? 1u : 0u;
+    args.list.prev_cam = ctx->list_prev_cam;
+    ctx->list_prev_cam = args.cam; ctx->list_has_prev_cam = true;        // the costs this launch leaves are those of this camera
+    return BLOK_OK;
 }
 
 // Rect / Tiles launches run the beam pre-pass first, on the same stream (tiles_of_rank: Tiles only; frames: several frames of a rank's
@@ -327,7 +445,7 @@ int launch_timed(blok_hip_ctx* ctx, blok::RayMode mode, blok::TraceArgs args, ui
     facts.one_wave_blocks = blok::kBlock == 64;
     facts.wave_tiles = blocks * n_frames;
     const uint32_t geometry_key = blocks * 31u + n_beams * n_frames;
-    facts.have_hint = list_hint(ctx, stream, geometry_key, &facts.hint_per_segment);
+    facts.have_hint = list_hint(ctx, stream, geometry_key, facts.hint);
     facts.device_busy = facts.has_beam && ctx->launch_form == blok::kFormAuto && device_busy_elsewhere(ctx, stream);
     blok::LaunchPlan plan = blok::plan_launch(facts);
     if (frames && (plan.kind == blok::LaunchKind::Queues || plan.kind == blok::LaunchKind::Joint)) plan.kind = blok::LaunchKind::TwoLaunches;      // several frames per launch: the two-launch or the list forms
@@ -343,22 +461,35 @@ int launch_timed(blok_hip_ctx* ctx, blok::RayMode mode, blok::TraceArgs args, ui
         const uint32_t per_search = (args.beam_tile / blok::kWaveW) * (args.beam_tile / blok::kWaveH);
         const int rc = live_list(ctx, args, stream, n_beams * n_frames, per_search);
         if (rc != BLOK_OK) return rc;
-        args.list.walkers_per_seg = plan.walkers / blok::kListSegments;
+        for (uint32_t c = 0; c < blok::kListClasses; ++c) args.list.walkers[c] = plan.walkers_per_class[c];
+        if (mode == blok::RayMode::Rect && ctx->list_classes) { const int rc2 = list_costs(ctx, args, blocks, stream); if (rc2 != BLOK_OK) return rc2; }
         auto& slot = ctx->beam_buffers[stream];
         slot.list_hint_valid = true; slot.list_hint_key = geometry_key;      // the searches of this launch write the hint
     }
+    // static forms over a rectangle: longest-first order of a camera at rest, and walk waves for its live prefix only
+    const bool static_form = plan.kind == blok::LaunchKind::TwoLaunches || plan.kind == blok::LaunchKind::Joint;
+    const bool orderable = ctx->order.enabled && static_form && mode == blok::RayMode::Rect && !frames && n_beams && blocks >= blok::kOrderMinTiles && BLOK_XCD_MAP == 0;
+    blok::OrderPlan order_plan{};
+    if (orderable) { const int rc = order_before_launch(ctx, args, blocks, stream, &order_plan); if (rc != BLOK_OK) return rc; }
+    uint32_t walk_blocks = blocks;
+    if (args.order && args.rank_of && plan.may_use_prefix && args.launched <= blocks) {
+        // the search wave of a beam tile that is live now walks any wave tile of its own without a walk wave (a changed view), and writes
+        // the miss pixels of the empty ones
+        if (ctx->order.prefix_limit && args.launched > ctx->order.prefix_limit) args.launched = ctx->order.prefix_limit;      // tests: more work for the search waves
+        walk_blocks = args.launched;
+    } else { args.rank_of = nullptr; args.launched = 0u; }
     if (ctx->timing) BLOK_HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, stream));
-    args.miss_in_walk = (plan.kind == blok::LaunchKind::TwoLaunches || plan.kind == blok::LaunchKind::Joint) && ctx->miss_in_walk ? 1u : 0u;
+    args.miss_in_walk = static_form && !args.rank_of && ctx->miss_in_walk ? 1u : 0u;
     switch (plan.kind) {
         case blok::LaunchKind::Walk:
             if (frames) blok::launch_tile_frames(args, fr, stream); else blok::launch_trace(mode, args, blocks, stream);
             break;
         case blok::LaunchKind::TwoLaunches:
             if (frames) blok::launch_tile_frames(args, fr, stream);
-            else { blok::launch_beam(mode, args, n_beams, stream); blok::launch_trace(mode, args, blocks, stream); }
+            else { blok::launch_beam(mode, args, n_beams, stream); blok::launch_trace(mode, args, walk_blocks, stream); }
             break;
         case blok::LaunchKind::Queues: blok::launch_frame(mode, args, queue, frame_blocks, stream); break;
-        case blok::LaunchKind::Joint: blok::launch_joint(mode, args, n_beams, blocks, stream); break;
+        case blok::LaunchKind::Joint: blok::launch_joint(mode, args, n_beams, walk_blocks, stream); break;
         case blok::LaunchKind::ListJoint: blok::launch_list_joint(mode, args, frames ? &fr : nullptr, n_beams * n_frames, plan.walkers, stream); break;
         case blok::LaunchKind::ListTwoLaunches:
             if (frames) blok::launch_beam_frames(args, fr, stream); else blok::launch_beam(mode, args, n_beams, stream);
@@ -367,7 +498,8 @@ int launch_timed(blok_hip_ctx* ctx, blok::RayMode mode, blok::TraceArgs args, ui
     }
     BLOK_HIP_TRY(ctx, hipGetLastError());
     if (ctx->timing) { BLOK_HIP_TRY(ctx, hipEventRecord(ctx->ev_end, stream)); ctx->timed = true; }
-    if (facts.has_beam && ctx->launch_form == blok::kFormAuto) return note_frame_launch(ctx, stream);
+    if (orderable) { const int rc = order_after_launch(ctx, args, blocks, stream, order_plan); if (rc != BLOK_OK) return rc; }
+    if (facts.has_beam) return note_frame_launch(ctx, stream);          // (behind the sort, if one was started: it belongs to this launch)
     return BLOK_OK;
 }
 
@@ -452,6 +584,10 @@ void blok_hip_destroy(blok_hip_ctx* ctx) {
             if (p) (void)hipFree(p);
         if (kv.second.list_hint) (void)hipHostFree(kv.second.list_hint);
     }
+    if (ctx->d_list_cost) (void)hipFree(ctx->d_list_cost);
+    free_order(ctx);
+    if (ctx->order.h_live) (void)hipHostFree(ctx->order.h_live);
+    if (ctx->order.done) (void)hipEventDestroy(ctx->order.done);
     if (ctx->d_accum) (void)hipFree(ctx->d_accum);
     if (ctx->d_color) (void)hipFree(ctx->d_color);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
@@ -716,23 +852,26 @@ int blok_hip_trace_wave_tiles_device(blok_hip_ctx* ctx, const blok_camera* cam, 
     rc = live_list(ctx, a, stream, static_cast<uint32_t>(n_tiles), 1u);
     if (rc != BLOK_OK) return rc;
     const size_t cap = a.list.seg_capacity;
-    std::vector<unsigned long long> entries(cap * blok::kListSegments, 0ull), ctl(blok::kListSegments * blok::kListCtlWords, 0ull);
+    const uint32_t cls = blok::kListUnknownClass;          // one class: the caller's order is the order
+    std::vector<unsigned long long> entries(cap * blok::kListSegments * blok::kListClasses, 0ull), ctl(blok::kListSegments * blok::kListCtlWords, 0ull);
     uint32_t count[blok::kListSegments] = {};
     for (size_t i = 0; i < n_tiles; ++i) {                 // entry i -> segment i mod 8, slot i / 8: walk workgroup i takes it
         const uint32_t seg = static_cast<uint32_t>(i % blok::kListSegments);
         const float t0 = t0_host ? t0_host[i] : 0.0f;
         uint32_t bits; std::memcpy(&bits, &t0, sizeof(bits));
-        entries[seg * cap + i / blok::kListSegments] = (static_cast<unsigned long long>(a.list.serial) << 44) | (static_cast<unsigned long long>(tiles_host[i]) << 23) | (bits >> 8);
+        entries[(seg * blok::kListClasses + cls) * cap + i / blok::kListSegments] = (static_cast<unsigned long long>(a.list.serial) << 44) | (static_cast<unsigned long long>(tiles_host[i]) << 23) | (bits >> 8);
         count[seg] += 1u;
     }
-    for (uint32_t seg = 0; seg < blok::kListSegments; ++seg) ctl[seg * blok::kListCtlWords + blok::kListFinal] = (static_cast<unsigned long long>(a.list.serial) << 32) | count[seg];
+    for (uint32_t seg = 0; seg < blok::kListSegments; ++seg)
+        for (uint32_t c = 0; c < blok::kListClasses; ++c)
+            ctl[seg * blok::kListCtlWords + blok::kListFinal + c] = (static_cast<unsigned long long>(a.list.serial) << 32) | (c == cls ? count[seg] : 0u);
     BLOK_HIP_TRY(ctx, hipStreamSynchronize(stream));     // the stream's list may still be in use by an earlier launch
     BLOK_HIP_TRY(ctx, hipMemcpy(a.list.entries, entries.data(), entries.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
     BLOK_HIP_TRY(ctx, hipMemcpy(a.list.ctl, ctl.data(), ctl.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
     ctx->beam_buffers[stream].list_hint_valid = false;   // this list says nothing about the next frame's
     a.list.hint = nullptr;
     const uint32_t walkers = static_cast<uint32_t>((n_tiles + blok::kListSegments - 1u) / blok::kListSegments) * blok::kListSegments;
-    a.list.walkers_per_seg = walkers / blok::kListSegments;
+    for (uint32_t c = 0; c < blok::kListClasses; ++c) a.list.walkers[c] = c == cls ? walkers / blok::kListSegments : 0u;
     if (ctx->timing) BLOK_HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, stream));
     blok::launch_list_walk(blok::RayMode::Rect, a, nullptr, walkers, stream);
     BLOK_HIP_TRY(ctx, hipGetLastError());
@@ -1201,6 +1340,26 @@ int blok_hip_frame_queue_stalls(blok_hip_ctx* ctx, uint32_t* out_stalled_waves) 
 }
 
 int blok_hip_last_launch_kind(const blok_hip_ctx* ctx) { return ctx ? ctx->last_launch_kind : -1; }
+
+int blok_hip_set_tile_ordering(blok_hip_ctx* ctx, int resort_every_n_frames) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    if (resort_every_n_frames < 0) return set_error(ctx, BLOK_ERR_INVALID_ARG, "tile ordering: interval must be >= 0");
+    ctx->order.enabled = resort_every_n_frames != 0;
+    if (resort_every_n_frames) ctx->order.interval = ctx->order.interval_now = static_cast<uint32_t>(resort_every_n_frames);
+    return BLOK_OK;
+}
+
+int blok_hip_set_joint_prefix_limit(blok_hip_ctx* ctx, uint32_t max_walk_waves) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    ctx->order.prefix_limit = max_walk_waves;
+    return BLOK_OK;
+}
+
+int blok_hip_set_list_classes(blok_hip_ctx* ctx, int enabled) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    ctx->list_classes = enabled != 0;
+    return BLOK_OK;
+}
 
 int blok_hip_set_miss_writer(blok_hip_ctx* ctx, int in_walk) {
     if (!ctx) return BLOK_ERR_INVALID_ARG;

@@ -24,6 +24,7 @@
 #include "trace_kernels.h"
 #include "dense_kernels.h"
 #include "launch_policy.h"
+#include "tile_order.h"
 #include "path_args.h"
 #include "tree.h"
 
@@ -105,6 +106,30 @@ struct blok_hip_ctx {
         uint32_t* tile_map = nullptr; size_t n_tile_map = 0;            // sparse exchange, root: frame tile -> record (zero between launches)
     };
     std::unordered_map<hipStream_t, StreamScratch> beam_buffers;
+    // Longest-first scheduling of the walk for a camera at rest (tile_order.h; rectangle launches of the static forms): every walk wave
+    // leaves the clocks it spent in d_cost (one buffer per context, for the launch geometry in `key`).  Every `interval` launches a
+    // radix sort of a snapshot of those costs follows the frame on its stream: it writes the order buffer that is NOT in use, and a later
+    // launch adopts it once hipEventQuery says it is complete — no launch ever waits.  Decisions: launch_policy.h plan_order.
+    struct TileOrder {
+        bool enabled = true;
+        uint32_t interval = 8, interval_now = 8;          // interval_now grows while the view rests
+        uint32_t *d_cost = nullptr, *d_iota = nullptr, *d_order[2] = {nullptr, nullptr}, *d_rank_of[2] = {nullptr, nullptr};
+        uint32_t *d_keys_in = nullptr, *d_keys = nullptr;   // the sort's snapshot of the costs, and its sorted keys
+        void* d_temp = nullptr;
+        size_t temp_bytes = 0, capacity = 0;
+        uint32_t* h_live = nullptr;                         // pinned, two words: how many leading entries of d_order[k] walked (written by the device)
+        uint32_t live[2] = {0, 0};                          // ... as read when the order was adopted
+        uint32_t key[6] = {};
+        int current = -1, target = 0;                       // -1: no order yet (natural)
+        bool pending = false;
+        uint32_t frames_since_sort = 0, still_frames = 0, prefix_limit = 0;
+        blok_camera cam[2] = {}, last_cam{};                // camera each order buffer was measured under; camera of the last launch
+        hipEvent_t done = nullptr;
+    } order;
+    // list launches, rectangle frames: clocks per wave tile of the last frame of this launch geometry, and the camera they were measured under (trace_kernels.h: cost classes)
+    uint32_t* d_list_cost = nullptr; size_t list_cost_capacity = 0; uint32_t list_cost_key[6] = {};
+    blok_camera list_prev_cam{}; bool list_has_prev_cam = false;
+    bool list_classes = true;           // blok_hip_set_list_classes
     uint32_t* debug_clocks = nullptr;   // blok_hip_set_debug_wave_clocks (caller's device memory)
     int launch_form = blok::kFormAuto;  // blok_hip_set_fused (launch_policy.h: LaunchForm)
     int last_launch_kind = -1;          // launch_policy.h: LaunchKind of the latest rectangle / tile launch (blok_hip_last_launch_kind)

@@ -77,26 +77,41 @@ constexpr float kBeamNone = 3.0e38f;   // beam pre-pass result: "no cell of the 
 
 // Live list of a frame (list launches: list_joint_kernel / list_walk_kernel, trace_kernels.hip).  The searches of THIS frame say which
 // wave tiles need a walk at all: a search that finds its beam tile live appends one 64-bit entry per wave tile of it — serial | task |
-// start parameter — to the list of its segment (beam tile b -> segment b mod 8: one 64-bit add on the segment's tally reserves the
-// slots and counts the search as done), and walk wave (segment x, j) takes entries j, j + walkers_per_seg, ... of segment x.  The walk
-// therefore has no wave for a dead tile, needs nothing from an earlier frame, and in the joint form starts when the first searches end.
+// start parameter — to a list of its segment (beam tile b -> segment b mod 8; one 64-bit add per list reserves the slots, one more
+// counts the search as done), and the walk waves of that segment take the entries.  The walk therefore has no wave for a dead tile, needs
+// nothing from an earlier frame to be complete, and in the joint form starts when the first searches end.
+//
+// COST CLASSES.  A launch lasts as long as its last wave, and a wave of grazing rays takes 100+ us of a 200 us launch whatever its
+// priority (a chain of dependent instructions): such waves must start first.  What a wave tile will cost is best predicted by what it
+// cost in the previous frame — walk waves leave their clock count per wave tile — looked up where the tile's point at its start
+// parameter was on the previous frame's screen (a camera in motion), and used in four coarse classes (a full sort by a stale cost is
+// worse than none: profiles/r03_stale_cost_order_experiment.txt).  Each segment has one list per class; walk workgroups are dealt to the
+// classes heaviest first, as many per class as the previous launch's lists were long plus a margin (a hint: walk wave k of a class
+// takes entries k, k + n, ... of its list, so any numbers walk every entry).  Only the ORDER depends on the past; no pixel does.
+//
 // Segments follow the round-robin dispatch of workgroups to the 8 XCDs (workgroup i -> XCD i mod 8), so a walk wave only ever waits for
 // searches that were dispatched to its own XCD before it; nothing depends on that for exactness (a wave that gives up a bounded wait
 // leaves its entries to list_cleanup_kernel).
-constexpr uint32_t kListSegments = 8;
-// 64-bit control words per segment, two 128-byte lines: the tally the searches add to (entries reserved | searches done << 32) on one,
-// what the walk waves poll on the other — final (serial << 32 | length) and the serial of the last launch in which a walk wave gave up
+constexpr uint32_t kListSegments = 8, kListClasses = 4;
+// 64-bit control words per segment, two 128-byte lines: what the searches add to — searches done, entries reserved per class — on one,
+// what the walk waves poll on the other — per class final (serial << 32 | length), and the serial of the last launch in which a walk wave gave up
 constexpr uint32_t kListCtlWords = 32;
-constexpr uint32_t kListTally = 0, kListFinal = 16, kListGaveUp = 17;
+constexpr uint32_t kListDone = 0, kListTally = 1, kListFinal = 16, kListGaveUp = 20;
 constexpr uint32_t kListTaskBits = 21, kListT0Bits = 23, kListSerialBits = 20;
+constexpr uint32_t kListUnknownClass = 1;         // a wave tile nobody has a cost for
+// clocks (s_memtime) a walk wave took in the previous frame -> class 1, 2, 3: the median wave, 2.25 and 5 times as much
+constexpr uint32_t kListCostClass1 = 36000u, kListCostClass2 = 81000u, kListCostClass3 = 182000u;
 struct LiveList {
-    unsigned long long* entries;           // kListSegments x seg_capacity; null = not a list launch
+    unsigned long long* entries;           // [kListSegments][kListClasses][seg_capacity]; null = not a list launch
     unsigned long long* ctl;               // kListSegments x kListCtlWords
-    uint32_t* hint;                        // pinned host memory, kListSegments words: the segments' entry counts of the last launch (sizes the next walk grid)
-    uint32_t seg_capacity;                 // entries per segment (>= its beam tiles x wave tiles per beam tile)
+    uint32_t* hint;                        // pinned host memory, [kListSegments][kListClasses]: the lists' lengths of the last launch (size the next walk grid); may be null
+    uint32_t* cost;                        // per wave tile (task): clocks its walk wave took last time (0 = unknown); null = no classes (everything kListUnknownClass)
+    uint32_t seg_capacity;                 // entries per list (>= the segment's beam tiles x wave tiles per beam tile)
     uint32_t serial;                       // of this launch, 1 .. 2^20 - 1: an entry / a final word is valid when it carries it
-    uint32_t walkers_per_seg;              // walk workgroups per segment
+    uint32_t walkers[kListClasses];        // walk workgroups per segment and class
     uint32_t n_searches;                   // search workgroups of this launch (segment x has those with index = x mod 8)
+    uint32_t has_prev;                     // prev_cam is the camera the costs were measured under (else: looked up at the same screen position)
+    blok_camera prev_cam;
 };
 
 struct TraceArgs {
@@ -124,10 +139,17 @@ struct TraceArgs {
     // beam_kernel and read by the Rect / Tiles trace kernels of the same stream; null = no pre-pass
     float* beam;
     uint32_t beam_tile, beam_bx;           // beam_bx: beam tiles per row of the rectangle (Rect)
+    const uint32_t* order;                 // Rect: workgroup b walks tile order[b] (null = b): longest-first scheduling
+    uint32_t* cost_out;                    // Rect: per tile, the clocks its wave spent (null = not recorded)
     // joint launch (joint_kernel): the pre-pass waves and the walk waves are ONE grid; a beam tile's result is published as
     // (serial << 32 | start parameter bits) and a walk wave waits for its tile's word to carry this launch's serial
     unsigned long long* beam_slots;        // null = the two-launch form (TraceArgs::beam holds plain floats)
     uint32_t beam_serial;
+    // launch over a PREFIX of the order: walk waves are dispatched only for the first `launched` tiles of `order` (the tiles that walked when
+    // the order was made); rank_of[tile] >= launched = no walk wave exists for that tile, and the search wave of a live beam tile walks
+    // such tiles itself (a view that has changed; exact either way).  null = every tile has its walk wave.
+    const uint32_t* rank_of;
+    uint32_t launched;
     uint32_t* joint_gave_up;               // waves that gave up a bounded wait: joint form, for their tile's search (they start at the ray origin instead); list forms, for an entry (walked by the clean-up).  0 in a working system
     uint32_t miss_in_walk;                 // two-launch form: 1 = the walk's waves write the miss pixels of tiles the pre-pass found empty (they are launched anyway), 0 = the pre-pass does
     uint32_t beam_budget;                  // node visits a search may spend (0 = kBeamMaxVisits); running out is answered conservatively

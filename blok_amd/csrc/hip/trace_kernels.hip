@@ -82,15 +82,39 @@ __device__ __forceinline__ unsigned long long list_entry(uint32_t serial, uint32
 }
 constexpr uint32_t kListPollBudget = 1024u;      // polls (~1 us apart) before a walk wave stops waiting for an entry: ~1 ms, ten times the longest search
 
+// Which cost class a wave tile of a rectangle launch goes to: by the clocks the walk wave of the tile took last time, looked up where
+// the tile's point at its start parameter was on the previous frame's screen (trace_kernels.h: cost classes).  (bx, by): the wave tile.
+__device__ __forceinline__ uint32_t list_class_rect(const TraceArgs& A, const uint32_t bx, const uint32_t by, const uint32_t bx_count, const uint32_t by_count, const float t0) {
+    const LiveList& Q = A.list;
+    if (!Q.cost) return kListUnknownClass;
+    uint32_t was = by * bx_count + bx;                                    // the same screen position: a camera at rest, or no camera to compare with
+    if (Q.has_prev) {
+        const float inv_w = __builtin_amdgcn_rcpf(static_cast<float>(A.frame_w)), inv_h = __builtin_amdgcn_rcpf(static_cast<float>(A.frame_h));
+        const BeamVec d = beam_unit(beam_dir(A.cam, static_cast<float>(A.x0 + bx * kTileW) + 0.5f * kTileW, static_cast<float>(A.y0 + by * kTileH) + 0.5f * kTileH, inv_w, inv_h));
+        const blok_camera& P = Q.prev_cam;
+        const float rx = __builtin_fmaf(d.x, t0, A.cam.pos[0]) - P.pos[0], ry = __builtin_fmaf(d.y, t0, A.cam.pos[1]) - P.pos[1], rz = __builtin_fmaf(d.z, t0, A.cam.pos[2]) - P.pos[2];
+        const float z = rx * P.fwd[0] + ry * P.fwd[1] + rz * P.fwd[2];
+        if (!(z > 0.0f)) return kListUnknownClass;                        // behind the previous camera
+        const float iz = __builtin_amdgcn_rcpf(z * P.tan_half_fov);
+        const float u = (rx * P.right[0] + ry * P.right[1] + rz * P.right[2]) * iz * __builtin_amdgcn_rcpf(P.aspect), v = (rx * P.up[0] + ry * P.up[1] + rz * P.up[2]) * iz;
+        const float px = (u + 1.0f) * 0.5f * static_cast<float>(A.frame_w) - static_cast<float>(A.x0), py = (1.0f - v) * 0.5f * static_cast<float>(A.frame_h) - static_cast<float>(A.y0);
+        if (!(px >= 0.0f && py >= 0.0f && px < static_cast<float>(A.w) && py < static_cast<float>(A.h))) return kListUnknownClass;      // was off the rectangle (NaN included)
+        was = min(static_cast<uint32_t>(py) / kTileH, by_count - 1u) * bx_count + min(static_cast<uint32_t>(px) / kTileW, bx_count - 1u);
+    }
+    const uint32_t c = Q.cost[was];
+    if (c == 0u) return kListUnknownClass;
+    return c >= kListCostClass3 ? 3u : (c >= kListCostClass2 ? 2u : (c >= kListCostClass1 ? 1u : 0u));
+}
+
 // The search wave of beam tile b (search workgroup `search` of the launch) has found start parameter t0: a live tile's wave tiles
-// go onto the list of the search's segment, and the search is counted as done.  All 64 lanes.
+// go onto the lists of the search's segment, by cost class, and the search is counted as done.  All 64 lanes.
 template <RayMode MODE>
 __device__ __forceinline__ void list_publish(const TraceArgs& A, const uint32_t search, const uint32_t task_base, const uint32_t b, const float t0, const uint32_t lane) {
     const LiveList& Q = A.list;
     const uint32_t seg = search & (kListSegments - 1u);
     const uint32_t subs_x = A.beam_tile / kWaveW, subs_y = A.beam_tile / kWaveH;
     bool valid = false;
-    uint32_t task = 0;
+    uint32_t task = 0, cls = kListUnknownClass;
     if (t0 < kBeamNone && lane < subs_x * subs_y) {
         const uint32_t sx = lane % subs_x, sy = lane / subs_x;
         if constexpr (MODE == RayMode::Rect) {
@@ -98,6 +122,7 @@ __device__ __forceinline__ void list_publish(const TraceArgs& A, const uint32_t 
             const uint32_t bx = (b % A.beam_bx) * subs_x + sx, by = (b / A.beam_bx) * subs_y + sy;
             valid = bx < bx_count && by < by_count;                     // an edge tile of the rectangle may be cut
             task = by * bx_count + bx;
+            if (valid) cls = list_class_rect(A, bx, by, bx_count, by_count, t0);
         } else {
             const uint32_t per_side = A.tile / kTileW, bps = A.tile / A.beam_tile;
             const uint32_t local_tile = b / (bps * bps), rem = b % (bps * bps);
@@ -105,29 +130,34 @@ __device__ __forceinline__ void list_publish(const TraceArgs& A, const uint32_t 
             valid = true;
         }
     }
-    const unsigned long long vmask = __ballot(valid);
-    const uint32_t n = static_cast<uint32_t>(__builtin_popcountll(vmask));
     unsigned long long* const ctl = Q.ctl + seg * kListCtlWords;
-    const unsigned long long old = wave_fetch_add64(ctl + kListTally, (1ull << 32) | n);      // low word: entries reserved, high word: searches done
-    const uint32_t pos = static_cast<uint32_t>(old), done = static_cast<uint32_t>(old >> 32);
-    if (valid) {
-        const uint32_t slot = pos + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(vmask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(vmask), 0u));
-        if (slot < Q.seg_capacity) list_st(Q.entries + static_cast<size_t>(seg) * Q.seg_capacity + slot, list_entry(Q.serial, task_base + task, t0));
+    for (uint32_t c = 0; c < kListClasses; ++c) {                         // wave-uniform: one reservation per class this tile has entries for
+        const unsigned long long m = __ballot(valid && cls == c);
+        if (m == 0ull) continue;
+        const uint32_t n = static_cast<uint32_t>(__builtin_popcountll(m));
+        const uint32_t pos = static_cast<uint32_t>(wave_fetch_add64(ctl + kListTally + c, n));
+        if (valid && cls == c) {
+            const uint32_t slot = pos + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+            if (slot < Q.seg_capacity) list_st(Q.entries + (static_cast<size_t>(seg) * kListClasses + c) * Q.seg_capacity + slot, list_entry(Q.serial, task_base + task, t0));
+        }
     }
+    // every reservation of this search has returned (wave_fetch_add64 waits for its value) before the search counts itself as done
+    const uint32_t done = static_cast<uint32_t>(wave_fetch_add64(ctl + kListDone, 1ull));
     const uint32_t in_seg = (Q.n_searches + kListSegments - 1u - seg) / kListSegments;       // searches of this segment
-    if (done + 1u == in_seg && lane == 0) {
-        // the last search of the segment: every reservation has been made, so the length is final; the tally is ready for the next launch
-        const uint32_t total = min(pos + n, Q.seg_capacity);
-        list_st(ctl + kListFinal, (static_cast<unsigned long long>(Q.serial) << 32) | total);
-        list_st(ctl + kListTally, 0ull);
-        if (Q.hint) Q.hint[seg] = total;
+    if (done + 1u == in_seg && lane < kListClasses) {
+        // the last search of the segment: every reservation has been made, so the lengths are final; the counters are ready for the next launch
+        const uint32_t total = min(static_cast<uint32_t>(list_ld(ctl + kListTally + lane)), Q.seg_capacity);
+        list_st(ctl + kListFinal + lane, (static_cast<unsigned long long>(Q.serial) << 32) | total);
+        list_st(ctl + kListTally + lane, 0ull);
+        if (lane == 0) list_st(ctl + kListDone, 0ull);
+        if (Q.hint) Q.hint[seg * kListClasses + lane] = total;
     }
 }
 
 // Entry k of a segment, for all 64 lanes (wave-uniform result): true with the entry, false when the list is final and shorter, or when
 // the wait ran out (counted: the entry, should it still come, is left to list_cleanup_kernel).
-__device__ __forceinline__ bool list_await(unsigned long long* slot, unsigned long long* ctl, const uint32_t serial, const uint32_t k, uint32_t* gave_up,
-                                           uint32_t& task, float& t0) {
+__device__ __forceinline__ bool list_await(unsigned long long* slot, unsigned long long* final_word, unsigned long long* gave_up_word, const uint32_t serial, const uint32_t k,
+                                           uint32_t* gave_up, uint32_t& task, float& t0) {
     // The entry has its own word; the segment's `final` word is shared by every waiting wave of the segment, so it is looked at only
     // every 8th poll (it matters to the waves beyond the end of the list alone, and those have nothing to do anyway).
     for (uint32_t polls = 0; polls < kListPollBudget; ++polls) {
@@ -138,14 +168,20 @@ __device__ __forceinline__ bool list_await(unsigned long long* slot, unsigned lo
             t0 = __uint_as_float((lo & 0x7FFFFFu) << 8);
             return true;
         }
-        if ((polls & 7u) == 0u) {
-            const unsigned long long f = list_ld(ctl + kListFinal);
+#ifndef BLOK_LIST_FINAL_EVERY
+#define BLOK_LIST_FINAL_EVERY 8
+#endif
+#ifndef BLOK_LIST_SLEEP
+#define BLOK_LIST_SLEEP 32
+#endif
+        if ((polls & (BLOK_LIST_FINAL_EVERY - 1u)) == 0u) {
+            const unsigned long long f = list_ld(final_word);
             const uint32_t flo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(f)), fhi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(f >> 32));
             if (fhi == serial && k >= flo) return false;
         }
-        __builtin_amdgcn_s_sleep(32);
+        __builtin_amdgcn_s_sleep(BLOK_LIST_SLEEP);
     }
-    list_st(ctl + kListGaveUp, serial);          // "a wave of launch `serial` gave up in this segment": what list_cleanup_kernel looks at (every lane, same word)
+    list_st(gave_up_word, serial);               // "a wave of launch `serial` gave up in this segment": what list_cleanup_kernel looks at (every lane, same word)
     if (gave_up && threadIdx.x == 0) (void)__hip_atomic_fetch_add(gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return false;
 }
@@ -172,19 +208,26 @@ __device__ __forceinline__ void trace_block(const TraceArgs& A, const uint32_t b
         // where this wave's 8x8 pixels start inside the block (wave-uniform)
         const uint32_t wave_x = __builtin_amdgcn_readfirstlane((wave & 1u) * kWaveW), wave_y = __builtin_amdgcn_readfirstlane((wave >> 1) * kWaveH);
         uint32_t x, y;
+        [[maybe_unused]] uint64_t clock0 = 0;      // Rect: the wave's cost (clocks from here to its last record) goes to cost_slot
+        [[maybe_unused]] uint32_t* cost_slot = nullptr;
         float t0 = 0.0f;                           // start parameter of this wave's beam tile (beam.h); kBeamNone: the pre-pass
         size_t out_index;                          // has already written the tile's pixels as misses, nothing left to do
         bool inside;
         if constexpr (MODE == RayMode::Rect) {
             const uint32_t bx_count = (A.w + kTileW - 1u) / kTileW, by_count = (A.h + kTileH - 1u) / kTileH;
             uint32_t bx, by;
-            if constexpr (kListed) { bx = block % bx_count; by = block / bx_count; if (by >= by_count) return; }      // a list entry names the tile itself
-            else if (!block_to_tile(block, grid, bx_count, by_count, bx, by)) return;
+            // longest first: workgroup i walks tile order[i] (the tiles by descending cost of their wave in earlier frames of the same view,
+            // api.hip); any permutation gives the same frame.  A list entry names the tile itself.
+            const uint32_t b = (!kListed && A.order) ? A.order[block] : block;
+            if constexpr (kListed) { bx = b % bx_count; by = b / bx_count; if (by >= by_count) return; }
+            else if (!block_to_tile(b, grid, bx_count, by_count, bx, by)) return;
+            if constexpr (!kListed) cost_slot = A.cost_out ? A.cost_out + b : nullptr;
             if constexpr (kListed) t0 = listed_t0;
             else if (A.beam) {
                 const uint32_t beam_index = ((by * kTileH + wave_y) / A.beam_tile) * A.beam_bx + (bx * kTileW + wave_x) / A.beam_tile;
                 t0 = A.beam_slots ? await_beam(A.beam_slots + beam_index, A.beam_serial, A.joint_gave_up) : A.beam[beam_index];
                 if (t0 >= kBeamNone) {
+                    if (cost_slot && tid == 0) *cost_slot = 0u;
                     if (A.miss_in_walk) {
                         const uint32_t mx = bx * kTileW + lx, my = by * kTileH + ly;
                         const size_t at = static_cast<size_t>(my) * A.w + mx;
@@ -228,13 +271,15 @@ __device__ __forceinline__ void trace_block(const TraceArgs& A, const uint32_t b
             if constexpr (MODE == RayMode::Tiles) write_miss(sink);     // the tile buffer is dense
             return;
         }
-        [[maybe_unused]] uint64_t clock0 = 0;
-        if constexpr (kListed && MODE == RayMode::Rect) { if (A.debug_clocks) clock0 = __builtin_amdgcn_s_memtime(); }
+        if constexpr (MODE == RayMode::Rect) {
+            if constexpr (kListed) cost_slot = A.debug_clocks ? A.debug_clocks + block : nullptr;
+            if (cost_slot && tid == 0) clock0 = __builtin_amdgcn_s_memtime();      // the walk's cost: any wait for the tile's search is not part of it
+        }
         RayIn r = primary_ray(A, x, y);
         r.tmin = fmaxf(r.tmin, t0);
         trace_one(A, r, stk, sink);
-        if constexpr (kListed && MODE == RayMode::Rect) {
-            if (A.debug_clocks && tid == 0) A.debug_clocks[block] = static_cast<uint32_t>(__builtin_amdgcn_s_memtime() - clock0);
+        if constexpr (MODE == RayMode::Rect) {
+            if (cost_slot && tid == 0) *cost_slot = max(static_cast<uint32_t>(__builtin_amdgcn_s_memtime() - clock0), 256u);     // it walked: any key >= 256 clocks counts as live in the next order
         }
     }
 }
@@ -266,8 +311,9 @@ __global__ __launch_bounds__(kBlock) void trace_frames_kernel(const TraceArgs A,
 
 // One wave per beam tile: TraceArgs::beam[tile] = conservative start parameter of the tile's rays, or kBeamNone.
 // list_search / list_task_base (list launches): this search's index in the launch and the first task id of its frame.
+// lds_stack: the walk's stack for the wave tiles a search walks itself (launches over a prefix of the order, TraceArgs::rank_of), else null.
 template <RayMode MODE>
-__device__ __forceinline__ void beam_block(const TraceArgs& A, const uint32_t b, const uint32_t n_beam_tiles,
+__device__ __forceinline__ void beam_block(const TraceArgs& A, const uint32_t b, const uint32_t n_beam_tiles, [[maybe_unused]] uint4* lds_stack = nullptr,
                                            const uint32_t list_search = 0u, const uint32_t list_task_base = 0u) {
     const uint32_t lane = threadIdx.x;
     if (b >= n_beam_tiles) return;
@@ -308,11 +354,36 @@ __device__ __forceinline__ void beam_block(const TraceArgs& A, const uint32_t b,
             write_miss(Sink{A.out ? A.out + out_index : nullptr, A.out_rgba ? A.out_rgba + out_index : nullptr});
         }
     }
+    if constexpr (MODE == RayMode::Rect && kBlock == 64) {
+        // joint launch over a prefix of the order: the wave-sized tiles of this (live) beam tile that no walk wave was dispatched for —
+        // the view has changed since the order was made — are walked here, one after the other
+        if (A.rank_of && lds_stack && t0 < kBeamNone) {
+            const uint32_t bx_count = (A.w + kTileW - 1u) / kTileW;
+            const uint32_t bx0 = (px - A.x0) / kTileW, bx1 = (px_end - A.x0 + kTileW - 1u) / kTileW;
+            const uint32_t by0 = (py - A.y0) / kTileH, by1 = (py_end - A.y0 + kTileH - 1u) / kTileH;
+            for (uint32_t by = by0; by < by1; ++by)
+                for (uint32_t bx = bx0; bx < bx1; ++bx) {
+                    const uint32_t tile = by * bx_count + bx;
+                    if (__builtin_amdgcn_readfirstlane(A.rank_of[tile]) < A.launched) continue;
+                    const uint64_t clock0 = __builtin_amdgcn_s_memtime();
+                    const uint32_t rx = bx * kTileW + lane % kWaveW, ry = by * kTileH + lane / kWaveW;
+                    if (rx < A.w && ry < A.h) {
+                        const size_t at = static_cast<size_t>(ry) * A.w + rx;
+                        RayIn r = primary_ray(A, A.x0 + rx, A.y0 + ry);
+                        r.tmin = fmaxf(r.tmin, t0);
+                        trace_one(A, r, lds_stack + lane, Sink{A.out ? A.out + at : nullptr, A.out_rgba ? A.out_rgba + at : nullptr});
+                    }
+                    // it walked: the next sort puts it into the prefix (any key >= 256 clocks counts as live)
+                    if (A.cost_out && lane == 0) A.cost_out[tile] = max(static_cast<uint32_t>(__builtin_amdgcn_s_memtime() - clock0), 256u);
+                }
+        }
+    }
 }
 
 template <RayMode MODE>
 __global__ __launch_bounds__(64) void beam_kernel(const TraceArgs A, const uint32_t n_beam_tiles) {
-    beam_block<MODE>(A, blockIdx.x, n_beam_tiles, blockIdx.x, 0u);
+    extern __shared__ uint4 lds_stack[];       // launch_beam sizes it whenever the searches may walk (TraceArgs::rank_of), else 0 bytes and unused
+    beam_block<MODE>(A, blockIdx.x, n_beam_tiles, A.rank_of ? lds_stack : nullptr, blockIdx.x, 0u);
 }
 
 // ---- joint launch: the pre-pass waves and the walk waves in ONE grid, statically ------------------------------------------
@@ -326,7 +397,7 @@ template <RayMode MODE>
 __global__ __launch_bounds__(kBlock) void joint_kernel(const TraceArgs A, const uint32_t n_beam_tiles) {
     extern __shared__ uint4 lds_stack[];
     if (blockIdx.x < n_beam_tiles) {
-        if (threadIdx.x < 64u) beam_block<MODE>(A, blockIdx.x, n_beam_tiles);
+        if (threadIdx.x < 64u) beam_block<MODE>(A, blockIdx.x, n_beam_tiles, lds_stack);
         return;
     }
     trace_block<MODE>(A, blockIdx.x - n_beam_tiles, gridDim.x - n_beam_tiles, lds_stack);
@@ -336,30 +407,46 @@ __global__ __launch_bounds__(64) void beam_frames_kernel(const TraceArgs A, cons
     const uint32_t f = blockIdx.x / F.beams_per_frame;
     if (f >= F.n_frames) return;
     const TraceArgs L = frame_args(A, F, f);
-    beam_block<RayMode::Tiles>(L, blockIdx.x - f * F.beams_per_frame, F.beams_per_frame, blockIdx.x, f * F.blocks_per_frame);
+    beam_block<RayMode::Tiles>(L, blockIdx.x - f * F.beams_per_frame, F.beams_per_frame, nullptr, blockIdx.x, f * F.blocks_per_frame);
 }
 
 // ---- list launches: the walk takes its wave tiles from the frame's live list (trace_kernels.h: LiveList) -------------------------
 // No reference counterpart (one traceRaysKHR per frame, renderer_raytracing.cpp:666-685).  Walk workgroup `walker` of the launch (on
 // XCD `seg` if workgroups go round the XCDs in index order) takes entries walker / 8, + walkers_per_seg, ... of segment `seg`: normally
 // one entry — the grid is sized from the previous launch's list, with a margin — and more only when the view has changed a lot.
+// One listed wave tile: walked, and (rectangle launches) the clocks it took left for the next frame's classes.
+template <RayMode MODE, bool kFrames>
+__device__ __forceinline__ void list_task(const TraceArgs& A, const TileFrames& F, const uint32_t task, const float t0, uint4* lds_stack) {
+    if constexpr (kFrames) {
+        const uint32_t f = task / F.blocks_per_frame;
+        if (f >= F.n_frames) return;
+        const TraceArgs L = frame_args(A, F, f);
+        trace_block<MODE, true>(L, task - f * F.blocks_per_frame, F.blocks_per_frame, lds_stack, t0);
+    } else {
+        [[maybe_unused]] uint64_t clock0 = 0;
+        if constexpr (MODE == RayMode::Rect) { if (A.list.cost) clock0 = __builtin_amdgcn_s_memtime(); }
+        trace_block<MODE, true>(A, task, 0u, lds_stack, t0);
+        if constexpr (MODE == RayMode::Rect) {
+            if (A.list.cost && threadIdx.x == 0) A.list.cost[task] = max(static_cast<uint32_t>(__builtin_amdgcn_s_memtime() - clock0), 1u);
+        }
+    }
+}
+
 template <RayMode MODE, bool kFrames>
 __device__ __forceinline__ void list_walk(const TraceArgs& A, const TileFrames& F, const uint32_t walker, const uint32_t seg, uint4* lds_stack) {
     const LiveList& Q = A.list;
-    unsigned long long* const entries = Q.entries + static_cast<size_t>(seg) * Q.seg_capacity;
+    // the segment's walk workgroups are dealt to the classes heaviest first
+    uint32_t k = walker / kListSegments, cls = kListClasses - 1u;
+    while (cls != 0u && k >= Q.walkers[cls]) { k -= Q.walkers[cls]; cls -= 1u; }
+    const uint32_t stride = Q.walkers[cls];
+    if (k >= stride) return;                                               // more workgroups than the classes asked for
+    unsigned long long* const entries = Q.entries + (static_cast<size_t>(seg) * kListClasses + cls) * Q.seg_capacity;
     unsigned long long* const ctl = Q.ctl + seg * kListCtlWords;
-    for (uint32_t k = walker / kListSegments; k < Q.seg_capacity; k += Q.walkers_per_seg) {
+    for (; k < Q.seg_capacity; k += stride) {
         uint32_t task; float t0;
-        if (!list_await(entries + k, ctl, Q.serial, k, A.joint_gave_up, task, t0)) return;
+        if (!list_await(entries + k, ctl + kListFinal + cls, ctl + kListGaveUp, Q.serial, k, A.joint_gave_up, task, t0)) return;
         __hip_atomic_store(entries + k, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // taken (every lane, same word)
-        if constexpr (kFrames) {
-            const uint32_t f = task / F.blocks_per_frame;
-            if (f >= F.n_frames) continue;
-            const TraceArgs L = frame_args(A, F, f);
-            trace_block<MODE, true>(L, task - f * F.blocks_per_frame, F.blocks_per_frame, lds_stack, t0);
-        } else {
-            trace_block<MODE, true>(A, task, 0u, lds_stack, t0);
-        }
+        list_task<MODE, kFrames>(A, F, task, t0, lds_stack);
     }
 }
 
@@ -369,9 +456,9 @@ __device__ __forceinline__ void list_search(const TraceArgs& A, const TileFrames
         const uint32_t f = search / F.beams_per_frame;
         if (f >= F.n_frames) return;
         const TraceArgs L = frame_args(A, F, f);
-        beam_block<MODE>(L, search - f * F.beams_per_frame, F.beams_per_frame, search, f * F.blocks_per_frame);
+        beam_block<MODE>(L, search - f * F.beams_per_frame, F.beams_per_frame, nullptr, search, f * F.blocks_per_frame);
     } else {
-        beam_block<MODE>(A, search, A.list.n_searches, search, 0u);
+        beam_block<MODE>(A, search, A.list.n_searches, nullptr, search, 0u);
     }
 }
 
@@ -402,23 +489,16 @@ __global__ __launch_bounds__(kBlock) void list_cleanup_kernel(const TraceArgs A,
     const uint32_t seg = blockIdx.x & (kListSegments - 1u), part = blockIdx.x / kListSegments, parts = gridDim.x / kListSegments;
     unsigned long long* const ctl = Q.ctl + seg * kListCtlWords;
     if (__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(list_ld(ctl + kListGaveUp))) != Q.serial) return;      // nobody gave up in this launch
-    const unsigned long long f = list_ld(ctl + kListFinal);
-    const uint32_t total = static_cast<uint32_t>(f >> 32) == Q.serial ? min(static_cast<uint32_t>(f), Q.seg_capacity) : Q.seg_capacity;
-    unsigned long long* const entries = Q.entries + static_cast<size_t>(seg) * Q.seg_capacity;
-    for (uint32_t k = part; k < total; k += parts) {
-        const unsigned long long v = list_ld(entries + k);
-        const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v)), hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32));
-        if ((hi >> 12) != Q.serial) continue;
-        __hip_atomic_store(entries + k, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t task = ((hi & 0xFFFu) << 9) | (lo >> 23);
-        const float t0 = __uint_as_float((lo & 0x7FFFFFu) << 8);
-        if constexpr (kFrames) {
-            const uint32_t fr = task / F.blocks_per_frame;
-            if (fr >= F.n_frames) continue;
-            const TraceArgs L = frame_args(A, F, fr);
-            trace_block<MODE, true>(L, task - fr * F.blocks_per_frame, F.blocks_per_frame, lds_stack, t0);
-        } else {
-            trace_block<MODE, true>(A, task, 0u, lds_stack, t0);
+    for (uint32_t cls = 0; cls < kListClasses; ++cls) {
+        const unsigned long long f = list_ld(ctl + kListFinal + cls);
+        const uint32_t total = static_cast<uint32_t>(f >> 32) == Q.serial ? min(static_cast<uint32_t>(f), Q.seg_capacity) : Q.seg_capacity;
+        unsigned long long* const entries = Q.entries + (static_cast<size_t>(seg) * kListClasses + cls) * Q.seg_capacity;
+        for (uint32_t k = part; k < total; k += parts) {
+            const unsigned long long v = list_ld(entries + k);
+            const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v)), hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32));
+            if ((hi >> 12) != Q.serial) continue;
+            __hip_atomic_store(entries + k, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            list_task<MODE, kFrames>(A, F, ((hi & 0xFFFu) << 9) | (lo >> 23), __uint_as_float((lo & 0x7FFFFFu) << 8), lds_stack);
         }
     }
 }
@@ -772,6 +852,8 @@ __global__ __launch_bounds__(64) void scatter_tiles_kernel(const ScatterArgs a) 
 
 uint32_t sky_rgba() { return kSkyRgba; }
 
+size_t frame_lds_bytes(const TraceArgs& args);
+
 void launch_compact_tiles(const CompactArgs& args, hipStream_t stream) {
     if (args.n_tiles && args.n_frames) hipLaunchKernelGGL(compact_tiles_kernel, dim3(args.n_tiles, args.n_frames), dim3(64), 0, stream, args);
 }
@@ -818,8 +900,6 @@ void launch_joint(RayMode mode, const TraceArgs& args, uint32_t n_beam_tiles, ui
     else hipLaunchKernelGGL(joint_kernel<RayMode::Tiles>, dim3(n_beam_tiles + n_blocks), dim3(kBlock), lds, stream, args, n_beam_tiles);
 }
 
-size_t frame_lds_bytes(const TraceArgs& args);
-
 void launch_list_joint(RayMode mode, const TraceArgs& args, const TileFrames* frames, uint32_t n_beam_tiles, uint32_t n_walkers, hipStream_t stream) {
     if (n_beam_tiles == 0 || mode == RayMode::Rays || !args.list.entries) return;
     const size_t lds = frame_lds_bytes(args);
@@ -853,9 +933,12 @@ uint32_t beam_tiles(RayMode mode, const TraceArgs& a, uint32_t tiles_of_rank) {
 
 void launch_beam(RayMode mode, const TraceArgs& args, uint32_t n_beam_tiles, hipStream_t stream) {
     if (n_beam_tiles == 0 || mode == RayMode::Rays) return;
-    // no dynamic LDS: the search keeps its stack in registers (beam.h), and the kernel declares none
-    if (mode == RayMode::Rect) hipLaunchKernelGGL(beam_kernel<RayMode::Rect>, dim3(n_beam_tiles), dim3(64), 0, stream, args, n_beam_tiles);
-    else hipLaunchKernelGGL(beam_kernel<RayMode::Tiles>, dim3(n_beam_tiles), dim3(64), 0, stream, args, n_beam_tiles);
+    // The search itself keeps its stack in registers (beam.h) and uses no LDS; the walk's stack is needed only when the search waves may
+    // walk wave tiles themselves (rank_of: a launch over a prefix of the order) — the ONLY use of lds_stack in beam_block, guarded by the
+    // same rank_of test there, so LDS is never indexed without having been sized here.
+    const size_t lds = args.rank_of ? frame_lds_bytes(args) : 0;
+    if (mode == RayMode::Rect) hipLaunchKernelGGL(beam_kernel<RayMode::Rect>, dim3(n_beam_tiles), dim3(64), lds, stream, args, n_beam_tiles);
+    else hipLaunchKernelGGL(beam_kernel<RayMode::Tiles>, dim3(n_beam_tiles), dim3(64), lds, stream, args, n_beam_tiles);
 }
 
 size_t frame_lds_bytes(const TraceArgs& args) { return static_cast<size_t>(args.levels > 1 ? args.levels - 1 : 1) * kBlock * sizeof(uint4); }

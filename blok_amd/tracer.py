@@ -196,6 +196,20 @@ class HipTracer:
     def set_debug_wave_clocks(self, dev_ptr):
         self._check(self._lib.blok_hip_set_debug_wave_clocks(self._ctx, C.c_void_p(dev_ptr) if dev_ptr else None))
 
+    def set_tile_ordering(self, resort_every_n_frames):
+        """Longest-first scheduling of the walk from earlier frames' per-wave clocks, re-sorted asynchronously every N frames
+        (default 8; 0 / False = off; True = 8); applied only to launches that have the chip to themselves; never changes a result."""
+        n = 8 if resort_every_n_frames is True else int(resort_every_n_frames or 0)
+        self._check(self._lib.blok_hip_set_tile_ordering(self._ctx, n))
+
+    def set_joint_prefix_limit(self, max_walk_waves: int):
+        """Diagnostic: cap on the walk waves of a joint launch; the rest is walked by the search waves (same frame)."""
+        self._check(self._lib.blok_hip_set_joint_prefix_limit(self._ctx, max_walk_waves))
+
+    def set_list_classes(self, enabled: bool):
+        """List launches: order the walk by the previous frame's measured cost, in four classes (default on); never changes a result."""
+        self._check(self._lib.blok_hip_set_list_classes(self._ctx, 1 if enabled else 0))
+
     def last_launch_kind(self) -> int:
         """Which kernels the latest rectangle / tile launch was issued as (blok_hip.h: blok_hip_last_launch_kind)."""
         return int(self._lib.blok_hip_last_launch_kind(self._ctx))

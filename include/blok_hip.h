@@ -448,6 +448,22 @@ int blok_hip_set_sun_map(blok_hip_ctx* ctx, int enabled);
  * conservative start parameter for that tile's rays, and tiles whose frustum meets no voxel are written as misses without
  * a walk.  Results are identical with and without it (tests/test_gpu_parity.py).  0 turns it off; default 32. */
 int blok_hip_set_beam(blok_hip_ctx* ctx, uint32_t beam_tile_pixels);
+/* Longest-first scheduling of the walk for a camera at rest (default: on, re-sorted every 8 launches; rectangle launches of at least
+ * 4096 wave tiles behind the pre-pass, static launch forms 0, 2, 3): every wave of the walk leaves the clocks it spent; every N-th launch a
+ * 16-bit radix sort of a snapshot of those costs (129 600 keys at 4K) follows the frame on its stream, a later launch adopts the finished
+ * order, and the walk's workgroups take their tiles in it, so the long grazing-ray waves — each a quarter of the launch long, whatever
+ * their priority — start first instead of forming the launch's tail.  The order also tells which tiles need a walk wave at all: launch
+ * forms 2 and 3 dispatch walk waves for the tiles that walked when the order was made only, and a tile that has become live since is
+ * walked by its search wave.  Used only within ~0.25 degree of the view it was measured in, and a camera in motion is neither measured
+ * nor sorted for: ordering by a stale cost is no better than row-major even one frame later (profiles/r03_stale_cost_order_experiment.txt).
+ * A view at rest is re-sorted ever less often (the interval doubles up to 64 launches).
+ * Pure scheduling: any order gives the same frame (tests/test_gpu_parity.py).  No reference counterpart
+ * (renderer_raytracing.cpp:666-685 leaves scheduling to the driver).  0 = off; N > 0 = re-sort every N launches.
+ * Measured (4K over 1024^3, one frame at a time): walk alone 216 us row-major, 168 us in this order. */
+int blok_hip_set_tile_ordering(blok_hip_ctx* ctx, int resort_every_n_frames);
+/* Diagnostic: the most walk waves a launch over the order's live prefix dispatches (0 = no limit).  Whatever is cut off is walked by the
+ * search waves; the frame is the same (the tests use it to exercise that path). */
+int blok_hip_set_joint_prefix_limit(blok_hip_ctx* ctx, uint32_t max_walk_waves);
 /* Who writes the miss pixels of the tiles the pre-pass found empty (two-launch form): 1 (default) = the walk launch's waves of
  * those tiles — they are launched anyway and have nothing else to do — 0 = the pre-pass wave of the tile, 1 024 pixels each, which
  * puts ~120 MB of stores on the pre-pass's critical path (4K, 73 % sky).  Never changes a result. */
@@ -471,19 +487,24 @@ int blok_hip_set_rt_taa_jitter(blok_hip_ctx* ctx, int enabled);
  *   1  one persistent launch with work queues: resident waves first take beam tiles, append the wave-sized sub-tiles of the live
  *      ones to per-part queues with an atomic reservation, then take walk tasks from those queues with one ticket each (measures
  *      slower on MI355X: same-address atomics run at 88 M/s);
- *   2  joint launch: the search waves and one walk wave per 8x8 pixels are ONE grid, statically — workgroups are dispatched in index
- *      order, the searches first; a walk wave waits (bounded) only while its own tile's search is still running, so the chip starts
- *      walking when the first searches end, not when the last one does;
- *   4  list-fed joint launch: as 2, but the walk waves take their 8x8-pixel tiles from the frame's LIVE LIST — a search that finds
- *      its beam tile live appends the tile's wave tiles, with their start parameter, to one of eight lists (one 64-bit add per search
- *      reserves the slots), walk wave j of a list takes its entries j, j + n, ... — so no wave is launched for a dead tile and nothing
- *      is needed from an earlier frame: the walk grid is sized from the previous launch's list length (a hint only; any size walks
- *      every entry).  A walk wave that waits in vain (bounded, ~1 ms) leaves its entries to a clean-up launch behind the frame;
- *   5  the same lists in two launches: the beam kernel fills them, the walk waves take them (nothing waits);
- *   3  (default) automatic: 4 for a launch that has the DEVICE to itself — no frame launch of another stream or context of this
- *      process still pending on it — else 5: beside other launches the waiting walk waves of a joint launch would only take wave slots
- *      from them, and two joint launches can starve each other's searches (bounded; the frame stays exact).
- * Measured at 4K over 1024^3, a launch alone: form 0 0.26 ms, 2 0.22 ms, 4 see DESIGN.md §6. */
+ *   2  joint launch: the search waves and the walk waves are ONE grid, statically — workgroups are dispatched in index order, the
+ *      searches first; a walk wave waits (bounded) only while its own tile's search is still running, so the chip starts walking
+ *      when the first searches end, not when the last one does.  With a longest-first order in force (blok_hip_set_tile_ordering)
+ *      walk waves are dispatched only for the tiles that walked when the order was made; a tile that has become live since is walked
+ *      by its search wave.  Not for frames in flight on several streams: the waiting waves hold slots other frames' waves would
+ *      use, and several joint launches in flight can wait for each other's searches in a circle until they give up (bounded; the
+ *      frame stays exact);
+ *   3  (default) automatic: 2 for a launch that has the DEVICE to itself — no frame launch of another stream or context of this
+ *      process still pending on it — else 0, over the order's live prefix when an order is in force;
+ *   4  list-fed joint launch: as 2, but the walk waves take their 8x8-pixel tiles from the frame's LIVE LISTS — a search that finds
+ *      its beam tile live appends the tile's wave tiles, with their start parameter, to lists by cost class (blok_hip_set_list_classes;
+ *      one 64-bit add per list reserves the slots), walk wave k of a list takes its entries k, k + n, ... — so no wave is launched for
+ *      a dead tile and no pixel depends on an earlier frame: the walk grid is sized from the previous launch's lists (a hint only; any
+ *      size walks every entry).  A walk wave that waits in vain (bounded, ~1 ms) leaves its entries to a clean-up launch behind the frame;
+ *   5  the same lists in two launches: the beam kernel fills them, the walk waves take them (nothing waits).
+ * Measured at 4K over 1024^3, a launch alone, camera at rest / orbiting by 1 degree per frame (profiles/r03_*): form 0 0.29 / 0.29 ms,
+ * 2 with the order 0.20 / (no order) 0.24, 4 0.23 / 0.26, 5 0.26 / 0.29 — the lists lose to the measured order because entries arrive in
+ * the order the searches finish, the heavy tiles last; they stay as the forms that need nothing from earlier frames. */
 int blok_hip_set_fused(blok_hip_ctx* ctx, int enabled);
 /* Health check of forms 1, 2 and 4: synchronises the device and returns how many waves ever gave up a bounded wait (0 in a working
  * system).  Form 1: for a queue entry (~0.5 s; frames since context creation may then be incomplete).  Form 2: for their tile's
@@ -507,6 +528,11 @@ int blok_hip_set_debug_wave_clocks(blok_hip_ctx* ctx, void* clocks_dev_or_null);
 /* Which kernels the latest rectangle / tile launch of the context was issued as: 0 walk alone (no pre-pass), 1 two launches, 2 queues,
  * 3 joint, 4 list-fed joint, 5 beam launch + list-fed walk; -1 before the first launch (what form 3 chose; tests and diagnostics). */
 int blok_hip_last_launch_kind(const blok_hip_ctx* ctx);
+/* Cost classes of the list launches (rectangle frames; default on): walk waves leave the clocks they took per wave tile, and the next
+ * frame's searches put every live wave tile into one of four lists by what its place on the previous frame's screen cost, heaviest
+ * list first — so the waves of grazing rays, a quarter of the launch long each, start first instead of forming its tail.  Only the
+ * order depends on the previous frame; 0 = one list in the order the searches finish.  Never changes a result. */
+int blok_hip_set_list_classes(blok_hip_ctx* ctx, int enabled);
 /* Enable/disable the per-launch HIP event pair (default off: nothing but the kernel is
  * enqueued by the *_device entries). */
 int blok_hip_set_timing(blok_hip_ctx* ctx, int enabled);
