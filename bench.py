@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0xB10C0001)
     ap.add_argument("--cpu-stride", type=int, default=1, help="CPU baseline traces every stride-th pixel in x and y")
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="pipeline depth; 0 = 3 for N <= 2, else 4 (reference: MAX_FRAMES_IN_FLIGHT = 2; at N = 1 three measure +3-4 % over two). "
+                    help="pipeline depth; 0 = 3 for N <= 2, else 4 (reference: MAX_FRAMES_IN_FLIGHT = 2; at N = 1 three measure +3-4 %% over two). "
                          "Measured on one GPU with a rank's tile share (scripts/tile_depth_test.py): a frame-share is a "
                          "beam + trace launch pair whose latency (~130 us alone) far exceeds its work (26-105 us), so "
                          "3-4 frames must be in flight to hide it")
@@ -224,16 +224,17 @@ def main():
 
     # --orbit: the camera of frame k stands on a circle around the vertical axis through the world's centre, orbit degrees
     # further per frame, there and back (ping-pong over 64 positions, so consecutive frames always differ by one step)
-    orbit_cams = None
-    if args.orbit > 0.0:
+    def orbit_arc(step_deg):
         n_f = float(args.n)
         centre = np.array([0.5 * n_f, 0.25 * n_f, 0.5 * n_f]); start = np.array([-0.35 * n_f, 0.85 * n_f, -0.35 * n_f]) - centre
         arc = []
         for i in range(64):
-            a = np.radians(args.orbit * i)
+            a = np.radians(step_deg * i)
             p = centre + np.array([start[0] * np.cos(a) - start[2] * np.sin(a), start[1], start[0] * np.sin(a) + start[2] * np.cos(a)])
             arc.append(W.camera_look_at(tuple(float(v) for v in p), tuple(float(v) for v in centre), 60.0, W_, H_))
-        orbit_cams = arc + arc[-2:0:-1]
+        return arc + arc[-2:0:-1]
+
+    orbit_cams = orbit_arc(args.orbit) if args.orbit > 0.0 else None
     frame_no = [0]
 
     def next_frame():
@@ -269,12 +270,13 @@ def main():
     # the frame's launch running ALONE: HIP events around single launches on one stream, one at a time (what a rocprofv3
     # kernel trace of `--frames-in-flight 1` shows; profiles/README.md).  One launch (frame_kernel) per frame in the
     # one-launch form, the beam_kernel + trace_kernel pair otherwise.
-    def solitary_ms(backend, reps):
+    def solitary_ms(backend, reps, cams=None):
         tracer.set_timing(True)
         ms = []
-        for k in range(-2, reps):           # two unmeasured launches first (the first sizes the second's walk grid)
-            if orbit_cams is not None:
-                backend.cam = orbit_cams[k % len(orbit_cams)]
+        cams = cams if cams is not None else orbit_cams
+        for k in range(-2, reps):           # two unmeasured launches first
+            if cams is not None:
+                backend.cam = cams[k % len(cams)]
             if world_size == 1:
                 backend.trace_full(pipe.hits, pipe._frame[0], stream.cuda_stream)
             else:
@@ -287,6 +289,11 @@ def main():
 
     gave_up = tracer.frame_queue_stalls()        # joint launches: walk waves that stopped waiting for their tile's search (they start at the ray origin: same frame, more work)
     kernel_ms_avg = solitary_ms(pipe.backend, min(args.steps, 20))
+    # ... and for a camera in motion (1 degree per frame around the world's centre): no order from earlier frames applies there
+    kernel_ms_moving = None
+    if world_size == 1 and args.orbit == 0.0 and not args.dense_dda:
+        moving = HipBackend(tracer, cam)
+        kernel_ms_moving = solitary_ms(moving, 16, orbit_arc(1.0))
     local_hits = (pipe.hits[:, 3] >> 24).sum()
     if dist is not None:
         dist.all_reduce(local_hits)
@@ -314,8 +321,10 @@ def main():
                      "hits_per_frame": int((pipe.hits[:, 3] >> 24).sum().item())}
             if not args.no_cpu_baseline:
                 c = oracle_counters(packed, pcam, W_, H_)
+                # nominal: the reference's per-visit byte count over the launch's duration — not a bound (pose B exceeds 1: the reference
+                # fetches 22 nodes per ray there, this structure a few)
                 entry.update({"hit_fraction": c["hit_fraction"], "algorithmic_bytes_per_ray": c["bytes_per_ray"],
-                              "frac_hbm_alone": c["bytes_per_ray"] * W_ * H_ / (entry["ms_per_frame_alone"] * 1e-3) / 1e9 / HBM_PEAK_GBS})
+                              "frac_nominal_alone": c["bytes_per_ray"] * W_ * H_ / (entry["ms_per_frame_alone"] * 1e-3) / 1e9 / HBM_PEAK_GBS})
             poses["ABC"[pose]] = entry
         pipe.backend = HipBackend(tracer, cam)
 
@@ -400,12 +409,30 @@ def main():
             achieved = alg["bytes_per_ray"] * rays_per_launch / (kernel_ms_avg * 1e-3) / 1e9
             overlapped_ms = device_ms / args.steps
             achieved_overlapped = alg["bytes_per_ray"] * rays_per_launch / (overlapped_ms * 1e-3) / 1e9
-            traffic = None
-            pmc = ROOT / "profiles" / "pmc_traffic.json"
-            if pmc.exists() and world_size == 1 and (args.n, W_, H_, args.pose) == (1024, 3840, 2160, 0):
-                traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_frame")
+            # counters of the frame's kernel from the committed rocprofv3 summary (profiles/<tag>_summary.json, scripts/r03/summarize.py): the
+            # run that measured them and its commit are named beside the figures; nothing is re-measured here
+            traffic, physical = None, None
+            summaries = sorted((ROOT / "profiles").glob("r0*_summary.json"))
+            if summaries and world_size == 1 and (args.n, W_, H_, args.pose, args.orbit) == (1024, 3840, 2160, 0, 0.0) and not args.dense_dda:
+                prof = json.loads(summaries[-1].read_text())
+                k = prof["kernels"].get("joint_kernel") or next(iter(prof["kernels"].values()), None)
+                if k:
+                    traffic = k.get("hbm_bytes_per_launch")
+                    physical = {"from": f"profiles/{summaries[-1].name} (tag {prof['tag']}, commit {prof['commit']}; rocprofv3 --pmc, separate passes, one frame in flight)",
+                                "kernel": k["kernel"].split("(anonymous namespace)::")[-1][:60], "kernel_us_in_that_run": k.get("duration_us_unprofiled"),
+                                "hbm_bytes_per_launch": traffic, "hbm_bytes_per_launch_upper": k.get("hbm_bytes_per_launch_upper"),
+                                "hbm_traffic_frac": (traffic / (k["duration_us_unprofiled"] * 1e-6) / 1e9 / HBM_PEAK_GBS) if traffic and k.get("duration_us_unprofiled") else None,
+                                "valu_wave_instructions_per_launch": k.get("valu_wave_instructions_per_launch"),
+                                "valu_issue_interval_cycles_per_simd": k.get("valu_issue_interval_cycles_per_simd"), "valu_issue_frac": k.get("valu_issue_frac"),
+                                "lane_utilisation": k.get("lane_utilisation"),
+                                "note": "what bounds the kernel is VALU issue under divergence, not memory: hbm_traffic_frac is the counted HBM bytes over the launch's duration against 8 TB/s; "
+                                        "valu_issue_frac = the issue interval the loop's instruction mix needs alone on a SIMD / the measured interval; lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU)"}
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                               "frac_moving": (alg["bytes_per_ray"] * rays_per_launch / (kernel_ms_moving * 1e-3) / 1e9 / HBM_PEAK_GBS) if kernel_ms_moving else None,
+                               "kernel_ms_moving": kernel_ms_moving,
+                               "moving": "the same launch alone with the camera turning 1 degree per frame around the world's centre (no order from earlier frames applies; pose-A bytes per ray)" if kernel_ms_moving else None,
+                               "physical": physical,
                                "kernel": launch, "kernel_ms": kernel_ms_avg,
                                "timing": f"HIP events around single launches, one at a time on an otherwise idle chip; {args.settle} settle + {args.warmup} warmup frames before the timed region, 2 unmeasured launches before the single ones",
                                "frac_overlapped": achieved_overlapped / HBM_PEAK_GBS, "achieved_overlapped": achieved_overlapped,

@@ -283,10 +283,7 @@ BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t in
             if (t0 >= kBeamNone) r.tmax = 0.0f;                   // the tile's frustum meets no voxel: empty interval, immediate miss
         }
         BLOK_PATH_KIND(shadow_phase ? 1u : (bounce == 0u ? 0u : 2u));
-#ifndef BLOK_PATH_SPLIT
-#define BLOK_PATH_SPLIT 0
-#endif
-        const HitInfo hit = walk<BLOK_PATH_SPLIT != 0>(A, r, stk);
+        const HitInfo hit = walk(A, r, stk);
 
         bool end_sample = false, continue_path = false;
         if (shadow_phase) {

@@ -172,12 +172,6 @@ BLOK_DEV WalkRay walk_ray(const TraceArgs& A, float ox, float oy, float oz, floa
     return R;
 }
 
-// T of the far planes of the world box (the ray leaves the tree at their minimum).
-BLOK_DEV float world_exit(const TraceArgs& A, const WalkRay& R) {
-    const float fW = kCoordBias + static_cast<float>(1 << (2 * A.levels));
-    return fminf(fminf(plane_t(R.ax, fW), plane_t(R.ay, fW)), plane_t(R.az, fW));
-}
-
 // The walk's start for the interval [tmin, tmax): world box, then the root's start cell.  Not walking = the interval misses the box.
 BLOK_DEV void walk_enter(const TraceArgs& A, const WalkRay& R, float tmin, float tmax, WalkState& s) {
     const uint32_t L = A.levels;
@@ -200,16 +194,8 @@ BLOK_DEV void walk_enter(const TraceArgs& A, const WalkRay& R, float tmin, float
     enter_axis(R.az, s.fz, s.tFz, s.size, s2, s3, s.tCur);
 }
 
-// Lanes that entered this walk (split_lanes) and loop trips between looks at who is still walking.
-#ifndef BLOK_SPLIT_FIRST
-#define BLOK_SPLIT_FIRST 24
-#endif
-constexpr uint32_t kSplitFirstTrip = BLOK_SPLIT_FIRST, kSplitCheckEvery = 4u, kSplitMaxStragglers = 8u, kSplitMaxSegments = 32u, kSplitMinSegments = 4u;
-
-// The loop.  kMaySplit: from trip kSplitFirstTrip on, every kSplitCheckEvery-th trip looks at how many of the `lanes` that entered are
-// still walking; when they are few enough for each to get >= kSplitMinSegments lanes, the loop stops (for the whole wave) and says so.
-template <bool kMaySplit>
-BLOK_DEV bool walk_loop(const TraceArgs& A, const WalkRay& R, const float tmax, WalkState& s, uint4* stk, [[maybe_unused]] const uint32_t lanes) {
+// The loop: from the state walk_enter left to the first reported voxel, the end of the interval or the world's far side.
+BLOK_DEV void walk_loop(const TraceArgs& A, const WalkRay& R, const float tmax, WalkState& s, uint4* stk) {
     const uint32_t L = A.levels;
     // Invariant: tCur starts at max(world entry, tmin) and never decreases — a cell's far planes are never
     // before the plane through which it was entered (T is monotone along each axis and the start cell of a
@@ -218,19 +204,10 @@ BLOK_DEV bool walk_loop(const TraceArgs& A, const WalkRay& R, const float tmax, 
     float fx = s.fx, fy = s.fy, fz = s.fz, tFx = s.tFx, tFy = s.tFy, tFz = s.tFz, tCur = s.tCur, size = s.size;
     uint32_t lvl = s.lvl, bit = s.bit;
     NodeRec node = s.node;
-    bool found = false, split = false, walking = s.walking;
-    [[maybe_unused]] uint32_t trips = 0;           // loop trips of the WAVE (the same in every lane still walking)
+    bool found = false;
+    const bool walking = s.walking;
     while (walking) {
         BLOK_STAT(0, lvl);
-#if !defined(BLOK_TRACE_HOST_HARNESS)
-        if constexpr (kMaySplit) {
-            trips += 1u;
-            if (trips >= kSplitFirstTrip && (trips & (kSplitCheckEvery - 1u)) == 0u) {
-                const uint32_t left = static_cast<uint32_t>(__builtin_popcountll(__ballot(true)));      // the lanes still in the loop
-                if (left <= kSplitMaxStragglers && left * kSplitMinSegments <= lanes) { split = true; break; }
-            }
-        }
-#endif
         const uint32_t shift = 2 * lvl;
         bit = (digit2(__float_as_uint(fx), shift) | (digit2(__float_as_uint(fy), shift) << 2) | (digit2(__float_as_uint(fz), shift) << 4)) ^ R.mirror;
         const bool occupied = mask_bit(node, bit);
@@ -277,10 +254,7 @@ BLOK_DEV bool walk_loop(const TraceArgs& A, const WalkRay& R, const float tmax, 
         tFx = plane_t(R.ax, fx + size); tFy = plane_t(R.ay, fy + size); tFz = plane_t(R.az, fz + size);
     }
     s.fx = fx; s.fy = fy; s.fz = fz; s.tCur = tCur; s.bit = bit; s.node = node; s.found = found;
-    s.walking = split && walking && !found;        // still owes the rest of its interval (the loop stopped for a split)
-    // (a lane that broke out of the loop by itself — found, left the box, passed tmax — is done; `split` is wave-uniform only among
-    // the lanes that were still in the loop, so it is combined by the caller)
-    return split;
+    s.walking = false;
 }
 
 // The reported voxel of a finished walk: intersect.rint:136-141, hit.rchit:58-74.  r: the ray itself (origin, direction).
@@ -313,29 +287,15 @@ BLOK_DEV HitInfo walk_hit(const TraceArgs& A, const RayIn& r, const WalkRay& R, 
     return out;
 }
 
-#if !defined(BLOK_TRACE_HOST_HARNESS)
-BLOK_DEV float lane_value(float v, uint32_t lane) { return __shfl(v, static_cast<int>(lane)); }
-BLOK_DEV uint32_t lane_value(uint32_t v, uint32_t lane) { return static_cast<uint32_t>(__shfl(static_cast<int>(v), static_cast<int>(lane))); }
-#endif
-
 // Walks one ray.  `stk` points at this lane's slot of the LDS node stack (stride kBlock entries between
 // levels; slot l-2 holds the node of level l on the current path).
 //
-// STRAGGLERS.  A wave lasts as long as its longest ray, and ray lengths have a heavy tail: behind the pre-pass the median wave of the
-// benchmark frame leaves the loop after ~25 trips, the longest (a few rays grazing the terrain across the world) after 250, each trip a
-// chain of dependent instructions that no priority shortens — such a wave takes 130 us of a 200 us launch with one or two lanes busy, and
-// wherever it starts late it IS the launch's tail.  So when only a few lanes of a wave are still walking, the loop stops and the rest
-// of each of those rays is CUT INTO SEGMENTS [b_j, b_j+1) of its remaining parameter interval, one per lane of the wave (the lanes that
-// are done have nothing else to do): every lane walks its segment from the root, and a ray's answer is the hit of its first segment
-// that reports one.  That is the same answer bit for bit: a voxel is reported iff max(entry, tmin) < min(exit, tmax) with
-// t = max(entry, tmin) (trace_kernels.h), so the true first hit V — entry e — is reported, with t = e, by the segment that contains e;
-// no earlier segment reports anything (it would be a reported voxel with a smaller entry), and neither does that segment before V
-// (the same, or a voxel straddling its start b_j, whose entry is smaller still).  A voxel straddling a later boundary is reported there
-// with t = b_j, but later segments are never looked at.  And a walk restarted at tmin = the parameter a ray had reached continues the
-// same sequence of cells (the restart counts exactly the planes with T <= tCur as crossed; cells skipped have empty intervals).
-// kSplit: whether this call site cuts stragglers into segments (the path loop's incoherent rays; primary rays are long or short
-// tile by tile, not ray by ray — scripts/r03/straggler_stats.py — so their kernels leave it out and keep their registers).
-template <bool kSplit = false>
+// Tried in round 3 and removed (profiles/r03_paths_straggler_split_ab.txt, r03_walk_order_experiment*.txt): cutting the rest
+// of a wave's last few rays into parameter segments for its idle lanes (exact: a ray's answer is the hit of its first segment that
+// reports one; all parity tests passed) — primary rays are long or short tile by tile, not ray by ray, so there is nobody idle to
+// help, and in the path loop the restarts cost more than the shorter rounds gave back (64 spp: 46.9 -> 51.2 ms); raising a wave's issue
+// priority with its age (a long wave is a chain of dependent instructions: no priority shortens it); running the descend path only when
+// enough lanes want it (waiting lanes stretch the critical path: -7 to -14 %).
 BLOK_DEV HitInfo walk(const TraceArgs& A, const RayIn& r, uint4* stk) {
     BLOK_STAT(4, 0);                       // a walk begins
     HitInfo out;
@@ -343,77 +303,9 @@ BLOK_DEV HitInfo walk(const TraceArgs& A, const RayIn& r, uint4* stk) {
     const WalkRay R = walk_ray(A, r.ox, r.oy, r.oz, safe_inv(r.dx), safe_inv(r.dy), safe_inv(r.dz));
     WalkState s;
     walk_enter(A, R, r.tmin, r.tmax, s);
-#if defined(BLOK_TRACE_HOST_HARNESS) || defined(BLOK_NO_SPLIT)
-    (void)walk_loop<false>(A, R, r.tmax, s, stk, 0u);
+    walk_loop(A, R, r.tmax, s, stk);
     if (s.found) out = walk_hit(A, r, R, s);
     return out;
-#else
-    if constexpr (!kSplit) {
-        (void)walk_loop<false>(A, R, r.tmax, s, stk, 0u);
-        if (s.found) out = walk_hit(A, r, R, s);
-        return out;
-    }
-    const unsigned long long entered = __ballot(true);                       // the lanes of this call
-    const uint32_t lanes = static_cast<uint32_t>(__builtin_popcountll(entered));
-    const bool split = __ballot(walk_loop<true>(A, R, r.tmax, s, stk, lanes)) != 0ull;      // wave-uniform (lanes that had left the loop say false)
-    if (s.found) out = walk_hit(A, r, R, s);
-    if (!split) return out;
-
-    // ---- the rest of the stragglers' rays, cut into segments
-    const unsigned long long owing = __ballot(s.walking);                    // the stragglers (1 .. kSplitMaxStragglers lanes)
-    const uint32_t n = static_cast<uint32_t>(__builtin_popcountll(owing));
-    if (n == 0u) return out;
-    uint32_t segs = kSplitMaxSegments;                                       // per straggler: the largest power of two <= lanes / n (>= kSplitMinSegments by the loop's test)
-    while (segs * n > lanes) segs >>= 1;
-    const uint32_t seg_shift = static_cast<uint32_t>(__builtin_ctz(segs));
-    const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(entered >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(entered), 0u));   // among the lanes of this call
-    const uint32_t group = rank >> seg_shift, j = rank & (segs - 1u);
-    uint32_t src = 64u;                                                      // the straggler this lane helps (none: group >= n)
-    {
-        unsigned long long m = owing;
-        for (uint32_t g = 0; g < n; ++g) {                                   // wave-uniform: <= kSplitMaxStragglers turns
-            const uint32_t id = static_cast<uint32_t>(__builtin_ctzll(m));
-            m &= m - 1ull;
-            if (group == g) src = id;
-        }
-    }
-    const uint32_t from = src < 64u ? src : 0u;
-    // the straggler's ray and where it stands (every lane of the call fetches; the stragglers are among them, so the sources are active)
-    const float sox = lane_value(R.ax.o, from), soy = lane_value(R.ay.o, from), soz = lane_value(R.az.o, from);
-    const float six = lane_value(R.ax.inv, from), siy = lane_value(R.ay.inv, from), siz = lane_value(R.az.inv, from);
-    const float s_cur = lane_value(s.tCur, from), s_max = lane_value(r.tmax, from);
-    const WalkRay H = walk_ray(A, sox, soy, soz, six, siy, siz);
-    // boundaries b_k = cur + (end - cur) * k / segs, the same expression in the lane that ends at b_k and the lane that starts there;
-    // the first segment starts where the ray stands, the last ends at the ray's own tmax
-    const float s_end = fminf(s_max, world_exit(A, H));
-    const float span = s_end - s_cur, inv_segs = 1.0f / static_cast<float>(segs);
-    const float b_lo = s_cur + span * (static_cast<float>(j) * inv_segs), b_hi = s_cur + span * (static_cast<float>(j + 1u) * inv_segs);
-    const float h_min = j == 0u ? s_cur : b_lo;
-    float h_max = j + 1u == segs ? s_max : b_hi;
-    if (src >= 64u || !(span > 0.0f)) h_max = 0.0f;                           // nothing to help with (an empty interval enters nothing); span <= 0: the ray is at its end,
-    WalkState h;                                                             // and its first segment (h_min = cur, h_max = tmax) settles that
-    if (src < 64u && !(span > 0.0f) && j == 0u) h_max = s_max;
-    walk_enter(A, H, h_min, h_max, h);
-    (void)walk_loop<false>(A, H, h_max, h, stk, 0u);
-    // a straggler's answer: its lowest segment with a hit (helpers of one straggler are consecutive lanes of the call, so that is the
-    // lowest such lane); its state goes to the straggler, which finishes the record with its own ray
-    for (uint32_t g = 0; g < n; ++g) {
-        const unsigned long long hits = __ballot(h.found && group == g);
-        unsigned long long m = owing;
-        for (uint32_t k = 0; k < g; ++k) m &= m - 1ull;
-        const uint32_t owner = static_cast<uint32_t>(__builtin_ctzll(m));
-        if (hits == 0ull) continue;
-        const uint32_t w = static_cast<uint32_t>(__builtin_ctzll(hits));
-        WalkState got;
-        got.fx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(h.fx), w)); got.fy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(h.fy), w));
-        got.fz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(h.fz), w)); got.tCur = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(h.tCur), w));
-        got.node.lo = __builtin_amdgcn_readlane(h.node.lo, w); got.node.hi = __builtin_amdgcn_readlane(h.node.hi, w); got.node.base = __builtin_amdgcn_readlane(h.node.base, w);
-        got.bit = __builtin_amdgcn_readlane(h.bit, w);
-        if (threadIdx.x % 64u == owner) { s.fx = got.fx; s.fy = got.fy; s.fz = got.fz; s.tCur = got.tCur; s.node = got.node; s.bit = got.bit; s.found = true; }
-    }
-    if (s.walking && s.found) out = walk_hit(A, r, R, s);
-    return out;
-#endif
 }
 
 // Walks one ray and writes its 16-byte record and/or RGBA8 pixel.
