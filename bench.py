@@ -103,6 +103,32 @@ def build_world(n: int, seed: int):
     return cm.pack_chunks_to_gpu_svo(W.scene_materials(seed))
 
 
+def build_world_shared(n: int, seed: int, dist, rank: int):
+    """N > 1: ONE CPU build per job instead of one per rank — rank 0 builds the world and broadcasts the three arrays of WorldSvoGpu
+    (149 MB of SvoNodes for 1024^3) over the process group; every rank then uploads its replica (replicated world)."""
+    if dist is None:
+        return build_world(n, seed)
+    import torch
+    from blok_amd import world as W
+    from blok_amd._ffi import MATERIAL, SUB_CHUNK, SVO_NODE
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    arrays = None
+    sizes = torch.zeros(3, dtype=torch.int64, device=dev)
+    if rank == 0:
+        packed = build_world(n, seed)
+        arrays = [np.ascontiguousarray(a).view(np.uint8).reshape(-1) for a in (packed.nodes, packed.sub_chunks, packed.materials)]
+        sizes = torch.tensor([a.size for a in arrays], dtype=torch.int64, device=dev)
+    dist.broadcast(sizes, src=0)
+    got = []
+    for i in range(3):
+        t = torch.from_numpy(arrays[i]).to(dev) if rank == 0 else torch.empty(int(sizes[i]), dtype=torch.uint8, device=dev)
+        dist.broadcast(t, src=0)
+        got.append(t.cpu().numpy())
+    if rank == 0:
+        return packed
+    return W.PackedWorld(got[0].view(SVO_NODE), got[1].view(SUB_CHUNK), got[2].view(MATERIAL))
+
+
 def usable_cores() -> int:
     """Host cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (a GPU box of the pool shows
     256 hardware threads but grants a 16-CPU share per GPU; threads beyond the quota are only throttled)."""
@@ -196,7 +222,7 @@ def main():
     from blok_amd.tracer import HipTracer
 
     W_, H_ = args.width, args.height
-    packed = build_world(args.n, args.seed)
+    packed = build_world_shared(args.n, args.seed, dist, rank)
     cam = W.scene_camera(args.n, args.pose, W_, H_, args.seed)
     tracer = HipTracer(W_, H_, device=device_index).init()
     if args.dense_dda:
@@ -444,6 +470,9 @@ def main():
         print(json.dumps(out), flush=True)
     tracer.shutdown()
     if dist is not None:
+        # rank 0 has been on the CPU (oracle byte counts) while the others got here at once: everybody leaves together, so no rank tears
+        # the group down under a peer that still owes a collective
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -185,6 +185,7 @@ HIP_SYMBOLS = {
     "blok_hip_multi_draw_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "blok_hip_multi_set_exchange": (C.c_int, [C.c_void_p, C.c_int]),
     "blok_hip_multi_exchange": (C.c_char_p, [C.c_void_p]),
+    "blok_hip_multi_debug_deny_peer_access": (C.c_int, [C.c_void_p, C.c_int]),
     "blok_hip_multi_draw_frames_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]),
     "blok_hip_multi_draw_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "blok_hip_multi_download_hits": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]),

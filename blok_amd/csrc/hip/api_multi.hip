@@ -75,6 +75,7 @@ struct blok_hip_multi {
     bool has_assembled = false;
     bool frame_is_sky = false;               // d_frame / d_tile_state are in the state sparse-pull assumes (all sky / all zero, or left by it)
     bool peer_readable = false;              // the root can read every device's memory
+    bool peer_denied = false, peer_readable_real = false;      // blok_hip_multi_debug_deny_peer_access
     int exchange = -1;                       // -1 = sparse-pull when possible, 0 = dense, 1 = sparse-pull (refused when impossible)
     Rccl rccl;
     bool use_rccl = false;
@@ -263,6 +264,16 @@ int blok_hip_multi_set_exchange(blok_hip_multi* m, int mode) {
 }
 
 const char* blok_hip_multi_exchange(const blok_hip_multi* m) { return !m ? "" : sparse_pull(m) ? "sparse-pull" : "dense"; }
+
+// Diagnostic: behave as if the root could not read the other devices' memory (what hipDeviceCanAccessPeer / hipDeviceEnablePeerAccess
+// report on a node without peer access): sparse-pull is then unavailable and every call takes the dense exchange over RCCL or peer copies.
+int blok_hip_multi_debug_deny_peer_access(blok_hip_multi* m, int deny) {
+    if (!m) return BLOK_ERR_INVALID_ARG;
+    if (deny) { if (!m->peer_denied) m->peer_readable_real = m->peer_readable; m->peer_denied = true; m->peer_readable = false; }
+    else if (m->peer_denied) { m->peer_denied = false; m->peer_readable = m->peer_readable_real; }
+    if (m->exchange == 1 && !m->peer_readable) m->exchange = -1;          // a forced sparse-pull cannot stand
+    return BLOK_OK;
+}
 
 int blok_hip_multi_draw_frames_device(blok_hip_multi* m, const blok_camera* cams, uint32_t n_frames, const uint32_t** out_rgba8_dev_on_root) {
     if (!m) return BLOK_ERR_INVALID_ARG;

@@ -90,6 +90,21 @@ class HipMultiTracer:
     def exchange(self) -> str:
         return (self._lib.blok_hip_multi_exchange(self._m) or b"").decode()
 
+    def deny_peer_access(self, deny: bool):
+        """Diagnostic: as if the root could not read the other devices' memory (blok_hip.h)."""
+        self._check(self._lib.blok_hip_multi_debug_deny_peer_access(self._m, 1 if deny else 0))
+
+    def draw_frames_async(self, cams):
+        """Enqueues one call (1..8 cameras) and returns at once; the root's device frames are valid after synchronize()."""
+        import numpy as np
+        cams = np.ascontiguousarray(np.concatenate([np.asarray(c).reshape(-1) for c in cams]), dtype=self._ffi.CAMERA)
+        ptr = self._C.c_void_p()
+        self._check(self._lib.blok_hip_multi_draw_frames_device(self._m, self._ffi.ptr(cams), len(cams), self._C.byref(ptr)))
+        return ptr.value
+
+    def synchronize(self):
+        self._check(self._lib.blok_hip_multi_synchronize(self._m))
+
     def rank_hits(self, rank: int):
         import numpy as np
         n = int(self._lib.blok_hip_tiles_for_rank(self.width, self.height, self.tile, rank, self.n)) * self.tile * self.tile

@@ -578,6 +578,9 @@ int  blok_hip_multi_draw_frame(blok_hip_multi* m, const blok_camera* cam, uint32
  *   "dense" (mode 0): the RGBA8 tiles of every rank travel whole (blok_hip_multi_transport), then an un-permute kernel. */
 int  blok_hip_multi_set_exchange(blok_hip_multi* m, int mode);
 const char* blok_hip_multi_exchange(const blok_hip_multi* m);        /* what the next call will use: "sparse-pull" or "dense" */
+/* Diagnostic: deny != 0 = behave as if the root had no peer access to the other devices (sparse-pull unavailable, mode 1 refused, every
+ * call takes the dense exchange over blok_hip_multi_transport); 0 = back to what the node really offers.  The frames are the same. */
+int  blok_hip_multi_debug_deny_peer_access(blok_hip_multi* m, int deny);
 int  blok_hip_multi_draw_frames_device(blok_hip_multi* m, const blok_camera* cams, uint32_t n_frames, const uint32_t** out_rgba8_dev_on_root);
 int  blok_hip_multi_draw_frames(blok_hip_multi* m, const blok_camera* cams, uint32_t n_frames, uint32_t* out_rgba8_host);
 /* first-hit records of the first frame of the last call */

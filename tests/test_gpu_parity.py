@@ -1008,6 +1008,27 @@ def test_multi_device_entry_one_process(tracer_cls, scene1024):
                     h, w = min(tile, Ht - y0), min(tile, Wd - x0)
                     block = got[k * tile * tile:(k + 1) * tile * tile].reshape(tile, tile)[:h, :w]
                     assert records_equal(block.reshape(-1), hits[y0:y0 + h, x0:x0 + w].reshape(-1)).all(), (devices, name, r, k)
+        # as on a node without peer access: sparse-pull is refused, the default falls back to the dense exchange, same frames
+        if n > 1:
+            mt.set_exchange(1)
+            mt.deny_peer_access(True)
+            assert mt.exchange == "dense"
+            with pytest.raises(BlokError):
+                mt.set_exchange(1)
+            for mode in (-1, 0):
+                mt.set_exchange(mode)
+                assert mt.exchange == "dense" and (mt.draw_frame(cam) == want).all(), (devices, "denied", mode)
+            mt.deny_peer_access(False)
+            mt.set_exchange(-1)
+            assert mt.exchange == "sparse-pull" and (mt.draw_frame(cams[1]) == wants[1]).all()
+            # calls are asynchronous: back-to-back calls without a synchronize in between must not tear the first one's frames (a peer's
+            # next trace / compact waits for the root's assembly of the previous call)
+            for mode in (-1, 0):
+                mt.set_exchange(mode)
+                for k in range(6):
+                    mt.draw_frames_async([cams[k % 3]])
+                mt.synchronize()
+                assert (mt.draw_frame(cams[2]) == wants[2]).all(), (devices, "async", mode)
         with pytest.raises(BlokError):
             mt.draw_frames([cam] * 9)
         mt.shutdown()

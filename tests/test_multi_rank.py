@@ -288,3 +288,36 @@ def test_coded_exchange_reference_round_trip():
             most = max(most, int(c[:F].max()))
         got = T.scatter_code_tile_frames(gathered, n, stride, tile, most, F, w, h, albedo)
         assert (got == want).all()
+
+
+def _share_worker(rank, world_size, port, out_dir):
+    sys.path.insert(0, str(ROOT))
+    import hashlib
+    import torch.distributed as dist
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    built = []
+    real = bench.build_world
+    bench.build_world = lambda n, seed: (built.append(rank), real(n, seed))[1]       # who actually builds
+    pw = bench.build_world_shared(64, 0xB10C0001, dist, rank)
+    digest = hashlib.sha256(pw.nodes.tobytes() + pw.sub_chunks.tobytes() + pw.materials.tobytes()).hexdigest()
+    (Path(out_dir) / f"share{rank}.txt").write_text(f"{digest} {len(built)} {len(pw.nodes)} {len(pw.sub_chunks)} {len(pw.materials)}")
+    dist.barrier()                                            # bench.py's exit: everybody leaves together
+    dist.destroy_process_group()
+
+
+def test_world_is_built_once_and_broadcast_world_size_2(tmp_path):
+    """bench.py --gpus N: rank 0 builds the world, the others receive the three arrays of WorldSvoGpu over the process group."""
+    import torch.multiprocessing as mp
+    sys.path.insert(0, str(ROOT))
+    import hashlib
+    import bench
+    port = _free_port()
+    mp.spawn(_share_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    want = bench.build_world(64, 0xB10C0001)
+    digest = hashlib.sha256(want.nodes.tobytes() + want.sub_chunks.tobytes() + want.materials.tobytes()).hexdigest()
+    rows = [(tmp_path / f"share{r}.txt").read_text().split() for r in range(2)]
+    assert rows[0][0] == rows[1][0] == digest and len(want.nodes) > 1000
+    assert (rows[0][1], rows[1][1]) == ("1", "0")            # one build, on rank 0
