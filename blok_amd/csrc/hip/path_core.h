@@ -114,9 +114,17 @@ BLOK_DEV V3 sample_ggx(float ux, float uy, V3 n, float roughness) {    // :115-1
 // pow(x, k) for the shader's integer exponents 5, 8, 128 by multiplication (<= 4 ulp from a correctly rounded
 // pow; GLSL's own pow is exp2(y*log2(x)) at driver precision).  Far inside the stated colour tolerance, and
 // ~10x fewer instructions than the library powf on a path where every miss sample evaluates two of them.
+#ifdef BLOK_PATH_LIBM_POW
+// host harness only: the oracle's literal pow(x, k), to show that nothing BUT these three differs between the kernel body and the
+// oracle on one libm (tests/test_paths.py)
+BLOK_DEV float pow5(float x) { return powf(x, 5.0f); }
+BLOK_DEV float pow8(float x) { return powf(x, 8.0f); }
+BLOK_DEV float pow128(float x) { return powf(x, 128.0f); }
+#else
 BLOK_DEV float pow5(float x) { const float x2 = x * x; return x2 * x2 * x; }
 BLOK_DEV float pow8(float x) { const float x2 = x * x; const float x4 = x2 * x2; return x4 * x4; }
 BLOK_DEV float pow128(float x) { float y = pow8(x); y = y * y; y = y * y; y = y * y; return y * y; }
+#endif
 
 BLOK_DEV V3 fresnel_schlick(float cos_theta, V3 f0) {                  // :132-134
     const float w = pow5(fmaxf(1.0f - cos_theta, 0.0f));

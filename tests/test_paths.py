@@ -37,18 +37,28 @@ def world64():
 
 @pytest.mark.parametrize("pose,spp,bounces", [(0, 8, 2), (1, 4, 4), (2, 1, 1)])
 def test_kernel_body_matches_oracle_on_cpu(world64, pose, spp, bounces):
-    """Same libm on both sides and the same operation order: the G-buffer must agree bit for bit; the colour differs
-    only through the kernel's multiplicative pow(x, 5 | 8 | 128) (a few ulp), i.e. by orders of magnitude less than
-    the tolerance, except where such an ulp flips a lobe / roulette decision or a grazing bounce ray (rare)."""
+    """Same libm on both sides and the same operation order.  (1) With the shader's three pow(x, 5 | 8 | 128) through libm, as the
+    oracle writes them, the kernel body equals the oracle BIT FOR BIT in every plane, colour included: nothing else differs.  (2) The
+    shipped body does those powers by multiplication (a few ulp from libm's): the G-buffer is still exact, and every pixel's colour
+    stays inside the stated contract 1e-4 + 1e-3 |ref|; the pixels that move by more than 1e-6 + 1e-5 |ref| — where such an ulp
+    flips a lobe choice, a roulette decision or a grazing bounce ray, so that the sample takes another path — are few (< 0.2 %)."""
     pw, mats, lat = world64
     cam = W.scene_camera(64, pose, 80, 60, SEED)
     ref, ctr = O.render_paths(lat, mats, cam, 80, 60, spp=spp, max_bounces=bounces, frame_index=7, threads=4)
-    got = H.HostKernel(pw.nodes, pw.sub_chunks).render_paths(cam, mats, 80, 60, spp=spp, max_bounces=bounces, frame_index=7)
     assert ctr["rays"] > 80 * 60 * spp
+    exact = H.render_paths_libm_pow(pw.nodes, pw.sub_chunks, cam, mats, 80, 60, spp=spp, max_bounces=bounces, frame_index=7)
+    for k in ("world_pos", "normal_roughness", "albedo_metallic", "color"):
+        assert np.array_equal(ref[k], exact[k]), k
+    got = H.HostKernel(pw.nodes, pw.sub_chunks).render_paths(cam, mats, 80, 60, spp=spp, max_bounces=bounces, frame_index=7)
     for k in ("world_pos", "normal_roughness", "albedo_metallic"):
         assert np.array_equal(ref[k], got[k]), k
-    ok = (np.abs(got["color"] - ref["color"]) <= 1e-6 + 1e-5 * np.abs(ref["color"])).all(axis=2)
-    assert ok.mean() >= 0.998, ok.mean()
+    err = np.abs(got["color"] - ref["color"])
+    moved = ~(err <= 1e-6 + 1e-5 * np.abs(ref["color"])).all(axis=2)
+    assert moved.mean() < 0.002, moved.mean()
+    # a sample that takes another path changes its pixel by up to (sample radiance) / spp — not an arithmetic error: such pixels are
+    # bounded by the firefly clamp instead (raygen.rgen:386-389), all the others by the contract
+    assert (err[~moved] <= 1e-4 + 1e-3 * np.abs(ref["color"][~moved])).all()
+    assert np.isfinite(got["color"]).all() and (got["color"][..., :3] <= 100.0 + 1e-3).all()
     assert np.isfinite(ref["color"]).all() and (ref["color"][..., 3] == 1).all()
 
 

@@ -424,9 +424,14 @@ def test_gpu_chain_matches_oracle(gbuffer_frames):
     ldr = torch.zeros(n, dtype=torch.int32, device="cuda"); sharp = torch.zeros_like(ldr)
 
     def close(got, ref, what):
+        # EVERY pixel.  The device differs from the host only in expf (variance.comp's weights) by a few ulp; every stage is compared
+        # on the SAME inputs — the TAA resolve gets the device's own denoised plane — because taa.comp's variance clip takes
+        # sqrt(max(E[c^2] - mean^2, 0)) of the 3x3 neighbourhood (:95-107): where that neighbourhood is nearly uniform the difference
+        # cancels, and a 1e-6 change of the input moves the clip box by 1e-3 (measured end to end: 0.07 % of the pixels off by up to
+        # 2e-2, all of them in the TAA plane, none in the denoiser's; profiles/r03_post_chain_outliers.txt).
         ok = np.abs(got - ref) <= 1e-5 + 1e-4 * np.abs(ref)
         ok = ok.reshape(Ht, Wd, -1).all(axis=2)
-        assert ok.mean() >= 0.999, (what, ok.mean())
+        assert ok.all(), (what, int((~ok).sum()), float(np.abs(got - ref).max()))
         return ok
 
     for k, cam in enumerate(cams):
@@ -444,12 +449,13 @@ def test_gpu_chain_matches_oracle(gbuffer_frames):
         ok = close(den.cpu().numpy().reshape(Ht, Wd, 4), ref_den, f"denoised {k}")
         hist, mom, hl, var, mot = tr.denoise_state()
         close(hist, o.prev["color"], f"history {k}"); close(mom, o.prev["moments"], f"moments {k}")
-        assert (hl == o.prev["hist_len"]).mean() >= 0.999
+        assert np.array_equal(hl, o.prev["hist_len"])
         close(var[..., None], o.variance[..., None], f"variance {k}")
         assert np.array_equal(mot, np.vectorize(O.q16)(o.motion).astype(np.float32))
-        ref_taa = o.taa(ref_den, k)
-        ok &= close(taa.cpu().numpy().reshape(Ht, Wd, 4), ref_taa, f"taa {k}")
-        ref_sharp = O.sharpen(O.tonemap(ref_taa).reshape(Ht, Wd))
+        got_taa = taa.cpu().numpy().reshape(Ht, Wd, 4)
+        ref_taa = o.taa(den.cpu().numpy().reshape(Ht, Wd, 4), k)            # the device's denoised plane in, see close()
+        ok &= close(got_taa, ref_taa, f"taa {k}")
+        ref_sharp = O.sharpen(O.tonemap(got_taa).reshape(Ht, Wd))           # tonemap + sharpen of the device's resolved plane: <= 1 LSB
         got_sharp = sharp.cpu().numpy().view(np.uint32).reshape(Ht, Wd)
         d = np.abs(got_sharp.view(np.uint8).reshape(Ht, Wd, 4).astype(int) - ref_sharp.view(np.uint8).reshape(Ht, Wd, 4).astype(int))
         inner = ok.copy()                                                   # a differing neighbour reaches into the 3x3 sharpen footprint
@@ -490,21 +496,22 @@ def test_gpu_explicit_motion_planes_and_settings():
             tr.taa_device(den.data_ptr(), res.data_ptr(), k, 0.8, 0.95, motion_ptr=dev[3].data_ptr())
             torch.cuda.synchronize()
             ref = o.denoise(color, wp, nr, ident, k, motion=motion)
-            ref_res = o.taa(ref, k, 0.8, 0.95, motion=motion)
-            for got, want, what in ((den.cpu().numpy().reshape(h, w, 4), ref, "denoised"), (res.cpu().numpy().reshape(h, w, 4), ref_res, "resolved")):
+            got_den = den.cpu().numpy().reshape(h, w, 4)
+            ref_res = o.taa(got_den, k, 0.8, 0.95, motion=motion)           # every stage on the same inputs (see test_gpu_chain_matches_oracle)
+            for got, want, what in ((got_den, ref, "denoised"), (res.cpu().numpy().reshape(h, w, 4), ref_res, "resolved")):
                 ok = (np.abs(got - want) <= 1e-5 + 1e-4 * np.abs(want)).all(axis=2)
-                assert ok.mean() >= 0.999, (iters, k, what, ok.mean())
+                assert ok.all(), (iters, k, what, int((~ok).sum()), float(np.abs(got - want).max()))
             hist, mom, hl, var, mot = tr.denoise_state()
             assert np.array_equal(mot, np.vectorize(O.q16)(motion).astype(np.float32))
-            assert (hl == o.prev["hist_len"]).mean() >= 0.999
+            assert np.array_equal(hl, o.prev["hist_len"])
         assert (hl > 1).mean() > 0.3                       # small motion: most of the surface keeps its history
         tr.shutdown()
 
 
 @pytest.mark.gpu
 def test_gpu_chain_at_1080p_matches_oracle():
-    """The same comparison at a real frame size (1920x1080 over the 256^3 scene, two frames): every plane within the stated
-    tolerance on >= 99.9 % of the pixels."""
+    """The same comparison at a real frame size (1920x1080 over the 256^3 scene, two frames): every pixel of every plane within the
+    stated tolerance, each stage on the same inputs."""
     import torch
     from blok_amd.tracer import HipTracer
     w, h = 1920, 1080
@@ -530,10 +537,11 @@ def test_gpu_chain_at_1080p_matches_oracle():
         torch.cuda.synchronize()
         host = {name: t.cpu().numpy().reshape(h, w, 4) for name, t in P.items()}
         ref = o.denoise(host["color"], host["world_pos"], host["normal_roughness"], prev, k)
-        ref_res = o.taa(ref, k)
-        for got, want, what in ((den.cpu().numpy().reshape(h, w, 4), ref, "denoised"), (res.cpu().numpy().reshape(h, w, 4), ref_res, "resolved")):
+        got_den = den.cpu().numpy().reshape(h, w, 4)
+        ref_res = o.taa(got_den, k)
+        for got, want, what in ((got_den, ref, "denoised"), (res.cpu().numpy().reshape(h, w, 4), ref_res, "resolved")):
             ok = (np.abs(got - want) <= 1e-5 + 1e-4 * np.abs(want)).all(axis=2)
-            assert ok.mean() >= 0.999, (k, what, ok.mean())
+            assert ok.all(), (k, what, int((~ok).sum()), float(np.abs(got - want).max()))
     hl = tr.denoise_state()[2]
     assert (hl[host["world_pos"][..., 3] < 9000] > 1).mean() > 0.8
     tr.shutdown()
