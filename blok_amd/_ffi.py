@@ -192,6 +192,7 @@ HIP_SYMBOLS = {
     "blok_hip_set_beam_budget": (C.c_int, [C.c_void_p, C.c_uint32]),
     "blok_hip_set_miss_writer": (C.c_int, [C.c_void_p, C.c_int]),
     "blok_hip_last_launch_kind": (C.c_int, [C.c_void_p]),
+    "blok_hip_set_volume_layout": (C.c_int, [C.c_void_p, C.c_int]),
     "blok_hip_set_list_classes": (C.c_int, [C.c_void_p, C.c_int]),
     "blok_hip_set_joint_prefix_limit": (C.c_int, [C.c_void_p, C.c_uint32]),
     "blok_hip_set_tile_ordering": (C.c_int, [C.c_void_p, C.c_int]),

@@ -28,8 +28,9 @@ void free_post(blok_hip_ctx* ctx) {
 }
 
 void free_world(blok_hip_ctx* ctx) {
-    if (ctx->d_nodes) (void)hipFree(ctx->d_nodes);
-    if (ctx->d_tree_materials) (void)hipFree(ctx->d_tree_materials);
+    if (ctx->d_nodes && !ctx->tree_owned_by_volume) (void)hipFree(ctx->d_nodes);
+    if (ctx->d_tree_materials && !ctx->tree_owned_by_volume) (void)hipFree(ctx->d_tree_materials);
+    ctx->tree_owned_by_volume = false;
     if (ctx->d_materials) (void)hipFree(ctx->d_materials);
     if (ctx->d_sun_map) (void)hipFree(ctx->d_sun_map);
     ctx->d_sun_map = nullptr; ctx->has_sun_map = false;
@@ -109,10 +110,35 @@ int rebuild_sun_map(blok_hip_ctx* ctx) {
     m.nu = static_cast<uint32_t>(std::ceil((hi[0] - m.u0) / m.texel)) + 1u; m.nv = static_cast<uint32_t>(std::ceil((hi[1] - m.v0) / m.texel)) + 1u;
     BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_sun_map), static_cast<size_t>(m.nu) * m.nv * sizeof(float)));
     m.map = ctx->d_sun_map;
+    m.iu0 = m.iv0 = 0; m.sub_nu = m.nu; m.sub_nv = m.nv;
     blok::launch_sun_map(m, nullptr);
     BLOK_HIP_TRY(ctx, hipGetLastError());
     BLOK_HIP_TRY(ctx, hipDeviceSynchronize());
     ctx->has_sun_map = true;
+    return BLOK_OK;
+}
+
+// After an edit of the installed world that left its lattice alone (same origin, same levels): only the texels whose prism can meet the
+// edited box [lo, hi) (world voxels) are searched again, on the new tree.  Anything else: the whole map.
+int update_sun_map(blok_hip_ctx* ctx, const int32_t lo[3], const int32_t hi[3], bool same_lattice) {
+    if (!same_lattice || !ctx->has_sun_map || !ctx->d_sun_map || ctx->world_voxel_size != 1.0f || !ctx->has_world || ctx->stats.n_voxels == 0) return rebuild_sun_map(ctx);
+    blok::SunMapArgs& m = ctx->sun;
+    m.trace.nodes = ctx->d_nodes; m.trace.materials = ctx->d_tree_materials;
+    if (lo[0] >= hi[0] || lo[1] >= hi[1] || lo[2] >= hi[2]) return BLOK_OK;            // nothing was edited
+    double ulo = 1e30, uhi = -1e30, vlo = 1e30, vhi = -1e30;
+    for (int c = 0; c < 8; ++c) {
+        const double p[3] = {double((c & 1) ? hi[0] : lo[0]), double((c & 2) ? hi[1] : lo[1]), double((c & 4) ? hi[2] : lo[2])};
+        const double pu = m.u[0] * p[0] + m.u[1] * p[1] + m.u[2] * p[2], pv = m.v[0] * p[0] + m.v[1] * p[1] + m.v[2] * p[2];
+        ulo = std::min(ulo, pu); uhi = std::max(uhi, pu); vlo = std::min(vlo, pv); vhi = std::max(vhi, pv);
+    }
+    const auto texel_of = [&](double x, double x0, uint32_t n) { const double t = std::floor((x - x0) / m.texel); return static_cast<int64_t>(std::min<double>(std::max<double>(t, -1.0), double(n))); };
+    const int64_t iu0 = std::max<int64_t>(texel_of(ulo, m.u0, m.nu) - 1, 0), iu1 = std::min<int64_t>(texel_of(uhi, m.u0, m.nu) + 1, int64_t(m.nu) - 1);
+    const int64_t iv0 = std::max<int64_t>(texel_of(vlo, m.v0, m.nv) - 1, 0), iv1 = std::min<int64_t>(texel_of(vhi, m.v0, m.nv) + 1, int64_t(m.nv) - 1);
+    if (iu1 < iu0 || iv1 < iv0) return BLOK_OK;
+    m.iu0 = static_cast<uint32_t>(iu0); m.iv0 = static_cast<uint32_t>(iv0); m.sub_nu = static_cast<uint32_t>(iu1 - iu0 + 1); m.sub_nv = static_cast<uint32_t>(iv1 - iv0 + 1);
+    blok::launch_sun_map(m, nullptr);
+    BLOK_HIP_TRY(ctx, hipGetLastError());
+    BLOK_HIP_TRY(ctx, hipDeviceSynchronize());
     return BLOK_OK;
 }
 

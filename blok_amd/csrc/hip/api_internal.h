@@ -38,6 +38,7 @@ struct blok_hip_ctx {
     size_t n_materials = 0;
     bool has_world = false;
     bool built_on_device = false;     // structure built by gpu_build.hip (else tree_build.cpp on the host)
+    bool tree_owned_by_volume = false; // d_nodes / d_tree_materials belong to the resident volume's scratch (gpu_build.h): never freed here
     bool force_host_build = false;
     blok_world_stats stats{};
     float voxel_size = 1.0f;            // for the next blok_hip_upload_world (blok_hip_set_voxel_size)
@@ -83,6 +84,8 @@ struct blok_hip_ctx {
     // device-resident dense store (gpu_build.h: GpuVolume)
     blok::GpuVolume volume;
     bool has_volume = false;
+    bool volume_keyed_layout = true;   // blok_hip_set_volume_layout: the next blok_hip_volume_create may use the keyed brick layout (gpu_build.h)
+    std::vector<unsigned char> volume_materials;      // the material table the last blok_hip_volume_rebuild installed (compared, not re-uploaded, when unchanged)
     // "last occluder" map of the shadow rays (beam.h: prism_far), rebuilt with every world
     float* d_sun_map = nullptr;
     bool sun_map_enabled = true, has_sun_map = false;
@@ -162,6 +165,7 @@ void free_world(blok_hip_ctx* ctx);
 int install_materials(blok_hip_ctx* ctx, const blok_material* materials, size_t n_materials);
 int install_tree(blok_hip_ctx* ctx, const blok::HostTree& tree, const blok_material* materials, size_t n_materials);
 int rebuild_sun_map(blok_hip_ctx* ctx);
+int update_sun_map(blok_hip_ctx* ctx, const int32_t lo[3], const int32_t hi[3], bool same_lattice);
 int ensure_frame(blok_hip_ctx* ctx, size_t records);
 blok::TraceArgs base_args(const blok_hip_ctx* ctx, const blok_camera* cam);
 int prepare_beam(blok_hip_ctx* ctx, blok::RayMode mode, blok::TraceArgs& args, hipStream_t stream, uint32_t tiles_of_rank, uint32_t* n_beams);

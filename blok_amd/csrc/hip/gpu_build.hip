@@ -431,7 +431,10 @@ DenseCtx volume_ctx(const GpuVolume& v) {
 }
 
 // Recomputes the masks of the bricks that contain voxels [lo, hi) (box-local voxel coordinates).
+GpuBuildStatus keyed_refresh(GpuVolume* v, const uint32_t lo[3], const uint32_t hi[3], std::string* why);
 GpuBuildStatus volume_refresh(GpuVolume* v, const uint32_t lo[3], const uint32_t hi[3], std::string* why) {
+    if (v->keyed) return keyed_refresh(v, lo, hi, why);
+    for (int a = 0; a < 3; ++a) { v->edit_lo[a] = std::min(v->edit_lo[a], lo[a]); v->edit_hi[a] = std::max(v->edit_hi[a], hi[a]); }
     DenseCtx d = volume_ctx(*v);
     d.rx0 = lo[0] / 4u; d.ry0 = lo[1] / 4u; d.rz0 = lo[2] / 4u;
     d.rbx = (hi[0] + 3u) / 4u - d.rx0; d.rby = (hi[1] + 3u) / 4u - d.ry0; d.rbz = (hi[2] + 3u) / 4u - d.rz0;
@@ -485,10 +488,241 @@ __global__ __launch_bounds__(256) void volume_brush_kernel(const BrushCtx b) {
     b.density[i] = b.mode == 0 ? (d < b.value ? b.value : d) : (b.value < d ? b.value : d);     // std::max / std::min, brush.cpp:52-57
 }
 
+
+// ---- keyed layout (gpu_build.h: GpuVolume::keyed) -------------------------------------------------------------------------------
+// Key of a cell from its coordinates in units of its own size: `digits` 2-bit digit triples, least significant level first
+// (x | y << 2 | z << 4 per digit, the tree's child bit order).  A brick's key has levels-1 digits, a level-l cell's levels-l.
+__host__ __device__ inline uint64_t cell_key(uint32_t cx, uint32_t cy, uint32_t cz, uint32_t digits) {
+    uint64_t key = 0;
+    for (uint32_t j = 0; j < digits; ++j)
+        key |= static_cast<uint64_t>(((cx >> (2u * j)) & 3u) | (((cy >> (2u * j)) & 3u) << 2) | (((cz >> (2u * j)) & 3u) << 4)) << (6u * j);
+    return key;
+}
+__device__ inline void key_cell(uint64_t key, uint32_t digits, uint32_t& cx, uint32_t& cy, uint32_t& cz) {
+    cx = cy = cz = 0;
+    for (uint32_t j = 0; j < digits; ++j) {
+        const uint32_t d = static_cast<uint32_t>(key >> (6u * j)) & 63u;
+        cx |= (d & 3u) << (2u * j); cy |= ((d >> 2) & 3u) << (2u * j); cz |= (d >> 4) << (2u * j);
+    }
+}
+
+struct KeyedCtx {
+    const float* density; const uint32_t* ids;
+    uint32_t nx, ny, nz, levels;
+    uint64_t* masks; uint8_t* dirty;
+};
+struct CellRange { uint32_t x0, y0, z0, nx, ny, nz; };      // cells [x0, x0 + nx) x ... in units of the level's cell size
+
+// One lane per brick of the range: its 64-bit voxel mask from the dense store (filled iff density > 0, chunk_manager.cpp:121), to its key.
+__global__ __launch_bounds__(256) void keyed_brick_kernel(const KeyedCtx v, const CellRange r) {
+    const uint64_t tid = static_cast<uint64_t>(blockIdx.x) * 256u + threadIdx.x;
+    if (tid >= static_cast<uint64_t>(r.nx) * r.ny * r.nz) return;
+    const uint32_t b_x = r.x0 + static_cast<uint32_t>(tid % r.nx), b_y = r.y0 + static_cast<uint32_t>((tid / r.nx) % r.ny),
+                   b_z = r.z0 + static_cast<uint32_t>(tid / (static_cast<uint64_t>(r.nx) * r.ny));
+    uint64_t mask = 0;
+    for (uint32_t z = 0; z < 4u; ++z)
+        for (uint32_t y = 0; y < 4u; ++y) {
+            const uint32_t vy = b_y * 4u + y, vz = b_z * 4u + z;
+            if (vy >= v.ny || vz >= v.nz) continue;
+            const size_t row = (static_cast<size_t>(vz) * v.ny + vy) * v.nx + b_x * 4u;
+            for (uint32_t x = 0; x < 4u; ++x)
+                if (b_x * 4u + x < v.nx && v.density[row + x] > 0.0f) mask |= 1ull << (x | (y << 2) | (z << 4));
+        }
+    const uint64_t g = cell_key(b_x, b_y, b_z, v.levels - 1u);
+    v.masks[g] = mask;
+    v.dirty[g] = 1;                       // its material ids are read from the dense store at the next build (an id can change under an unchanged mask)
+}
+
+// One lane per cell of level l in the range: its occupancy word from the 64 cells below it (the brick masks for l = 2).
+__global__ __launch_bounds__(256) void occupancy_kernel(const uint64_t* below, uint64_t* occ, const uint32_t digits, const CellRange r) {
+    const uint64_t tid = static_cast<uint64_t>(blockIdx.x) * 256u + threadIdx.x;
+    if (tid >= static_cast<uint64_t>(r.nx) * r.ny * r.nz) return;
+    const uint64_t c = cell_key(r.x0 + static_cast<uint32_t>(tid % r.nx), r.y0 + static_cast<uint32_t>((tid / r.nx) % r.ny),
+                                r.z0 + static_cast<uint32_t>(tid / (static_cast<uint64_t>(r.nx) * r.ny)), digits);
+    const uint64_t* child = below + c * 64u;
+    uint64_t word = 0;
+    for (uint32_t b = 0; b < 64u; ++b) word |= static_cast<uint64_t>(child[b] != 0ull) << b;
+    occ[c] = word;
+}
+
+// (word != 0) << 32 | popcount(word): one exclusive scan of these gives, per cell, the rank of its node within its level (high half) and the
+// index of its first child within the level below (low half); packed[n] = 0 makes scanned[n] the level's totals.
+__global__ __launch_bounds__(256) void pack_kernel(const uint64_t* occ, uint64_t n, uint64_t* packed) {
+    const uint64_t c = static_cast<uint64_t>(blockIdx.x) * 256u + threadIdx.x;
+    if (c > n) return;
+    const uint64_t w = c < n ? occ[c] : 0ull;
+    packed[c] = (static_cast<uint64_t>(w != 0ull) << 32) | static_cast<uint64_t>(__popcll(w));
+}
+
+// The nodes of level l: a non-empty cell's word is its node's mask; base = where the level below starts + the cell's first child.
+// Level 2 also lists its non-empty cells (cells2), for the brick gather.
+__global__ __launch_bounds__(256) void level_nodes_kernel(const uint64_t* occ, const uint64_t* scanned, uint64_t n, uint32_t level_start, uint32_t below_start,
+                                                          uint4* tree, uint32_t* cells2) {
+    const uint64_t c = static_cast<uint64_t>(blockIdx.x) * 256u + threadIdx.x;
+    if (c >= n) return;
+    const uint64_t w = occ[c];
+    if (w == 0ull) return;
+    const uint64_t s = scanned[c];
+    const uint32_t rank = static_cast<uint32_t>(s >> 32);
+    tree[level_start + rank] = make_uint4(static_cast<uint32_t>(w), static_cast<uint32_t>(w >> 32), below_start + static_cast<uint32_t>(s), 0u);
+    if (cells2) cells2[rank] = static_cast<uint32_t>(c);
+}
+
+// One wave per non-empty level-2 cell, lane b = its brick b: the brick's mask, key and voxel count at its place in the sorted list.
+__global__ __launch_bounds__(64) void gather_bricks_kernel(const uint64_t* occ2, const uint64_t* scanned2, const uint32_t* cells2, const uint64_t* masks,
+                                                           uint64_t* masks_sorted, uint32_t* src, uint32_t* counts) {
+    const uint32_t c = cells2[blockIdx.x], b = threadIdx.x;
+    const uint64_t w = occ2[c];
+    if (!((w >> b) & 1ull)) return;
+    const uint32_t i = static_cast<uint32_t>(scanned2[c]) + static_cast<uint32_t>(__popcll(w & ((1ull << b) - 1ull)));
+    const uint32_t g = c * 64u + b;
+    const uint64_t m = masks[g];
+    masks_sorted[i] = m; src[i] = g; counts[i] = static_cast<uint32_t>(__popcll(m));
+}
+
+// One lane per (brick, voxel bit): the voxel's material id at its rank — from the previous build's array when the brick has not been
+// touched since (its mask, hence every rank, is the same), from the dense store otherwise.
+__global__ __launch_bounds__(256) void keyed_material_kernel(const KeyedCtx v, const uint64_t* masks_sorted, const uint32_t* src, const uint32_t* mat_base,
+                                                             uint32_t n_bricks, const uint32_t* old_base, const uint32_t* previous, uint32_t* materials) {
+    const uint64_t tid = static_cast<uint64_t>(blockIdx.x) * 256u + threadIdx.x;
+    const uint32_t i = static_cast<uint32_t>(tid >> 6), bit = static_cast<uint32_t>(tid & 63u);
+    if (i >= n_bricks) return;
+    const uint64_t mask = masks_sorted[i];
+    if (!((mask >> bit) & 1ull)) return;
+    const uint32_t g = src[i];
+    const uint32_t rank = static_cast<uint32_t>(__popcll(mask & ((1ull << bit) - 1ull)));
+    uint32_t id;
+    if (previous && !v.dirty[g] && old_base[g] != 0xFFFFFFFFu) id = previous[old_base[g] + rank];
+    else {
+        uint32_t bx, by, bz;
+        key_cell(g, v.levels - 1u, bx, by, bz);
+        id = v.ids[(static_cast<size_t>(bz * 4u + (bit >> 4)) * v.ny + (by * 4u + ((bit >> 2) & 3u))) * v.nx + bx * 4u + (bit & 3u)];
+    }
+    materials[mat_base[i] + rank] = id;
+}
+
+// Brick nodes, and the bookkeeping for the next build: where each brick's ids now lie, nothing dirty.
+__global__ __launch_bounds__(256) void keyed_brick_nodes_kernel(const uint64_t* masks_sorted, const uint32_t* src, const uint32_t* mat_base, uint32_t n, uint4* out,
+                                                                uint32_t* old_base, uint8_t* dirty) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t m = masks_sorted[i];
+    out[i] = make_uint4(static_cast<uint32_t>(m), static_cast<uint32_t>(m >> 32), mat_base[i], 0u);
+    old_base[src[i]] = mat_base[i];
+    dirty[src[i]] = 0;
+}
+
+KeyedCtx keyed_ctx(const GpuVolume& v) {
+    KeyedCtx k{};
+    k.density = v.d_density; k.ids = v.d_ids; k.nx = v.nx; k.ny = v.ny; k.nz = v.nz; k.levels = v.levels; k.masks = v.d_masks; k.dirty = v.d_dirty;
+    return k;
+}
+
+// Masks of the bricks that contain voxels [lo, hi) and the occupancy words above them, level by level.
+GpuBuildStatus keyed_refresh(GpuVolume* v, const uint32_t lo[3], const uint32_t hi[3], std::string* why) {
+    if (hi[0] <= lo[0] || hi[1] <= lo[1] || hi[2] <= lo[2]) return GpuBuildStatus::Ok;
+    const KeyedCtx k = keyed_ctx(*v);
+    for (uint32_t l = 1; l <= v->levels; ++l) {
+        CellRange r{};
+        r.x0 = lo[0] >> (2u * l); r.y0 = lo[1] >> (2u * l); r.z0 = lo[2] >> (2u * l);
+        r.nx = ((hi[0] - 1u) >> (2u * l)) - r.x0 + 1u; r.ny = ((hi[1] - 1u) >> (2u * l)) - r.y0 + 1u; r.nz = ((hi[2] - 1u) >> (2u * l)) - r.z0 + 1u;
+        const uint64_t total = static_cast<uint64_t>(r.nx) * r.ny * r.nz;
+        if (l == 1) hipLaunchKernelGGL(keyed_brick_kernel, dim3(blocks_for(total)), dim3(256), 0, nullptr, k, r);
+        else hipLaunchKernelGGL(occupancy_kernel, dim3(blocks_for(total)), dim3(256), 0, nullptr, l == 2 ? v->d_masks : v->d_occ[l - 1], v->d_occ[l], v->levels - l, r);
+        GB_TRY(hipGetLastError());
+    }
+    for (int a = 0; a < 3; ++a) { v->edit_lo[a] = std::min(v->edit_lo[a], lo[a]); v->edit_hi[a] = std::max(v->edit_hi[a], hi[a]); }
+    return GpuBuildStatus::Ok;
+}
+
+template <class T> hipError_t grow(T** p, uint64_t* capacity, uint64_t need, uint64_t headroom_num = 5, uint64_t headroom_den = 4) {
+    if (*capacity >= need && *p) return hipSuccess;
+    if (*p) { hipError_t e = hipDeviceSynchronize(); if (e != hipSuccess) return e; (void)hipFree(*p); *p = nullptr; *capacity = 0; }
+    const uint64_t want = std::max<uint64_t>(need * headroom_num / headroom_den, need) + 64u;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(p), want * sizeof(T));
+    if (e == hipSuccess) *capacity = want;
+    return e;
+}
+
+// The rebuild of a keyed volume: scans over the occupancy pyramid, the gather of the non-empty bricks, the node writes.
+GpuBuildStatus keyed_build(GpuVolume* v, GpuTree* out, std::string* why) {
+    auto& S = v->scratch;
+    const uint32_t L = v->levels;
+    uint64_t cells[8] = {};                                                 // cells of level l = 64^(L - l)
+    for (uint32_t l = 2; l <= L; ++l) cells[l] = 1ull << (6u * (L - l));
+    // 1. per level: pack, scan (totals in the extra element)
+    for (uint32_t l = 2; l <= L; ++l) {
+        if (!S.d_packed[l]) { GB_TRY(hipMalloc(reinterpret_cast<void**>(&S.d_packed[l]), (cells[l] + 1u) * sizeof(uint64_t))); GB_TRY(hipMalloc(reinterpret_cast<void**>(&S.d_scanned[l]), (cells[l] + 1u) * sizeof(uint64_t))); }
+        hipLaunchKernelGGL(pack_kernel, dim3(blocks_for(cells[l] + 1u)), dim3(256), 0, nullptr, v->d_occ[l], cells[l], S.d_packed[l]);
+        GB_TRY(hipGetLastError());
+        size_t need = 0;
+        GB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, need, S.d_packed[l], S.d_scanned[l], static_cast<int>(cells[l] + 1u)));
+        if (need > S.scan_temp_bytes) { if (S.d_scan_temp) { GB_TRY(hipDeviceSynchronize()); (void)hipFree(S.d_scan_temp); } S.d_scan_temp = nullptr; GB_TRY(hipMalloc(&S.d_scan_temp, need * 2 + 256)); S.scan_temp_bytes = need * 2 + 256; }
+        size_t bytes = S.scan_temp_bytes;
+        GB_TRY(hipcub::DeviceScan::ExclusiveSum(S.d_scan_temp, bytes, S.d_packed[l], S.d_scanned[l], static_cast<int>(cells[l] + 1u)));
+    }
+    if (!S.d_info) GB_TRY(hipMalloc(reinterpret_cast<void**>(&S.d_info), 32 * sizeof(uint64_t)));
+    for (uint32_t l = 2; l <= L; ++l) GB_TRY(hipMemcpyAsync(S.d_info + l, S.d_scanned[l] + cells[l], sizeof(uint64_t), hipMemcpyDeviceToDevice, nullptr));
+    uint64_t totals[8] = {};
+    GB_TRY(hipMemcpy(totals, S.d_info, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));              // the one wait in the middle: the launch sizes below
+    uint32_t n_nodes[9] = {};                                               // nodes per level; n_nodes[1] = bricks
+    for (uint32_t l = 2; l <= L; ++l) { n_nodes[l] = static_cast<uint32_t>(totals[l] >> 32); if (l == 2) n_nodes[1] = static_cast<uint32_t>(totals[l]); }
+    const uint32_t n_bricks = n_nodes[1];
+    if (n_bricks == 0) return GpuBuildStatus::UseHostBuilder;
+    uint32_t start[9] = {};                                                 // root first: start[L] = 0, ..., start[1] = where the bricks begin
+    { uint64_t at = 0; for (uint32_t l = L; l >= 1; --l) { start[l] = static_cast<uint32_t>(at); at += n_nodes[l]; } if (at > 0xFFFFFFFFull) { *why = "volume: more than 2^32 tree nodes"; return GpuBuildStatus::Unsupported; } }
+    const uint64_t n_tree = static_cast<uint64_t>(start[1]) + n_bricks;
+    const int next = S.current == 0 ? 1 : 0;
+    GB_TRY(grow(&S.d_tree[next], &S.tree_capacity[next], n_tree));
+    GB_TRY(grow(&S.d_materials[next], &S.material_capacity[next], static_cast<uint64_t>(n_bricks) * 64u, 1, 1));      // by its bound: no wait for the count
+    if (S.brick_capacity < n_bricks + 1ull) {
+        GB_TRY(hipDeviceSynchronize());
+        for (void* p : {static_cast<void*>(S.d_masks_sorted), static_cast<void*>(S.d_src), static_cast<void*>(S.d_counts), static_cast<void*>(S.d_mat_base)}) if (p) (void)hipFree(p);
+        const uint64_t want = (n_bricks + 1ull) * 5u / 4u + 64u;
+        GB_TRY(hipMalloc(reinterpret_cast<void**>(&S.d_masks_sorted), want * sizeof(uint64_t))); GB_TRY(hipMalloc(reinterpret_cast<void**>(&S.d_src), want * sizeof(uint32_t)));
+        GB_TRY(hipMalloc(reinterpret_cast<void**>(&S.d_counts), want * sizeof(uint32_t))); GB_TRY(hipMalloc(reinterpret_cast<void**>(&S.d_mat_base), want * sizeof(uint32_t)));
+        S.brick_capacity = want;
+    }
+    GB_TRY(grow(&S.d_cells2, &S.cells2_capacity, n_nodes[2]));
+    // 2. nodes of levels L .. 2, the list of non-empty level-2 cells
+    for (uint32_t l = L; l >= 2; --l) {
+        hipLaunchKernelGGL(level_nodes_kernel, dim3(blocks_for(cells[l])), dim3(256), 0, nullptr, v->d_occ[l], S.d_scanned[l], cells[l], start[l], start[l - 1],
+                           S.d_tree[next], l == 2 ? S.d_cells2 : nullptr);
+        GB_TRY(hipGetLastError());
+    }
+    // 3. the non-empty bricks in key order, their voxel counts, the material offsets
+    hipLaunchKernelGGL(gather_bricks_kernel, dim3(n_nodes[2]), dim3(64), 0, nullptr, v->d_occ[2], S.d_scanned[2], S.d_cells2, v->d_masks, S.d_masks_sorted, S.d_src, S.d_counts);
+    GB_TRY(hipGetLastError());
+    GB_TRY(hipMemsetAsync(S.d_counts + n_bricks, 0, sizeof(uint32_t), nullptr));
+    {
+        size_t need = 0;
+        GB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, need, S.d_counts, S.d_mat_base, static_cast<int>(n_bricks + 1u)));
+        if (need > S.scan_temp_bytes) { GB_TRY(hipDeviceSynchronize()); if (S.d_scan_temp) (void)hipFree(S.d_scan_temp); S.d_scan_temp = nullptr; GB_TRY(hipMalloc(&S.d_scan_temp, need * 2 + 256)); S.scan_temp_bytes = need * 2 + 256; }
+        size_t bytes = S.scan_temp_bytes;
+        GB_TRY(hipcub::DeviceScan::ExclusiveSum(S.d_scan_temp, bytes, S.d_counts, S.d_mat_base, static_cast<int>(n_bricks + 1u)));
+    }
+    // 4. material ids (untouched bricks from the previous build's array), brick nodes
+    const KeyedCtx k = keyed_ctx(*v);
+    const uint32_t* previous = S.have_previous_materials && S.current >= 0 ? S.d_materials[S.current] : nullptr;
+    hipLaunchKernelGGL(keyed_material_kernel, dim3(blocks_for(static_cast<uint64_t>(n_bricks) * 64u)), dim3(256), 0, nullptr, k, S.d_masks_sorted, S.d_src, S.d_mat_base,
+                       n_bricks, S.d_old_base, previous, S.d_materials[next]);
+    GB_TRY(hipGetLastError());
+    hipLaunchKernelGGL(keyed_brick_nodes_kernel, dim3(blocks_for(n_bricks)), dim3(256), 0, nullptr, S.d_masks_sorted, S.d_src, S.d_mat_base, n_bricks, S.d_tree[next] + start[1],
+                       S.d_old_base, v->d_dirty);
+    GB_TRY(hipGetLastError());
+    uint32_t n_voxels = 0;
+    GB_TRY(hipMemcpy(&n_voxels, S.d_mat_base + n_bricks, sizeof(uint32_t), hipMemcpyDeviceToHost));      // also: everything above has completed
+    S.current = next; S.have_previous_materials = true;
+    out->d_nodes = S.d_tree[next]; out->d_materials = S.d_materials[next]; out->owned_by_volume = true;
+    out->n_nodes = n_tree; out->n_voxels = n_voxels; out->levels = L;
+    for (int a = 0; a < 3; ++a) out->origin[a] = v->origin[a];
+    return GpuBuildStatus::Ok;
+}
+
 }  // namespace
 
 GpuBuildStatus gpu_volume_create(const int32_t origin[3], uint32_t nx, uint32_t ny, uint32_t nz, uint32_t chunk, float voxel_size,
-                                 GpuVolume* out, std::string* why) {
+                                 GpuVolume* out, std::string* why, bool allow_keyed) {
     *out = GpuVolume{};
     if (!nx || !ny || !nz || !chunk || !(voxel_size == 1.0f)) { *why = "volume: empty box, zero chunk size or voxel size other than 1"; return GpuBuildStatus::Unsupported; }
     for (int a = 0; a < 3; ++a) {
@@ -504,21 +738,43 @@ GpuBuildStatus gpu_volume_create(const int32_t origin[3], uint32_t nx, uint32_t 
     for (int a = 0; a < 3; ++a) v.origin[a] = origin[a];
     v.chunk = chunk; v.voxel_size = voxel_size;
     if (v.bricks() > 0x7FFFFFFFull) { *why = "volume: more than 2^31 bricks"; return GpuBuildStatus::Unsupported; }
+    // keyed layout (gpu_build.h) whenever its 64^(L-1) mask words are affordable: always up to 5 levels (16.7 M words), beyond that for
+    // volumes that fill most of their cube
+    v.n_keys = levels >= 2 ? 1ull << (6u * (levels - 1u)) : 0;
+    v.keyed = allow_keyed && levels >= 2 && v.n_keys <= std::max<uint64_t>(1ull << 24, 8ull * v.bricks()) && v.n_keys <= 0x7FFFFFFFull;
     DeviceBuffers mem;
     GB_TRY(mem.alloc(&v.d_density, v.cells())); GB_TRY(mem.alloc(&v.d_ids, v.cells()));
-    GB_TRY(mem.alloc(&v.d_masks, v.bricks())); GB_TRY(mem.alloc(&v.d_flag, v.bricks() + 1)); GB_TRY(mem.alloc(&v.d_slot, v.bricks() + 1));
     GB_TRY(hipMemset(v.d_density, 0, v.cells() * sizeof(float))); GB_TRY(hipMemset(v.d_ids, 0, v.cells() * sizeof(uint32_t)));
-    GB_TRY(hipMemset(v.d_masks, 0, v.bricks() * sizeof(uint64_t))); GB_TRY(hipMemset(v.d_flag, 0, (v.bricks() + 1) * sizeof(uint32_t)));
+    std::vector<void*> keep = {v.d_density, v.d_ids};
+    if (v.keyed) {
+        GB_TRY(mem.alloc(&v.d_masks, v.n_keys)); GB_TRY(mem.alloc(&v.d_dirty, v.n_keys)); GB_TRY(mem.alloc(&v.scratch.d_old_base, v.n_keys));
+        GB_TRY(hipMemset(v.d_masks, 0, v.n_keys * sizeof(uint64_t))); GB_TRY(hipMemset(v.d_dirty, 1, v.n_keys)); GB_TRY(hipMemset(v.scratch.d_old_base, 0xFF, v.n_keys * sizeof(uint32_t)));
+        keep.insert(keep.end(), {static_cast<void*>(v.d_masks), static_cast<void*>(v.d_dirty), static_cast<void*>(v.scratch.d_old_base)});
+        for (uint32_t l = 2; l <= levels; ++l) {
+            const uint64_t n = 1ull << (6u * (levels - l));
+            GB_TRY(mem.alloc(&v.d_occ[l], n)); GB_TRY(hipMemset(v.d_occ[l], 0, n * sizeof(uint64_t)));
+            keep.push_back(v.d_occ[l]);
+        }
+    } else {
+        GB_TRY(mem.alloc(&v.d_masks, v.bricks())); GB_TRY(mem.alloc(&v.d_flag, v.bricks() + 1)); GB_TRY(mem.alloc(&v.d_slot, v.bricks() + 1));
+        GB_TRY(hipMemset(v.d_masks, 0, v.bricks() * sizeof(uint64_t))); GB_TRY(hipMemset(v.d_flag, 0, (v.bricks() + 1) * sizeof(uint32_t)));
+        keep.insert(keep.end(), {static_cast<void*>(v.d_masks), static_cast<void*>(v.d_flag), static_cast<void*>(v.d_slot)});
+    }
     GB_TRY(hipDeviceSynchronize());
-    for (void* p : {static_cast<void*>(v.d_density), static_cast<void*>(v.d_ids), static_cast<void*>(v.d_masks), static_cast<void*>(v.d_flag), static_cast<void*>(v.d_slot)}) mem.release(p);
+    for (void* p : keep) mem.release(p);
     *out = v;
     return GpuBuildStatus::Ok;
 }
 
 void gpu_volume_destroy(GpuVolume* v) {
     if (!v) return;
-    for (void* p : {static_cast<void*>(v->d_density), static_cast<void*>(v->d_ids), static_cast<void*>(v->d_masks), static_cast<void*>(v->d_flag), static_cast<void*>(v->d_slot)})
+    auto& S = v->scratch;
+    for (void* p : {static_cast<void*>(v->d_density), static_cast<void*>(v->d_ids), static_cast<void*>(v->d_masks), static_cast<void*>(v->d_flag), static_cast<void*>(v->d_slot),
+                    static_cast<void*>(v->d_dirty), S.d_scan_temp, static_cast<void*>(S.d_cells2), static_cast<void*>(S.d_masks_sorted), static_cast<void*>(S.d_src),
+                    static_cast<void*>(S.d_counts), static_cast<void*>(S.d_mat_base), static_cast<void*>(S.d_old_base), static_cast<void*>(S.d_info),
+                    static_cast<void*>(S.d_tree[0]), static_cast<void*>(S.d_tree[1]), static_cast<void*>(S.d_materials[0]), static_cast<void*>(S.d_materials[1])})
         if (p) (void)hipFree(p);
+    for (int l = 0; l < 8; ++l) for (void* p : {static_cast<void*>(v->d_occ[l]), static_cast<void*>(S.d_packed[l]), static_cast<void*>(S.d_scanned[l])}) if (p) (void)hipFree(p);
     *v = GpuVolume{};
 }
 
@@ -598,6 +854,7 @@ GpuBuildStatus gpu_volume_brush(GpuVolume* v, const float center[3], float radiu
 
 GpuBuildStatus gpu_volume_build(GpuVolume* v, GpuTree* out, std::string* why) {
     *out = GpuTree{};
+    if (v->keyed) return keyed_build(v, out, why);
     const DenseCtx d = volume_ctx(*v);
     const uint64_t total = v->bricks();
     DeviceBuffers mem;

@@ -115,8 +115,8 @@ BLOK_DEV V3 sample_ggx(float ux, float uy, V3 n, float roughness) {    // :115-1
 // pow; GLSL's own pow is exp2(y*log2(x)) at driver precision).  Far inside the stated colour tolerance, and
 // ~10x fewer instructions than the library powf on a path where every miss sample evaluates two of them.
 #ifdef BLOK_PATH_LIBM_POW
-// host harness only: the oracle's literal pow(x, k), to show that nothing BUT these three differs between the kernel body and the
-// oracle on one libm (tests/test_paths.py)
+// host harness only: the shader's literal pow(x, k) through libm, to show that nothing BUT these three differs between the kernel body
+// and the CPU restatement of the shader on one libm (tests/test_paths.py)
 BLOK_DEV float pow5(float x) { return powf(x, 5.0f); }
 BLOK_DEV float pow8(float x) { return powf(x, 8.0f); }
 BLOK_DEV float pow128(float x) { return powf(x, 128.0f); }

@@ -239,6 +239,7 @@ struct SunMapArgs {                        // beam.h: prism_far, one wave per te
     float u0, v0, texel;
     uint32_t nu, nv;
     float* map;
+    uint32_t iu0, iv0, sub_nu, sub_nv;     // the texels this launch computes: [iu0, iu0 + sub_nu) x [iv0, iv0 + sub_nv) (the whole map, or what an edit can have changed)
 };
 void launch_sun_map(const SunMapArgs& args, hipStream_t stream);
 

@@ -712,11 +712,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 
 __global__ __launch_bounds__(64) void sun_map_kernel(const SunMapArgs a) {
     const uint32_t b = blockIdx.x, lane = threadIdx.x;
-    if (b >= a.nu * a.nv) return;
+    if (b >= a.sub_nu * a.sub_nv) return;
+    const uint32_t iu = a.iu0 + b % a.sub_nu, iv = a.iv0 + b / a.sub_nu;
+    if (iu >= a.nu || iv >= a.nv) return;
     const SunFrame f{{a.u[0], a.u[1], a.u[2]}, {a.v[0], a.v[1], a.v[2]}, {a.s[0], a.s[1], a.s[2]}};
-    const float u_lo = a.u0 + static_cast<float>(b % a.nu) * a.texel, v_lo = a.v0 + static_cast<float>(b / a.nu) * a.texel;
+    const float u_lo = a.u0 + static_cast<float>(iu) * a.texel, v_lo = a.v0 + static_cast<float>(iv) * a.texel;
     const float last = prism_far(a.trace, f, u_lo, u_lo + a.texel, v_lo, v_lo + a.texel, lane);
-    if (lane == 0) a.map[b] = last;
+    if (lane == 0) a.map[static_cast<size_t>(iv) * a.nu + iu] = last;
 }
 
 // raygen.rgen main(): one lane per pixel of the rectangle, same 16x16 / 8x8 pixel mapping as the trace kernel.
@@ -959,7 +961,7 @@ void launch_frame(RayMode mode, const TraceArgs& args, const FrameQueue& queue, 
 }
 
 void launch_sun_map(const SunMapArgs& args, hipStream_t stream) {
-    const uint32_t n = args.nu * args.nv;
+    const uint32_t n = args.sub_nu * args.sub_nv;
     if (n) hipLaunchKernelGGL(sun_map_kernel, dim3(n), dim3(64), 0, stream, args);
 }
 

@@ -62,6 +62,10 @@ class HipTracer:
                                                      int(chunk_size), float(voxel_size)))
         self._volume_shape = (int(shape_xyz[2]), int(shape_xyz[1]), int(shape_xyz[0]))        # arrays are [z][y][x]
 
+    def set_volume_layout(self, keyed: bool):
+        """Diagnostic (blok_hip.h): whether the next volume_create may use the keyed brick layout (default) or the row-major one."""
+        self._check(self._lib.blok_hip_set_volume_layout(self._ctx, 1 if keyed else 0))
+
     def volume_destroy(self):
         self._check(self._lib.blok_hip_volume_destroy(self._ctx))
 

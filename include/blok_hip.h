@@ -433,6 +433,11 @@ int blok_hip_volume_apply_brush(blok_hip_ctx* ctx, const float center[3], float 
 /* = rebuildDirtyChunks + packChunksToGpuSvo + Renderer::updateWorld for the box: installs the world made of the voxels with
  * density > 0 and their material ids, with the given material table. */
 int blok_hip_volume_rebuild(blok_hip_ctx* ctx, const blok_material* materials, size_t n_materials);
+/* Diagnostic: 0 = the next blok_hip_volume_create keeps its brick masks in row-major order and rebuilds by scanning, keying and sorting
+ * all bricks (the general path, ~2.4 ms for a 1024^3 box); 1 (default) = bricks indexed by their tree key under a pyramid of occupancy
+ * words, rebuilt by scans over the pyramid (~0.2 ms), whenever the box's 64^(levels-1) mask words are affordable.  Both give the same
+ * node and material arrays, byte for byte (tests/test_brush.py). */
+int blok_hip_set_volume_layout(blok_hip_ctx* ctx, int keyed);
 
 /* Scheduling knob of the path kernel (no reference counterpart): 0 = every lane walks whatever ray it has pending; 1 = a wave walks
  * one kind of ray at a time (primary, else shadow, else bounce); 2 (default) = one kind at a time and the oldest sample first, so the

@@ -139,3 +139,66 @@ def test_device_resident_volume_edits_and_rebuild():
     vol.volume_upload(None, None)
     assert vol.volume_rebuild(mats).n_voxels == 0 and (vol.draw_frame(cam)["hit"] == 0).all()
     vol.shutdown(); ref_tr.shutdown()
+
+
+@pytest.mark.gpu
+def test_keyed_volume_rebuild_equals_the_general_rebuild():
+    """The rebuild of a keyed volume (bricks indexed by their tree key under a pyramid of occupancy words: scans over the pyramid, material
+    ids of untouched bricks taken over from the previous build) against the general one (all bricks scanned, keyed, radix-sorted, upper
+    levels grouped on the host) over the same edit history: node and material arrays byte for byte after every rebuild — bricks and
+    whole 16^3 / 64^3 cells appearing and vanishing, a material id changing under an unchanged mask, density without a material,
+    several edits per rebuild, a rebuild without an edit, the box emptied and refilled — and the path kernel's frames (the shadow
+    rays' last-occluder map is patched for the edited region only)."""
+    from blok_amd.tracer import HipTracer
+    C_ = 128
+    w, h = 160, 120
+    mats = W.scene_materials(SEED)
+    rng = np.random.default_rng(5)
+    a, b = HipTracer(w, h).init(), HipTracer(w, h).init()
+    b.set_volume_layout(False)
+    origin, shape = (-64, -16, 0), (200, 120, 136)                      # ragged: not a multiple of 4 bricks per level-2 cell, levels = 4
+    for t in (a, b):
+        t.volume_create(origin, shape, C_, 1.0)
+    ids = W.scene_dense(64, SEED)
+    z, y, x = np.nonzero(ids)
+    xyz = np.stack([x, y, z], 1).astype(np.int32)
+    cam = W.camera_look_at((90.0, 80.0, -40.0), (30.0, 20.0, 30.0), 60.0, w, h)
+
+    def both(fn):
+        for t in (a, b):
+            fn(t)
+
+    def check(tag):
+        sa, sb = a.volume_rebuild(mats), b.volume_rebuild(mats)
+        assert (sa.n_voxels, sa.n_tree_nodes, sa.levels, tuple(sa.origin)) == (sb.n_voxels, sb.n_tree_nodes, sb.levels, tuple(sb.origin)), tag
+        if sa.n_voxels == 0:
+            return sa
+        na, ma = a.download_tree(); nb, mb = b.download_tree()
+        assert na.tobytes() == nb.tobytes(), tag
+        assert ma.tobytes() == mb.tobytes(), tag
+        pa, pb = a.trace_paths(cam, spp=2, max_bounces=2, frame_index=3), b.trace_paths(cam, spp=2, max_bounces=2, frame_index=3)
+        for k in pa:
+            assert pa[k].tobytes() == pb[k].tobytes(), (tag, k)
+        return sa
+
+    both(lambda t: t.volume_set_voxels(xyz, ids[z, y, x], np.ones(len(xyz), dtype=np.float32)))
+    first = check("scene")
+    assert first.n_voxels == len(xyz) and first.levels == 4
+    check("no edit")                                                      # nothing dirty: every material id comes from the previous build
+    both(lambda t: t.volume_apply_brush((30.0, 25.0, 30.0), 8.0, 0.0, 1))
+    check("dig")
+    both(lambda t: t.volume_apply_brush((100.0, 90.0, 100.0), 9.5, 1.0, 0))            # a ball in empty space: new bricks, new 16^3 and 64^3 cells, no material ids
+    check("ball")
+    both(lambda t: t.volume_set_voxels([[10, 3, 12], [10, 3, 12], [11, 3, 12]], [77, 78, 5], [1.0, 1.0, 1.0]))   # ids change, masks may not
+    check("ids")
+    for k in range(4):                                                    # several edits, one rebuild
+        c = tuple(float(v) for v in rng.uniform((-40, 0, 20), (110, 80, 110)))
+        both(lambda t: t.volume_apply_brush(c, float(rng.integers(2, 12)), float(k % 2), k % 2))
+    check("several")
+    both(lambda t: t.volume_apply_brush((100.0, 90.0, 100.0), 12.0, 0.0, 1))            # the ball goes: its bricks and cells vanish
+    check("ball gone")
+    both(lambda t: t.volume_upload(None, None))
+    assert check("empty").n_voxels == 0
+    both(lambda t: t.volume_set_voxels(xyz[::3], ids[z, y, x][::3], np.ones(len(xyz[::3]), dtype=np.float32)))
+    assert check("refilled").n_voxels == len(xyz[::3])
+    a.shutdown(); b.shutdown()
