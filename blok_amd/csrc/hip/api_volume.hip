@@ -78,10 +78,8 @@ int blok_hip_volume_apply_brush(blok_hip_ctx* ctx, const float center[3], float 
     if (rc != BLOK_OK) return rc;
     if (!center || (mode != 0 && mode != 1) || !(radius >= 0.0f)) return set_error(ctx, BLOK_ERR_INVALID_ARG, "bad brush arguments");
     std::string why;
-    rc = volume_status(ctx, blok::gpu_volume_brush(&ctx->volume, center, radius, value, mode, &why), why);
-    if (rc != BLOK_OK) return rc;
-    BLOK_HIP_TRY(ctx, hipDeviceSynchronize());
-    return BLOK_OK;
+    // enqueued on the null stream, like the rebuild that follows it: nothing waits here (a failing kernel shows at the next call that does)
+    return volume_status(ctx, blok::gpu_volume_brush(&ctx->volume, center, radius, value, mode, &why), why);
 }
 
 int blok_hip_volume_rebuild(blok_hip_ctx* ctx, const blok_material* materials, size_t n_materials) {

@@ -554,6 +554,34 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint64_t* occ, uint64_t
     packed[c] = (static_cast<uint64_t>(w != 0ull) << 32) | static_cast<uint64_t>(__popcll(w));
 }
 
+// The small levels (<= 4096 cells each: everything above level 2 of a 1024^3 world) in ONE workgroup: pack and exclusive scan of each, the
+// totals of every level — level 2's from its own (device-wide) scan — into info[level].
+struct SmallLevels { const uint64_t* occ[8]; uint64_t* scanned[8]; uint64_t cells[8]; uint32_t first, last; const uint64_t* big_total[8]; };
+__global__ __launch_bounds__(1024) void small_levels_kernel(const SmallLevels s, uint64_t* info) {
+    using Scan = hipcub::BlockScan<uint64_t, 1024>;
+    __shared__ typename Scan::TempStorage temp;
+    for (uint32_t l = 2; l < 8; ++l) if (s.big_total[l] && threadIdx.x == 0) info[l] = *s.big_total[l];
+    for (uint32_t l = s.first; l <= s.last; ++l) {
+        const uint64_t n = s.cells[l];
+        uint64_t v[4], sum = 0;
+        for (uint32_t k = 0; k < 4u; ++k) {
+            const uint64_t c = static_cast<uint64_t>(threadIdx.x) * 4u + k;
+            const uint64_t w = c < n ? s.occ[l][c] : 0ull;
+            v[k] = (static_cast<uint64_t>(w != 0ull) << 32) | static_cast<uint64_t>(__popcll(w));
+            sum += v[k];
+        }
+        uint64_t before, total;
+        Scan(temp).ExclusiveSum(sum, before, total);
+        for (uint32_t k = 0; k < 4u; ++k) {
+            const uint64_t c = static_cast<uint64_t>(threadIdx.x) * 4u + k;
+            if (c < n) s.scanned[l][c] = before;
+            before += v[k];
+        }
+        if (threadIdx.x == 0) { s.scanned[l][n] = total; info[l] = total; }
+        __syncthreads();
+    }
+}
+
 // The nodes of level l: a non-empty cell's word is its node's mask; base = where the level below starts + the cell's first child.
 // Level 2 also lists its non-empty cells (cells2), for the brick gather.
 __global__ __launch_bounds__(256) void level_nodes_kernel(const uint64_t* occ, const uint64_t* scanned, uint64_t n, uint32_t level_start, uint32_t below_start,
@@ -570,8 +598,9 @@ __global__ __launch_bounds__(256) void level_nodes_kernel(const uint64_t* occ, c
 
 // One wave per non-empty level-2 cell, lane b = its brick b: the brick's mask, key and voxel count at its place in the sorted list.
 __global__ __launch_bounds__(64) void gather_bricks_kernel(const uint64_t* occ2, const uint64_t* scanned2, const uint32_t* cells2, const uint64_t* masks,
-                                                           uint64_t* masks_sorted, uint32_t* src, uint32_t* counts) {
+                                                           uint64_t* masks_sorted, uint32_t* src, uint32_t* counts, uint32_t n_bricks) {
     const uint32_t c = cells2[blockIdx.x], b = threadIdx.x;
+    if (blockIdx.x == 0 && b == 0) counts[n_bricks] = 0u;            // the scan's extra element: its result there is the number of voxels
     const uint64_t w = occ2[c];
     if (!((w >> b) & 1ull)) return;
     const uint32_t i = static_cast<uint32_t>(scanned2[c]) + static_cast<uint32_t>(__popcll(w & ((1ull << b) - 1ull)));
@@ -650,9 +679,14 @@ GpuBuildStatus keyed_build(GpuVolume* v, GpuTree* out, std::string* why) {
     const uint32_t L = v->levels;
     uint64_t cells[8] = {};                                                 // cells of level l = 64^(L - l)
     for (uint32_t l = 2; l <= L; ++l) cells[l] = 1ull << (6u * (L - l));
-    // 1. per level: pack, scan (totals in the extra element)
+    // 1. per level: (word != 0) << 32 | popcount, exclusively scanned, totals in the extra element — levels of <= 4096 cells all in one
+    //    workgroup, larger ones with a device-wide scan each
+    if (!S.d_info) GB_TRY(hipMalloc(reinterpret_cast<void**>(&S.d_info), 32 * sizeof(uint64_t)));
+    SmallLevels small{};
+    small.first = 8; small.last = 0;
     for (uint32_t l = 2; l <= L; ++l) {
         if (!S.d_packed[l]) { GB_TRY(hipMalloc(reinterpret_cast<void**>(&S.d_packed[l]), (cells[l] + 1u) * sizeof(uint64_t))); GB_TRY(hipMalloc(reinterpret_cast<void**>(&S.d_scanned[l]), (cells[l] + 1u) * sizeof(uint64_t))); }
+        if (cells[l] <= 4096u) { small.occ[l] = v->d_occ[l]; small.scanned[l] = S.d_scanned[l]; small.cells[l] = cells[l]; small.first = std::min(small.first, l); small.last = std::max(small.last, l); continue; }
         hipLaunchKernelGGL(pack_kernel, dim3(blocks_for(cells[l] + 1u)), dim3(256), 0, nullptr, v->d_occ[l], cells[l], S.d_packed[l]);
         GB_TRY(hipGetLastError());
         size_t need = 0;
@@ -660,9 +694,10 @@ GpuBuildStatus keyed_build(GpuVolume* v, GpuTree* out, std::string* why) {
         if (need > S.scan_temp_bytes) { if (S.d_scan_temp) { GB_TRY(hipDeviceSynchronize()); (void)hipFree(S.d_scan_temp); } S.d_scan_temp = nullptr; GB_TRY(hipMalloc(&S.d_scan_temp, need * 2 + 256)); S.scan_temp_bytes = need * 2 + 256; }
         size_t bytes = S.scan_temp_bytes;
         GB_TRY(hipcub::DeviceScan::ExclusiveSum(S.d_scan_temp, bytes, S.d_packed[l], S.d_scanned[l], static_cast<int>(cells[l] + 1u)));
+        small.big_total[l] = S.d_scanned[l] + cells[l];
     }
-    if (!S.d_info) GB_TRY(hipMalloc(reinterpret_cast<void**>(&S.d_info), 32 * sizeof(uint64_t)));
-    for (uint32_t l = 2; l <= L; ++l) GB_TRY(hipMemcpyAsync(S.d_info + l, S.d_scanned[l] + cells[l], sizeof(uint64_t), hipMemcpyDeviceToDevice, nullptr));
+    hipLaunchKernelGGL(small_levels_kernel, dim3(1), dim3(1024), 0, nullptr, small, S.d_info);      // (small.first > small.last: just the big levels' totals)
+    GB_TRY(hipGetLastError());
     uint64_t totals[8] = {};
     GB_TRY(hipMemcpy(totals, S.d_info, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));              // the one wait in the middle: the launch sizes below
     uint32_t n_nodes[9] = {};                                               // nodes per level; n_nodes[1] = bricks
@@ -691,9 +726,8 @@ GpuBuildStatus keyed_build(GpuVolume* v, GpuTree* out, std::string* why) {
         GB_TRY(hipGetLastError());
     }
     // 3. the non-empty bricks in key order, their voxel counts, the material offsets
-    hipLaunchKernelGGL(gather_bricks_kernel, dim3(n_nodes[2]), dim3(64), 0, nullptr, v->d_occ[2], S.d_scanned[2], S.d_cells2, v->d_masks, S.d_masks_sorted, S.d_src, S.d_counts);
+    hipLaunchKernelGGL(gather_bricks_kernel, dim3(n_nodes[2]), dim3(64), 0, nullptr, v->d_occ[2], S.d_scanned[2], S.d_cells2, v->d_masks, S.d_masks_sorted, S.d_src, S.d_counts, n_bricks);
     GB_TRY(hipGetLastError());
-    GB_TRY(hipMemsetAsync(S.d_counts + n_bricks, 0, sizeof(uint32_t), nullptr));
     {
         size_t need = 0;
         GB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, need, S.d_counts, S.d_mat_base, static_cast<int>(n_bricks + 1u)));
