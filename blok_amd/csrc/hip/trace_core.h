@@ -295,7 +295,10 @@ BLOK_DEV HitInfo walk_hit(const TraceArgs& A, const RayIn& r, const WalkRay& R, 
 // reports one; all parity tests passed) — primary rays are long or short tile by tile, not ray by ray, so there is nobody idle to
 // help, and in the path loop the restarts cost more than the shorter rounds gave back (64 spp: 46.9 -> 51.2 ms); raising a wave's issue
 // priority with its age (a long wave is a chain of dependent instructions: no priority shortens it); running the descend path only when
-// enough lanes want it (waiting lanes stretch the critical path: -7 to -14 %).
+// enough lanes want it (waiting lanes stretch the critical path: -7 to -14 %); the path loop's shadow ray and bounce ray of a hit as a
+// PAIR walked in one loop, a lane going on to its second ray while others are still on their first (profiles/
+// r03_paths_shadow_bounce_pair_ab.txt: same frames, 46.3 -> 72 ms — two rays' state on top of the path state spills inside the loop, and
+// the loop body as a function over a state struct alone costs the primary kernels a fifth: the loop keeps its state in locals).
 BLOK_DEV HitInfo walk(const TraceArgs& A, const RayIn& r, uint4* stk) {
     BLOK_STAT(4, 0);                       // a walk begins
     HitInfo out;
