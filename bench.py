@@ -46,8 +46,9 @@ def parse():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--pose", type=int, default=0, help="camera pose A/B/C = 0/1/2 (SURVEY.md §8(d))")
     ap.add_argument("--tile", type=int, default=32)
-    ap.add_argument("--settle", type=int, default=0, help="untimed frames before the warmup steps (none needed: a frame takes nothing from earlier frames but the size of its walk grid, "
-                    "which the first warmup frame provides); reported in config.settle_frames")
+    ap.add_argument("--settle", type=int, default=32, help="untimed frames before the warmup steps: the longest-first order of a view at rest is per-view state (measured from the second "
+                    "frame of a view, sorted behind it, adopted a few frames later, re-sorted ever less often), prepared like the world upload; 0 = start cold "
+                    "(-4 %% over 20 frames: profiles/r03c_settle_frames.txt).  Reported in config.settle_frames and roofline.timing; roofline.frac_moving is the figure that uses no such state")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0xB10C0001)
     ap.add_argument("--cpu-stride", type=int, default=1, help="CPU baseline traces every stride-th pixel in x and y")
     ap.add_argument("--frames-in-flight", type=int, default=0,

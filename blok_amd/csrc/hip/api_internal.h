@@ -128,6 +128,7 @@ struct blok_hip_ctx {
         uint32_t frames_since_sort = 0, still_frames = 0, prefix_limit = 0;
         blok_camera cam[2] = {}, last_cam{};                // camera each order buffer was measured under; camera of the last launch
         hipEvent_t done = nullptr;
+        std::unordered_map<hipStream_t, hipEvent_t> guards;    // per stream of the context: behind its last launch at the time of the latest adoption
     } order;
     // list launches, rectangle frames: clocks per wave tile of the last frame of this launch geometry, and the camera they were measured under (trace_kernels.h: cost classes)
     uint32_t* d_list_cost = nullptr; size_t list_cost_capacity = 0; uint32_t list_cost_key[6] = {};

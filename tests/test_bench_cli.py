@@ -21,7 +21,7 @@ def test_help_and_defaults():
         a = bench.parse()
     finally:
         sys.argv = argv
-    assert (a.gpus, a.n, a.width, a.height, a.pose, a.settle, a.orbit) == (1, 1024, 3840, 2160, 0, 0, 0.0)
+    assert (a.gpus, a.n, a.width, a.height, a.pose, a.settle, a.orbit) == (1, 1024, 3840, 2160, 0, 32, 0.0)
     assert a.steps > 0 and a.warmup >= 0 and a.fused == 3
 
 
