@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--fused", type=int, default=3, help="launch form of a frame (blok_hip_set_fused): 0 = beam kernel then trace kernel, 1 = one persistent launch with work queues (measured slower), "
                     "2 = joint launch (searches and one walk wave per wave tile in one grid), 4 = list-fed joint launch (walk waves take the live wave tiles from the list the frame's searches publish), "
                     "5 = beam kernel, then list-fed walk, 3 = automatic: 4 when a launch has the device to itself, else 5")
+    ap.add_argument("--moving-order", type=int, default=1, help="camera in motion, launch alone on the device: walk in the previous frame's dilated order carried over by a whole-tile shift (0 = row-major)")
     ap.add_argument("--tile-ordering", type=int, default=8, help="camera at rest: longest-first scheduling of the walk from earlier frames' per-wave clocks, re-sorted every N launches (0 = off)")
     ap.add_argument("--list-classes", type=int, default=1, help="list launches: order the walk by the previous frame's measured cost in four classes (0 = the order the searches finish in)")
     ap.add_argument("--orbit", type=float, default=0.0, help="degrees the camera turns around the world's centre per frame (0 = static camera)")
@@ -236,6 +237,7 @@ def main():
     tracer.set_fused(args.fused)
     tracer.set_list_classes(bool(args.list_classes))
     tracer.set_tile_ordering(args.tile_ordering)
+    tracer.set_moving_order(bool(args.moving_order))
 
     if args.frames_in_flight <= 0:
         args.frames_in_flight = 3 if world_size <= 2 else 4
@@ -400,10 +402,10 @@ def main():
         elif args.fused == 2:
             launch = "joint_kernel per frame (searches and walk waves in one grid)"
         elif args.fused in (3, 4, 5):
-            launch = {3: "list_joint_kernel per frame when the launch has the device to itself (searches and list-fed walk waves in one grid), beam_kernel + list_walk_kernel with frames in flight",
-                      4: "list_joint_kernel per frame (searches and list-fed walk waves in one grid)", 5: "beam_kernel + list_walk_kernel per frame"}[args.fused] + \
-                     "; walk waves only for the wave tiles the frame's own searches found live"
-
+            launch = {3: "joint_kernel per frame when the launch has the device to itself (searches and walk waves in one grid; walk waves for the live prefix of the longest-first order), "
+                         "beam_kernel + trace_kernel over the same prefix with frames in flight",
+                      4: "list_joint_kernel per frame (searches and list-fed walk waves in one grid; walk waves only for the wave tiles the frame's own searches found live)",
+                      5: "beam_kernel + list_walk_kernel per frame (walk waves only for the wave tiles the frame's own searches found live)"}[args.fused]
         else:
             launch = "beam_kernel + trace_kernel per frame"
         out = {
@@ -421,7 +423,7 @@ def main():
                        "tile_records_gathered_per_frame_and_rank": (pipe.records_gathered / max(1, pipe.frames_done)) if world_size > 1 and args.sparse_gather else None,
                        "tiles_per_rank": pipe.per_rank if world_size > 1 else None,
                        "camera_orbit_deg_per_frame": args.orbit,
-                       "frames_in_flight": args.frames_in_flight, "settle_frames": args.settle, "walk_waves_that_gave_up_waiting": gave_up, "device_ms_per_step": device_ms / args.steps, "kernel_ms_alone": kernel_ms_avg, "beam_tile": args.beam,
+                       "frames_in_flight": args.frames_in_flight, "settle_frames": args.settle, "walk_waves_that_gave_up_waiting": gave_up, "device_ms_per_step": device_ms / args.steps, "kernel_ms_alone": kernel_ms_avg, "kernel_ms_alone_moving": kernel_ms_moving, "beam_tile": args.beam,
                        "poses": poses, "also_measured_paths": paths},
         }
         alg = None
@@ -458,7 +460,8 @@ def main():
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                "frac_moving": (alg["bytes_per_ray"] * rays_per_launch / (kernel_ms_moving * 1e-3) / 1e9 / HBM_PEAK_GBS) if kernel_ms_moving else None,
                                "kernel_ms_moving": kernel_ms_moving,
-                               "moving": "the same launch alone with the camera turning 1 degree per frame around the world's centre (no order from earlier frames applies; pose-A bytes per ray)" if kernel_ms_moving else None,
+                               "moving": ("the same launch alone with the camera turning 1 degree per frame around the world's centre, every frame a view never seen before (pose-A bytes per ray); "
+                                          + ("walked in the previous frame's dilated order carried over by a whole-tile shift" if args.moving_order else "row-major order")) if kernel_ms_moving else None,
                                "physical": physical,
                                "kernel": launch, "kernel_ms": kernel_ms_avg,
                                "timing": f"HIP events around single launches, one at a time on an otherwise idle chip; {args.settle} settle + {args.warmup} warmup frames before the timed region, 2 unmeasured launches before the single ones",

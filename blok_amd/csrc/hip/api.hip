@@ -274,7 +274,7 @@ void forget_device_activity(const blok_hip_ctx* ctx) {
         if (it->first.first == ctx) { (void)hipEventDestroy(it->second); it = act.last.erase(it); } else ++it;
 }
 
-// ---- longest-first order of a camera at rest (api_internal.h: TileOrder; decisions in launch_policy.h: plan_order) -------------------
+// ---- longest-first order of the walk's wave tiles (api_internal.h: TileOrder; decisions in launch_policy.h: plan_order, plan_shift) ------
 // Has the view hardly changed?  Within ~0.25 degree: direction, position as seen from the world's centre, and the same lens.
 static bool camera_near(const blok_hip_ctx* ctx, const blok_camera& a, const blok_camera& b) {
     const float dot = a.fwd[0] * b.fwd[0] + a.fwd[1] * b.fwd[1] + a.fwd[2] * b.fwd[2];
@@ -291,14 +291,14 @@ static bool camera_near(const blok_hip_ctx* ctx, const blok_camera& a, const blo
 static void free_order(blok_hip_ctx* ctx) {
     auto& O = ctx->order;
     for (void* p : {static_cast<void*>(O.d_cost), static_cast<void*>(O.d_iota), static_cast<void*>(O.d_order[0]), static_cast<void*>(O.d_order[1]), static_cast<void*>(O.d_rank_of[0]),
-                    static_cast<void*>(O.d_rank_of[1]), static_cast<void*>(O.d_keys_in), static_cast<void*>(O.d_keys), O.d_temp})
+                    static_cast<void*>(O.d_rank_of[1]), static_cast<void*>(O.d_keys_in), static_cast<void*>(O.d_keys), O.d_class_scratch, O.d_temp})
         if (p) (void)hipFree(p);
-    O.d_cost = O.d_iota = O.d_order[0] = O.d_order[1] = O.d_rank_of[0] = O.d_rank_of[1] = O.d_keys_in = O.d_keys = nullptr;
+    O.d_cost = O.d_iota = O.d_order[0] = O.d_order[1] = O.d_rank_of[0] = O.d_rank_of[1] = O.d_keys_in = O.d_keys = nullptr; O.d_class_scratch = nullptr;
     O.d_temp = nullptr; O.capacity = 0;
 }
 
 // Before an orderable launch: buffers for the launch geometry, adoption of a finished sort, the plan; fills args.order / rank_of / launched / cost_out.
-static int order_before_launch(blok_hip_ctx* ctx, blok::TraceArgs& args, uint32_t blocks, hipStream_t stream, blok::OrderPlan* plan) {
+static int order_before_launch(blok_hip_ctx* ctx, blok::TraceArgs& args, uint32_t blocks, hipStream_t stream, bool alone, blok::OrderPlan* plan) {
     auto& O = ctx->order;
     const uint32_t key[6] = {args.x0, args.y0, args.w, args.h, ctx->width, ctx->height};
     if (O.capacity < blocks) {
@@ -311,8 +311,10 @@ static int order_before_launch(blok_hip_ctx* ctx, blok::TraceArgs& args, uint32_
         for (uint32_t** p : {&O.d_cost, &O.d_iota, &O.d_order[0], &O.d_order[1], &O.d_rank_of[0], &O.d_rank_of[1], &O.d_keys_in, &O.d_keys})
             BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(p), bytes));
         if (!O.h_live) BLOK_HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&O.h_live), 2 * sizeof(uint32_t), hipHostMallocDefault));
+        if (!O.h_depth) BLOK_HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&O.h_depth), 6 * sizeof(float), hipHostMallocDefault));
         O.temp_bytes = blok::tile_order_temp_bytes(want);
         BLOK_HIP_TRY(ctx, hipMalloc(&O.d_temp, O.temp_bytes ? O.temp_bytes : 16));
+        BLOK_HIP_TRY(ctx, hipMalloc(&O.d_class_scratch, blok::tile_order_class_sort_bytes_max(want)));
         if (!O.done) BLOK_HIP_TRY(ctx, hipEventCreateWithFlags(&O.done, hipEventDisableTiming));
         BLOK_HIP_TRY(ctx, blok::launch_iota(O.d_iota, want, stream));          // the identity, whatever the geometry: written once
         O.capacity = want;
@@ -323,11 +325,12 @@ static int order_before_launch(blok_hip_ctx* ctx, blok::TraceArgs& args, uint32_
         // geometry finishes into a buffer nobody will adopt: its event is simply never asked again)
         BLOK_HIP_TRY(ctx, hipMemsetAsync(O.d_cost, 0, static_cast<size_t>(blocks) * sizeof(uint32_t), stream));
         std::memcpy(O.key, key, sizeof(key));
-        O.current = -1; O.pending = false; O.frames_since_sort = 0; O.still_frames = 0; O.interval_now = O.interval;
+        O.current = -1; O.pending = false; O.frames_since_sort = 0; O.still_frames = 0; O.interval_now = O.interval; O.have_residual = false;
     }
     if (O.pending && hipEventQuery(O.done) == hipSuccess) {              // the sort launched some frames ago has finished
         O.current = O.target;
         O.live[O.current] = O.h_live[O.current];                         // written by the device before the event
+        if (O.dilated[O.current]) { O.inv_depth[O.current][0] = O.h_depth[O.current * 3 + 1]; O.inv_depth[O.current][1] = O.h_depth[O.current * 3 + 2]; }
         O.pending = false; O.frames_since_sort = 0;
         // From here on no launch reads the OTHER buffer any more; the launches that may still be reading it are those already issued, on
         // any stream of this context.  A marker behind each of them now is what the next sort — which overwrites that buffer, many
@@ -349,17 +352,37 @@ static int order_before_launch(blok_hip_ctx* ctx, blok::TraceArgs& args, uint32_
     f.near_last_view = camera_near(ctx, args.cam, O.last_cam);
     f.sort_pending = O.pending; f.still_frames = O.still_frames;
     f.frames_since_sort = O.frames_since_sort; f.interval = O.interval; f.interval_now = O.interval_now;
+    f.moving_enabled = O.moving; f.alone = alone; f.alone_before = O.alone_before; O.alone_before = alone;
+    f.order_dilated = f.have_order && O.dilated[O.current];
+    blok::ShiftPlan shift{};
+    if (f.order_dilated && f.moving_enabled && f.alone) {
+        blok::ShiftFacts sf{};
+        static_assert(sizeof(blok::PolicyCamera) == sizeof(blok_camera), "launch_policy.h: PolicyCamera is blok_camera");
+        std::memcpy(&sf.then, &O.cam[O.current], sizeof(blok_camera)); std::memcpy(&sf.now, &args.cam, sizeof(blok_camera));
+        sf.inv_depth_mean = O.inv_depth[O.current][0]; sf.inv_depth_sigma = O.inv_depth[O.current][1];
+        sf.frame_w = ctx->width; sf.frame_h = ctx->height;
+        sf.tiles_x = (args.w + blok::kTileW - 1u) / blok::kTileW; sf.tiles_y = (args.h + blok::kTileH - 1u) / blok::kTileH; sf.tile_w = blok::kTileW; sf.tile_h = blok::kTileH;
+        sf.radius = O.radius[O.current];
+        shift = blok::plan_shift(sf);
+        f.shift_ok = shift.ok;
+        O.have_residual = true; O.last_residual = shift.residual;         // also when it is too large to use: the next dilation grows with it
+    }
     *plan = blok::plan_order(f);
     O.still_frames = plan->still_frames; O.last_cam = args.cam;
     args.order = plan->use_order ? O.d_order[O.current] : nullptr;
-    args.cost_out = plan->measure ? O.d_cost : nullptr;                  // a camera in motion is not measured (nor sorted for)
-    if (args.order) { args.rank_of = O.d_rank_of[O.current]; args.launched = O.live[O.current]; }
+    args.cost_out = plan->measure ? O.d_cost : nullptr;
+    args.order_sx = args.order_sy = 0u;
+    O.last_use = plan->use_order ? (plan->shifted ? 2 : 1) : 0; O.last_sx = O.last_sy = 0u;
+    if (args.order) {
+        args.rank_of = O.d_rank_of[O.current]; args.launched = O.live[O.current];
+        if (plan->shifted) { args.order_sx = O.last_sx = shift.sx; args.order_sy = O.last_sy = shift.sy; }
+    }
     return BLOK_OK;
 }
 
 // After it: the sort, if the plan says so — on the LAUNCH stream, behind the frame (a stream of its own would be one HIP stream more than
 // the hardware queues the frame streams and the null stream occupy: measured, that alone costs 18 % of the pipelined rate).
-static int order_after_launch(blok_hip_ctx* ctx, const blok::TraceArgs& args, uint32_t blocks, hipStream_t stream, const blok::OrderPlan& plan) {
+static int order_after_launch(blok_hip_ctx* ctx, const blok::TraceArgs& args, uint32_t blocks, uint32_t n_beams, hipStream_t stream, const blok::OrderPlan& plan) {
     auto& O = ctx->order;
     O.frames_since_sort += 1;
     O.interval_now = plan.next_interval_now;
@@ -368,13 +391,23 @@ static int order_after_launch(blok_hip_ctx* ctx, const blok::TraceArgs& args, ui
     // Nothing still running may read the target buffer: it was last current before the previous adoption, and everything issued before
     // that adoption is in front of the markers recorded then (order_before_launch).
     for (auto& kv : O.guards) if (kv.first != stream && kv.second) BLOK_HIP_TRY(ctx, hipStreamWaitEvent(stream, kv.second, 0));
-    // the sort reads a SNAPSHOT of the costs: frames in flight on other streams keep writing the live buffer, and a radix sort that saw a
-    // key change between its histogram and its scatter would not produce a permutation
-    BLOK_HIP_TRY(ctx, hipMemcpyAsync(O.d_keys_in, O.d_cost, static_cast<size_t>(blocks) * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
-    BLOK_HIP_TRY(ctx, blok::launch_tile_order_sort(O.d_keys_in, O.d_keys, O.d_iota, O.d_order[target], O.d_temp, O.temp_bytes, blocks, stream));
-    BLOK_HIP_TRY(ctx, blok::launch_tile_order_finish(O.d_order[target], O.d_keys, blocks, O.d_rank_of[target], O.h_live + target, stream));
+    uint32_t radius = 0;
+    if (plan.dilate) {
+        // a camera in motion: a counting sort of the dilated clocks (three small launches; it reads the live cost buffer — any mixture of old
+        // and new costs is as good a key, and what it sorts is its own copy), and the frame's depths go along for the next launch's shift
+        radius = blok::plan_dilation(O.have_residual, O.last_residual);
+        const uint32_t tiles_x = (args.w + blok::kTileW - 1u) / blok::kTileW, tiles_y = (args.h + blok::kTileH - 1u) / blok::kTileH;
+        BLOK_HIP_TRY(ctx, blok::launch_tile_order_class_sort(O.d_cost, tiles_x, tiles_y, radius, O.d_class_scratch, O.d_order[target], O.d_rank_of[target], O.h_live + target,
+                                                             args.beam, args.beam_slots, args.beam_serial, n_beams, O.h_depth + target * 3, stream));
+    } else {
+        // the sort reads a SNAPSHOT of the costs: frames in flight on other streams keep writing the live buffer, and a radix sort that saw a
+        // key change between its histogram and its scatter would not produce a permutation
+        BLOK_HIP_TRY(ctx, hipMemcpyAsync(O.d_keys_in, O.d_cost, static_cast<size_t>(blocks) * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+        BLOK_HIP_TRY(ctx, blok::launch_tile_order_sort(O.d_keys_in, O.d_keys, O.d_iota, O.d_order[target], O.d_temp, O.temp_bytes, blocks, stream));
+        BLOK_HIP_TRY(ctx, blok::launch_tile_order_finish(O.d_order[target], O.d_keys, blocks, O.d_rank_of[target], O.h_live + target, stream));
+    }
     BLOK_HIP_TRY(ctx, hipEventRecord(O.done, stream));
-    O.target = target; O.cam[target] = args.cam; O.pending = true;
+    O.target = target; O.cam[target] = args.cam; O.dilated[target] = plan.dilate; O.radius[target] = radius; O.pending = true;
     return BLOK_OK;
 }
 
@@ -480,7 +513,8 @@ int launch_timed(blok_hip_ctx* ctx, blok::RayMode mode, blok::TraceArgs args, ui
     facts.wave_tiles = blocks * n_frames;
     const uint32_t geometry_key = blocks * 31u + n_beams * n_frames;
     facts.have_hint = list_hint(ctx, stream, geometry_key, facts.hint);
-    facts.device_busy = facts.has_beam && ctx->launch_form == blok::kFormAuto && device_busy_elsewhere(ctx, stream);
+    const bool busy = facts.has_beam && (ctx->launch_form == blok::kFormAuto || (ctx->order.enabled && ctx->order.moving)) && device_busy_elsewhere(ctx, stream);
+    facts.device_busy = busy && ctx->launch_form == blok::kFormAuto;
     blok::LaunchPlan plan = blok::plan_launch(facts);
     if (frames && (plan.kind == blok::LaunchKind::Queues || plan.kind == blok::LaunchKind::Joint)) plan.kind = blok::LaunchKind::TwoLaunches;      // several frames per launch: the two-launch or the list forms
     ctx->last_launch_kind = static_cast<int>(plan.kind);
@@ -504,7 +538,8 @@ int launch_timed(blok_hip_ctx* ctx, blok::RayMode mode, blok::TraceArgs args, ui
     const bool static_form = plan.kind == blok::LaunchKind::TwoLaunches || plan.kind == blok::LaunchKind::Joint;
     const bool orderable = ctx->order.enabled && static_form && mode == blok::RayMode::Rect && !frames && n_beams && blocks >= blok::kOrderMinTiles && BLOK_XCD_MAP == 0;
     blok::OrderPlan order_plan{};
-    if (orderable) { const int rc = order_before_launch(ctx, args, blocks, stream, &order_plan); if (rc != BLOK_OK) return rc; }
+    if (orderable) { const int rc = order_before_launch(ctx, args, blocks, stream, !busy, &order_plan); if (rc != BLOK_OK) return rc; }
+    else ctx->order.last_use = 0;
     uint32_t walk_blocks = blocks;
     if (args.order && args.rank_of && plan.may_use_prefix && args.launched <= blocks) {
         // the search wave of a beam tile that is live now walks any wave tile of its own without a walk wave (a changed view), and writes
@@ -532,7 +567,7 @@ int launch_timed(blok_hip_ctx* ctx, blok::RayMode mode, blok::TraceArgs args, ui
     }
     BLOK_HIP_TRY(ctx, hipGetLastError());
     if (ctx->timing) { BLOK_HIP_TRY(ctx, hipEventRecord(ctx->ev_end, stream)); ctx->timed = true; }
-    if (orderable) { const int rc = order_after_launch(ctx, args, blocks, stream, order_plan); if (rc != BLOK_OK) return rc; }
+    if (orderable) { const int rc = order_after_launch(ctx, args, blocks, n_beams, stream, order_plan); if (rc != BLOK_OK) return rc; }
     if (facts.has_beam) return note_frame_launch(ctx, stream);          // (behind the sort, if one was started: it belongs to this launch)
     return BLOK_OK;
 }
@@ -621,6 +656,7 @@ void blok_hip_destroy(blok_hip_ctx* ctx) {
     if (ctx->d_list_cost) (void)hipFree(ctx->d_list_cost);
     free_order(ctx);
     if (ctx->order.h_live) (void)hipHostFree(ctx->order.h_live);
+    if (ctx->order.h_depth) (void)hipHostFree(ctx->order.h_depth);
     if (ctx->order.done) (void)hipEventDestroy(ctx->order.done);
     for (auto& kv : ctx->order.guards) if (kv.second) (void)hipEventDestroy(kv.second);
     if (ctx->d_accum) (void)hipFree(ctx->d_accum);
@@ -1382,6 +1418,19 @@ int blok_hip_set_tile_ordering(blok_hip_ctx* ctx, int resort_every_n_frames) {
     ctx->order.enabled = resort_every_n_frames != 0;
     if (resort_every_n_frames) ctx->order.interval = ctx->order.interval_now = static_cast<uint32_t>(resort_every_n_frames);
     return BLOK_OK;
+}
+
+int blok_hip_set_moving_order(blok_hip_ctx* ctx, int enabled) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    ctx->order.moving = enabled != 0;
+    return BLOK_OK;
+}
+
+int blok_hip_last_order_use(const blok_hip_ctx* ctx, int32_t* out_shift_x, int32_t* out_shift_y) {
+    if (!ctx) return -1;
+    if (out_shift_x) *out_shift_x = static_cast<int32_t>(ctx->order.last_sx);
+    if (out_shift_y) *out_shift_y = static_cast<int32_t>(ctx->order.last_sy);
+    return ctx->order.last_use;
 }
 
 int blok_hip_set_joint_prefix_limit(blok_hip_ctx* ctx, uint32_t max_walk_waves) {

@@ -128,6 +128,16 @@ struct blok_hip_ctx {
         uint32_t frames_since_sort = 0, still_frames = 0, prefix_limit = 0;
         blok_camera cam[2] = {}, last_cam{};                // camera each order buffer was measured under; camera of the last launch
         hipEvent_t done = nullptr;
+        // a camera in motion (launch_policy.h): orders sorted from dilated clocks, carried to the next view by a whole-tile shift
+        bool moving = true;                                 // blok_hip_set_moving_order
+        void* d_class_scratch = nullptr;                    // tile_order.h: count table and class bytes of the counting sort
+        bool dilated[2] = {false, false};
+        uint32_t radius[2] = {0, 0};
+        float* h_depth = nullptr;                           // pinned, 2 x 3 floats: count, mean, sigma of the live beam tiles' inverse start parameters (written by the device)
+        float inv_depth[2][2] = {};                         // ... mean and sigma as read when the order was adopted
+        bool have_residual = false; float last_residual = 0.0f;     // what the latest shift left over (sizes the next dilation)
+        bool alone_before = false;                          // the previous orderable launch had the device to itself
+        int last_use = 0; uint32_t last_sx = 0, last_sy = 0;        // the latest launch: 0 natural order, 1 an order of its own view, 2 a carried one (blok_hip_last_order_use)
         std::unordered_map<hipStream_t, hipEvent_t> guards;    // per stream of the context: behind its last launch at the time of the latest adoption
     } order;
     // list launches, rectangle frames: clocks per wave tile of the last frame of this launch geometry, and the camera they were measured under (trace_kernels.h: cost classes)

@@ -21,6 +21,126 @@ __global__ __launch_bounds__(256) void order_finish_kernel(const uint32_t* order
     if (live && (i + 1u == n || sort_key(cost_sorted[i + 1u]) == 0u)) *live_out = i + 1u;
     if (i == 0u && !live) *live_out = 0u;
 }
+// ---- a camera in motion: counting sort of DILATED costs, three small launches behind the frame -------------------------------------
+// The key of a tile is the largest cost within `radius` tiles of it — the heavy tiles of the next frame are NEAR the heavy tiles of this
+// one (silhouettes, grazing rays), not on them: ordering by the undilated costs of even a quarter of a degree ago is no better than
+// row-major, by the dilated ones within a few per cent of the frame's own (profiles/r03_moving_order_experiment.txt) — reduced to one of
+// 64 classes, four to the octave of clocks (a finer order of dilated costs gains nothing).  Sorted by class, heaviest first, within a
+// class by 16x16-tile block of the screen and position in it: (1) every block dilates its tiles through LDS and counts its classes,
+// (2) one workgroup scans the 64 x blocks counts (laid out heaviest class first, so the scan IS the order) and leaves the length of the
+// live prefix, (3) every block writes its tiles to their places, and the inverse permutation with them.  Deterministic; reads the live
+// cost buffer once per use (frames on other streams may be writing it: any mixture of old and new costs is as good a key).
+constexpr uint32_t kClassBlock = 16u, kClasses = 64u, kMaxRadius = 8u;
+__device__ __forceinline__ uint32_t cost_class(uint32_t m) {          // 0 = nothing walked near here; 1..63 by quarter octaves from 256 clocks up
+    if (m == 0u) return 0u;
+    const uint32_t q = __float_as_uint(static_cast<float>(m)) >> 21;     // exponent and two mantissa bits
+    return q <= 540u ? 1u : (q - 539u > 63u ? 63u : q - 539u);
+}
+// flat index of (class, block) in the count table: heaviest class first
+__device__ __forceinline__ uint32_t count_slot(uint32_t cls, uint32_t block, uint32_t n_blocks) { return (kClasses - 1u - cls) * n_blocks + block; }
+
+__global__ __launch_bounds__(256) void order_class_kernel(const uint32_t* cost, uint8_t* cls_out, uint32_t* counts, uint32_t tiles_x, uint32_t tiles_y, uint32_t radius) {
+    __shared__ uint32_t region[(kClassBlock + 2u * kMaxRadius) * (kClassBlock + 2u * kMaxRadius)];
+    __shared__ uint32_t rows[(kClassBlock + 2u * kMaxRadius) * kClassBlock];
+    __shared__ uint32_t hist[kClasses];
+    const uint32_t side = kClassBlock + 2u * radius;
+    const uint32_t blocks_x = (tiles_x + kClassBlock - 1u) / kClassBlock;
+    const uint32_t bx = blockIdx.x % blocks_x, by = blockIdx.x / blocks_x;
+    const int32_t ox = static_cast<int32_t>(bx * kClassBlock) - static_cast<int32_t>(radius), oy = static_cast<int32_t>(by * kClassBlock) - static_cast<int32_t>(radius);
+    if (threadIdx.x < kClasses) hist[threadIdx.x] = 0u;
+    for (uint32_t i = threadIdx.x; i < side * side; i += 256u) {
+        const int32_t x = ox + static_cast<int32_t>(i % side), y = oy + static_cast<int32_t>(i / side);
+        region[i] = (x >= 0 && y >= 0 && x < static_cast<int32_t>(tiles_x) && y < static_cast<int32_t>(tiles_y)) ? cost[static_cast<uint32_t>(y) * tiles_x + static_cast<uint32_t>(x)] : 0u;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < side * kClassBlock; i += 256u) {          // along x
+        const uint32_t col = i % kClassBlock, row = i / kClassBlock;
+        uint32_t m = 0u;
+        for (uint32_t k = 0; k <= 2u * radius; ++k) m = max(m, region[row * side + col + k]);
+        rows[i] = m;
+    }
+    __syncthreads();
+    const uint32_t lx = threadIdx.x % kClassBlock, ly = threadIdx.x / kClassBlock;
+    const uint32_t tx = bx * kClassBlock + lx, ty = by * kClassBlock + ly;
+    if (tx < tiles_x && ty < tiles_y) {                                          // along y
+        uint32_t m = 0u;
+        for (uint32_t k = 0; k <= 2u * radius; ++k) m = max(m, rows[(ly + k) * kClassBlock + lx]);
+        const uint32_t c = cost_class(m);
+        cls_out[ty * tiles_x + tx] = static_cast<uint8_t>(c);
+        atomicAdd(&hist[c], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < kClasses) counts[count_slot(threadIdx.x, blockIdx.x, gridDim.x)] = hist[threadIdx.x];
+}
+
+// counts -> exclusive prefix sums, in place; *live_out = tiles of the classes 1..63; stats_out as order_depth_kernel below.  ONE workgroup.
+__global__ __launch_bounds__(1024) void order_scan_kernel(uint32_t* counts, uint32_t n_blocks, uint32_t* live_out,
+                                                          const float* beam, const unsigned long long* slots, uint32_t serial, uint32_t n_beams, float* stats_out) {
+    __shared__ uint32_t wave_sum[16];
+    __shared__ float part[3][16];
+    const uint32_t n = kClasses * n_blocks, per = (n + 1023u) / 1024u;
+    const uint32_t begin = min(threadIdx.x * per, n), end = min(begin + per, n);
+    uint32_t sum = 0u;
+    for (uint32_t i = begin; i < end; ++i) sum += counts[i];
+    uint32_t incl = sum;                                                         // inclusive scan of the threads' sums: in the wave, then over the waves
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t off = 1u; off < 64u; off <<= 1) { const uint32_t v = __shfl_up(incl, off); if (lane >= off) incl += v; }
+    if (lane == 63u) wave_sum[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0u;
+    for (uint32_t w = 0; w < wave; ++w) base += wave_sum[w];
+    uint32_t run = base + incl - sum;
+    for (uint32_t i = begin; i < end; ++i) { const uint32_t c = counts[i]; counts[i] = run; run += c; }
+    // class 0 is the last class of the table: everything in front of it walked, or lies within `radius` tiles of a tile that did.  The thread
+    // whose range holds the first slot of class 0 has just written that slot's offset.
+    const uint32_t first_dead = (kClasses - 1u) * n_blocks;
+    if (begin <= first_dead && first_dead < end) *live_out = counts[first_dead];
+    // the frame's depths: count, mean and standard deviation of the live beam tiles' inverse start parameters
+    float cnt = 0.0f, s1 = 0.0f, s2 = 0.0f;
+    for (uint32_t i = threadIdx.x; i < n_beams; i += 1024u) {
+        float t;
+        if (slots) { const unsigned long long v = slots[i]; t = static_cast<uint32_t>(v >> 32) == serial ? __uint_as_float(static_cast<uint32_t>(v)) : 3.0e38f; }
+        else t = beam[i];
+        if (t < 1.0e38f) { const float inv = __builtin_amdgcn_rcpf(fmaxf(t, 1.0f)); cnt += 1.0f; s1 += inv; s2 += inv * inv; }
+    }
+    for (int off = 32; off > 0; off >>= 1) { cnt += __shfl_down(cnt, off); s1 += __shfl_down(s1, off); s2 += __shfl_down(s2, off); }
+    if (lane == 0u) { part[0][wave] = cnt; part[1][wave] = s1; part[2][wave] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        cnt = s1 = s2 = 0.0f;
+        for (uint32_t w = 0; w < 16u; ++w) { cnt += part[0][w]; s1 += part[1][w]; s2 += part[2][w]; }
+        const float mean = cnt > 0.0f ? s1 / cnt : 0.0f;
+        stats_out[0] = cnt; stats_out[1] = mean; stats_out[2] = cnt > 0.0f ? sqrtf(fmaxf(s2 / cnt - mean * mean, 0.0f)) : 0.0f;
+    }
+}
+
+__global__ __launch_bounds__(256) void order_scatter_kernel(const uint8_t* cls_in, const uint32_t* offsets, uint32_t* order, uint32_t* rank_of, uint32_t tiles_x, uint32_t tiles_y) {
+    __shared__ uint32_t wave_count[4][kClasses];
+    const uint32_t blocks_x = (tiles_x + kClassBlock - 1u) / kClassBlock;
+    const uint32_t bx = blockIdx.x % blocks_x, by = blockIdx.x / blocks_x;
+    const uint32_t tx = bx * kClassBlock + threadIdx.x % kClassBlock, ty = by * kClassBlock + threadIdx.x / kClassBlock;
+    const bool valid = tx < tiles_x && ty < tiles_y;
+    const uint32_t tile = ty * tiles_x + tx;
+    const uint32_t cls = valid ? cls_in[tile] : 0xFFu;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    wave_count[wave][lane] = 0u;                                                 // kClasses == 64 == lanes
+    uint32_t rank_in_wave = 0u;
+    unsigned long long remaining = __ballot(valid);
+    while (remaining) {                                                          // one round per class present in the wave
+        const uint32_t c = __builtin_amdgcn_readlane(cls, static_cast<int>(__builtin_ctzll(remaining)));
+        const unsigned long long m = __ballot(valid && cls == c);
+        if (valid && cls == c) rank_in_wave = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+        if (lane == 0u) wave_count[wave][c] = static_cast<uint32_t>(__builtin_popcountll(m));
+        remaining &= ~m;
+    }
+    __syncthreads();
+    if (!valid) return;
+    uint32_t at = offsets[count_slot(cls, blockIdx.x, gridDim.x)] + rank_in_wave;
+    for (uint32_t w = 0; w < wave; ++w) at += wave_count[w][cls];
+    order[at] = tile;
+    rank_of[tile] = at;
+}
+
 }  // namespace
 
 size_t tile_order_temp_bytes(uint32_t n) {
@@ -41,6 +161,30 @@ hipError_t launch_iota(uint32_t* v, uint32_t n, hipStream_t stream) {
 hipError_t launch_tile_order_sort(const uint32_t* cost, uint32_t* cost_sorted_scratch, const uint32_t* iota, uint32_t* order_out, void* temp,
                                   size_t temp_bytes, uint32_t n, hipStream_t stream) {
     return hipcub::DeviceRadixSort::SortPairsDescending(temp, temp_bytes, cost, cost_sorted_scratch, iota, order_out, static_cast<int>(n), 8, 24, stream);
+}
+
+size_t tile_order_class_sort_bytes(uint32_t tiles_x, uint32_t tiles_y) {
+    const size_t blocks = static_cast<size_t>((tiles_x + kClassBlock - 1u) / kClassBlock) * ((tiles_y + kClassBlock - 1u) / kClassBlock);
+    return blocks * kClasses * sizeof(uint32_t) + static_cast<size_t>(tiles_x) * tiles_y;      // the count table, then a class byte per tile
+}
+
+size_t tile_order_class_sort_bytes_max(uint32_t n) {
+    // blocks <= (tx/16 + 1)(ty/16 + 1) <= n/256 + n/8 + 1 for tx ty <= n: 256 bytes of counts per block, one class byte per tile
+    return static_cast<size_t>(n) * 35u + 4096u;
+}
+
+hipError_t launch_tile_order_class_sort(const uint32_t* cost, uint32_t tiles_x, uint32_t tiles_y, uint32_t radius, void* scratch, uint32_t* order_out, uint32_t* rank_of,
+                                        uint32_t* live_out, const float* beam, const unsigned long long* slots, uint32_t serial, uint32_t n_beams, float* stats_out,
+                                        hipStream_t stream) {
+    if (!tiles_x || !tiles_y) return hipSuccess;
+    if (radius > kMaxRadius) radius = kMaxRadius;
+    const uint32_t blocks = ((tiles_x + kClassBlock - 1u) / kClassBlock) * ((tiles_y + kClassBlock - 1u) / kClassBlock);
+    uint32_t* counts = static_cast<uint32_t*>(scratch);
+    uint8_t* cls = reinterpret_cast<uint8_t*>(counts + static_cast<size_t>(blocks) * kClasses);
+    hipLaunchKernelGGL(order_class_kernel, dim3(blocks), dim3(256), 0, stream, cost, cls, counts, tiles_x, tiles_y, radius);
+    hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(1024), 0, stream, counts, blocks, live_out, beam, slots, serial, n_beams, stats_out);
+    hipLaunchKernelGGL(order_scatter_kernel, dim3(blocks), dim3(256), 0, stream, cls, counts, order_out, rank_of, tiles_x, tiles_y);
+    return hipGetLastError();
 }
 
 hipError_t launch_tile_order_finish(const uint32_t* order, const uint32_t* cost_sorted, uint32_t n, uint32_t* rank_of, uint32_t* live_out, hipStream_t stream) {

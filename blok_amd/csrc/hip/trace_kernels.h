@@ -150,6 +150,9 @@ struct TraceArgs {
     // such tiles itself (a view that has changed; exact either way).  null = every tile has its walk wave.
     const uint32_t* rank_of;
     uint32_t launched;
+    // an order made for ANOTHER view, carried over by a whole-tile shift (a camera in motion, api.hip): entry (tx, ty) of the order names
+    // tile ((tx + order_sx) mod tiles_x, (ty + order_sy) mod tiles_y) of this launch — still a permutation.  0, 0 = none.
+    uint32_t order_sx, order_sy;
     uint32_t* joint_gave_up;               // waves that gave up a bounded wait: joint form, for their tile's search (they start at the ray origin instead); list forms, for an entry (walked by the clean-up).  0 in a working system
     uint32_t miss_in_walk;                 // two-launch form: 1 = the walk's waves write the miss pixels of tiles the pre-pass found empty (they are launched anyway), 0 = the pre-pass does
     uint32_t beam_budget;                  // node visits a search may spend (0 = kBeamMaxVisits); running out is answered conservatively

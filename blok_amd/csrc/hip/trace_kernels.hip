@@ -220,8 +220,14 @@ __device__ __forceinline__ void trace_block(const TraceArgs& A, const uint32_t b
             // api.hip); any permutation gives the same frame.  A list entry names the tile itself.
             const uint32_t b = (!kListed && A.order) ? A.order[block] : block;
             if constexpr (kListed) { bx = b % bx_count; by = b / bx_count; if (by >= by_count) return; }
-            else if (!block_to_tile(b, grid, bx_count, by_count, bx, by)) return;
-            if constexpr (!kListed) cost_slot = A.cost_out ? A.cost_out + b : nullptr;
+            else {
+                if (!block_to_tile(b, grid, bx_count, by_count, bx, by)) return;
+                if (A.order) {                                           // the order's tile, carried to this view (wave-uniform; 0, 0 for an order of this view)
+                    bx += A.order_sx; if (bx >= bx_count) bx -= bx_count;
+                    by += A.order_sy; if (by >= by_count) by -= by_count;
+                }
+                cost_slot = A.cost_out ? A.cost_out + (by * bx_count + bx) : nullptr;
+            }
             if constexpr (kListed) t0 = listed_t0;
             else if (A.beam) {
                 const uint32_t beam_index = ((by * kTileH + wave_y) / A.beam_tile) * A.beam_bx + (bx * kTileW + wave_x) / A.beam_tile;
@@ -358,13 +364,15 @@ __device__ __forceinline__ void beam_block(const TraceArgs& A, const uint32_t b,
         // joint launch over a prefix of the order: the wave-sized tiles of this (live) beam tile that no walk wave was dispatched for —
         // the view has changed since the order was made — are walked here, one after the other
         if (A.rank_of && lds_stack && t0 < kBeamNone) {
-            const uint32_t bx_count = (A.w + kTileW - 1u) / kTileW;
+            const uint32_t bx_count = (A.w + kTileW - 1u) / kTileW, by_count = (A.h + kTileH - 1u) / kTileH;
             const uint32_t bx0 = (px - A.x0) / kTileW, bx1 = (px_end - A.x0 + kTileW - 1u) / kTileW;
             const uint32_t by0 = (py - A.y0) / kTileH, by1 = (py_end - A.y0 + kTileH - 1u) / kTileH;
             for (uint32_t by = by0; by < by1; ++by)
                 for (uint32_t bx = bx0; bx < bx1; ++bx) {
                     const uint32_t tile = by * bx_count + bx;
-                    if (__builtin_amdgcn_readfirstlane(A.rank_of[tile]) < A.launched) continue;
+                    // where the order knows this tile: the shift taken off again
+                    const uint32_t ox = bx >= A.order_sx ? bx - A.order_sx : bx + bx_count - A.order_sx, oy = by >= A.order_sy ? by - A.order_sy : by + by_count - A.order_sy;
+                    if (__builtin_amdgcn_readfirstlane(A.rank_of[oy * bx_count + ox]) < A.launched) continue;
                     const uint64_t clock0 = __builtin_amdgcn_s_memtime();
                     const uint32_t rx = bx * kTileW + lane % kWaveW, ry = by * kTileH + lane / kWaveW;
                     if (rx < A.w && ry < A.h) {

@@ -206,6 +206,16 @@ class HipTracer:
         n = 8 if resort_every_n_frames is True else int(resort_every_n_frames or 0)
         self._check(self._lib.blok_hip_set_tile_ordering(self._ctx, n))
 
+    def set_moving_order(self, enabled: bool):
+        """Longest-first scheduling for a camera in motion: the previous frame's clocks, dilated, carried to this view by a whole-tile
+        shift (default on; launches alone on the device only); never changes a result."""
+        self._check(self._lib.blok_hip_set_moving_order(self._ctx, 1 if enabled else 0))
+
+    def last_order_use(self):
+        """Diagnostic: (0 row-major | 1 order of this view | 2 order carried from another view, shift_x, shift_y) of the latest rectangle launch."""
+        sx, sy = C.c_int32(0), C.c_int32(0)
+        return self._lib.blok_hip_last_order_use(self._ctx, C.byref(sx), C.byref(sy)), sx.value, sy.value
+
     def set_joint_prefix_limit(self, max_walk_waves: int):
         """Diagnostic: cap on the walk waves of a joint launch; the rest is walked by the search waves (same frame)."""
         self._check(self._lib.blok_hip_set_joint_prefix_limit(self._ctx, max_walk_waves))

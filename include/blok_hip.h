@@ -466,6 +466,19 @@ int blok_hip_set_beam(blok_hip_ctx* ctx, uint32_t beam_tile_pixels);
  * (renderer_raytracing.cpp:666-685 leaves scheduling to the driver).  0 = off; N > 0 = re-sort every N launches.
  * Measured (4K over 1024^3, one frame at a time): walk alone 216 us row-major, 168 us in this order. */
 int blok_hip_set_tile_ordering(blok_hip_ctx* ctx, int resort_every_n_frames);
+/* The same for a camera in MOTION (round 3; default on): the heavy tiles of the next frame are near the heavy tiles of this one, not on
+ * them.  After a frame that had the device to itself, the sort keys every tile by the largest clocks within a few tiles of it (2-8, sized
+ * by what the previous shift left over), and the next launch carries that order to its own view by ONE whole-tile shift of the screen
+ * — entry (tx, ty) names tile (tx + sx, ty + sy) modulo the grid, still a permutation — computed on the host from the two cameras and
+ * the depth range of the frame the order was measured on (blok_amd/csrc/hip/launch_policy.h: plan_shift).  Used while what the shift
+ * leaves over (parallax, the stretch of a rotation towards the screen's edge) stays within twice the dilation; beyond that, and beside
+ * frames in flight on other streams, a moving camera's launches keep row-major order as before.  Pure scheduling, as above.
+ * Measured (4K over 1024^3, walk alone, camera orbiting by 1-2 degrees per frame): 209-216 us row-major, 171-178 us carried order, 167-170
+ * us in the order of the frame's own clocks (profiles/r03_moving_order_experiment.txt).  0 = off. */
+int blok_hip_set_moving_order(blok_hip_ctx* ctx, int enabled);
+/* Diagnostic: what the latest rectangle launch walked in — 0 row-major order, 1 an order of its own view, 2 an order carried over from
+ * another view by the shift returned through the pointers (wave tiles, modulo the grid; either may be null); -1 = null context. */
+int blok_hip_last_order_use(const blok_hip_ctx* ctx, int32_t* out_shift_x, int32_t* out_shift_y);
 /* Diagnostic: the most walk waves a launch over the order's live prefix dispatches (0 = no limit).  Whatever is cut off is walked by the
  * search waves; the frame is the same (the tests use it to exercise that path). */
 int blok_hip_set_joint_prefix_limit(blok_hip_ctx* ctx, uint32_t max_walk_waves);

@@ -75,6 +75,9 @@ for step in steps:
     qx = np.clip(((u0 + 1) * 0.5 * Wd) // 8, 0, bx - 1).astype(np.int64); qy = np.clip(((1 - v0) * 0.5 * Ht) // 8, 0, by - 1).astype(np.int64)
     behind = ~(z > 0)
     repro = np.where(behind, 0.0, full0[qy * bx + qx])
+    from scipy.ndimage import maximum_filter
+    grid0 = full0.reshape(by, bx)
+    dil = {k: np.where(behind, 0.0, maximum_filter(grid0, size=k, mode="nearest")[qy, qx]) for k in (3, 5, 9, 17)}
     stale = full0[tiles1]
     nat = np.argsort(tiles1, kind="stable")
     print(f"camera step {step} degrees per frame: {len(tiles1)} live wave tiles; correlation of own clocks with stale {np.corrcoef(own, stale)[0, 1]:.2f}, with reprojected {np.corrcoef(own, repro)[0, 1]:.2f}", flush=True)
@@ -91,4 +94,29 @@ for step in steps:
     show_n("reprojected clocks", repro_n); show_n("reprojected clocks, 8 classes", classes(repro_n))
     show_n("reprojected, 4 classes", np.floor(classes(repro_n) / 2))
     show_n("reprojected, 2 classes (heavy first)", (classes(repro_n) >= 5).astype(np.float64))
+    # ONE whole-tile shift for the frame (median displacement of the live tiles) instead of a reprojection per tile: an order made
+    # behind frame k over frame k's screen can then be used for frame k+1 by adding the shift to every entry (a bijection on the torus)
+    sx = int(np.median(qx - tiles1 % bx)); sy = int(np.median(qy - tiles1 // bx))
+    tx1 = (tiles1 % bx + sx) % bx; ty1 = (tiles1 // bx + sy) % by
+    print(f"   whole-frame shift {sx}, {sy} wave tiles; residual displacement after it: median {np.median(np.hypot(qx - tiles1 % bx - sx, qy - tiles1 // bx - sy)):.1f}, 99th percentile {np.percentile(np.hypot(qx - tiles1 % bx - sx, qy - tiles1 // bx - sy), 99):.1f} tiles", flush=True)
+    for k in (1, 3, 5, 9, 17):
+        g = maximum_filter(grid0, size=k, mode="nearest") if k > 1 else grid0
+        sh = g[ty1, tx1][nat]
+        show_n(f"shifted frame, max over {k}x{k}", sh); show_n(f"shifted frame, max over {k}x{k}, 8 classes", classes(sh))
+    def octave_classes(c, per_octave):                       # absolute classes: what a kernel can compute without a median
+        return np.where(c > 0, np.floor(np.log2(np.maximum(c, 1.0)) * per_octave), 0.0)
+    for k in (9,):
+        g = maximum_filter(grid0, size=k, mode="nearest")
+        sh = g[ty1, tx1][nat]
+        for po in (1, 2, 4):
+            show_n(f"shifted frame, max over {k}x{k}, {po} classes per octave", octave_classes(sh, po))
+    heavy = np.argsort(-own_n)[:200]                          # where the 200 truly heaviest tiles stand in each predicted order
+    def standing(key):
+        rank = np.empty(len(key), dtype=np.int64); rank[np.argsort(-key, kind="stable")] = np.arange(len(key))
+        r = rank[heavy]; return f"median rank {int(np.median(r))}, worst {int(r.max())} of {len(key)}"
+    print(f"   the 200 heaviest tiles: reprojected {standing(repro_n)}", flush=True)
+    for k, dk in dil.items():
+        dn = dk[nat]
+        print(f"   the 200 heaviest tiles: max over {k}x{k} {standing(dn)}", flush=True)
+        show_n(f"reprojected, max over {k}x{k}", dn); show_n(f"reprojected, max over {k}x{k}, 8 classes", classes(dn))
 tr.shutdown()

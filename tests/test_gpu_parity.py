@@ -471,6 +471,71 @@ def test_tile_ordering_is_pure_scheduling(tracer_cls, scene1024):
     a.shutdown(); b.shutdown()
 
 
+def test_carried_order_of_a_moving_camera_is_pure_scheduling(tracer_cls, scene1024):
+    """A camera in motion (blok_hip_set_moving_order): the frame's clocks, dilated, are sorted behind it, and the next launch walks in that
+    order carried to its own view by a whole-tile shift of the screen — walk waves only for the order's live prefix, whatever else has
+    become live walked by the search waves.  4K over 1024^3, camera orbiting the world by 0.3 to 5 degrees per frame, back and forth,
+    with a jump, a stop and a rectangle in between; launch forms 3 (automatic), 2 (joint) and 0 (two launches); a capped prefix: every
+    frame equals the frame of a context with all ordering off, records and RGBA8, the carried order was in use on most of them, and no
+    wave gave up waiting."""
+    import torch
+    cm, pw = scene1024
+    Wd, Ht = 3840, 2160
+    ref = tracer_cls(Wd, Ht).init(); ref.add_world(pw); ref.set_fused(0); ref.set_tile_ordering(False)
+    tr = tracer_cls(Wd, Ht).init(); tr.add_world(pw)
+    hits = torch.zeros((Wd * Ht, 4), dtype=torch.int32, device="cuda"); rgba = torch.zeros(Wd * Ht, dtype=torch.int32, device="cuda")
+    want_h = torch.zeros_like(hits); want_c = torch.zeros_like(rgba)
+    centre = np.array([512.0, 256.0, 512.0]); start = np.array([-358.0, 870.0, -358.0]) - centre
+
+    def orbit(deg, lift=0.0):
+        r = np.radians(deg)
+        p = centre + np.array([start[0] * np.cos(r) - start[2] * np.sin(r), start[1] + lift, start[0] * np.sin(r) + start[2] * np.cos(r)])
+        return W.camera_look_at(tuple(float(v) for v in p), tuple(float(v) for v in centre), 60.0, Wd, Ht)
+
+    uses = []
+
+    def same(cam, tag, rect=None):
+        hits.fill_(5); rgba.fill_(5); want_h.fill_(5); want_c.fill_(5)
+        tr.draw_frame_device(cam, hits.data_ptr(), rgba.data_ptr(), rect=rect)
+        ref.draw_frame_device(cam, want_h.data_ptr(), want_c.data_ptr(), rect=rect)
+        torch.cuda.synchronize()
+        uses.append(tr.last_order_use())
+        assert torch.equal(hits, want_h) and torch.equal(rgba, want_c), (tag, uses[-1])
+
+    angle, lift = 5.0, 0.0
+    for form in (3, 2, 0):
+        tr.set_fused(form)
+        uses.clear()
+        for k, step in enumerate([0.3] * 4 + [1.0] * 6 + [-1.0] * 3 + [2.0] * 4 + [5.0] * 3 + [0.0] * 4 + [1.0] * 3):
+            angle += step
+            lift = 3.0 * k if step else lift                               # step 0: the camera really rests
+            same(orbit(angle, lift=lift), (form, k, step))
+        carried = [u for u in uses if u[0] == 2]
+        assert len(carried) >= 15, uses                                   # in use on most frames ...
+        assert any(u[1] or u[2] for u in carried), uses                    # ... with a real shift on some
+        assert any(u[0] == 1 for u in uses[-8:-3]), uses                   # the stop: the view's own order takes over
+        same(W.scene_camera(1024, 1, Wd, Ht, SEED), (form, "jump"))         # into the world, grazing: nothing carries over
+        assert uses[-1][0] == 0, uses[-1]
+        same(orbit(angle), (form, "jump back"))
+        for k in range(3):                                                 # a rectangle in between: its own geometry, its own orders
+            angle += 1.0
+            same(orbit(angle), (form, "rect", k), rect=(512, 256, 2048, 1024))
+        assert uses[-1][0] == 2, uses
+    tr.set_fused(3)
+    tr.set_joint_prefix_limit(6000)                                        # most of the frame left to the search waves
+    for k in range(4):
+        angle += 1.0
+        same(orbit(angle), ("capped prefix", k))
+    tr.set_joint_prefix_limit(0)
+    assert tr.frame_queue_stalls() == 0
+    tr.set_moving_order(False)
+    for k in range(3):
+        angle += 1.0
+        same(orbit(angle), ("off", k))
+        assert uses[-1][0] == 0
+    tr.shutdown(); ref.shutdown()
+
+
 def test_list_launches_equal_the_two_launch_form(tracer_cls, scene1024):
     """List launches (blok_hip_set_fused 4, 5 and the automatic default 3): the walk waves take their wave tiles from the list the
     frame's own searches publish, and the walk grid is sized from the previous launch's list — a hint.  4K over 1024^3: a static
