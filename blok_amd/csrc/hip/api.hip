@@ -311,7 +311,7 @@ static int order_before_launch(blok_hip_ctx* ctx, blok::TraceArgs& args, uint32_
         for (uint32_t** p : {&O.d_cost, &O.d_iota, &O.d_order[0], &O.d_order[1], &O.d_rank_of[0], &O.d_rank_of[1], &O.d_keys_in, &O.d_keys})
             BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(p), bytes));
         if (!O.h_live) BLOK_HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&O.h_live), 2 * sizeof(uint32_t), hipHostMallocDefault));
-        if (!O.h_depth) BLOK_HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&O.h_depth), 6 * sizeof(float), hipHostMallocDefault));
+        if (!O.h_depth) BLOK_HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&O.h_depth), 2 * blok::kOrderDepthPartials * 3 * sizeof(float), hipHostMallocDefault));
         O.temp_bytes = blok::tile_order_temp_bytes(want);
         BLOK_HIP_TRY(ctx, hipMalloc(&O.d_temp, O.temp_bytes ? O.temp_bytes : 16));
         BLOK_HIP_TRY(ctx, hipMalloc(&O.d_class_scratch, blok::tile_order_class_sort_bytes_max(want)));
@@ -330,7 +330,14 @@ static int order_before_launch(blok_hip_ctx* ctx, blok::TraceArgs& args, uint32_
     if (O.pending && hipEventQuery(O.done) == hipSuccess) {              // the sort launched some frames ago has finished
         O.current = O.target;
         O.live[O.current] = O.h_live[O.current];                         // written by the device before the event
-        if (O.dilated[O.current]) { O.inv_depth[O.current][0] = O.h_depth[O.current * 3 + 1]; O.inv_depth[O.current][1] = O.h_depth[O.current * 3 + 2]; }
+        if (O.dilated[O.current]) {
+            // the frame's depths: mean and standard deviation of its live beam tiles' inverse start parameters, from the sort's partial sums
+            double cnt = 0.0, s1 = 0.0, s2 = 0.0;
+            const float* part = O.h_depth + O.current * blok::kOrderDepthPartials * 3;
+            for (uint32_t k = 0; k < blok::kOrderDepthPartials; ++k) { cnt += part[k * 3]; s1 += part[k * 3 + 1]; s2 += part[k * 3 + 2]; }
+            const double mean = cnt > 0.0 ? s1 / cnt : 0.0, var = cnt > 0.0 ? s2 / cnt - mean * mean : 0.0;
+            O.inv_depth[O.current][0] = static_cast<float>(mean); O.inv_depth[O.current][1] = static_cast<float>(var > 0.0 ? std::sqrt(var) : 0.0);
+        }
         O.pending = false; O.frames_since_sort = 0;
         // From here on no launch reads the OTHER buffer any more; the launches that may still be reading it are those already issued, on
         // any stream of this context.  A marker behind each of them now is what the next sort — which overwrites that buffer, many
@@ -398,7 +405,7 @@ static int order_after_launch(blok_hip_ctx* ctx, const blok::TraceArgs& args, ui
         radius = blok::plan_dilation(O.have_residual, O.last_residual);
         const uint32_t tiles_x = (args.w + blok::kTileW - 1u) / blok::kTileW, tiles_y = (args.h + blok::kTileH - 1u) / blok::kTileH;
         BLOK_HIP_TRY(ctx, blok::launch_tile_order_class_sort(O.d_cost, tiles_x, tiles_y, radius, O.d_class_scratch, O.d_order[target], O.d_rank_of[target], O.h_live + target,
-                                                             args.beam, args.beam_slots, args.beam_serial, n_beams, O.h_depth + target * 3, stream));
+                                                             args.beam, args.beam_slots, args.beam_serial, n_beams, O.h_depth + target * blok::kOrderDepthPartials * 3, stream));
     } else {
         // the sort reads a SNAPSHOT of the costs: frames in flight on other streams keep writing the live buffer, and a radix sort that saw a
         // key change between its histogram and its scatter would not produce a permutation

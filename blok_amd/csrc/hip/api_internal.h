@@ -133,7 +133,7 @@ struct blok_hip_ctx {
         void* d_class_scratch = nullptr;                    // tile_order.h: count table and class bytes of the counting sort
         bool dilated[2] = {false, false};
         uint32_t radius[2] = {0, 0};
-        float* h_depth = nullptr;                           // pinned, 2 x 3 floats: count, mean, sigma of the live beam tiles' inverse start parameters (written by the device)
+        float* h_depth = nullptr;                           // pinned, 2 x 64 x 3 floats: partial count, sum, sum of squares of the live beam tiles' inverse start parameters (written by the device)
         float inv_depth[2][2] = {};                         // ... mean and sigma as read when the order was adopted
         bool have_residual = false; float last_residual = 0.0f;     // what the latest shift left over (sizes the next dilation)
         bool alone_before = false;                          // the previous orderable launch had the device to itself

@@ -73,49 +73,50 @@ __global__ __launch_bounds__(256) void order_class_kernel(const uint32_t* cost, 
     if (threadIdx.x < kClasses) counts[count_slot(threadIdx.x, blockIdx.x, gridDim.x)] = hist[threadIdx.x];
 }
 
-// counts -> exclusive prefix sums, in place; *live_out = tiles of the classes 1..63; stats_out as order_depth_kernel below.  ONE workgroup.
-__global__ __launch_bounds__(1024) void order_scan_kernel(uint32_t* counts, uint32_t n_blocks, uint32_t* live_out,
-                                                          const float* beam, const unsigned long long* slots, uint32_t serial, uint32_t n_beams, float* stats_out) {
-    __shared__ uint32_t wave_sum[16];
-    __shared__ float part[3][16];
-    const uint32_t n = kClasses * n_blocks, per = (n + 1023u) / 1024u;
-    const uint32_t begin = min(threadIdx.x * per, n), end = min(begin + per, n);
-    uint32_t sum = 0u;
-    for (uint32_t i = begin; i < end; ++i) sum += counts[i];
-    uint32_t incl = sum;                                                         // inclusive scan of the threads' sums: in the wave, then over the waves
+// (2) workgroup c scans the block counts of class c in place (exclusive: where block b's tiles of the class start inside the class) and
+// leaves the class total; it also reduces its share of the frame's beam tiles to a partial (count, sum, sum of squares) of their inverse
+// start parameters — depth_out[c * 3 ..], summed on the host (api.hip): no workgroup waits for another, nothing is added atomically.
+__global__ __launch_bounds__(256) void order_rows_kernel(uint32_t* counts, uint32_t n_blocks, uint32_t* totals,
+                                                         const float* beam, const unsigned long long* slots, uint32_t serial, uint32_t n_beams, float* depth_out) {
+    __shared__ uint32_t wave_sum[4];
+    __shared__ float part[3][4];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    for (uint32_t off = 1u; off < 64u; off <<= 1) { const uint32_t v = __shfl_up(incl, off); if (lane >= off) incl += v; }
-    if (lane == 63u) wave_sum[wave] = incl;
-    __syncthreads();
-    uint32_t base = 0u;
-    for (uint32_t w = 0; w < wave; ++w) base += wave_sum[w];
-    uint32_t run = base + incl - sum;
-    for (uint32_t i = begin; i < end; ++i) { const uint32_t c = counts[i]; counts[i] = run; run += c; }
-    // class 0 is the last class of the table: everything in front of it walked, or lies within `radius` tiles of a tile that did.  The thread
-    // whose range holds the first slot of class 0 has just written that slot's offset.
-    const uint32_t first_dead = (kClasses - 1u) * n_blocks;
-    if (begin <= first_dead && first_dead < end) *live_out = counts[first_dead];
-    // the frame's depths: count, mean and standard deviation of the live beam tiles' inverse start parameters
+    uint32_t* const row = counts + static_cast<size_t>(kClasses - 1u - blockIdx.x) * n_blocks;      // heaviest class first (count_slot)
+    uint32_t carry = 0u;
+    for (uint32_t base = 0; base < n_blocks; base += 256u) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < n_blocks ? row[i] : 0u;
+        uint32_t incl = v;
+        for (uint32_t off = 1u; off < 64u; off <<= 1) { const uint32_t u = __shfl_up(incl, off); if (lane >= off) incl += u; }
+        __syncthreads();                                                         // (the previous round's wave_sum has been read)
+        if (lane == 63u) wave_sum[wave] = incl;
+        __syncthreads();
+        uint32_t before = carry;
+        for (uint32_t w = 0; w < wave; ++w) before += wave_sum[w];
+        if (i < n_blocks) row[i] = before + incl - v;
+        carry += wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+    }
+    if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+    const uint32_t share = (n_beams + kClasses - 1u) / kClasses, b0 = blockIdx.x * share, b1 = min(b0 + share, n_beams);
     float cnt = 0.0f, s1 = 0.0f, s2 = 0.0f;
-    for (uint32_t i = threadIdx.x; i < n_beams; i += 1024u) {
+    for (uint32_t i = b0 + threadIdx.x; i < b1; i += 256u) {
         float t;
         if (slots) { const unsigned long long v = slots[i]; t = static_cast<uint32_t>(v >> 32) == serial ? __uint_as_float(static_cast<uint32_t>(v)) : 3.0e38f; }
         else t = beam[i];
-        if (t < 1.0e38f) { const float inv = __builtin_amdgcn_rcpf(fmaxf(t, 1.0f)); cnt += 1.0f; s1 += inv; s2 += inv * inv; }
+        if (t < 1.0e38f) { const float inv = 1.0f / fmaxf(t, 1.0f); cnt += 1.0f; s1 += inv; s2 += inv * inv; }
     }
     for (int off = 32; off > 0; off >>= 1) { cnt += __shfl_down(cnt, off); s1 += __shfl_down(s1, off); s2 += __shfl_down(s2, off); }
     if (lane == 0u) { part[0][wave] = cnt; part[1][wave] = s1; part[2][wave] = s2; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        cnt = s1 = s2 = 0.0f;
-        for (uint32_t w = 0; w < 16u; ++w) { cnt += part[0][w]; s1 += part[1][w]; s2 += part[2][w]; }
-        const float mean = cnt > 0.0f ? s1 / cnt : 0.0f;
-        stats_out[0] = cnt; stats_out[1] = mean; stats_out[2] = cnt > 0.0f ? sqrtf(fmaxf(s2 / cnt - mean * mean, 0.0f)) : 0.0f;
-    }
+    if (threadIdx.x < 3u) depth_out[blockIdx.x * 3u + threadIdx.x] = part[threadIdx.x][0] + part[threadIdx.x][1] + part[threadIdx.x][2] + part[threadIdx.x][3];
 }
 
-__global__ __launch_bounds__(256) void order_scatter_kernel(const uint8_t* cls_in, const uint32_t* offsets, uint32_t* order, uint32_t* rank_of, uint32_t tiles_x, uint32_t tiles_y) {
+// (3) every block writes its tiles to their places: class base (the totals of the heavier classes) + the block's start inside the class +
+// the tile's rank among the block's tiles of that class; the inverse permutation with them.  Block 0 leaves the length of the live prefix.
+__global__ __launch_bounds__(256) void order_scatter_kernel(const uint8_t* cls_in, const uint32_t* offsets, const uint32_t* totals, uint32_t* order, uint32_t* rank_of,
+                                                            uint32_t* live_out, uint32_t tiles_x, uint32_t tiles_y) {
     __shared__ uint32_t wave_count[4][kClasses];
+    __shared__ uint32_t class_base[kClasses];
     const uint32_t blocks_x = (tiles_x + kClassBlock - 1u) / kClassBlock;
     const uint32_t bx = blockIdx.x % blocks_x, by = blockIdx.x / blocks_x;
     const uint32_t tx = bx * kClassBlock + threadIdx.x % kClassBlock, ty = by * kClassBlock + threadIdx.x / kClassBlock;
@@ -124,6 +125,14 @@ __global__ __launch_bounds__(256) void order_scatter_kernel(const uint8_t* cls_i
     const uint32_t cls = valid ? cls_in[tile] : 0xFFu;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     wave_count[wave][lane] = 0u;                                                 // kClasses == 64 == lanes
+    if (wave == 0u) {
+        // lane l stands for class 63 - l: an exclusive scan over the lanes = the tiles of all heavier classes
+        const uint32_t mine = totals[kClasses - 1u - lane];
+        uint32_t incl = mine;
+        for (uint32_t off = 1u; off < 64u; off <<= 1) { const uint32_t u = __shfl_up(incl, off); if (lane >= off) incl += u; }
+        class_base[kClasses - 1u - lane] = incl - mine;
+        if (blockIdx.x == 0u && lane == 63u) *live_out = incl - mine;           // class 0 comes last: everything in front of it walked, or lies within `radius` tiles of a tile that did
+    }
     uint32_t rank_in_wave = 0u;
     unsigned long long remaining = __ballot(valid);
     while (remaining) {                                                          // one round per class present in the wave
@@ -135,7 +144,7 @@ __global__ __launch_bounds__(256) void order_scatter_kernel(const uint8_t* cls_i
     }
     __syncthreads();
     if (!valid) return;
-    uint32_t at = offsets[count_slot(cls, blockIdx.x, gridDim.x)] + rank_in_wave;
+    uint32_t at = class_base[cls] + offsets[count_slot(cls, blockIdx.x, gridDim.x)] + rank_in_wave;
     for (uint32_t w = 0; w < wave; ++w) at += wave_count[w][cls];
     order[at] = tile;
     rank_of[tile] = at;
@@ -165,7 +174,7 @@ hipError_t launch_tile_order_sort(const uint32_t* cost, uint32_t* cost_sorted_sc
 
 size_t tile_order_class_sort_bytes(uint32_t tiles_x, uint32_t tiles_y) {
     const size_t blocks = static_cast<size_t>((tiles_x + kClassBlock - 1u) / kClassBlock) * ((tiles_y + kClassBlock - 1u) / kClassBlock);
-    return blocks * kClasses * sizeof(uint32_t) + static_cast<size_t>(tiles_x) * tiles_y;      // the count table, then a class byte per tile
+    return (blocks + 1u) * kClasses * sizeof(uint32_t) + static_cast<size_t>(tiles_x) * tiles_y;      // the count table, the class totals, then a class byte per tile
 }
 
 size_t tile_order_class_sort_bytes_max(uint32_t n) {
@@ -174,16 +183,17 @@ size_t tile_order_class_sort_bytes_max(uint32_t n) {
 }
 
 hipError_t launch_tile_order_class_sort(const uint32_t* cost, uint32_t tiles_x, uint32_t tiles_y, uint32_t radius, void* scratch, uint32_t* order_out, uint32_t* rank_of,
-                                        uint32_t* live_out, const float* beam, const unsigned long long* slots, uint32_t serial, uint32_t n_beams, float* stats_out,
+                                        uint32_t* live_out, const float* beam, const unsigned long long* slots, uint32_t serial, uint32_t n_beams, float* depth_out,
                                         hipStream_t stream) {
     if (!tiles_x || !tiles_y) return hipSuccess;
     if (radius > kMaxRadius) radius = kMaxRadius;
     const uint32_t blocks = ((tiles_x + kClassBlock - 1u) / kClassBlock) * ((tiles_y + kClassBlock - 1u) / kClassBlock);
     uint32_t* counts = static_cast<uint32_t*>(scratch);
-    uint8_t* cls = reinterpret_cast<uint8_t*>(counts + static_cast<size_t>(blocks) * kClasses);
+    uint32_t* totals = counts + static_cast<size_t>(blocks) * kClasses;
+    uint8_t* cls = reinterpret_cast<uint8_t*>(totals + kClasses);
     hipLaunchKernelGGL(order_class_kernel, dim3(blocks), dim3(256), 0, stream, cost, cls, counts, tiles_x, tiles_y, radius);
-    hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(1024), 0, stream, counts, blocks, live_out, beam, slots, serial, n_beams, stats_out);
-    hipLaunchKernelGGL(order_scatter_kernel, dim3(blocks), dim3(256), 0, stream, cls, counts, order_out, rank_of, tiles_x, tiles_y);
+    hipLaunchKernelGGL(order_rows_kernel, dim3(kClasses), dim3(256), 0, stream, counts, blocks, totals, beam, slots, serial, n_beams, depth_out);
+    hipLaunchKernelGGL(order_scatter_kernel, dim3(blocks), dim3(256), 0, stream, cls, counts, totals, order_out, rank_of, live_out, tiles_x, tiles_y);
     return hipGetLastError();
 }
 
