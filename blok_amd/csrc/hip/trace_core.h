@@ -230,12 +230,39 @@ BLOK_DEV void walk_loop(const TraceArgs& A, const WalkRay& R, const float tmax, 
             // a filled voxel: reported iff its clipped interval is non-empty (intersect.rint:189-193)
             if (tCur < fminf(tExit, tmax)) { found = true; break; }
         }
+#ifdef BLOK_WALK_SKIP
+        // nothing else of this node lies ahead of the ray (all rays travel towards +q on every axis: what is ahead of cell (dx, dy, dz) is
+        // the box of cells >= it) -> leave the NODE through its far planes at once, as if it were an empty cell of the level above: the
+        // same (axis, T) as the last of the single steps would reach, by the same tie rule, and the fine position is dropped on ascent anyway
+        if (lvl + 1u < L) {
+            const uint32_t wx = bit & 3u, wy = (bit >> 2) & 3u, wz = bit >> 4;
+            const uint32_t nx = (R.mirror & 3u) ? (0xFu >> (3u - wx)) : ((0xFu << wx) & 0xFu);
+            const uint32_t ny = (R.mirror & 12u) ? (0xFFFFu >> (4u * (3u - wy))) : ((0xFFFFu << (4u * wy)) & 0xFFFFu);
+            const uint32_t xy = (nx * 0x11111111u) & (ny * 0x00010001u);
+            const unsigned long long az = (R.mirror & 48u) ? (~0ull >> (16u * (3u - wz))) : (~0ull << (16u * wz));
+            const unsigned long long here = 1ull << bit;
+            const unsigned long long m = ((static_cast<unsigned long long>(node.hi) << 32) | node.lo) & ((static_cast<unsigned long long>(xy) << 32) | xy) & az & ~here;
+            if (m == 0ull) {
+                BLOK_STAT(4, lvl + 1u);
+                lvl += 1u;
+                size = cell_size(lvl);
+                const uint32_t keep = ~((1u << (2 * lvl)) - 1u);
+                fx = __uint_as_float(__float_as_uint(fx) & keep); fy = __uint_as_float(__float_as_uint(fy) & keep); fz = __uint_as_float(__float_as_uint(fz) & keep);
+                const uint4 c = stk[(lvl - 1) * kBlock];
+                node.lo = c.x; node.hi = c.y; node.base = c.z;
+                tFx = plane_t(R.ax, fx + size); tFy = plane_t(R.ay, fy + size); tFz = plane_t(R.az, fz + size);
+            }
+        }
+        const float tExit2 = fminf(fminf(tFx, tFy), tFz);
+#else
+        const float tExit2 = tExit;
+#endif
         // step: cross the nearest far plane (x, then y, then z on ties)
         BLOK_STAT(2, lvl);
-        tCur = tExit;
+        tCur = tExit2;
         if (!(tCur < tmax)) break;
-        const bool sx = tFx == tExit;
-        const bool sy = !sx && tFy == tExit;
+        const bool sx = tFx == tExit2;
+        const bool sy = !sx && tFy == tExit2;
         const bool sz = !sx && !sy;
         fx += sx ? size : 0.0f; fy += sy ? size : 0.0f; fz += sz ? size : 0.0f;
         // the stepped coordinate is now a multiple of 4^k for the level k whose cell boundary was crossed (its mantissa
