@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void brick_node_kernel(const uint64_t* masks_s
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     const uint64_t m = masks_sorted[i];
-    out[i] = make_uint4(static_cast<uint32_t>(m), static_cast<uint32_t>(m >> 32), mat_base[i], node_box(m));
+    out[i] = make_uint4(static_cast<uint32_t>(m), static_cast<uint32_t>(m >> 32), mat_base[i], 0u);
 }
 
 struct DeviceBuffers {          // frees everything it still owns on scope exit
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(256) void level_nodes_kernel(const uint64_t* occ, c
     if (w == 0ull) return;
     const uint64_t s = scanned[c];
     const uint32_t rank = static_cast<uint32_t>(s >> 32);
-    tree[level_start + rank] = make_uint4(static_cast<uint32_t>(w), static_cast<uint32_t>(w >> 32), below_start + static_cast<uint32_t>(s), node_box(w));
+    tree[level_start + rank] = make_uint4(static_cast<uint32_t>(w), static_cast<uint32_t>(w >> 32), below_start + static_cast<uint32_t>(s), 0u);
     if (cells2) cells2[rank] = static_cast<uint32_t>(c);
 }
 
@@ -636,7 +636,7 @@ __global__ __launch_bounds__(256) void keyed_brick_nodes_kernel(const uint64_t* 
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     const uint64_t m = masks_sorted[i];
-    out[i] = make_uint4(static_cast<uint32_t>(m), static_cast<uint32_t>(m >> 32), mat_base[i], node_box(m));
+    out[i] = make_uint4(static_cast<uint32_t>(m), static_cast<uint32_t>(m >> 32), mat_base[i], 0u);
     old_base[src[i]] = mat_base[i];
     dirty[src[i]] = 0;
 }

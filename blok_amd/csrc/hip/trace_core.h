@@ -143,18 +143,13 @@ struct HitInfo {
 // What a walk needs of its ray: the three axes (origin, safe inverse direction, mirroring) and the child-bit constant.
 struct WalkRay {
     Axis ax, ay, az;
-    uint32_t mirror, mirror9;
+    uint32_t mirror;
 };
-// The guard bits of node_box (tree.h), and a node's box as this ray sees it: per axis the LARGEST occupied digit in mirrored coordinates —
-// the largest world digit, or 3 - the smallest on an axis the ray travels negatively — still three bits apart with the guard bits set.
-// (Bits 9 and up carry leftovers of the other field; the subtraction in the walk never borrows that far.)
-constexpr uint32_t kBoxGuard = 0x124u;
-BLOK_DEV uint32_t box_limit(uint32_t box, uint32_t mirror9) { return (((box >> 9) & mirror9) | (box & ~mirror9)) ^ mirror9; }
 // Where a walk is: the current cell (mirrored min corner, level, parent node), the T of its far planes, the ray parameter at which it
 // was entered, and — once `found` — the reported voxel (cell, node, bit, tCur).
 struct WalkState {
     float fx, fy, fz, tFx, tFy, tFz, tCur, size;
-    uint32_t lvl, bit, lim;
+    uint32_t lvl, bit;
     NodeRec node;
     bool walking, found;     // walking: the loop still has work for this lane
 };
@@ -174,7 +169,6 @@ BLOK_DEV WalkRay walk_ray(const TraceArgs& A, float ox, float oy, float oz, floa
     R.ay.c = (static_cast<float>(A.origin[1] + (negy ? W : 0)) + (negy ? kCoordBias : -kCoordBias)) * vs;
     R.az.c = (static_cast<float>(A.origin[2] + (negz ? W : 0)) + (negz ? kCoordBias : -kCoordBias)) * vs;
     R.mirror = (negx ? 3u : 0u) | (negy ? 12u : 0u) | (negz ? 48u : 0u);
-    R.mirror9 = (negx ? 3u : 0u) | (negy ? 3u << 3 : 0u) | (negz ? 3u << 6 : 0u);      // the same, digits three bits apart (tree.h: node_box)
     return R;
 }
 
@@ -189,11 +183,11 @@ BLOK_DEV void walk_enter(const TraceArgs& A, const WalkRay& R, float tmin, float
     s.fx = kCoordBias; s.fy = kCoordBias; s.fz = kCoordBias;   // mirrored min corner of the current cell (2^23 + q)
     s.lvl = L - 1;                        // current cells have size 4^lvl; `node` is their parent
     s.size = cell_size(s.lvl);
-    s.node.lo = s.node.hi = s.node.base = 0u; s.lim = 0u;
+    s.node.lo = s.node.hi = s.node.base = 0u;
     s.walking = s.tCur < fminf(fminf(fminf(s.tFx, s.tFy), s.tFz), tmax);
     if (!s.walking) return;
     const uint4 q = A.nodes[0];
-    s.node.lo = q.x; s.node.hi = q.y; s.node.base = q.z; s.lim = box_limit(q.w, R.mirror9);
+    s.node.lo = q.x; s.node.hi = q.y; s.node.base = q.z;
     const float s2 = s.size + s.size, s3 = s2 + s.size;
     enter_axis(R.ax, s.fx, s.tFx, s.size, s2, s3, s.tCur);
     enter_axis(R.ay, s.fy, s.tFy, s.size, s2, s3, s.tCur);
@@ -210,7 +204,6 @@ BLOK_DEV void walk_loop(const TraceArgs& A, const WalkRay& R, const float tmax, 
     float fx = s.fx, fy = s.fy, fz = s.fz, tFx = s.tFx, tFy = s.tFy, tFz = s.tFz, tCur = s.tCur, size = s.size;
     uint32_t lvl = s.lvl, bit = s.bit;
     NodeRec node = s.node;
-    uint32_t lim = s.lim;                  // box_limit of `node` (the skip test below)
     bool found = false;
     const bool walking = s.walking;
     while (walking) {
@@ -221,9 +214,9 @@ BLOK_DEV void walk_loop(const TraceArgs& A, const WalkRay& R, const float tmax, 
         if (occupied && lvl != 0) {
             // descend: remember the node we are leaving, fetch the child, pick its start cell
             BLOK_STAT(1, lvl);
-            stk[(lvl - 1) * kBlock] = make_uint4(node.lo, node.hi, node.base, lim);    // node of level lvl+1
+            stk[(lvl - 1) * kBlock] = make_uint4(node.lo, node.hi, node.base, 0u);     // node of level lvl+1
             const uint4 c = A.nodes[node.base + mask_rank(node, bit)];
-            node.lo = c.x; node.hi = c.y; node.base = c.z; lim = box_limit(c.w, R.mirror9);
+            node.lo = c.x; node.hi = c.y; node.base = c.z;
             lvl -= 1;
             size *= 0.25f;
             const float s2 = size + size, s3 = s2 + size;
@@ -237,25 +230,26 @@ BLOK_DEV void walk_loop(const TraceArgs& A, const WalkRay& R, const float tmax, 
             // a filled voxel: reported iff its clipped interval is non-empty (intersect.rint:189-193)
             if (tCur < fminf(tExit, tmax)) { found = true; break; }
         }
-#ifndef BLOK_WALK_NO_SKIP
-        // Nothing else of this node lies ahead: all rays travel towards +q on every axis, so what a ray can still meet in the node is the
-        // box of cells whose digits are >= the current cell's — and if the current digit on some axis is beyond the largest occupied one
-        // (node_box, tree.h; `lim` holds those digits for this ray's mirroring with guard bits between them: the subtraction clears a guard
-        // bit exactly where digit > limit), that box is empty.  The NODE is then left through its far planes at once, as if it were an empty
-        // cell of the level above: the same (axis, T) the last of the single steps would reach, by the same tie rule, and the fine position
-        // is dropped on ascent anyway — so the records cannot change (tests, and scripts/r03/skip_ahead_estimate.py on the CPU: same
-        // records, wave-iterations x 0.88).  At the root "nothing ahead" is a miss.
-        {
-            const uint32_t d9 = digit2(__float_as_uint(fx), shift) | (digit2(__float_as_uint(fy), shift) << 3) | (digit2(__float_as_uint(fz), shift) << 6);
-            if (((lim - d9) & kBoxGuard) != kBoxGuard) {
+#ifdef BLOK_WALK_SKIP
+        // nothing else of this node lies ahead of the ray (all rays travel towards +q on every axis: what is ahead of cell (dx, dy, dz) is
+        // the box of cells >= it) -> leave the NODE through its far planes at once, as if it were an empty cell of the level above: the
+        // same (axis, T) as the last of the single steps would reach, by the same tie rule, and the fine position is dropped on ascent anyway
+        if (lvl + 1u < L) {
+            const uint32_t wx = bit & 3u, wy = (bit >> 2) & 3u, wz = bit >> 4;
+            const uint32_t nx = (R.mirror & 3u) ? (0xFu >> (3u - wx)) : ((0xFu << wx) & 0xFu);
+            const uint32_t ny = (R.mirror & 12u) ? (0xFFFFu >> (4u * (3u - wy))) : ((0xFFFFu << (4u * wy)) & 0xFFFFu);
+            const uint32_t xy = (nx * 0x11111111u) & (ny * 0x00010001u);
+            const unsigned long long az = (R.mirror & 48u) ? (~0ull >> (16u * (3u - wz))) : (~0ull << (16u * wz));
+            const unsigned long long here = 1ull << bit;
+            const unsigned long long m = ((static_cast<unsigned long long>(node.hi) << 32) | node.lo) & ((static_cast<unsigned long long>(xy) << 32) | xy) & az & ~here;
+            if (m == 0ull) {
                 BLOK_STAT(4, lvl + 1u);
-                if (lvl + 1u >= L) break;
                 lvl += 1u;
                 size = cell_size(lvl);
                 const uint32_t keep = ~((1u << (2 * lvl)) - 1u);
                 fx = __uint_as_float(__float_as_uint(fx) & keep); fy = __uint_as_float(__float_as_uint(fy) & keep); fz = __uint_as_float(__float_as_uint(fz) & keep);
                 const uint4 c = stk[(lvl - 1) * kBlock];
-                node.lo = c.x; node.hi = c.y; node.base = c.z; lim = c.w;
+                node.lo = c.x; node.hi = c.y; node.base = c.z;
                 tFx = plane_t(R.ax, fx + size); tFy = plane_t(R.ay, fy + size); tFz = plane_t(R.az, fz + size);
             }
         }
@@ -282,7 +276,7 @@ BLOK_DEV void walk_loop(const TraceArgs& A, const WalkRay& R, const float tmax, 
             const uint32_t keep = ~((1u << (2 * up)) - 1u);        // clears mantissa bits only: the exponent field stays
             fx = __uint_as_float(__float_as_uint(fx) & keep); fy = __uint_as_float(__float_as_uint(fy) & keep); fz = __uint_as_float(__float_as_uint(fz) & keep);
             const uint4 c = stk[(lvl - 1) * kBlock];               // node of level lvl+1
-            node.lo = c.x; node.hi = c.y; node.base = c.z; lim = c.w;
+            node.lo = c.x; node.hi = c.y; node.base = c.z;
         }
         tFx = plane_t(R.ax, fx + size); tFy = plane_t(R.ay, fy + size); tFz = plane_t(R.az, fz + size);
     }

@@ -24,29 +24,9 @@ struct TreeNode {
     uint32_t mask_lo;
     uint32_t mask_hi;
     uint32_t base;      // level >= 2: index of child 0 in nodes[];  level 1: index into materials[]
-    uint32_t box;       // node_box(mask): the bounding box of the set bits, for the walk's "nothing of this node lies ahead" test
+    uint32_t reserved;
 };
 static_assert(sizeof(TreeNode) == 16, "one node is one 16-byte load");
-
-// Bounding box of the occupied children (or voxels) of a node, as digits 0..3 per axis spread three bits apart — x at bits 0-1, y at 3-4,
-// z at 6-7, the bits 2, 5, 8 between them SET (guard bits: `limit - digits` then leaves a guard bit set exactly where limit >= digit) —
-// the largest digits in bits 0-8, the smallest in bits 9-17.  A function of the mask alone, so every builder writes the same word.
-// 0 for an empty mask.
-#if defined(__HIPCC__)
-__host__ __device__
-#endif
-inline uint32_t node_box(uint64_t mask) {
-    if (mask == 0ull) return 0u;
-    uint32_t lo[3] = {3u, 3u, 3u}, hi[3] = {0u, 0u, 0u};
-    for (uint32_t j = 0; j < 4u; ++j) {
-        const bool on[3] = {(mask & (0x1111111111111111ull << j)) != 0ull, (mask & (0x000F000F000F000Full << (4u * j))) != 0ull, (mask & (0xFFFFull << (16u * j))) != 0ull};
-        for (int a = 0; a < 3; ++a)
-            if (on[a]) { if (j < lo[a]) lo[a] = j; if (j > hi[a]) hi[a] = j; }
-    }
-    const uint32_t guard = 0x124u;
-    const uint32_t most = hi[0] | (hi[1] << 3) | (hi[2] << 6) | guard, least = lo[0] | (lo[1] << 3) | (lo[2] << 6) | guard;
-    return most | (least << 9);
-}
 
 constexpr uint32_t kMaxLevels = 7;   // 4^7 = 16384 voxels per axis (hit records carry int16 coordinates)
 

@@ -101,7 +101,6 @@ bool build_tree(std::vector<VoxelRec>& voxels, HostTree& out, const char** why) 
         TreeNode* dst = out.nodes.data() + start[l];
         for (size_t i = 0; i < level_nodes[l].size(); ++i) {
             dst[i] = level_nodes[l][i];
-            dst[i].box = node_box((uint64_t(dst[i].mask_hi) << 32) | dst[i].mask_lo);
             if (l >= 2) dst[i].base += start[l - 1];
         }
     }
@@ -135,7 +134,6 @@ bool build_upper_levels(const std::vector<uint64_t>& brick_keys, uint32_t levels
     for (uint32_t l = levels; l >= 2; --l)
         for (size_t i = 0; i < level_nodes[l].size(); ++i) {
             TreeNode n = level_nodes[l][i];
-            n.box = node_box((uint64_t(n.mask_hi) << 32) | n.mask_lo);
             n.base += start[l - 1];
             upper[start[l] + i] = n;
         }

@@ -11,7 +11,7 @@ from tests import harness_ffi as H, oracle_ffi as O
 ROOT = Path('.').resolve(); SRC = ROOT / "tests/host_harness"
 pose = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 libs = {}
-for name, flags in (("plain", []), ("skip", ["-DBLOK_WALK_SKIP=1"]), ("box", ["-DBLOK_WALK_SKIP=2"])):
+for name, flags in (("plain", []), ("skip", ["-DBLOK_WALK_SKIP"])):
     out = ROOT / "build/skip" / f"libhh_{name}.so"
     subprocess.run(["g++", "-O2", "-std=c++20", "-fPIC", "-ffp-contract=off", f"-I{ROOT / 'include'}", f"-I{ROOT / 'blok_amd/csrc/hip'}", f"-I{SRC}", "-shared", "-o", os.fspath(out),
                     os.fspath(SRC / "harness.cpp"), os.fspath(ROOT / "blok_amd/csrc/hip/tree_build.cpp")] + flags, check=True)
@@ -45,16 +45,13 @@ for name, L in libs.items():
         ray_it += int(it.sum()); wmax = it.reshape(hgt // 8, 8, w // 8, 8).max(axis=(1, 3)); wave_it += int(wmax.sum()); waves += int((wmax > 0).sum())
         outs.append(out.copy())
     res[name] = dict(ray_it=ray_it, wave_it=wave_it, waves=waves, tot=tot_all, outs=outs)
-for other in ("skip", "box"):
-    for a, b in zip(res["plain"]["outs"], res[other]["outs"]):
-        assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), "records differ"
+for a, b in zip(res["plain"]["outs"], res["skip"]["outs"]):
+    assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), "records differ"
 print(f"pose {pose}: records identical on {len(res['plain']['outs'])} bands of {Wd}x{B}")
-for name in ("plain", "skip", "box"):
+for name in ("plain", "skip"):
     r = res[name]
     print(f"{name:6s} iterations per ray-in-live-tiles (sum) {r['ray_it']}, wave-iterations {r['wave_it']} over {r['waves']} walking waves = {r['wave_it'] / max(1, r['waves']):.2f} per wave")
     for e, nm in enumerate(["iter", "descend", "step", "ascend", "walks / skips by level+1"]):
         print(f"        {nm:26s}", r['tot'][e].tolist())
-p = res["plain"]
-for other, what in (("skip", "exact: no occupied child in the box of cells ahead"), ("box", "beyond the bounding box of the occupied children on some axis")):
-    s = res[other]
-    print(f"{what}: wave-iterations {s['wave_it'] / p['wave_it']:.3f} x, ray iterations {s['ray_it'] / p['ray_it']:.3f} x")
+p, s = res["plain"], res["skip"]
+print(f"wave-iterations {s['wave_it'] / p['wave_it']:.3f} x, ray iterations {s['ray_it'] / p['ray_it']:.3f} x")
