@@ -10,7 +10,7 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 CMD="python3 bench.py --steps 60 --warmup 10 --settle 32 --frames-in-flight 1 --no-cpu-baseline --no-paths --no-poses"
 echo "== kernel trace, one frame in flight" && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $CMD > $OUT/trace.log 2>&1 || { echo trace failed; tail -5 $OUT/trace.log; exit 1; }
 echo "== kernel trace, default bench configuration" && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace2 -o trace2 -- python3 bench.py --steps 60 --warmup 10 --settle 32 --no-cpu-baseline --no-paths --no-poses > $OUT/trace2.log 2>&1 || echo "trace2 failed"
-echo "== kernel trace, camera orbiting 1 degree per frame, one frame in flight" && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace3 -o trace3 -- $CMD --orbit 1 > $OUT/trace3.log 2>&1 || echo "trace3 failed"
+echo "== kernel trace, camera orbiting 1 degree per frame, frames alone one at a time (the carried order and its upkeep kernels)" && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace3 -o trace3 -- python3 scripts/r03/solitary_orbit.py 1 96 1 > $OUT/trace3.log 2>&1 || echo "trace3 failed"
 echo "== kernel trace, path kernel 64 spp" && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/paths_trace -o paths -- python3 scripts/r03/profile_paths64.py 64 3 > $OUT/paths_trace.log 2>&1 || echo "paths trace failed"
 i=0
 for PMC in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" \

@@ -90,7 +90,7 @@ for kernel, c in counters("paths_pmc").items():
     e["duration_us_64spp"] = sum(d) / len(d) / 1e3 if d else None
     summary["paths"]["path_kernel"] = e
 for row in orbit:
-    if any(n in row["Name"] for n in ("joint_kernel", "trace_kernel", "beam_kernel")):
+    if any(n in row["Name"] for n in ("joint_kernel", "trace_kernel", "beam_kernel", "order_class_kernel", "order_rows_kernel", "order_scatter_kernel")):
         summary.setdefault("orbit1", {})[re.search(r"(\w+_kernel)", row["Name"]).group(1)] = {"calls": int(row["Calls"]), "average_us": float(row["AverageNs"]) / 1e3}
 (dst / f"{tag}_pmc.json").write_text(json.dumps(raw, indent=1))
 (dst / f"{tag}_summary.json").write_text(json.dumps(summary, indent=1))
