@@ -521,6 +521,10 @@ def test_carried_order_of_a_moving_camera_is_pure_scheduling(tracer_cls, scene10
             angle += 1.0
             same(orbit(angle), (form, "rect", k), rect=(512, 256, 2048, 1024))
         assert uses[-1][0] == 2, uses
+        for k in range(4):                                                 # an odd rectangle (251 x 126 wave tiles: cut blocks in the counting sort), the camera rising: vertical shifts
+            lift += 40.0
+            same(orbit(angle, lift=lift), (form, "odd rect", k), rect=(100, 60, 2001, 1003))
+        assert uses[-1][0] == 2 and any(u[2] for u in uses[-3:]), uses
     tr.set_fused(3)
     tr.set_joint_prefix_limit(6000)                                        # most of the frame left to the search waves
     for k in range(4):
