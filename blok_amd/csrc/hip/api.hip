@@ -325,6 +325,7 @@ static int order_before_launch(blok_hip_ctx* ctx, blok::TraceArgs& args, uint32_
         // geometry finishes into a buffer nobody will adopt: its event is simply never asked again)
         BLOK_HIP_TRY(ctx, hipMemsetAsync(O.d_cost, 0, static_cast<size_t>(blocks) * sizeof(uint32_t), stream));
         std::memcpy(O.key, key, sizeof(key));
+        O.orphan = O.orphan || O.pending;                                    // (a sort of the old geometry may still be writing an order buffer)
         O.current = -1; O.pending = false; O.frames_since_sort = 0; O.still_frames = 0; O.interval_now = O.interval; O.have_residual = false;
     }
     if (O.pending && hipEventQuery(O.done) == hipSuccess) {              // the sort launched some frames ago has finished
@@ -398,6 +399,8 @@ static int order_after_launch(blok_hip_ctx* ctx, const blok::TraceArgs& args, ui
     // Nothing still running may read the target buffer: it was last current before the previous adoption, and everything issued before
     // that adoption is in front of the markers recorded then (order_before_launch).
     for (auto& kv : O.guards) if (kv.first != stream && kv.second) BLOK_HIP_TRY(ctx, hipStreamWaitEvent(stream, kv.second, 0));
+    // ... and nothing may still be WRITING it: a sort left behind by a change of launch geometry, possibly on another stream
+    if (O.orphan) { BLOK_HIP_TRY(ctx, hipStreamWaitEvent(stream, O.done, 0)); O.orphan = false; }
     uint32_t radius = 0;
     if (plan.dilate) {
         // a camera in motion: a counting sort of the dilated clocks (three small launches; it reads the live cost buffer — any mixture of old

@@ -125,6 +125,7 @@ struct blok_hip_ctx {
         uint32_t key[6] = {};
         int current = -1, target = 0;                       // -1: no order yet (natural)
         bool pending = false;
+        bool orphan = false;                                // a sort of a previous launch geometry may still be running (the next sort waits for it)
         uint32_t frames_since_sort = 0, still_frames = 0, prefix_limit = 0;
         blok_camera cam[2] = {}, last_cam{};                // camera each order buffer was measured under; camera of the last launch
         hipEvent_t done = nullptr;

@@ -24,13 +24,14 @@ centre = np.array([512.0, 60.0, 512.0])
 frames = 0; worst = 0.0; t_end = time.time() + seconds; phase = 0
 while time.time() < t_end:
     phase += 1
-    kind = rng.choice(["rest", "creep", "orbit", "jump", "flight", "contexts"])
+    kind = rng.choice(["rest", "creep", "orbit", "jump", "flight", "contexts", "rects"])
     a0 = rng.uniform(0, 2 * np.pi); r = rng.uniform(500, 1100); hgt = rng.uniform(150, 600)
     def cam_at(a):
         return W.camera_look_at((centre[0] + r * np.cos(a), hgt, centre[2] + r * np.sin(a)), tuple(centre), 60.0, Wd, Ht)
     cams = {"rest": [cam_at(a0)] * 40, "creep": [cam_at(a0 + np.radians(0.04 * k)) for k in range(40)],
             "jump": [cam_at(a0 + (k // 5) * 0.7) for k in range(30)], "flight": [cam_at(a0)] * 45,
-            "orbit": [cam_at(a0 + np.radians(rng.choice([0.5, 1.0, 2.0]) * k)) for k in range(40)], "contexts": [cam_at(a0)] * 24 + [cam_at(a0 + np.radians(k)) for k in range(24)]}[kind]
+            "orbit": [cam_at(a0 + np.radians(rng.choice([0.5, 1.0, 2.0]) * k)) for k in range(40)], "contexts": [cam_at(a0)] * 24 + [cam_at(a0 + np.radians(k)) for k in range(24)],
+            "rects": [cam_at(a0 + np.radians(0.7 * k)) for k in range(30)]}[kind]
     slow = 0.0
     if kind == "flight":
         ref.draw_frame_device(cams[0], want[0].data_ptr(), want[1].data_ptr())
@@ -42,6 +43,24 @@ while time.time() < t_end:
         for b in bufs:
             assert torch.equal(b[0], want[0]) and torch.equal(b[1], want[1]), (phase, kind)
         frames += len(cams)
+    elif kind == "rects":
+        # the launch geometry changes from frame to frame and from stream to stream (orders are per geometry: sorts of the geometry just
+        # left may still be running), camera moving and resting
+        t0 = time.perf_counter()
+        for k, c in enumerate(cams):
+            c = cams[k if k < 20 else 20]
+            x0, y0 = int(rng.integers(0, 40)) * 32, int(rng.integers(0, 20)) * 32
+            w, h = int(rng.integers(1500, Wd - x0 - 100)), int(rng.integers(900, Ht - y0 - 50))
+            rect = None if k % 3 == 0 else (x0, y0, w, h)
+            for b in (bufs[k % 3], want):
+                b[0].fill_(7); b[1].fill_(7)
+            ref.draw_frame_device(c, want[0].data_ptr(), want[1].data_ptr(), rect=rect)
+            tr.draw_frame_device(c, bufs[k % 3][0].data_ptr(), bufs[k % 3][1].data_ptr(), rect=rect, stream=streams[k % 3].cuda_stream)
+            torch.cuda.synchronize()
+            assert torch.equal(bufs[k % 3][0], want[0]) and torch.equal(bufs[k % 3][1], want[1]), (phase, kind, k, rect)
+            carried += int(tr.last_order_use()[0] == 2)
+            frames += 1
+        slow = (time.perf_counter() - t0) / len(cams) * 1e3
     elif kind == "contexts":
         # both contexts launch at once, each on its own stream, 3 frames each per round: whichever launches second sees the other's frame pending
         t0 = time.perf_counter()
