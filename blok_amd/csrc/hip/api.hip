@@ -909,6 +909,45 @@ int blok_hip_beam_prepass(blok_hip_ctx* ctx, const blok_camera* cam, uint32_t x0
     return BLOK_OK;
 }
 
+// The counting sort behind a moving camera's frames (tile_order.h), on the caller's costs: order, its inverse, the live prefix and the
+// depth sums, to the host.
+int blok_hip_debug_class_order(blok_hip_ctx* ctx, const uint32_t* cost_host, uint32_t tiles_x, uint32_t tiles_y, uint32_t radius, const float* beam_host, uint32_t n_beams,
+                               uint32_t* out_order_host, uint32_t* out_rank_of_host, uint32_t* out_live, float* out_depth_sums3) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    if (!cost_host || !out_order_host || !out_rank_of_host || !out_live || !tiles_x || !tiles_y || static_cast<uint64_t>(tiles_x) * tiles_y > (1u << 24) || radius > 8u)
+        return set_error(ctx, BLOK_ERR_INVALID_ARG, "class order: costs, outputs, a grid of at most 2^24 tiles and a radius of at most 8");
+    BLOK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t n = tiles_x * tiles_y;
+    uint32_t *d_cost = nullptr, *d_order = nullptr, *d_rank = nullptr, *d_live = nullptr;
+    float *d_beam = nullptr, *d_depth = nullptr;
+    void* d_scratch = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_cost), n * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_order), n * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_rank), n * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_live), sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_depth), blok::kOrderDepthPartials * 3 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_beam), (n_beams ? n_beams : 1u) * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&d_scratch, blok::tile_order_class_sort_bytes(tiles_x, tiles_y));
+    if (e == hipSuccess) e = hipMemcpy(d_cost, cost_host, n * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess && n_beams && beam_host) e = hipMemcpy(d_beam, beam_host, n_beams * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(d_order, 0xFF, n * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(d_rank, 0xFF, n * sizeof(uint32_t));
+    if (e == hipSuccess) e = blok::launch_tile_order_class_sort(d_cost, tiles_x, tiles_y, radius, d_scratch, d_order, d_rank, d_live, d_beam, nullptr, 0u, beam_host ? n_beams : 0u, d_depth, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(out_order_host, d_order, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out_rank_of_host, d_rank, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out_live, d_live, sizeof(uint32_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && out_depth_sums3) {
+        float part[blok::kOrderDepthPartials * 3];
+        e = hipMemcpy(part, d_depth, sizeof(part), hipMemcpyDeviceToHost);
+        out_depth_sums3[0] = out_depth_sums3[1] = out_depth_sums3[2] = 0.0f;
+        for (uint32_t k = 0; k < blok::kOrderDepthPartials; ++k) for (int c = 0; c < 3; ++c) out_depth_sums3[c] += part[k * 3 + c];
+    }
+    for (void* p : {static_cast<void*>(d_cost), static_cast<void*>(d_order), static_cast<void*>(d_rank), static_cast<void*>(d_live), static_cast<void*>(d_depth), static_cast<void*>(d_beam), d_scratch})
+        if (p) (void)hipFree(p);
+    BLOK_HIP_TRY(ctx, e);
+    return BLOK_OK;
+}
+
 // Walks exactly the listed 8x8-pixel wave tiles of the rectangle, in list order (walk workgroup j takes entry j).
 int blok_hip_trace_wave_tiles_device(blok_hip_ctx* ctx, const blok_camera* cam, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
                                      const uint32_t* tiles_host, const float* t0_host, size_t n_tiles, void* out_hits_dev, void* out_rgba_dev, void* hip_stream) {

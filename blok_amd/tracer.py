@@ -211,6 +211,17 @@ class HipTracer:
         shift (default on; launches alone on the device only); never changes a result."""
         self._check(self._lib.blok_hip_set_moving_order(self._ctx, 1 if enabled else 0))
 
+    def debug_class_order(self, cost, radius, beam=None):
+        """Test hook: (order, rank_of, live, depth sums) of blok_hip_debug_class_order for a 2-D array of per-wave-tile costs."""
+        cost = np.ascontiguousarray(cost, dtype=np.uint32)
+        ty, tx = cost.shape
+        order = np.zeros(tx * ty, dtype=np.uint32); rank = np.zeros(tx * ty, dtype=np.uint32)
+        live = C.c_uint32(0); sums = np.zeros(3, dtype=np.float32)
+        b = None if beam is None else np.ascontiguousarray(beam, dtype=np.float32)
+        self._check(self._lib.blok_hip_debug_class_order(self._ctx, C.c_void_p(cost.ctypes.data), tx, ty, int(radius), C.c_void_p(b.ctypes.data) if b is not None else None,
+                                                         0 if b is None else len(b), C.c_void_p(order.ctypes.data), C.c_void_p(rank.ctypes.data), C.byref(live), C.c_void_p(sums.ctypes.data)))
+        return order, rank, live.value, sums
+
     def last_order_use(self):
         """Diagnostic: (0 row-major | 1 order of this view | 2 order carried from another view, shift_x, shift_y) of the latest rectangle launch."""
         sx, sy = C.c_int32(0), C.c_int32(0)

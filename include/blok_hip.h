@@ -476,6 +476,13 @@ int blok_hip_set_tile_ordering(blok_hip_ctx* ctx, int resort_every_n_frames);
  * Measured (4K over 1024^3, walk alone, camera orbiting by 1-2 degrees per frame): 209-216 us row-major, 171-178 us carried order, 167-170
  * us in the order of the frame's own clocks (profiles/r03_moving_order_experiment.txt).  0 = off. */
 int blok_hip_set_moving_order(blok_hip_ctx* ctx, int enabled);
+/* Diagnostic / test hook: the counting sort that follows a moving camera's frames, run on the caller's host arrays — cost[tiles_x * tiles_y]
+ * (row-major wave tiles), dilation radius <= 8, optionally n_beams start parameters (>= 1e38 = none) — and read back: out_order (tiles by
+ * descending class of the largest cost within `radius` tiles: 64 classes, four to the octave from 256 up, 0 = nothing near; within a class by
+ * 16x16-tile block of the grid, row-major, then row-major inside the block), its inverse, *out_live = entries of classes > 0, and
+ * out_depth_sums3 = (count, sum, sum of squares) of 1 / max(start parameter, 1) over the beam tiles that have one (may be null). */
+int blok_hip_debug_class_order(blok_hip_ctx* ctx, const uint32_t* cost_host, uint32_t tiles_x, uint32_t tiles_y, uint32_t radius, const float* beam_host, uint32_t n_beams,
+                               uint32_t* out_order_host, uint32_t* out_rank_of_host, uint32_t* out_live, float* out_depth_sums3);
 /* Diagnostic: what the latest rectangle launch walked in — 0 row-major order, 1 an order of its own view, 2 an order carried over from
  * another view by the shift returned through the pointers (wave tiles, modulo the grid; either may be null); -1 = null context. */
 int blok_hip_last_order_use(const blok_hip_ctx* ctx, int32_t* out_shift_x, int32_t* out_shift_y);

@@ -471,6 +471,50 @@ def test_tile_ordering_is_pure_scheduling(tracer_cls, scene1024):
     a.shutdown(); b.shutdown()
 
 
+def test_class_order_kernels_match_their_numpy_reference(tracer_cls):
+    """The three launches that follow a moving camera's frames (tile_order.hip: dilate + classify + count per 16x16-tile block; scan the block
+    counts class by class; scatter) against numpy: the order is the tiles by descending class of the largest cost within `radius` tiles —
+    64 classes, four to the octave from 256 clocks up — within a class by block (row-major) and row-major inside the block; rank_of its
+    inverse; live = the tiles of the classes above 0; the depth sums those of 1 / max(t, 1) over the beam tiles that have a start parameter.
+    Grids that do and do not fill their last blocks, every radius 0..8, costs with big empty regions, all-empty and all-equal costs."""
+    from scipy.ndimage import maximum_filter
+    tr = tracer_cls(256, 256).init()
+    rng = np.random.default_rng(11)
+
+    def reference(cost, radius):
+        ty, tx = cost.shape
+        m = maximum_filter(cost.astype(np.int64), size=2 * radius + 1, mode="constant", cval=0).astype(np.uint32) if radius else cost
+        q = (m.astype(np.float32).view(np.uint32) >> 21).astype(np.int64)
+        cls = np.where(m == 0, 0, np.clip(np.where(q <= 540, 1, q - 539), 1, 63))
+        yy, xx = np.mgrid[0:ty, 0:tx]
+        blocks_x = (tx + 15) // 16
+        block = (yy // 16) * blocks_x + xx // 16
+        inside = (yy % 16) * 16 + xx % 16
+        key = (63 - cls).astype(np.int64) * (1 << 40) + block.astype(np.int64) * 256 + inside
+        order = np.argsort(key.reshape(-1), kind="stable").astype(np.uint32)
+        return order, int((cls > 0).sum())
+
+    for (tx, ty) in ((480, 270), (251, 126), (64, 64), (17, 300), (1, 1)):
+        for radius in (0, 1, 2, 4, 8):
+            cost = np.zeros((ty, tx), dtype=np.uint32)
+            n_spots = max(1, tx * ty // 40)
+            cost.reshape(-1)[rng.integers(0, tx * ty, n_spots)] = np.maximum(256, (2.0 ** rng.uniform(8, 22, n_spots)).astype(np.uint32))
+            if tx > 100:
+                cost[: ty // 3, :] = 0                                  # a third of the screen with nothing in it
+            beam = np.where(rng.random(777) < 0.4, 3.0e38, rng.uniform(0.25, 5000.0, 777)).astype(np.float32)
+            order, rank, live, sums = tr.debug_class_order(cost, radius, beam)
+            want, want_live = reference(cost, radius)
+            assert np.array_equal(order, want), (tx, ty, radius, int((order != want).sum()))
+            assert np.array_equal(rank[order], np.arange(tx * ty, dtype=np.uint32)) and live == want_live, (tx, ty, radius)
+            inv = 1.0 / np.maximum(beam[beam < 1e38].astype(np.float64), 1.0)
+            assert sums[0] == len(inv) and abs(sums[1] - inv.sum()) <= 1e-4 * inv.sum() and abs(sums[2] - (inv * inv).sum()) <= 1e-4 * (inv * inv).sum(), sums
+    for cost in (np.zeros((126, 251), dtype=np.uint32), np.full((126, 251), 5000, dtype=np.uint32)):
+        order, rank, live, _ = tr.debug_class_order(cost, 3)
+        want, want_live = reference(cost, 3)
+        assert np.array_equal(order, want) and live == want_live and np.array_equal(rank[order], np.arange(cost.size, dtype=np.uint32))
+    tr.shutdown()
+
+
 def test_carried_order_of_a_moving_camera_is_pure_scheduling(tracer_cls, scene1024):
     """A camera in motion (blok_hip_set_moving_order): the frame's clocks, dilated, are sorted behind it, and the next launch walks in that
     order carried to its own view by a whole-tile shift of the screen — walk waves only for the order's live prefix, whatever else has
