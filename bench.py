@@ -461,7 +461,9 @@ def main():
                                "frac_moving": (alg["bytes_per_ray"] * rays_per_launch / (kernel_ms_moving * 1e-3) / 1e9 / HBM_PEAK_GBS) if kernel_ms_moving else None,
                                "kernel_ms_moving": kernel_ms_moving,
                                "moving": ("the same launch alone with the camera turning 1 degree per frame around the world's centre, every frame a view never seen before (pose-A bytes per ray); "
-                                          + ("walked in the previous frame's dilated order carried over by a whole-tile shift" if args.moving_order else "row-major order")) if kernel_ms_moving else None,
+                                          + ("walked in the previous frame's dilated order carried over by a whole-tile shift; the three 4-5 us launches that keep that order follow each frame on its stream and are "
+                                             "NOT in kernel_ms_moving (wall-clock period of synchronised frames with them: 257 us against 274 us in row-major order, profiles/r03_moving_order_solitary_frames.txt)"
+                                             if args.moving_order else "row-major order")) if kernel_ms_moving else None,
                                "physical": physical,
                                "kernel": launch, "kernel_ms": kernel_ms_avg,
                                "timing": f"HIP events around single launches, one at a time on an otherwise idle chip; {args.settle} settle + {args.warmup} warmup frames before the timed region, 2 unmeasured launches before the single ones",
