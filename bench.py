@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--fused", type=int, default=3, help="launch form of a frame (blok_hip_set_fused): 0 = beam kernel then trace kernel, 1 = one persistent launch with work queues (measured slower), "
                     "2 = joint launch (searches and one walk wave per wave tile in one grid), 4 = list-fed joint launch (walk waves take the live wave tiles from the list the frame's searches publish), "
                     "5 = beam kernel, then list-fed walk, 3 = automatic: 4 when a launch has the device to itself, else 5")
+    ap.add_argument("--beam-budget", type=int, default=0, help="node visits a beam search may spend (0 = the library's default, 256); running out is answered conservatively")
     ap.add_argument("--moving-order", type=int, default=1, help="camera in motion, launch alone on the device: walk in the previous frame's dilated order carried over by a whole-tile shift (0 = row-major)")
     ap.add_argument("--tile-ordering", type=int, default=8, help="camera at rest: longest-first scheduling of the walk from earlier frames' per-wave clocks, re-sorted every N launches (0 = off)")
     ap.add_argument("--list-classes", type=int, default=1, help="list launches: order the walk by the previous frame's measured cost in four classes (0 = the order the searches finish in)")
@@ -238,6 +239,8 @@ def main():
     tracer.set_list_classes(bool(args.list_classes))
     tracer.set_tile_ordering(args.tile_ordering)
     tracer.set_moving_order(bool(args.moving_order))
+    if args.beam_budget:
+        tracer.set_beam_budget(args.beam_budget)
 
     if args.frames_in_flight <= 0:
         args.frames_in_flight = 3 if world_size <= 2 else 4
