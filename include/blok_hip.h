@@ -459,15 +459,16 @@ int blok_hip_set_beam(blok_hip_ctx* ctx, uint32_t beam_tile_pixels);
  * order, and the walk's workgroups take their tiles in it, so the long grazing-ray waves — each a quarter of the launch long, whatever
  * their priority — start first instead of forming the launch's tail.  The order also tells which tiles need a walk wave at all: launch
  * forms 2 and 3 dispatch walk waves for the tiles that walked when the order was made only, and a tile that has become live since is
- * walked by its search wave.  Used only within ~0.25 degree of the view it was measured in, and a camera in motion is neither measured
- * nor sorted for: ordering by a stale cost is no better than row-major even one frame later (profiles/r03_stale_cost_order_experiment.txt).
+ * walked by its search wave.  An order of a view's own clocks is used only within ~0.25 degree of that view: ordering by a stale cost is
+ * no better than row-major even one frame later (profiles/r03_stale_cost_order_experiment.txt); a camera in motion gets an order of
+ * another kind (blok_hip_set_moving_order below).
  * A view at rest is re-sorted ever less often (the interval doubles up to 64 launches).
  * Pure scheduling: any order gives the same frame (tests/test_gpu_parity.py).  No reference counterpart
  * (renderer_raytracing.cpp:666-685 leaves scheduling to the driver).  0 = off; N > 0 = re-sort every N launches.
  * Measured (4K over 1024^3, one frame at a time): walk alone 216 us row-major, 168 us in this order. */
 int blok_hip_set_tile_ordering(blok_hip_ctx* ctx, int resort_every_n_frames);
 /* The same for a camera in MOTION (round 3; default on): the heavy tiles of the next frame are near the heavy tiles of this one, not on
- * them.  After a frame that had the device to itself, the sort keys every tile by the largest clocks within a few tiles of it (2-8, sized
+ * them.  After a frame that had the device to itself (and whose predecessor had too), a counting sort in three small launches keys every tile by the largest clocks within a few tiles of it (2-8, sized
  * by what the previous shift left over), and the next launch carries that order to its own view by ONE whole-tile shift of the screen
  * — entry (tx, ty) names tile (tx + sx, ty + sy) modulo the grid, still a permutation — computed on the host from the two cameras and
  * the depth range of the frame the order was measured on (blok_amd/csrc/hip/launch_policy.h: plan_shift).  Used while what the shift
