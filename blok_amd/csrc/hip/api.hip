@@ -384,6 +384,10 @@ static int order_before_launch(blok_hip_ctx* ctx, blok::TraceArgs& args, uint32_
     if (args.order) {
         args.rank_of = O.d_rank_of[O.current]; args.launched = O.live[O.current];
         if (plan->shifted) { args.order_sx = O.last_sx = shift.sx; args.order_sy = O.last_sy = shift.sy; }
+        if (O.debug_shift) {                                             // any shift of any order is a permutation: the frame must not change
+            const uint32_t tiles_x = (args.w + blok::kTileW - 1u) / blok::kTileW, tiles_y = (args.h + blok::kTileH - 1u) / blok::kTileH;
+            args.order_sx = O.last_sx = O.debug_sx % tiles_x; args.order_sy = O.last_sy = O.debug_sy % tiles_y;
+        }
     }
     return BLOK_OK;
 }
@@ -1466,6 +1470,12 @@ int blok_hip_set_tile_ordering(blok_hip_ctx* ctx, int resort_every_n_frames) {
     if (resort_every_n_frames < 0) return set_error(ctx, BLOK_ERR_INVALID_ARG, "tile ordering: interval must be >= 0");
     ctx->order.enabled = resort_every_n_frames != 0;
     if (resort_every_n_frames) ctx->order.interval = ctx->order.interval_now = static_cast<uint32_t>(resort_every_n_frames);
+    return BLOK_OK;
+}
+
+int blok_hip_debug_force_order_shift(blok_hip_ctx* ctx, int enabled, uint32_t shift_x, uint32_t shift_y) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    ctx->order.debug_shift = enabled != 0; ctx->order.debug_sx = shift_x; ctx->order.debug_sy = shift_y;
     return BLOK_OK;
 }
 

@@ -222,6 +222,10 @@ class HipTracer:
                                                          0 if b is None else len(b), C.c_void_p(order.ctypes.data), C.c_void_p(rank.ctypes.data), C.byref(live), C.c_void_p(sums.ctypes.data)))
         return order, rank, live.value, sums
 
+    def debug_force_order_shift(self, shift=None):
+        """Test hook: every ordered launch applies this (x, y) whole-tile shift to its order; None = off."""
+        self._check(self._lib.blok_hip_debug_force_order_shift(self._ctx, 0 if shift is None else 1, *(shift or (0, 0))))
+
     def last_order_use(self):
         """Diagnostic: (0 row-major | 1 order of this view | 2 order carried from another view, shift_x, shift_y) of the latest rectangle launch."""
         sx, sy = C.c_int32(0), C.c_int32(0)

@@ -484,6 +484,9 @@ int blok_hip_set_moving_order(blok_hip_ctx* ctx, int enabled);
  * out_depth_sums3 = (count, sum, sum of squares) of 1 / max(start parameter, 1) over the beam tiles that have one (may be null). */
 int blok_hip_debug_class_order(blok_hip_ctx* ctx, const uint32_t* cost_host, uint32_t tiles_x, uint32_t tiles_y, uint32_t radius, const float* beam_host, uint32_t n_beams,
                                uint32_t* out_order_host, uint32_t* out_rank_of_host, uint32_t* out_live, float* out_depth_sums3);
+/* Test hook: every launch that walks in an order (of either kind) applies this whole-tile shift to it (taken modulo the launch's grid)
+ * instead of the one the cameras give — any shift of any order is a permutation of the tiles, so the frames must not change. */
+int blok_hip_debug_force_order_shift(blok_hip_ctx* ctx, int enabled, uint32_t shift_x, uint32_t shift_y);
 /* Diagnostic: what the latest rectangle launch walked in — 0 row-major order, 1 an order of its own view, 2 an order carried over from
  * another view by the shift returned through the pointers (wave tiles, modulo the grid; either may be null); -1 = null context. */
 int blok_hip_last_order_use(const blok_hip_ctx* ctx, int32_t* out_shift_x, int32_t* out_shift_y);

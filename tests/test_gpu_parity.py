@@ -569,6 +569,17 @@ def test_carried_order_of_a_moving_camera_is_pure_scheduling(tracer_cls, scene10
             lift += 40.0
             same(orbit(angle, lift=lift), (form, "odd rect", k), rect=(100, 60, 2001, 1003))
         assert uses[-1][0] == 2 and any(u[2] for u in uses[-3:]), uses
+    # any shift of any order is a permutation: forced shifts that wrap the whole screen, with the full prefix and with a capped one
+    # (tiles without a walk wave are found through the shift taken off again), in the joint and in the two-launch form
+    tr.set_fused(3)
+    for k, forced in enumerate([(479, 269), (240, 135), (1, 0), (0, 1), (123456, 7777), (37, 200)]):
+        tr.debug_force_order_shift(forced)
+        tr.set_joint_prefix_limit(0 if k % 2 == 0 else 9000)
+        tr.set_fused(3 if k % 3 else 0)
+        same(orbit(angle), ("forced shift", forced))
+        same(orbit(angle), ("forced shift, at rest", forced))
+        same(orbit(angle), ("forced shift, own order", forced), rect=(100, 60, 2001, 1003))
+    tr.debug_force_order_shift(None)
     tr.set_fused(3)
     tr.set_joint_prefix_limit(6000)                                        # most of the frame left to the search waves
     for k in range(4):
