@@ -297,29 +297,37 @@ static void free_order(blok_hip_ctx* ctx) {
     O.d_temp = nullptr; O.capacity = 0;
 }
 
-// Before an orderable launch: buffers for the launch geometry, adoption of a finished sort, the plan; fills args.order / rank_of / launched / cost_out.
+// The order's buffers, for at least `blocks` wave tiles and never fewer than the full frame has: allocated by blok_hip_create / _resize, so
+// that no *_device launch ever allocates or waits for the device on their account (the regrow below is what is left for a caller that
+// resizes between launches: a device-wide wait, because frames in flight and a pending sort may use the old buffers).
+int order_buffers(blok_hip_ctx* ctx, uint32_t blocks, hipStream_t stream) {
+    auto& O = ctx->order;
+    const uint32_t want = std::max<uint32_t>(blocks, blok::rect_grid_blocks(ctx->width, ctx->height));
+    if (O.capacity >= want) return BLOK_OK;
+    BLOK_HIP_TRY(ctx, hipDeviceSynchronize());
+    free_order(ctx);
+    const size_t bytes = static_cast<size_t>(want) * sizeof(uint32_t);
+    for (uint32_t** p : {&O.d_cost, &O.d_iota, &O.d_order[0], &O.d_order[1], &O.d_rank_of[0], &O.d_rank_of[1], &O.d_keys_in, &O.d_keys})
+        BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(p), bytes));
+    if (!O.h_live) BLOK_HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&O.h_live), 2 * sizeof(uint32_t), hipHostMallocDefault));
+    if (!O.h_depth) BLOK_HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&O.h_depth), 2 * blok::kOrderDepthPartials * 3 * sizeof(float), hipHostMallocDefault));
+    O.temp_bytes = blok::tile_order_temp_bytes(want);
+    BLOK_HIP_TRY(ctx, hipMalloc(&O.d_temp, O.temp_bytes ? O.temp_bytes : 16));
+    BLOK_HIP_TRY(ctx, hipMalloc(&O.d_class_scratch, blok::tile_order_class_sort_bytes_max(want)));
+    if (!O.done) BLOK_HIP_TRY(ctx, hipEventCreateWithFlags(&O.done, hipEventDisableTiming));
+    BLOK_HIP_TRY(ctx, blok::launch_iota(O.d_iota, want, stream));              // the identity, whatever the geometry: written once
+    BLOK_HIP_TRY(ctx, hipMemsetAsync(O.d_cost, 0, bytes, stream));
+    O.capacity = want;
+    std::memset(O.key, 0xFF, sizeof(O.key));
+    O.current = -1; O.pending = false; O.orphan = false;
+    return BLOK_OK;
+}
+
+// Before an orderable launch: adoption of a finished sort, the plan; fills args.order / rank_of / launched / cost_out.
 static int order_before_launch(blok_hip_ctx* ctx, blok::TraceArgs& args, uint32_t blocks, hipStream_t stream, bool alone, blok::OrderPlan* plan) {
     auto& O = ctx->order;
     const uint32_t key[6] = {args.x0, args.y0, args.w, args.h, ctx->width, ctx->height};
-    if (O.capacity < blocks) {
-        // (Re)grown for the largest rectangle seen — the full frame the first time a frame is drawn; the only device-wide wait of the
-        // ordering, and only because frames in flight and a pending sort may use the old buffers.
-        BLOK_HIP_TRY(ctx, hipDeviceSynchronize());
-        free_order(ctx);
-        const uint32_t want = std::max<uint32_t>(blocks, blok::rect_grid_blocks(ctx->width, ctx->height));
-        const size_t bytes = static_cast<size_t>(want) * sizeof(uint32_t);
-        for (uint32_t** p : {&O.d_cost, &O.d_iota, &O.d_order[0], &O.d_order[1], &O.d_rank_of[0], &O.d_rank_of[1], &O.d_keys_in, &O.d_keys})
-            BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(p), bytes));
-        if (!O.h_live) BLOK_HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&O.h_live), 2 * sizeof(uint32_t), hipHostMallocDefault));
-        if (!O.h_depth) BLOK_HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&O.h_depth), 2 * blok::kOrderDepthPartials * 3 * sizeof(float), hipHostMallocDefault));
-        O.temp_bytes = blok::tile_order_temp_bytes(want);
-        BLOK_HIP_TRY(ctx, hipMalloc(&O.d_temp, O.temp_bytes ? O.temp_bytes : 16));
-        BLOK_HIP_TRY(ctx, hipMalloc(&O.d_class_scratch, blok::tile_order_class_sort_bytes_max(want)));
-        if (!O.done) BLOK_HIP_TRY(ctx, hipEventCreateWithFlags(&O.done, hipEventDisableTiming));
-        BLOK_HIP_TRY(ctx, blok::launch_iota(O.d_iota, want, stream));          // the identity, whatever the geometry: written once
-        O.capacity = want;
-        std::memset(O.key, 0xFF, sizeof(O.key));
-    }
+    if (O.capacity < blocks) { const int rc = order_buffers(ctx, blocks, stream); if (rc != BLOK_OK) return rc; }      // (never after create / resize: a rectangle has no more tiles than the frame)
     if (std::memcmp(key, O.key, sizeof(key)) != 0) {
         // another launch geometry starts in natural order with no costs; in stream order, nothing waits (a sort still pending for the old
         // geometry finishes into a buffer nobody will adopt: its event is simply never asked again)
@@ -642,6 +650,11 @@ int blok_hip_create(blok_hip_ctx** out_ctx, int device_ordinal, uint32_t width, 
         delete ctx;
         return set_error(nullptr, BLOK_ERR_HIP, "hipEventCreate failed");
     }
+    if (order_buffers(ctx, 0u, nullptr) != BLOK_OK || hipDeviceSynchronize() != hipSuccess) {      // the frame's scheduling buffers: here, so that no launch allocates
+        const std::string why = ctx->error;
+        blok_hip_destroy(ctx);
+        return set_error(nullptr, BLOK_ERR_OOM, "scheduling buffers: " + why);
+    }
     *out_ctx = ctx;
     return BLOK_OK;
 }
@@ -650,6 +663,10 @@ int blok_hip_resize(blok_hip_ctx* ctx, uint32_t width, uint32_t height) {
     if (!ctx) return BLOK_ERR_INVALID_ARG;
     if (!width || !height) return set_error(ctx, BLOK_ERR_INVALID_ARG, "zero-sized frame");
     ctx->width = width; ctx->height = height;     // the accumulation buffer is re-created on the next progressive frame
+    BLOK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int rc = order_buffers(ctx, 0u, nullptr);      // grown here (a blocking entry), not by the next launch
+    if (rc != BLOK_OK) return rc;
+    BLOK_HIP_TRY(ctx, hipDeviceSynchronize());
     return BLOK_OK;
 }
 
