@@ -275,17 +275,23 @@ void forget_device_activity(const blok_hip_ctx* ctx) {
 }
 
 // ---- longest-first order of the walk's wave tiles (api_internal.h: TileOrder; decisions in launch_policy.h: plan_order, plan_shift) ------
-// Has the view hardly changed?  Within ~0.25 degree: direction, position as seen from the world's centre, and the same lens.
+// Is it the same view?  An order sorted from a view's own clocks — and above all the set of tiles that walked in it, the only ones a prefix
+// launch dispatches walk waves for — is that view's: a camera creeping by a quarter of a degree per frame (round 2's window) kept such
+// an order in force while the silhouettes moved out from under it, and every tile that had become live was walked by its search wave,
+// one after the other (measured: 0.32-0.37 ms per frame for a slow pan against 0.25 in row-major order).  So "at rest" means at rest: the
+// basis within 1e-5 per component (0.0006 degree), the position within a thousandth of a voxel (and a millionth of its distance to the
+// world), the same lens.  Whatever moves more is a camera in motion and gets the order made for that (launch_policy.h).
 static bool camera_near(const blok_hip_ctx* ctx, const blok_camera& a, const blok_camera& b) {
-    const float dot = a.fwd[0] * b.fwd[0] + a.fwd[1] * b.fwd[1] + a.fwd[2] * b.fwd[2];
     const float half = 0.5f * std::ldexp(1.0f, 2 * static_cast<int>(ctx->stats.levels)) * ctx->world_voxel_size;
-    float d2 = 0.0f, r2 = 0.0f;
+    float d2 = 0.0f, r2 = 0.0f, turn = 0.0f;
     for (int k = 0; k < 3; ++k) {
         const float centre = static_cast<float>(ctx->stats.origin[k]) * ctx->world_voxel_size + half;
         d2 += (a.pos[k] - b.pos[k]) * (a.pos[k] - b.pos[k]);
         r2 += (a.pos[k] - centre) * (a.pos[k] - centre);
+        turn = std::max(turn, std::max(std::fabs(a.fwd[k] - b.fwd[k]), std::max(std::fabs(a.right[k] - b.right[k]), std::fabs(a.up[k] - b.up[k]))));
     }
-    return dot > 0.99999f && d2 <= 1.6e-5f * std::max(r2, 1.0f) && std::fabs(a.tan_half_fov - b.tan_half_fov) < 1e-6f && std::fabs(a.aspect - b.aspect) < 1e-6f;
+    const float still = 1.0e-3f * ctx->world_voxel_size;
+    return turn <= 1.0e-5f && d2 <= std::max(still * still, 1.0e-12f * r2) && std::fabs(a.tan_half_fov - b.tan_half_fov) < 1e-6f && std::fabs(a.aspect - b.aspect) < 1e-6f;
 }
 
 static void free_order(blok_hip_ctx* ctx) {

@@ -42,8 +42,8 @@ struct LaunchPlan {
 // ---- longest-first order of the walk's wave tiles (static forms; api.hip: TileOrder) ---------------------------------------------------
 // A camera at rest: the tiles sorted by the clocks their waves took in this very view.  An order sorted from another view's clocks is
 // worse than none — the heavy tiles are silhouettes and grazing rays, a quarter of a degree moves them (measured: ordering by a stale cost
-// is no better than row-major even one frame later, profiles/r03_stale_cost_order_experiment.txt) — so that order is used only within
-// ~0.25 degree of the view it was measured in.
+// is no better than row-major even one frame later, profiles/r03_stale_cost_order_experiment.txt) — so that order is used for the view it
+// was measured in only (api.hip: camera_near — the same camera up to float noise).
 // A camera in motion (round 3): the heavy tiles of the next frame are NEAR the heavy tiles of this one.  The sort that follows a frame
 // alone on the device keys every tile by the largest clocks within `radius` tiles of it (tile_order.hip), and the next launch carries that
 // order to its own view by ONE whole-tile shift of the screen (plan_shift: entry (tx, ty) names tile (tx + sx, ty + sy) modulo the

@@ -459,9 +459,10 @@ int blok_hip_set_beam(blok_hip_ctx* ctx, uint32_t beam_tile_pixels);
  * order, and the walk's workgroups take their tiles in it, so the long grazing-ray waves — each a quarter of the launch long, whatever
  * their priority — start first instead of forming the launch's tail.  The order also tells which tiles need a walk wave at all: launch
  * forms 2 and 3 dispatch walk waves for the tiles that walked when the order was made only, and a tile that has become live since is
- * walked by its search wave.  An order of a view's own clocks is used only within ~0.25 degree of that view: ordering by a stale cost is
- * no better than row-major even one frame later (profiles/r03_stale_cost_order_experiment.txt); a camera in motion gets an order of
- * another kind (blok_hip_set_moving_order below).
+ * walked by its search wave.  An order of a view's own clocks is used for that view only (the same camera up to float noise: 0.0006 degree,
+ * a thousandth of a voxel): ordering by a stale cost is no better than row-major even one frame later, and the prefix of a view that has crept
+ * away leaves the new silhouettes to the search waves (profiles/r03_stale_cost_order_experiment.txt, r03_moving_order_solitary_frames.txt);
+ * any camera in motion, however slow, gets an order of another kind (blok_hip_set_moving_order below).
  * A view at rest is re-sorted ever less often (the interval doubles up to 64 launches).
  * Pure scheduling: any order gives the same frame (tests/test_gpu_parity.py).  No reference counterpart
  * (renderer_raytracing.cpp:666-685 leaves scheduling to the driver).  0 = off; N > 0 = re-sort every N launches.

@@ -13,6 +13,7 @@ from blok_amd.tracer import HipTracer
 step = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 which = sys.argv[3] if len(sys.argv) > 3 else "both"
+motion = sys.argv[4] if len(sys.argv) > 4 else "orbit"      # orbit: around the world's centre; yaw: turning on the spot; dolly: flying forward by `step` voxels per frame
 n, Wd, Ht, seed = 1024, 3840, 2160, 0xB10C0001
 cm = W.ChunkManager(128, 1.0); cm.generate_scene(n, seed); cm.rebuild_dirty_chunks()
 pw = cm.pack_chunks_to_gpu_svo(W.scene_materials(seed))
@@ -21,6 +22,15 @@ hits = torch.zeros((Wd * Ht, 4), dtype=torch.int32, device="cuda"); rgba = torch
 
 def orbit_cam(deg):
     nf = float(n)
+    if motion != "orbit":
+        pos = np.array([-0.35 * nf, 0.85 * nf, -0.35 * nf]); centre = np.array([0.5 * nf, 0.25 * nf, 0.5 * nf])
+        if motion == "yaw":
+            d = centre - pos; a = np.radians(deg - 3.0)
+            target = pos + np.array([d[0] * np.cos(a) - d[2] * np.sin(a), d[1], d[0] * np.sin(a) + d[2] * np.cos(a)])
+            return W.camera_look_at(tuple(float(v) for v in pos), tuple(float(v) for v in target), 60.0, Wd, Ht)
+        fwd = (centre - pos) / np.linalg.norm(centre - pos)
+        p = pos + fwd * (deg - 3.0)
+        return W.camera_look_at(tuple(float(v) for v in p), tuple(float(v) for v in (p + fwd * 100.0)), 60.0, Wd, Ht)
     centre = np.array([0.5 * nf, 0.25 * nf, 0.5 * nf]); start = np.array([-0.35 * nf, 0.85 * nf, -0.35 * nf]) - centre
     a = np.radians(deg)
     p = centre + np.array([start[0] * np.cos(a) - start[2] * np.sin(a), start[1], start[0] * np.sin(a) + start[2] * np.cos(a)])
@@ -39,7 +49,7 @@ for mo in ([1, 0] if which == "both" else [int(which)]):
             ms.append(tr.last_kernel_ms()); u = tr.last_order_use(); uses.append(u[0]); shifts.append((u[1], u[2]))
     period = (time.perf_counter() - t_begin) / frames * 1e3
     tr.set_timing(False)
-    print(f"orbit {step} deg/frame, moving order {'on ' if mo else 'off'}: launch {np.mean(ms) * 1e3:6.1f} us (median {np.median(ms) * 1e3:6.1f}, max {np.max(ms) * 1e3:6.1f}); "
+    print(f"{motion} {step} per frame, moving order {'on ' if mo else 'off'}: launch {np.mean(ms) * 1e3:6.1f} us (median {np.median(ms) * 1e3:6.1f}, max {np.max(ms) * 1e3:6.1f}); "
           f"wall period {period * 1e3:6.1f} us per frame incl. upkeep and synchronisation; carried order on {sum(1 for u in uses if u == 2)} of {frames} frames, "
           f"shifts {sorted(set(shifts))[:6]}", flush=True)
 tr.shutdown()
