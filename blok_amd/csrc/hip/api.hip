@@ -68,7 +68,7 @@ int install_tree(blok_hip_ctx* ctx, const blok::HostTree& tree, const blok_mater
     ctx->stats.tree_bytes = node_bytes + tree.materials.size() * sizeof(uint32_t);
     ctx->stats.levels = tree.levels;
     for (int a = 0; a < 3; ++a) ctx->stats.origin[a] = tree.origin[a];
-    ctx->has_world = true;
+    ctx->has_world = true; ctx->world_version += 1u;
     ctx->world_voxel_size = ctx->pending_voxel_size;
     return rebuild_sun_map(ctx);
 }
@@ -332,7 +332,7 @@ int order_buffers(blok_hip_ctx* ctx, uint32_t blocks, hipStream_t stream) {
 // Before an orderable launch: adoption of a finished sort, the plan; fills args.order / rank_of / launched / cost_out.
 static int order_before_launch(blok_hip_ctx* ctx, blok::TraceArgs& args, uint32_t blocks, hipStream_t stream, bool alone, blok::OrderPlan* plan) {
     auto& O = ctx->order;
-    const uint32_t key[6] = {args.x0, args.y0, args.w, args.h, ctx->width, ctx->height};
+    const uint32_t key[7] = {args.x0, args.y0, args.w, args.h, ctx->width, ctx->height, ctx->world_version};
     if (O.capacity < blocks) { const int rc = order_buffers(ctx, blocks, stream); if (rc != BLOK_OK) return rc; }      // (never after create / resize: a rectangle has no more tiles than the frame)
     if (std::memcmp(key, O.key, sizeof(key)) != 0) {
         // another launch geometry starts in natural order with no costs; in stream order, nothing waits (a sort still pending for the old
@@ -745,7 +745,7 @@ int blok_hip_upload_world(blok_hip_ctx* ctx, const blok_svo_node* nodes, size_t 
             for (int a = 0; a < 3; ++a) ctx->stats.origin[a] = gpu.origin[a];
             ctx->stats.n_ref_nodes = n_nodes;
             ctx->stats.n_sub_chunks = n_sub_chunks;
-            ctx->has_world = true;
+            ctx->has_world = true; ctx->world_version += 1u;
             ctx->built_on_device = true;
             ctx->world_voxel_size = vs;
             return rebuild_sun_map(ctx);
@@ -853,7 +853,7 @@ int blok_hip_upload_dense(blok_hip_ctx* ctx, const uint32_t* ids, uint32_t nx, u
             ctx->stats.tree_bytes = gpu.n_nodes * sizeof(blok::TreeNode) + gpu.n_voxels * sizeof(uint32_t);
             ctx->stats.levels = gpu.levels;
             for (int a = 0; a < 3; ++a) ctx->stats.origin[a] = gpu.origin[a];
-            ctx->has_world = true;
+            ctx->has_world = true; ctx->world_version += 1u;
             ctx->built_on_device = true;
             const int rc_sun = rebuild_sun_map(ctx);
             if (rc_sun != BLOK_OK || !ctx->dense_dda) return rc_sun;

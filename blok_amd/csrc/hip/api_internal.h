@@ -38,6 +38,7 @@ struct blok_hip_ctx {
     size_t n_materials = 0;
     bool has_world = false;
     bool built_on_device = false;     // structure built by gpu_build.hip (else tree_build.cpp on the host)
+    uint32_t world_version = 0;        // counts uploads and rebuilds: scheduling state measured on another world is dropped (TileOrder::key)
     bool tree_owned_by_volume = false; // d_nodes / d_tree_materials belong to the resident volume's scratch (gpu_build.h): never freed here
     bool force_host_build = false;
     blok_world_stats stats{};
@@ -122,7 +123,7 @@ struct blok_hip_ctx {
         size_t temp_bytes = 0, capacity = 0;
         uint32_t* h_live = nullptr;                         // pinned, two words: how many leading entries of d_order[k] walked (written by the device)
         uint32_t live[2] = {0, 0};                          // ... as read when the order was adopted
-        uint32_t key[6] = {};
+        uint32_t key[7] = {};                               // launch rectangle, frame size, world version
         int current = -1, target = 0;                       // -1: no order yet (natural)
         bool pending = false;
         bool orphan = false;                                // a sort of a previous launch geometry may still be running (the next sort waits for it)

@@ -131,6 +131,10 @@ int blok_hip_volume_rebuild(blok_hip_ctx* ctx, const blok_material* materials, s
     ctx->stats.levels = gpu.levels;
     for (int a = 0; a < 3; ++a) ctx->stats.origin[a] = gpu.origin[a];
     ctx->has_world = true;
+    // (an edited world keeps the view's order: a brush changes few tiles' costs, and the tiles that have become live are walked by their
+    // search waves until the next sort — which comes at the base interval again; measured, a brush of radius 10 before every frame: 207 us
+    // per frame with the order kept, 270 with it dropped)
+    ctx->order.interval_now = ctx->order.interval;
     ctx->built_on_device = true;
     if (same_lattice) { ctx->d_sun_map = keep_sun; ctx->has_sun_map = keep_has_sun; }
     return update_sun_map(ctx, lo, hi, same_lattice);
