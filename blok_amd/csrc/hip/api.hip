@@ -541,7 +541,17 @@ int launch_timed(blok_hip_ctx* ctx, blok::RayMode mode, blok::TraceArgs args, ui
     facts.wave_tiles = blocks * n_frames;
     const uint32_t geometry_key = blocks * 31u + n_beams * n_frames;
     facts.have_hint = list_hint(ctx, stream, geometry_key, facts.hint);
-    const bool busy = facts.has_beam && (ctx->launch_form == blok::kFormAuto || (ctx->order.enabled && ctx->order.moving)) && device_busy_elsewhere(ctx, stream);
+    bool busy = false;
+    // A launch that is being captured into a hipGraph is replayed with these very arguments: it gets the plain two-launch form and none of
+    // the per-frame bookkeeping (event queries and records outside the graph, serial numbers, orders adopted between frames).
+    bool capturing = false;
+    if (stream) {
+        hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &status) == hipSuccess) capturing = status != hipStreamCaptureStatusNone;
+        else (void)hipGetLastError();
+    }
+    if (capturing) facts.form = blok::kFormTwoLaunches;
+    else busy = facts.has_beam && (ctx->launch_form == blok::kFormAuto || (ctx->order.enabled && ctx->order.moving)) && device_busy_elsewhere(ctx, stream);
     facts.device_busy = busy && ctx->launch_form == blok::kFormAuto;
     blok::LaunchPlan plan = blok::plan_launch(facts);
     if (frames && (plan.kind == blok::LaunchKind::Queues || plan.kind == blok::LaunchKind::Joint)) plan.kind = blok::LaunchKind::TwoLaunches;      // several frames per launch: the two-launch or the list forms
@@ -564,7 +574,7 @@ int launch_timed(blok_hip_ctx* ctx, blok::RayMode mode, blok::TraceArgs args, ui
     }
     // static forms over a rectangle: longest-first order of a camera at rest, and walk waves for its live prefix only
     const bool static_form = plan.kind == blok::LaunchKind::TwoLaunches || plan.kind == blok::LaunchKind::Joint;
-    const bool orderable = ctx->order.enabled && static_form && mode == blok::RayMode::Rect && !frames && n_beams && blocks >= blok::kOrderMinTiles && BLOK_XCD_MAP == 0;
+    const bool orderable = !capturing && ctx->order.enabled && static_form && mode == blok::RayMode::Rect && !frames && n_beams && blocks >= blok::kOrderMinTiles && BLOK_XCD_MAP == 0;
     blok::OrderPlan order_plan{};
     if (orderable) { const int rc = order_before_launch(ctx, args, blocks, stream, !busy, &order_plan); if (rc != BLOK_OK) return rc; }
     else ctx->order.last_use = 0;
@@ -575,7 +585,7 @@ int launch_timed(blok_hip_ctx* ctx, blok::RayMode mode, blok::TraceArgs args, ui
         if (ctx->order.prefix_limit && args.launched > ctx->order.prefix_limit) args.launched = ctx->order.prefix_limit;      // tests: more work for the search waves
         walk_blocks = args.launched;
     } else { args.rank_of = nullptr; args.launched = 0u; }
-    if (ctx->timing) BLOK_HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, stream));
+    if (ctx->timing && !capturing) BLOK_HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, stream));
     args.miss_in_walk = static_form && !args.rank_of && ctx->miss_in_walk ? 1u : 0u;
     switch (plan.kind) {
         case blok::LaunchKind::Walk:
@@ -594,9 +604,9 @@ int launch_timed(blok_hip_ctx* ctx, blok::RayMode mode, blok::TraceArgs args, ui
             break;
     }
     BLOK_HIP_TRY(ctx, hipGetLastError());
-    if (ctx->timing) { BLOK_HIP_TRY(ctx, hipEventRecord(ctx->ev_end, stream)); ctx->timed = true; }
+    if (ctx->timing && !capturing) { BLOK_HIP_TRY(ctx, hipEventRecord(ctx->ev_end, stream)); ctx->timed = true; }
     if (orderable) { const int rc = order_after_launch(ctx, args, blocks, n_beams, stream, order_plan); if (rc != BLOK_OK) return rc; }
-    if (facts.has_beam) return note_frame_launch(ctx, stream);          // (behind the sort, if one was started: it belongs to this launch)
+    if (facts.has_beam && !capturing) return note_frame_launch(ctx, stream);          // (behind the sort, if one was started: it belongs to this launch)
     return BLOK_OK;
 }
 

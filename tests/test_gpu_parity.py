@@ -471,6 +471,38 @@ def test_tile_ordering_is_pure_scheduling(tracer_cls, scene1024):
     a.shutdown(); b.shutdown()
 
 
+def test_a_frame_launch_can_be_captured_into_a_graph_and_replayed(tracer_cls):
+    """the *_device forms neither allocate nor synchronise, so a caller may capture them into a hipGraph.  A launch that is
+    being captured takes the plain two-launch form with none of the per-frame bookkeeping (event queries and records, serial numbers, an
+    order adopted between frames would all be frozen into the graph or illegal during capture); replays give the frame of a direct launch."""
+    import torch
+    n, Wd, Ht = 256, 1920, 1080
+    cm = W.ChunkManager(128, 1.0); cm.generate_scene(n, SEED); cm.rebuild_dirty_chunks()
+    pw = cm.pack_chunks_to_gpu_svo(W.scene_materials(SEED))
+    tr = tracer_cls(Wd, Ht).init(); tr.add_world(pw)
+    cam = W.scene_camera(n, 0, Wd, Ht, SEED)
+    hits = torch.zeros((Wd * Ht, 4), dtype=torch.int32, device="cuda"); rgba = torch.zeros(Wd * Ht, dtype=torch.int32, device="cuda")
+    want_h = torch.zeros_like(hits); want_c = torch.zeros_like(rgba)
+    tr.draw_frame_device(cam, want_h.data_ptr(), want_c.data_ptr()); torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    for _ in range(3):                                   # the stream's buffers exist before the capture (a capture cannot allocate)
+        tr.draw_frame_device(cam, hits.data_ptr(), rgba.data_ptr(), stream=s.cuda_stream)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        tr.draw_frame_device(cam, hits.data_ptr(), rgba.data_ptr(), stream=s.cuda_stream)
+    assert tr.last_launch_kind() == 1                    # two launches
+    for _ in range(4):
+        hits.fill_(9); rgba.fill_(9)
+        g.replay(); torch.cuda.synchronize()
+        assert torch.equal(hits, want_h) and torch.equal(rgba, want_c)
+    # and the context goes on as before afterwards
+    tr.draw_frame_device(cam, hits.data_ptr(), rgba.data_ptr(), stream=s.cuda_stream); torch.cuda.synchronize()
+    assert torch.equal(hits, want_h) and tr.last_launch_kind() in (1, 3)
+    del g
+    tr.shutdown()
+
+
 def test_class_order_kernels_match_their_numpy_reference(tracer_cls):
     """The three launches that follow a moving camera's frames (tile_order.hip: dilate + classify + count per 16x16-tile block; scan the block
     counts class by class; scatter) against numpy: the order is the tiles by descending class of the largest cost within `radius` tiles —
