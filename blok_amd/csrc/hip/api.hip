@@ -584,6 +584,21 @@ int launch_timed(blok_hip_ctx* ctx, blok::RayMode mode, blok::TraceArgs args, ui
         // the miss pixels of the empty ones
         if (ctx->order.prefix_limit && args.launched > ctx->order.prefix_limit) args.launched = ctx->order.prefix_limit;      // tests: more work for the search waves
         walk_blocks = args.launched;
+        // an order carried over by a shift says nothing about the strips of the screen the shift brings in: every tile there gets a walk
+        // workgroup of its own, in front of the prefix (trace_kernels.h: TraceArgs::n_strip)
+        if (args.order_sx || args.order_sy) {
+            const uint32_t tiles_x = (args.w + blok::kTileW - 1u) / blok::kTileW, tiles_y = (args.h + blok::kTileH - 1u) / blok::kTileH;
+            const bool left = args.order_sx * 2u <= tiles_x, top = args.order_sy * 2u <= tiles_y;      // the shift as a signed number: towards +x / +y brings in the low columns / rows
+            // (each strip wider by what the shift leaves over near the edge it comes in through: a rotation stretches the screen there)
+            const float res = ctx->order.have_residual && ctx->order.last_residual >= 0.0f ? std::min(ctx->order.last_residual, 8.0f) : 0.0f;
+            const uint32_t extra = static_cast<uint32_t>(std::ceil(res));
+            args.strip_nx = left ? args.order_sx : tiles_x - args.order_sx; if (args.strip_nx) args.strip_nx = std::min(args.strip_nx + extra, tiles_x);
+            args.strip_ny = top ? args.order_sy : tiles_y - args.order_sy; if (args.strip_ny) args.strip_ny = std::min(args.strip_ny + extra, tiles_y);
+            args.strip_x0 = left ? 0u : tiles_x - args.strip_nx;
+            args.strip_y0 = top ? 0u : tiles_y - args.strip_ny;
+            args.n_strip = args.strip_nx * tiles_y + (tiles_x - args.strip_nx) * args.strip_ny;
+            walk_blocks += args.n_strip;
+        }
     } else { args.rank_of = nullptr; args.launched = 0u; }
     if (ctx->timing && !capturing) BLOK_HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, stream));
     args.miss_in_walk = static_form && !args.rank_of && ctx->miss_in_walk ? 1u : 0u;

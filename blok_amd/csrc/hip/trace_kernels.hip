@@ -218,13 +218,23 @@ __device__ __forceinline__ void trace_block(const TraceArgs& A, const uint32_t b
             uint32_t bx, by;
             // longest first: workgroup i walks tile order[i] (the tiles by descending cost of their wave in earlier frames of the same view,
             // api.hip); any permutation gives the same frame.  A list entry names the tile itself.
-            const uint32_t b = (!kListed && A.order) ? A.order[block] : block;
-            if constexpr (kListed) { bx = b % bx_count; by = b / bx_count; if (by >= by_count) return; }
+            if constexpr (kListed) { bx = block % bx_count; by = block / bx_count; if (by >= by_count) return; }
             else {
-                if (!block_to_tile(b, grid, bx_count, by_count, bx, by)) return;
-                if (A.order) {                                           // the order's tile, carried to this view (wave-uniform; 0, 0 for an order of this view)
-                    bx += A.order_sx; if (bx >= bx_count) bx -= bx_count;
-                    by += A.order_sy; if (by >= by_count) by -= by_count;
+                if (A.n_strip && block < A.n_strip) {
+                    // a tile of the strips the shift brought in: columns first (strip_nx wide, every row), then what is left of the rows
+                    const uint32_t in_columns = A.strip_nx * by_count;
+                    if (block < in_columns) { bx = A.strip_x0 + block % A.strip_nx; by = block / A.strip_nx; }
+                    else { const uint32_t k = block - in_columns, w = bx_count - A.strip_nx; bx = k % w; if (bx >= A.strip_x0) bx += A.strip_nx; by = A.strip_y0 + k / w; }
+                    if (bx >= bx_count || by >= by_count) return;
+                } else {
+                    const uint32_t entry = block - A.n_strip;
+                    const uint32_t tile = A.order ? A.order[entry] : entry;
+                    if (!block_to_tile(tile, grid, bx_count, by_count, bx, by)) return;
+                    if (A.order) {                                       // the order's tile, carried to this view (wave-uniform; 0, 0 for an order of this view)
+                        bx += A.order_sx; if (bx >= bx_count) bx -= bx_count;
+                        by += A.order_sy; if (by >= by_count) by -= by_count;
+                        if (A.n_strip && (bx - A.strip_x0 < A.strip_nx || by - A.strip_y0 < A.strip_ny)) return;      // landed in a strip: that tile has its own workgroup
+                    }
                 }
                 cost_slot = A.cost_out ? A.cost_out + (by * bx_count + bx) : nullptr;
             }
@@ -371,6 +381,7 @@ __device__ __forceinline__ void beam_block(const TraceArgs& A, const uint32_t b,
                 for (uint32_t bx = bx0; bx < bx1; ++bx) {
                     const uint32_t tile = by * bx_count + bx;
                     // where the order knows this tile: the shift taken off again
+                    if (A.n_strip && (bx - A.strip_x0 < A.strip_nx || by - A.strip_y0 < A.strip_ny)) continue;      // a strip tile: it has a walk workgroup of its own
                     const uint32_t ox = bx >= A.order_sx ? bx - A.order_sx : bx + bx_count - A.order_sx, oy = by >= A.order_sy ? by - A.order_sy : by + by_count - A.order_sy;
                     if (__builtin_amdgcn_readfirstlane(A.rank_of[oy * bx_count + ox]) < A.launched) continue;
                     const uint64_t clock0 = __builtin_amdgcn_s_memtime();

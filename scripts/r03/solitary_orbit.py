@@ -13,6 +13,7 @@ from blok_amd.tracer import HipTracer
 step = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 which = sys.argv[3] if len(sys.argv) > 3 else "both"
+begin = float(sys.argv[5]) if len(sys.argv) > 5 else 0.0        # yaw / dolly: where the motion begins (degrees / voxels)
 motion = sys.argv[4] if len(sys.argv) > 4 else "orbit"      # orbit: around the world's centre; yaw: turning on the spot; dolly: flying forward by `step` voxels per frame
 n, Wd, Ht, seed = 1024, 3840, 2160, 0xB10C0001
 cm = W.ChunkManager(128, 1.0); cm.generate_scene(n, seed); cm.rebuild_dirty_chunks()
@@ -25,11 +26,11 @@ def orbit_cam(deg):
     if motion != "orbit":
         pos = np.array([-0.35 * nf, 0.85 * nf, -0.35 * nf]); centre = np.array([0.5 * nf, 0.25 * nf, 0.5 * nf])
         if motion == "yaw":
-            d = centre - pos; a = np.radians(deg - 3.0)
+            d = centre - pos; a = np.radians(deg - 3.0 + begin)
             target = pos + np.array([d[0] * np.cos(a) - d[2] * np.sin(a), d[1], d[0] * np.sin(a) + d[2] * np.cos(a)])
             return W.camera_look_at(tuple(float(v) for v in pos), tuple(float(v) for v in target), 60.0, Wd, Ht)
         fwd = (centre - pos) / np.linalg.norm(centre - pos)
-        p = pos + fwd * (deg - 3.0)
+        p = pos + fwd * (deg - 3.0 + begin)
         return W.camera_look_at(tuple(float(v) for v in p), tuple(float(v) for v in (p + fwd * 100.0)), 60.0, Wd, Ht)
     centre = np.array([0.5 * nf, 0.25 * nf, 0.5 * nf]); start = np.array([-0.35 * nf, 0.85 * nf, -0.35 * nf]) - centre
     a = np.radians(deg)
