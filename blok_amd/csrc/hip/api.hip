@@ -317,6 +317,7 @@ int order_buffers(blok_hip_ctx* ctx, uint32_t blocks, hipStream_t stream) {
         BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(p), bytes));
     if (!O.h_live) BLOK_HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&O.h_live), 2 * sizeof(uint32_t), hipHostMallocDefault));
     if (!O.h_depth) BLOK_HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&O.h_depth), 2 * blok::kOrderDepthPartials * 3 * sizeof(float), hipHostMallocDefault));
+    if (!O.h_fallback) { BLOK_HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&O.h_fallback), sizeof(uint32_t), hipHostMallocDefault)); *O.h_fallback = 0u; }
     O.temp_bytes = blok::tile_order_temp_bytes(want);
     BLOK_HIP_TRY(ctx, hipMalloc(&O.d_temp, O.temp_bytes ? O.temp_bytes : 16));
     BLOK_HIP_TRY(ctx, hipMalloc(&O.d_class_scratch, blok::tile_order_class_sort_bytes_max(want)));
@@ -584,6 +585,10 @@ int launch_timed(blok_hip_ctx* ctx, blok::RayMode mode, blok::TraceArgs args, ui
         // the miss pixels of the empty ones
         if (ctx->order.prefix_limit && args.launched > ctx->order.prefix_limit) args.launched = ctx->order.prefix_limit;      // tests: more work for the search waves
         walk_blocks = args.launched;
+        // what the previous prefix launch left to its search waves (read now: that launch is over, or nearly), counted afresh for this one
+        ctx->order.last_fallback = *static_cast<volatile uint32_t*>(ctx->order.h_fallback);
+        *static_cast<volatile uint32_t*>(ctx->order.h_fallback) = 0u;
+        args.fallback_tiles = ctx->order.h_fallback;
         // an order carried over by a shift says nothing about the strips of the screen the shift brings in: every tile there gets a walk
         // workgroup of its own, in front of the prefix (trace_kernels.h: TraceArgs::n_strip)
         if (args.order_sx || args.order_sy) {
@@ -719,6 +724,7 @@ void blok_hip_destroy(blok_hip_ctx* ctx) {
     free_order(ctx);
     if (ctx->order.h_live) (void)hipHostFree(ctx->order.h_live);
     if (ctx->order.h_depth) (void)hipHostFree(ctx->order.h_depth);
+    if (ctx->order.h_fallback) (void)hipHostFree(ctx->order.h_fallback);
     if (ctx->order.done) (void)hipEventDestroy(ctx->order.done);
     for (auto& kv : ctx->order.guards) if (kv.second) (void)hipEventDestroy(kv.second);
     if (ctx->d_accum) (void)hipFree(ctx->d_accum);
@@ -1525,6 +1531,11 @@ int blok_hip_debug_force_order_shift(blok_hip_ctx* ctx, int enabled, uint32_t sh
     if (!ctx) return BLOK_ERR_INVALID_ARG;
     ctx->order.debug_shift = enabled != 0; ctx->order.debug_sx = shift_x; ctx->order.debug_sy = shift_y;
     return BLOK_OK;
+}
+
+int64_t blok_hip_last_fallback_tiles(const blok_hip_ctx* ctx) {
+    if (!ctx || !ctx->order.h_fallback) return -1;
+    return static_cast<int64_t>(*static_cast<volatile uint32_t*>(ctx->order.h_fallback));
 }
 
 int blok_hip_set_moving_order(blok_hip_ctx* ctx, int enabled) {

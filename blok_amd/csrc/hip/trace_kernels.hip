@@ -377,6 +377,7 @@ __device__ __forceinline__ void beam_block(const TraceArgs& A, const uint32_t b,
             const uint32_t bx_count = (A.w + kTileW - 1u) / kTileW, by_count = (A.h + kTileH - 1u) / kTileH;
             const uint32_t bx0 = (px - A.x0) / kTileW, bx1 = (px_end - A.x0 + kTileW - 1u) / kTileW;
             const uint32_t by0 = (py - A.y0) / kTileH, by1 = (py_end - A.y0 + kTileH - 1u) / kTileH;
+            uint32_t walked = 0u;
             for (uint32_t by = by0; by < by1; ++by)
                 for (uint32_t bx = bx0; bx < bx1; ++bx) {
                     const uint32_t tile = by * bx_count + bx;
@@ -394,7 +395,9 @@ __device__ __forceinline__ void beam_block(const TraceArgs& A, const uint32_t b,
                     }
                     // it walked: the next sort puts it into the prefix (any key >= 256 clocks counts as live)
                     if (A.cost_out && lane == 0) A.cost_out[tile] = max(static_cast<uint32_t>(__builtin_amdgcn_s_memtime() - clock0), 256u);
+                    ++walked;
                 }
+            if (walked && A.fallback_tiles && lane == 0) (void)__hip_atomic_fetch_add(A.fallback_tiles, walked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }

@@ -226,6 +226,10 @@ class HipTracer:
         """Test hook: every ordered launch applies this (x, y) whole-tile shift to its order; None = off."""
         self._check(self._lib.blok_hip_debug_force_order_shift(self._ctx, 0 if shift is None else 1, *(shift or (0, 0))))
 
+    def last_fallback_tiles(self) -> int:
+        """Diagnostic: wave tiles the search waves of the latest prefix launch walked themselves (after a synchronise)."""
+        return int(self._lib.blok_hip_last_fallback_tiles(self._ctx))
+
     def last_order_use(self):
         """Diagnostic: (0 row-major | 1 order of this view | 2 order carried from another view, shift_x, shift_y) of the latest rectangle launch."""
         sx, sy = C.c_int32(0), C.c_int32(0)
