@@ -318,6 +318,7 @@ int order_buffers(blok_hip_ctx* ctx, uint32_t blocks, hipStream_t stream) {
     if (!O.h_live) BLOK_HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&O.h_live), 2 * sizeof(uint32_t), hipHostMallocDefault));
     if (!O.h_depth) BLOK_HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&O.h_depth), 2 * blok::kOrderDepthPartials * 3 * sizeof(float), hipHostMallocDefault));
     if (!O.h_fallback) { BLOK_HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&O.h_fallback), sizeof(uint32_t), hipHostMallocDefault)); *O.h_fallback = 0u; }
+    if (!O.d_fallback) BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&O.d_fallback), sizeof(uint32_t)));
     O.temp_bytes = blok::tile_order_temp_bytes(want);
     BLOK_HIP_TRY(ctx, hipMalloc(&O.d_temp, O.temp_bytes ? O.temp_bytes : 16));
     BLOK_HIP_TRY(ctx, hipMalloc(&O.d_class_scratch, blok::tile_order_class_sort_bytes_max(want)));
@@ -587,8 +588,8 @@ int launch_timed(blok_hip_ctx* ctx, blok::RayMode mode, blok::TraceArgs args, ui
         walk_blocks = args.launched;
         // what the previous prefix launch left to its search waves (read now: that launch is over, or nearly), counted afresh for this one
         ctx->order.last_fallback = *static_cast<volatile uint32_t*>(ctx->order.h_fallback);
-        *static_cast<volatile uint32_t*>(ctx->order.h_fallback) = 0u;
-        args.fallback_tiles = ctx->order.h_fallback;
+        BLOK_HIP_TRY(ctx, hipMemsetAsync(ctx->order.d_fallback, 0, sizeof(uint32_t), stream));
+        args.fallback_tiles = ctx->order.d_fallback;
         // an order carried over by a shift says nothing about the strips of the screen the shift brings in: every tile there gets a walk
         // workgroup of its own, in front of the prefix (trace_kernels.h: TraceArgs::n_strip)
         if (args.order_sx || args.order_sy) {
@@ -625,6 +626,7 @@ int launch_timed(blok_hip_ctx* ctx, blok::RayMode mode, blok::TraceArgs args, ui
     }
     BLOK_HIP_TRY(ctx, hipGetLastError());
     if (ctx->timing && !capturing) { BLOK_HIP_TRY(ctx, hipEventRecord(ctx->ev_end, stream)); ctx->timed = true; }
+    if (args.fallback_tiles) BLOK_HIP_TRY(ctx, hipMemcpyAsync(ctx->order.h_fallback, ctx->order.d_fallback, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     if (orderable) { const int rc = order_after_launch(ctx, args, blocks, n_beams, stream, order_plan); if (rc != BLOK_OK) return rc; }
     if (facts.has_beam && !capturing) return note_frame_launch(ctx, stream);          // (behind the sort, if one was started: it belongs to this launch)
     return BLOK_OK;
@@ -725,6 +727,7 @@ void blok_hip_destroy(blok_hip_ctx* ctx) {
     if (ctx->order.h_live) (void)hipHostFree(ctx->order.h_live);
     if (ctx->order.h_depth) (void)hipHostFree(ctx->order.h_depth);
     if (ctx->order.h_fallback) (void)hipHostFree(ctx->order.h_fallback);
+    if (ctx->order.d_fallback) (void)hipFree(ctx->order.d_fallback);
     if (ctx->order.done) (void)hipEventDestroy(ctx->order.done);
     for (auto& kv : ctx->order.guards) if (kv.second) (void)hipEventDestroy(kv.second);
     if (ctx->d_accum) (void)hipFree(ctx->d_accum);

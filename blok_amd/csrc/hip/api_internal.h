@@ -139,7 +139,8 @@ struct blok_hip_ctx {
         float inv_depth[2][2] = {};                         // ... mean and sigma as read when the order was adopted
         bool have_residual = false; float last_residual = 0.0f;     // what the latest shift left over (sizes the next dilation)
         bool debug_shift = false; uint32_t debug_sx = 0, debug_sy = 0;      // blok_hip_debug_force_order_shift: every ordered launch uses this shift (tests)
-        uint32_t* h_fallback = nullptr;                     // pinned: wave tiles the search waves of the latest prefix launch walked themselves (device adds, host resets)
+        uint32_t* d_fallback = nullptr;                     // wave tiles the search waves of the latest prefix launch walked themselves (cleared in stream order before it)
+        uint32_t* h_fallback = nullptr;                     // pinned: ... copied here behind the launch
         uint32_t last_fallback = 0;                         // ... as read before the next launch (blok_hip_last_fallback_tiles)
         bool alone_before = false;                          // the previous orderable launch had the device to itself
         int last_use = 0; uint32_t last_sx = 0, last_sy = 0;        // the latest launch: 0 natural order, 1 an order of its own view, 2 a carried one (blok_hip_last_order_use)

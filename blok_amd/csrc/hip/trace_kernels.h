@@ -159,7 +159,7 @@ struct TraceArgs {
     // order's entries that land there stand down; left to the search waves (one tile after the other) a pan that brings the world into the
     // frame took 0.5-0.9 ms per frame instead of 0.27 in row-major order.
     uint32_t strip_x0, strip_nx, strip_y0, strip_ny, n_strip;
-    uint32_t* fallback_tiles;              // prefix launches: how many wave tiles the search waves walked themselves is added here (null = not counted); may be pinned host memory
+    uint32_t* fallback_tiles;              // prefix launches: how many wave tiles the search waves walked themselves is added here (null = not counted); device memory
     uint32_t* joint_gave_up;               // waves that gave up a bounded wait: joint form, for their tile's search (they start at the ray origin instead); list forms, for an entry (walked by the clean-up).  0 in a working system
     uint32_t miss_in_walk;                 // two-launch form: 1 = the walk's waves write the miss pixels of tiles the pre-pass found empty (they are launched anyway), 0 = the pre-pass does
     uint32_t beam_budget;                  // node visits a search may spend (0 = kBeamMaxVisits); running out is answered conservatively

@@ -397,7 +397,7 @@ __device__ __forceinline__ void beam_block(const TraceArgs& A, const uint32_t b,
                     if (A.cost_out && lane == 0) A.cost_out[tile] = max(static_cast<uint32_t>(__builtin_amdgcn_s_memtime() - clock0), 256u);
                     ++walked;
                 }
-            if (walked && A.fallback_tiles && lane == 0) (void)__hip_atomic_fetch_add(A.fallback_tiles, walked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (walked && A.fallback_tiles && lane == 0) (void)__hip_atomic_fetch_add(A.fallback_tiles, walked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
