@@ -587,9 +587,13 @@ int launch_timed(blok_hip_ctx* ctx, blok::RayMode mode, blok::TraceArgs args, ui
         if (ctx->order.prefix_limit && args.launched > ctx->order.prefix_limit) args.launched = ctx->order.prefix_limit;      // tests: more work for the search waves
         walk_blocks = args.launched;
         // what the previous prefix launch left to its search waves (read now: that launch is over, or nearly), counted afresh for this one
-        ctx->order.last_fallback = *static_cast<volatile uint32_t*>(ctx->order.h_fallback);
-        BLOK_HIP_TRY(ctx, hipMemsetAsync(ctx->order.d_fallback, 0, sizeof(uint32_t), stream));
-        args.fallback_tiles = ctx->order.d_fallback;
+        // (a diagnostic, counted only for timed launches — blok_hip_set_timing: a clear in front of the frame and a copy behind it are two more
+        // operations on the stream of every frame)
+        if (ctx->timing) {
+            ctx->order.last_fallback = *static_cast<volatile uint32_t*>(ctx->order.h_fallback);
+            BLOK_HIP_TRY(ctx, hipMemsetAsync(ctx->order.d_fallback, 0, sizeof(uint32_t), stream));
+            args.fallback_tiles = ctx->order.d_fallback;
+        }
         // an order carried over by a shift says nothing about the strips of the screen the shift brings in: every tile there gets a walk
         // workgroup of its own, in front of the prefix (trace_kernels.h: TraceArgs::n_strip)
         if (args.order_sx || args.order_sy) {

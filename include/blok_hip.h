@@ -485,8 +485,8 @@ int blok_hip_set_moving_order(blok_hip_ctx* ctx, int enabled);
  * out_depth_sums3 = (count, sum, sum of squares) of 1 / max(start parameter, 1) over the beam tiles that have one (may be null). */
 int blok_hip_debug_class_order(blok_hip_ctx* ctx, const uint32_t* cost_host, uint32_t tiles_x, uint32_t tiles_y, uint32_t radius, const float* beam_host, uint32_t n_beams,
                                uint32_t* out_order_host, uint32_t* out_rank_of_host, uint32_t* out_live, float* out_depth_sums3);
-/* Diagnostic: wave tiles the search waves of the latest prefix launch have walked themselves so far (tiles live now that had no walk
- * workgroup: a changed view); read it after synchronising.  -1 = null context or nothing allocated yet. */
+/* Diagnostic: wave tiles the search waves of the latest TIMED prefix launch (blok_hip_set_timing) walked themselves (tiles live now that had
+ * no walk workgroup: a changed view); read it after synchronising.  -1 = null context or nothing allocated yet. */
 int64_t blok_hip_last_fallback_tiles(const blok_hip_ctx* ctx);
 /* Test hook: every launch that walks in an order (of either kind) applies this whole-tile shift to it (taken modulo the launch's grid)
  * instead of the one the cameras give — any shift of any order is a permutation of the tiles, so the frames must not change. */
