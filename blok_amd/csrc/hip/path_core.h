@@ -232,6 +232,9 @@ BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t in
     };
     if (P.spp != 0u && P.max_bounces != 0u) begin_sample();
 
+#ifdef BLOK_PATH_CLOCKS
+    uint32_t kind_clocks[3] = {0u, 0u, 0u}, kind_rounds[3] = {0u, 0u, 0u}, kind_lanes[3] = {0u, 0u, 0u};
+#endif
     while (s < P.spp && P.max_bounces != 0u) {
 #if !defined(BLOK_TRACE_HOST_HARNESS) && !defined(BLOK_PATH_NO_PHASES)
         {
@@ -291,7 +294,20 @@ BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t in
             if (t0 >= kBeamNone) r.tmax = 0.0f;                   // the tile's frustum meets no voxel: empty interval, immediate miss
         }
         BLOK_PATH_KIND(shadow_phase ? 1u : (bounce == 0u ? 0u : 2u));
+#ifdef BLOK_PATH_CLOCKS
+        const uint64_t kind_clock0 = __builtin_amdgcn_s_memtime();
+        const uint32_t round_kind = shadow_phase ? 1u : (bounce == 0u ? 0u : 2u);
+        const uint32_t round_lanes = static_cast<uint32_t>(__builtin_popcountll(__ballot(true)));
+#endif
         const HitInfo hit = walk(A, r, stk);
+#ifdef BLOK_PATH_CLOCKS
+        {   // diagnostic build (scripts/r03/paths_kind_clocks.py): the round's clocks are booked by its first active lane, under the kind of that lane
+            const uint32_t dt = static_cast<uint32_t>((__builtin_amdgcn_s_memtime() - kind_clock0) >> 4);
+            if ((threadIdx.x & 63u) == static_cast<uint32_t>(__builtin_ctzll(__ballot(true)))) {
+                kind_clocks[round_kind] += dt; kind_rounds[round_kind] += 1u; kind_lanes[round_kind] += round_lanes;
+            }
+        }
+#endif
 
         bool end_sample = false, continue_path = false;
         if (shadow_phase) {
@@ -395,6 +411,19 @@ BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t in
         }
     }
 
+#ifdef BLOK_PATH_CLOCKS
+    if (A.debug_clocks) {                                   // [kind] clocks / 16, rounds, active lanes: summed over the wave, added once
+        for (int k = 0; k < 3; ++k) {
+            uint32_t c = kind_clocks[k], n = kind_rounds[k], l = kind_lanes[k];
+            for (int off = 32; off > 0; off >>= 1) { c += __shfl_down(c, off); n += __shfl_down(n, off); l += __shfl_down(l, off); }
+            if ((threadIdx.x & 63u) == 0u) {
+                (void)__hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(A.debug_clocks) + k * 3 + 0, static_cast<unsigned long long>(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                (void)__hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(A.debug_clocks) + k * 3 + 1, static_cast<unsigned long long>(n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                (void)__hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(A.debug_clocks) + k * 3 + 2, static_cast<unsigned long long>(l), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+#endif
     V3 color = vdivs(accumulated, static_cast<float>(P.spp));                                 // :383
     const float max_val = max3f(color);                                                       // :386-389
     if (max_val > 100.0f) color = vscale(color, 100.0f / max_val);
