@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--cpu-stride", type=int, default=1, help="CPU baseline traces every stride-th pixel in x and y")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="pipeline depth; 0 = 3 for N <= 2, else 4 (reference: MAX_FRAMES_IN_FLIGHT = 2; at N = 1 three measure +3-4 %% over two). "
-                         "Measured on one GPU with a rank's tile share (scripts/tile_depth_test.py): a frame-share is a "
+                         "Measured on one GPU with a rank's tile share (scripts/tile_depth_probe.py): a frame-share is a "
                          "beam + trace launch pair whose latency (~130 us alone) far exceeds its work (26-105 us), so "
                          "3-4 frames must be in flight to hide it")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for "

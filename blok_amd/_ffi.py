@@ -140,6 +140,7 @@ HIP_SYMBOLS = {
     "blok_hip_resize": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     "blok_hip_destroy": (None, [C.c_void_p]),
     "blok_hip_last_error": (C.c_char_p, [C.c_void_p]),
+    "blok_hip_release_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "blok_hip_upload_world": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                         C.c_void_p, C.c_size_t]),
     "blok_hip_upload_dense": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
@@ -226,6 +227,7 @@ HIP_SYMBOLS = {
     "blok_hip_frame_queue_stalls": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "blok_hip_set_sun_map": (C.c_int, [C.c_void_p, C.c_int]),
     "blok_hip_set_ray_batching": (C.c_int, [C.c_void_p, C.c_int]),
+    "blok_hip_set_path_start": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "blok_denoise_settings_default": (None, [C.c_void_p]),
     "blok_hip_denoise_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.c_void_p,
                                           C.c_void_p, C.c_void_p]),

@@ -13,7 +13,7 @@ INCLUDE = ROOT / "include"
 HOST_SRC = [PKG / "csrc/host/world.cpp", PKG / "csrc/host/scene.cpp", PKG / "csrc/host/vox.cpp"]
 HIP_SRC = [PKG / "csrc/hip/api.hip", PKG / "csrc/hip/api_post.hip", PKG / "csrc/hip/api_volume.hip", PKG / "csrc/hip/api_multi.hip", PKG / "csrc/hip/trace_kernels.hip", PKG / "csrc/hip/dense_kernels.hip", PKG / "csrc/hip/tile_order.hip", PKG / "csrc/hip/gpu_build.hip",
            PKG / "csrc/hip/post_kernels.hip", PKG / "csrc/hip/tree_build.cpp"]
-HIP_HDR = sorted((PKG / "csrc/hip").glob("*.h")) + sorted((PKG / "csrc/common").glob("*.h")) + [INCLUDE / "blok_hip.h", INCLUDE / "blok_world.h"]
+HIP_HDR = sorted((PKG / "csrc/hip").glob("*.h")) + sorted((PKG / "csrc/common").glob("*.h")) + [INCLUDE / "blok_hip.h", INCLUDE / "blok_hip_debug.h", INCLUDE / "blok_world.h"]
 
 
 def _stale(target: Path, deps) -> bool:
@@ -45,10 +45,22 @@ def build_host(force: bool = False) -> Path:
 
 
 def build_hip(force: bool = False) -> Path:
+    """One object per translation unit (no device code crosses one), compiled in parallel into build/obj/, then linked."""
+    from concurrent.futures import ThreadPoolExecutor
     out = PKG / "libblok_hip.so"
-    if force or _stale(out, HIP_SRC + HIP_HDR):
-        _run([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++20", "-ffp-contract=off", "-fPIC", "-shared",
-              f"-I{INCLUDE}", f"-I{PKG / 'csrc/hip'}", "-o", out, *HIP_SRC, "-ldl"])
+    if not (force or _stale(out, HIP_SRC + HIP_HDR)):
+        return out
+    obj_dir = ROOT / "build" / "obj"
+    obj_dir.mkdir(parents=True, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-ffp-contract=off", "-fPIC", f"-I{INCLUDE}", f"-I{PKG / 'csrc/hip'}"]
+    jobs = []
+    for src in HIP_SRC:
+        obj = obj_dir / (src.stem + ".o")
+        if force or _stale(obj, [src] + HIP_HDR):
+            jobs.append([hipcc(), *flags, "-c", src, "-o", obj])
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+        list(pool.map(_run, jobs))
+    _run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *[obj_dir / (src.stem + ".o") for src in HIP_SRC], "-ldl"])
     return out
 
 

@@ -236,9 +236,14 @@ int prepare_beam(blok_hip_ctx* ctx, blok::RayMode mode, blok::TraceArgs& args, h
 // So every frame launch leaves an event behind on its stream in a process-wide table per device, and a launch asks whether any OTHER
 // (context, stream) of the device still has one pending.
 namespace {
+// Two markers per (context, stream), both recorded by the stream's own launches only (nothing here ever records on a stream other than
+// the one being launched on: a caller may have destroyed it, or be capturing it into a graph): `last` = behind its latest frame launch;
+// `held` = what `last` was when the context last asked for its launches to be remembered (hold_markers: the adoption of an order, a change
+// of launch geometry) — a marker that stays put while the stream goes on launching, which is what a later sort waits for.
+struct StreamMarks { hipEvent_t last = nullptr, held = nullptr; bool fresh = false; };
 struct DeviceActivity {
     std::mutex lock;
-    std::map<std::pair<const blok_hip_ctx*, hipStream_t>, hipEvent_t> last;      // latest frame launch of every (context, stream)
+    std::map<std::pair<const blok_hip_ctx*, hipStream_t>, StreamMarks> marks;
 };
 DeviceActivity& device_activity(int device) {
     static std::mutex table_lock;
@@ -252,8 +257,12 @@ static bool device_busy_elsewhere(const blok_hip_ctx* ctx, hipStream_t stream) {
     DeviceActivity& act = device_activity(ctx->device);
     std::lock_guard<std::mutex> g(act.lock);
     bool busy = false;
-    for (auto& kv : act.last)
-        if (!(kv.first.first == ctx && kv.first.second == stream) && hipEventQuery(kv.second) == hipErrorNotReady) { busy = true; break; }
+    for (auto& kv : act.marks) {
+        if (kv.first.first == ctx && kv.first.second == stream) continue;
+        for (hipEvent_t ev : {kv.second.last, kv.second.held})
+            if (ev && hipEventQuery(ev) == hipErrorNotReady) { busy = true; break; }
+        if (busy) break;
+    }
     (void)hipGetLastError();                               // hipErrorNotReady is an answer, not a failure
     return busy;
 }
@@ -261,17 +270,40 @@ static bool device_busy_elsewhere(const blok_hip_ctx* ctx, hipStream_t stream) {
 static int note_frame_launch(blok_hip_ctx* ctx, hipStream_t stream) {
     DeviceActivity& act = device_activity(ctx->device);
     std::lock_guard<std::mutex> g(act.lock);
-    hipEvent_t& ev = act.last[{ctx, stream}];
-    if (!ev) BLOK_HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    BLOK_HIP_TRY(ctx, hipEventRecord(ev, stream));
+    StreamMarks& m = act.marks[{ctx, stream}];
+    if (!m.last) BLOK_HIP_TRY(ctx, hipEventCreateWithFlags(&m.last, hipEventDisableTiming));
+    BLOK_HIP_TRY(ctx, hipEventRecord(m.last, stream));
+    m.fresh = true;
     return BLOK_OK;
 }
 
-void forget_device_activity(const blok_hip_ctx* ctx) {
+// Every launch of this context issued so far, on any of its streams, is in front of a `held` marker from here on.  No HIP call: the
+// marker a stream recorded behind its latest launch changes places with the one it held before (which that stream's next launch re-records).
+static void hold_markers(const blok_hip_ctx* ctx) {
     DeviceActivity& act = device_activity(ctx->device);
     std::lock_guard<std::mutex> g(act.lock);
-    for (auto it = act.last.begin(); it != act.last.end();)
-        if (it->first.first == ctx) { (void)hipEventDestroy(it->second); it = act.last.erase(it); } else ++it;
+    for (auto& kv : act.marks)
+        if (kv.first.first == ctx && kv.second.fresh) { std::swap(kv.second.last, kv.second.held); kv.second.fresh = false; }
+}
+
+// `stream` waits for the held markers of the context's OTHER streams (its own earlier work is in front of it anyway).
+static int wait_for_held_markers(blok_hip_ctx* ctx, hipStream_t stream) {
+    DeviceActivity& act = device_activity(ctx->device);
+    std::lock_guard<std::mutex> g(act.lock);
+    for (auto& kv : act.marks)
+        if (kv.first.first == ctx && kv.first.second != stream && kv.second.held) BLOK_HIP_TRY(ctx, hipStreamWaitEvent(stream, kv.second.held, 0));
+    return BLOK_OK;
+}
+
+void forget_device_activity(const blok_hip_ctx* ctx, bool one_stream, hipStream_t stream) {
+    DeviceActivity& act = device_activity(ctx->device);
+    std::lock_guard<std::mutex> g(act.lock);
+    for (auto it = act.marks.begin(); it != act.marks.end();)
+        if (it->first.first == ctx && (!one_stream || it->first.second == stream)) {
+            if (it->second.last) (void)hipEventDestroy(it->second.last);
+            if (it->second.held) (void)hipEventDestroy(it->second.held);
+            it = act.marks.erase(it);
+        } else ++it;
 }
 
 // ---- longest-first order of the walk's wave tiles (api_internal.h: TileOrder; decisions in launch_policy.h: plan_order, plan_shift) ------
@@ -342,6 +374,10 @@ static int order_before_launch(blok_hip_ctx* ctx, blok::TraceArgs& args, uint32_
         BLOK_HIP_TRY(ctx, hipMemsetAsync(O.d_cost, 0, static_cast<size_t>(blocks) * sizeof(uint32_t), stream));
         std::memcpy(O.key, key, sizeof(key));
         O.orphan = O.orphan || O.pending;                                    // (a sort of the old geometry may still be writing an order buffer)
+        // ... and frames in flight on other streams may still be READING the buffer that was current: the first sort of the new geometry,
+        // whichever buffer it targets, waits for the markers held from here (without this it waited for the markers of the last
+        // adoption only, which cover the readers of the other buffer)
+        hold_markers(ctx);
         O.current = -1; O.pending = false; O.frames_since_sort = 0; O.still_frames = 0; O.interval_now = O.interval; O.have_residual = false;
     }
     if (O.pending && hipEventQuery(O.done) == hipSuccess) {              // the sort launched some frames ago has finished
@@ -357,17 +393,10 @@ static int order_before_launch(blok_hip_ctx* ctx, blok::TraceArgs& args, uint32_
         }
         O.pending = false; O.frames_since_sort = 0;
         // From here on no launch reads the OTHER buffer any more; the launches that may still be reading it are those already issued, on
-        // any stream of this context.  A marker behind each of them now is what the next sort — which overwrites that buffer, many
-        // launches from now — has to wait for: long past by then, so the sort never holds up the frames in flight (waiting for the
-        // streams' LATEST launches instead did: a bubble in the three-deep pipeline per sort, 5 % of a 20-frame run).
-        DeviceActivity& act = device_activity(ctx->device);
-        std::lock_guard<std::mutex> g(act.lock);
-        for (auto& kv : act.last) {
-            if (kv.first.first != ctx) continue;
-            hipEvent_t& guard = O.guards[kv.first.second];
-            if (!guard) BLOK_HIP_TRY(ctx, hipEventCreateWithFlags(&guard, hipEventDisableTiming));
-            BLOK_HIP_TRY(ctx, hipEventRecord(guard, kv.first.second));
-        }
+        // any stream of this context.  The marker each stream left behind its latest launch is held from now: what the next sort — which
+        // overwrites that buffer, many launches from now — has to wait for: long past by then, so the sort never holds up the frames in
+        // flight (waiting for the streams' LATEST launches instead did: a bubble in the three-deep pipeline per sort, 5 % of a 20-frame run).
+        hold_markers(ctx);
     }
     (void)hipGetLastError();                                             // hipErrorNotReady is an answer, not a failure
     blok::OrderFacts f{};
@@ -389,7 +418,10 @@ static int order_before_launch(blok_hip_ctx* ctx, blok::TraceArgs& args, uint32_
         sf.radius = O.radius[O.current];
         shift = blok::plan_shift(sf);
         f.shift_ok = shift.ok;
-        O.have_residual = true; O.last_residual = shift.residual;         // also when it is too large to use: the next dilation grows with it
+        // what the shift leaves over sizes the next dilation and the strips — also when it is too large to use, the next dilation grows with it —
+        // but only when it was computed: a view plan_shift could not compare (another lens, a point behind the camera) says nothing, and
+        // the next sort takes the default radius (a residual of 0 from an early exit gave the smallest radius after the largest change)
+        O.have_residual = shift.measured; O.last_residual = shift.measured ? shift.residual : 0.0f;
     }
     *plan = blok::plan_order(f);
     O.still_frames = plan->still_frames; O.last_cam = args.cam;
@@ -416,9 +448,9 @@ static int order_after_launch(blok_hip_ctx* ctx, const blok::TraceArgs& args, ui
     O.interval_now = plan.next_interval_now;
     if (!plan.start_sort) return BLOK_OK;
     const int target = O.current == 0 ? 1 : 0;
-    // Nothing still running may read the target buffer: it was last current before the previous adoption, and everything issued before
-    // that adoption is in front of the markers recorded then (order_before_launch).
-    for (auto& kv : O.guards) if (kv.first != stream && kv.second) BLOK_HIP_TRY(ctx, hipStreamWaitEvent(stream, kv.second, 0));
+    // Nothing still running may read the target buffer: it was last current before the previous adoption (or change of geometry), and
+    // everything issued before that is in front of the markers held then (order_before_launch).
+    { const int rc = wait_for_held_markers(ctx, stream); if (rc != BLOK_OK) return rc; }
     // ... and nothing may still be WRITING it: a sort left behind by a change of launch geometry, possibly on another stream
     if (O.orphan) { BLOK_HIP_TRY(ctx, hipStreamWaitEvent(stream, O.done, 0)); O.orphan = false; }
     uint32_t radius = 0;
@@ -475,6 +507,7 @@ static int live_list(blok_hip_ctx* ctx, blok::TraceArgs& args, hipStream_t strea
         BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&slot.list_ctl), blok::kListSegments * blok::kListCtlWords * sizeof(unsigned long long)));
         BLOK_HIP_TRY(ctx, hipMemsetAsync(slot.list_ctl, 0, blok::kListSegments * blok::kListCtlWords * sizeof(unsigned long long), stream));
         BLOK_HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&slot.list_hint), blok::kListSegments * blok::kListClasses * sizeof(uint32_t), hipHostMallocDefault));
+        std::memset(slot.list_hint, 0, blok::kListSegments * blok::kListClasses * sizeof(uint32_t));      // read as a hint before the first launch has written it
         slot.list_hint_valid = false;
     }
     const bool wrapped = slot.list_serial + 1u >= (1u << blok::kListSerialBits);
@@ -712,6 +745,26 @@ int blok_hip_resize(blok_hip_ctx* ctx, uint32_t width, uint32_t height) {
     return BLOK_OK;
 }
 
+static void free_stream_scratch(blok_hip_ctx::StreamScratch& sc) {
+    for (void* p : {static_cast<void*>(sc.beam), static_cast<void*>(sc.ctl), static_cast<void*>(sc.entries), static_cast<void*>(sc.tile_map),
+                    static_cast<void*>(sc.slots), static_cast<void*>(sc.gave_up), static_cast<void*>(sc.list_entries), static_cast<void*>(sc.list_ctl)})
+        if (p) (void)hipFree(p);
+    if (sc.list_hint) (void)hipHostFree(sc.list_hint);
+    sc = blok_hip_ctx::StreamScratch{};
+}
+
+int blok_hip_release_stream(blok_hip_ctx* ctx, void* hip_stream) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    BLOK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // the stream's launches may still be using its scratch, and another stream's pending sort may be waiting for its marker
+    BLOK_HIP_TRY(ctx, hipDeviceSynchronize());
+    auto it = ctx->beam_buffers.find(stream);
+    if (it != ctx->beam_buffers.end()) { free_stream_scratch(it->second); ctx->beam_buffers.erase(it); }
+    forget_device_activity(ctx, true, stream);
+    return BLOK_OK;
+}
+
 void blok_hip_destroy(blok_hip_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
@@ -720,12 +773,7 @@ void blok_hip_destroy(blok_hip_ctx* ctx) {
     free_post(ctx);
     if (ctx->has_volume) blok::gpu_volume_destroy(&ctx->volume);
     forget_device_activity(ctx);
-    for (auto& kv : ctx->beam_buffers) {
-        for (void* p : {static_cast<void*>(kv.second.beam), static_cast<void*>(kv.second.ctl), static_cast<void*>(kv.second.entries), static_cast<void*>(kv.second.tile_map),
-                        static_cast<void*>(kv.second.slots), static_cast<void*>(kv.second.gave_up), static_cast<void*>(kv.second.list_entries), static_cast<void*>(kv.second.list_ctl)})
-            if (p) (void)hipFree(p);
-        if (kv.second.list_hint) (void)hipHostFree(kv.second.list_hint);
-    }
+    for (auto& kv : ctx->beam_buffers) free_stream_scratch(kv.second);
     if (ctx->d_list_cost) (void)hipFree(ctx->d_list_cost);
     free_order(ctx);
     if (ctx->order.h_live) (void)hipHostFree(ctx->order.h_live);
@@ -733,7 +781,6 @@ void blok_hip_destroy(blok_hip_ctx* ctx) {
     if (ctx->order.h_fallback) (void)hipHostFree(ctx->order.h_fallback);
     if (ctx->order.d_fallback) (void)hipFree(ctx->order.d_fallback);
     if (ctx->order.done) (void)hipEventDestroy(ctx->order.done);
-    for (auto& kv : ctx->order.guards) if (kv.second) (void)hipEventDestroy(kv.second);
     if (ctx->d_accum) (void)hipFree(ctx->d_accum);
     if (ctx->d_color) (void)hipFree(ctx->d_color);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
@@ -1300,6 +1347,8 @@ static int launch_path_frame(blok_hip_ctx* ctx, const blok_camera* cam, uint32_t
     p.trace.x0 = x0; p.trace.y0 = y0; p.trace.w = w; p.trace.h = h;
     p.spp = spp; p.max_bounces = max_bounces; p.frame_count = frame_index;
     p.batch_kinds = ctx->ray_batching;
+    p.resume_secondary = ctx->path_resume ? 1u : 0u;
+    p.fine_beam = ctx->path_fine_beam ? 1u : 0u;
     if (ctx->sun_map_enabled && ctx->has_sun_map) {         // shadow rays stop at the last occluder of their column
         const blok::SunMapArgs& m = ctx->sun;
         p.sun_map = ctx->d_sun_map;
@@ -1457,6 +1506,12 @@ int blok_hip_accum_download(blok_hip_ctx* ctx, float* out_rgba32f_host) {
     if (!ctx->d_accum) return set_error(ctx, BLOK_ERR_INVALID_ARG, "no accumulation buffer yet");
     BLOK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     BLOK_HIP_TRY(ctx, hipMemcpy(out_rgba32f_host, ctx->d_accum, ctx->accum_pixels * 4 * sizeof(float), hipMemcpyDeviceToHost));
+    return BLOK_OK;
+}
+
+int blok_hip_set_path_start(blok_hip_ctx* ctx, int resume_from_anchor, int wave_tile_beam) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    ctx->path_resume = resume_from_anchor != 0; ctx->path_fine_beam = wave_tile_beam != 0;
     return BLOK_OK;
 }
 

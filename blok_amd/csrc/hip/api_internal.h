@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "blok_hip.h"
+#include "blok_hip_debug.h"
 #include "gpu_build.h"
 #include <hip/hip_fp16.h>
 #include "post_kernels.h"
@@ -91,6 +92,7 @@ struct blok_hip_ctx {
     float* d_sun_map = nullptr;
     bool sun_map_enabled = true, has_sun_map = false;
     uint32_t ray_batching = 2;          // PathArgs::batch_kinds (blok_hip_set_ray_batching)
+    bool path_resume = false, path_fine_beam = true;      // PathArgs::resume_secondary / fine_beam (blok_hip_set_path_start)
     blok::SunMapArgs sun{};
     // beam pre-pass (beam.h): start parameters per beam tile, one buffer per stream (launches on one stream are
     // ordered, frames in flight on different streams must not share)
@@ -144,7 +146,6 @@ struct blok_hip_ctx {
         uint32_t last_fallback = 0;                         // ... as read before the next launch (blok_hip_last_fallback_tiles)
         bool alone_before = false;                          // the previous orderable launch had the device to itself
         int last_use = 0; uint32_t last_sx = 0, last_sy = 0;        // the latest launch: 0 natural order, 1 an order of its own view, 2 a carried one (blok_hip_last_order_use)
-        std::unordered_map<hipStream_t, hipEvent_t> guards;    // per stream of the context: behind its last launch at the time of the latest adoption
     } order;
     // list launches, rectangle frames: clocks per wave tile of the last frame of this launch geometry, and the camera they were measured under (trace_kernels.h: cost classes)
     uint32_t* d_list_cost = nullptr; size_t list_cost_capacity = 0; uint32_t list_cost_key[6] = {};
@@ -190,7 +191,7 @@ int prepare_queue(blok_hip_ctx* ctx, blok::RayMode mode, const blok::TraceArgs& 
 int check_trace(blok_hip_ctx* ctx, const blok_camera* cam);
 int launch_timed(blok_hip_ctx* ctx, blok::RayMode mode, blok::TraceArgs args, uint32_t blocks, hipStream_t stream, uint32_t tiles_of_rank = 0,
                  const blok::TileFrames* frames = nullptr);
-void forget_device_activity(const blok_hip_ctx* ctx);
+void forget_device_activity(const blok_hip_ctx* ctx, bool one_stream = false, hipStream_t stream = nullptr);
 bool rect_inside(const blok_hip_ctx* ctx, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h);
 // The root's assembly of a sparse exchange (blok_hip_scatter_*_tile_frames_device): the ranks' buffers either side by side in
 // `gathered_dev` or, rank_ptrs_dev != null, wherever a device array of n_ranks pointers says (peer-mapped memory of other devices).

@@ -120,7 +120,7 @@ struct ShiftFacts {
     uint32_t tiles_x, tiles_y, tile_w, tile_h; // the launch's grid of wave tiles
     uint32_t radius;                           // dilation the order was sorted with
 };
-struct ShiftPlan { bool ok; uint32_t sx, sy; float residual; };      // sx, sy already modulo the grid
+struct ShiftPlan { bool ok; uint32_t sx, sy; float residual; bool measured; };      // sx, sy already modulo the grid; measured: residual was computed (false on the early exits: another lens, a sample behind the camera, not finite)
 
 inline bool policy_project(const PolicyCamera& c, const float p[3], float& u, float& v) {
     const float r[3] = {p[0] - c.pos[0], p[1] - c.pos[1], p[2] - c.pos[2]};
@@ -132,7 +132,7 @@ inline bool policy_project(const PolicyCamera& c, const float p[3], float& u, fl
 }
 
 inline ShiftPlan plan_shift(const ShiftFacts& f) {
-    ShiftPlan p{false, 0u, 0u, 0.0f};
+    ShiftPlan p{false, 0u, 0u, 0.0f, false};
     if (!f.tiles_x || !f.tiles_y || !f.tile_w || !f.tile_h) return p;
     const float lens = f.then.tan_half_fov - f.now.tan_half_fov, asp = f.then.aspect - f.now.aspect;
     if (!(lens < 1e-6f && lens > -1e-6f && asp < 1e-6f && asp > -1e-6f)) return p;
@@ -166,6 +166,7 @@ inline ShiftPlan plan_shift(const ShiftFacts& f) {
         if (!(e <= p.residual)) p.residual = e;                                  // NaN sticks
     }
     const int ax = sx < 0 ? -sx : sx, ay = sy < 0 ? -sy : sy;
+    p.measured = true;
     p.ok = p.residual <= 2.0f * static_cast<float>(f.radius) + 0.5f && static_cast<uint32_t>(ax) * 4u <= f.tiles_x && static_cast<uint32_t>(ay) * 4u <= f.tiles_y;
     p.sx = static_cast<uint32_t>((sx % static_cast<int>(f.tiles_x) + static_cast<int>(f.tiles_x)) % static_cast<int>(f.tiles_x));
     p.sy = static_cast<uint32_t>((sy % static_cast<int>(f.tiles_y) + static_cast<int>(f.tiles_y)) % static_cast<int>(f.tiles_y));

@@ -44,6 +44,8 @@ struct PathArgs {
     float sun_u0, sun_v0, sun_inv_texel;
     uint32_t sun_nu, sun_nv;
     uint32_t batch_kinds;            // 1: the wave walks one kind of ray at a time; 2: and the oldest sample first (see shade_pixel)
+    uint32_t fine_beam;              // the path kernel searches a start parameter of its own for every wave tile (trace_kernels.hip: path_kernel)
+    uint32_t resume_secondary;       // rays enter the walk from the ancestors of the pixel's latest hit where there is one (trace_core.h: walk_resume); 0 = always from the root
     // The same G-buffer in the reference's own image formats (raygen.rgen:55-59; renderer_denoising.cpp:110-170), each optional:
     // normal + roughness RGBA16F, albedo + metallic RGBA8 (unorm), motion vectors RG16F (raygen.rgen:150-155, 409-413; needs
     // prev_view_proj = FrameUBO::prevViewProj, column-major).  48 B/pixel with the two float4 planes instead of 64.
@@ -183,7 +185,12 @@ BLOK_DEV void store_narrow(const PathArgs& P, size_t index, uint32_t px, uint32_
 // traces instead of the sum over samples of per-sample maxima, and that walk() exists once in the code.
 // t0: conservative start parameter of this pixel's primary rays from the beam pre-pass (beam.h), kBeamNone = they all
 // miss, 0 = none computed; it covers the sub-pixel jitter (+-0.25 pixel, the beam's frustum is grown by a whole pixel).
-BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t index, uint4* stk, float t0 = 0.0f) {
+// stk: the lane's slot of the walk's LDS stack; keep_lohi / keep_base (null: every ray starts at the root): the lane's slots of a second,
+// compact LDS area of levels - 2 entries (12 bytes each; the root needs none) that holds the ancestors of the pixel's anchor while the
+// walks of other rays overwrite the stack.
+// kResume: compiled with the anchor machinery (walk_resume); the build without it is the one without its register pressure.
+template <bool kResume = true>
+BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t index, uint4* stk, float t0 = 0.0f, uint2* keep_lohi = nullptr, uint32_t* keep_base = nullptr) {
     const TraceArgs& A = P.trace;
     const blok_camera& cam = A.cam;
     const V3 cam_pos = v3(cam.pos[0], cam.pos[1], cam.pos[2]);
@@ -210,6 +217,10 @@ BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t in
     V3 ray_org = cam_pos, ray_dir = cam_f, radiance = v3(0, 0, 0), throughput = v3(1, 1, 1);
     // surface state kept across the shadow trace
     bool shadow_phase = false;
+    // the pixel's anchor (walk_resume): a reported voxel whose ancestors lie in the side area (and, while stack_is_anchor, on the stack)
+    bool anchored = false, stack_is_anchor = false;
+    WalkAnchor anchor;
+    anchor.vx = anchor.vy = anchor.vz = 0; anchor.brick.lo = anchor.brick.hi = anchor.brick.base = 0u;
     V3 n = v3(0, 1, 0), albedo = v3(0, 0, 0), hit_pos = v3(0, 0, 0);
     float roughness = 0.0f, metallic = 0.0f, n_dot_l = 0.0f;
 
@@ -299,7 +310,35 @@ BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t in
         const uint32_t round_kind = shadow_phase ? 1u : (bounce == 0u ? 0u : 2u);
         const uint32_t round_lanes = static_cast<uint32_t>(__builtin_popcountll(__ballot(true)));
 #endif
-        const HitInfo hit = walk(A, r, stk);
+        HitInfo hit;
+        hit.found = false; hit.t = -1.0f; hit.material = 0u; hit.face = 0xFFu; hit.vx = hit.vy = hit.vz = 0; hit.brick.lo = hit.brick.hi = hit.brick.base = 0u;
+        {
+            BLOK_STAT(4, 0);                       // a walk begins
+            const WalkRay R = walk_ray(A, r.ox, r.oy, r.oz, safe_inv(r.dx), safe_inv(r.dy), safe_inv(r.dz));
+            WalkState ws;
+            // ONE loop for every kind of ray.  Whenever the pixel has an anchor — the latest reported voxel another ray starts from, its
+            // ancestors in the side area — the walk is put into the state the walk from the root would reach (walk_resume: exact for ANY
+            // anchor and any ray; it pays because a shadow / bounce ray starts next to the anchor and the next sample's primary ray, behind
+            // the wave tile's own start parameter, not far from it); otherwise it starts at the root.
+            bool resumed = false;
+            if (kResume && anchored && P.resume_secondary != 0u) {
+                if (!stack_is_anchor) {            // an earlier walk has overwritten the stack below the root's slot (which only ever holds the root)
+                    for (uint32_t j = 0; j + 2u < A.levels; ++j) { const uint2 c = keep_lohi[j * kBlock]; stk[j * kBlock] = make_uint4(c.x, c.y, keep_base[j * kBlock], 0u); }
+                    stack_is_anchor = true;
+                }
+                resumed = walk_resume(A, r, R, anchor, stk, ws);
+            }
+            if (!resumed) walk_enter(A, R, r.tmin, r.tmax, ws);
+            if (ws.walking) stack_is_anchor = false;
+            walk_loop(A, R, r.tmax, ws, stk);
+            if (ws.found) hit = walk_hit(A, r, R, ws);
+            // a report becomes the anchor when it is a first hit or another ray of this path will start from it; its ancestors go to the side
+            if (kResume && ws.found && !shadow_phase && keep_lohi != nullptr && (bounce == 0u || bounce + 1u < P.max_bounces)) {
+                anchor.vx = hit.vx; anchor.vy = hit.vy; anchor.vz = hit.vz; anchor.brick = hit.brick;
+                for (uint32_t j = 0; j + 2u < A.levels; ++j) { const uint4 c = stk[j * kBlock]; keep_lohi[j * kBlock] = make_uint2(c.x, c.y); keep_base[j * kBlock] = c.z; }
+                anchored = true; stack_is_anchor = true;
+            }
+        }
 #ifdef BLOK_PATH_CLOCKS
         {   // diagnostic build (scripts/r03/paths_kind_clocks.py): the round's clocks are booked by its first active lane, under the kind of that lane
             const uint32_t dt = static_cast<uint32_t>((__builtin_amdgcn_s_memtime() - kind_clock0) >> 4);

@@ -138,6 +138,7 @@ struct HitInfo {
     float t;
     uint32_t material, face;
     int vx, vy, vz;          // world voxel
+    NodeRec brick;           // the node record of the voxel's 4x4x4 brick (what walk_resume needs besides the LDS stack)
 };
 
 // What a walk needs of its ray: the three axes (origin, safe inverse direction, mirroring) and the child-bit constant.
@@ -230,39 +231,12 @@ BLOK_DEV void walk_loop(const TraceArgs& A, const WalkRay& R, const float tmax, 
             // a filled voxel: reported iff its clipped interval is non-empty (intersect.rint:189-193)
             if (tCur < fminf(tExit, tmax)) { found = true; break; }
         }
-#ifdef BLOK_WALK_SKIP
-        // nothing else of this node lies ahead of the ray (all rays travel towards +q on every axis: what is ahead of cell (dx, dy, dz) is
-        // the box of cells >= it) -> leave the NODE through its far planes at once, as if it were an empty cell of the level above: the
-        // same (axis, T) as the last of the single steps would reach, by the same tie rule, and the fine position is dropped on ascent anyway
-        if (lvl + 1u < L) {
-            const uint32_t wx = bit & 3u, wy = (bit >> 2) & 3u, wz = bit >> 4;
-            const uint32_t nx = (R.mirror & 3u) ? (0xFu >> (3u - wx)) : ((0xFu << wx) & 0xFu);
-            const uint32_t ny = (R.mirror & 12u) ? (0xFFFFu >> (4u * (3u - wy))) : ((0xFFFFu << (4u * wy)) & 0xFFFFu);
-            const uint32_t xy = (nx * 0x11111111u) & (ny * 0x00010001u);
-            const unsigned long long az = (R.mirror & 48u) ? (~0ull >> (16u * (3u - wz))) : (~0ull << (16u * wz));
-            const unsigned long long here = 1ull << bit;
-            const unsigned long long m = ((static_cast<unsigned long long>(node.hi) << 32) | node.lo) & ((static_cast<unsigned long long>(xy) << 32) | xy) & az & ~here;
-            if (m == 0ull) {
-                BLOK_STAT(4, lvl + 1u);
-                lvl += 1u;
-                size = cell_size(lvl);
-                const uint32_t keep = ~((1u << (2 * lvl)) - 1u);
-                fx = __uint_as_float(__float_as_uint(fx) & keep); fy = __uint_as_float(__float_as_uint(fy) & keep); fz = __uint_as_float(__float_as_uint(fz) & keep);
-                const uint4 c = stk[(lvl - 1) * kBlock];
-                node.lo = c.x; node.hi = c.y; node.base = c.z;
-                tFx = plane_t(R.ax, fx + size); tFy = plane_t(R.ay, fy + size); tFz = plane_t(R.az, fz + size);
-            }
-        }
-        const float tExit2 = fminf(fminf(tFx, tFy), tFz);
-#else
-        const float tExit2 = tExit;
-#endif
         // step: cross the nearest far plane (x, then y, then z on ties)
         BLOK_STAT(2, lvl);
-        tCur = tExit2;
+        tCur = tExit;
         if (!(tCur < tmax)) break;
-        const bool sx = tFx == tExit2;
-        const bool sy = !sx && tFy == tExit2;
+        const bool sx = tFx == tExit;
+        const bool sy = !sx && tFy == tExit;
         const bool sz = !sx && !sy;
         fx += sx ? size : 0.0f; fy += sy ? size : 0.0f; fz += sz ? size : 0.0f;
         // the stepped coordinate is now a multiple of 4^k for the level k whose cell boundary was crossed (its mantissa
@@ -311,7 +285,134 @@ BLOK_DEV HitInfo walk_hit(const TraceArgs& A, const RayIn& r, const WalkRay& R, 
     else                      face = ez > 0.0f ? 4u : 5u;
     out.found = true; out.t = tc; out.material = material; out.face = face;
     out.vx = vx; out.vy = vy; out.vz = vz;
+    out.brick = s.node;
     return out;
+}
+
+// ---- secondary rays: a walk entered from the previous hit's ancestors instead of the root --------------------------------------------
+// A shadow or bounce ray starts a hair off the voxel the lane has just walked to (raygen.rgen:284 hit + N * 0.001, :376 hit + N * 0.002), and the
+// LDS stack still holds that voxel's ancestors — node records, valid under any ray's mirroring.  walk_resume puts the new ray's walk
+// into the state the walk from the root would be in after its first descents, and then lets it leave at once every ancestor that holds
+// nothing the ray can still reach:
+//
+//  1. START VOXEL.  The walk from the root enters every node at the child slab that holds the ray at tS = max(world entry, tmin): per axis the
+//     number of interior planes with T <= tS (enter_axis).  T is monotone in q, so level by level this selects the ancestors of ONE
+//     voxel: per axis the q with T(q) <= tS < T(q + 1).  Here q is guessed from the point o + d tS and VERIFIED with the canonical T
+//     (two plane evaluations per axis, one more after a correction by one): the verified q is the root walk's, whatever the guess
+//     was.  T(0) <= T(q) <= tS on every axis then also says that the ray is inside the world box at tS = tmin, as the root walk's
+//     tCur = max(T(0)..., tmin) requires.  No verified q (the origin outside the box, a guess off by more than one): the caller walks from the root.
+//  2. COMMON ANCESTOR.  Above the lowest level m at which the start voxel and the reported voxel h share a node, the start voxel's
+//     ancestors are h's — all occupied (h is a filled voxel), so the root walk descends through exactly them, pushing the records the
+//     stack already holds, without changing tCur; it arrives at level m in node N_m with the far planes of the start voxel's level-m cell.
+//     That state is formed here directly (N_0 = the brick record kept from the hit, N_m = stack slot m - 1).
+//  3. LAUNCH PAD.  In mirrored coordinates every ray travels towards +q on all three axes: what it can still reach inside a node is the box
+//     of children >= its current child.  If no occupied child of N lies in that box the ray leaves N through N's far planes without
+//     a report — by the same (axis, T) the last of the single steps would take, and its fine position is dropped on the ascent anyway (the argument
+//     of round 3's leave-the-node-early experiment, profiles/r03_skip_ahead_estimate.txt; there it ran inside the loop and cost more
+//     than it saved, here it runs once per ray, where it pays most: a ray that leaves a surface spends most of its iterations climbing out
+//     of the levels it starts at the bottom of).  So the walk is entered at the lowest ancestor that does hold something ahead, with
+//     its own cell left at once like an empty one; no such ancestor up to the root: the ray reports nothing.
+struct WalkAnchor { int vx, vy, vz; NodeRec brick; };      // the reported voxel (world lattice) and its brick record
+
+// the children of a node a ray can still reach from child `bit` (un-mirrored digits x | y << 2 | z << 4): >= on an axis it travels
+// positively, <= on a mirrored one
+BLOK_DEV unsigned long long ahead_box(uint32_t bit, uint32_t mirror) {
+    const uint32_t wx = bit & 3u, wy = (bit >> 2) & 3u, wz = bit >> 4;
+    const uint32_t nx = (mirror & 3u) ? (0xFu >> (3u - wx)) : ((0xFu << wx) & 0xFu);
+    const uint32_t ny = (mirror & 12u) ? (0xFFFFu >> (4u * (3u - wy))) : ((0xFFFFu << (4u * wy)) & 0xFFFFu);
+    const uint32_t xy = (nx * 0x11111111u) & (ny * 0x00010001u);
+    const unsigned long long az = (mirror & 48u) ? (~0ull >> (16u * (3u - wz))) : (~0ull << (16u * wz));
+    return ((static_cast<unsigned long long>(xy) << 32) | xy) & az;
+}
+
+// One axis of step 1: f = 2^23 + q with T(q) <= tS < T(q + 1), t_far = T(q + 1); false if no such q next to the guess or outside [0, W).
+BLOK_DEV bool resume_axis(const Axis& a, bool neg, float point, float inv_vs, int origin, int W, float tS, float& f, float& t_far) {
+    const float w = floorf(point * inv_vs) - static_cast<float>(origin);          // the guess, in tree coordinates (any float will do)
+    const float u = neg ? static_cast<float>(W - 1) - w : w;
+    if (!(u >= 0.0f && u <= static_cast<float>(W - 1))) return false;             // NaN included
+    f = kCoordBias + u;
+    float t_lo = plane_t(a, f);
+    t_far = plane_t(a, f + 1.0f);
+    if (t_lo > tS) { f -= 1.0f; t_far = t_lo; t_lo = plane_t(a, f); }
+    else if (t_far <= tS) { f += 1.0f; t_lo = t_far; t_far = plane_t(a, f + 1.0f); }
+    return t_lo <= tS && tS < t_far && f >= kCoordBias && f <= kCoordBias + static_cast<float>(W - 1);
+}
+
+// false: nothing was set up, walk_enter must be called.  true: `s` is ready for walk_loop (or says that there is nothing to walk).
+BLOK_DEV bool walk_resume(const TraceArgs& A, const RayIn& r, const WalkRay& R, const WalkAnchor& anchor, const uint4* stk, WalkState& s) {
+    const uint32_t L = A.levels;
+    const int W = 1 << (2 * L);
+    const float tS = r.tmin;
+    const bool negx = !(R.ax.inv > 0.0f), negy = !(R.ay.inv > 0.0f), negz = !(R.az.inv > 0.0f);
+    const float inv_vs = rn_div(1.0f, A.voxel_size);
+    float fx, fy, fz, tFx, tFy, tFz;
+    bool ok = resume_axis(R.ax, negx, __builtin_fmaf(r.dx, tS, r.ox), inv_vs, A.origin[0], W, tS, fx, tFx);
+    ok = resume_axis(R.ay, negy, __builtin_fmaf(r.dy, tS, r.oy), inv_vs, A.origin[1], W, tS, fy, tFy) && ok;
+    ok = resume_axis(R.az, negz, __builtin_fmaf(r.dz, tS, r.oz), inv_vs, A.origin[2], W, tS, fz, tFz) && ok;
+    if (!ok) { BLOK_STAT(7, 0); return false; }
+    BLOK_STAT(5, 0);                       // a walk begins from an anchor
+    s.found = false; s.bit = 0u; s.tCur = tS;
+    s.walking = tS < r.tmax;               // the root walk's  tCur < min(world far planes, tmax): the far planes are beyond T(q + 1) > tS
+    s.fx = fx; s.fy = fy; s.fz = fz; s.tFx = tFx; s.tFy = tFy; s.tFz = tFz; s.lvl = 0u; s.size = 1.0f; s.node = anchor.brick;
+    if (!s.walking) return true;
+    // step 2: the lowest level at which start voxel and anchor share a node
+    const uint32_t qx = __float_as_uint(fx) & 0x7FFFFFu, qy = __float_as_uint(fy) & 0x7FFFFFu, qz = __float_as_uint(fz) & 0x7FFFFFu;
+    const uint32_t ux = negx ? static_cast<uint32_t>(W - 1) - qx : qx, uy = negy ? static_cast<uint32_t>(W - 1) - qy : qy, uz = negz ? static_cast<uint32_t>(W - 1) - qz : qz;
+    const uint32_t hx = static_cast<uint32_t>(anchor.vx - A.origin[0]), hy = static_cast<uint32_t>(anchor.vy - A.origin[1]), hz = static_cast<uint32_t>(anchor.vz - A.origin[2]);
+    const uint32_t diff = (ux ^ hx) | (uy ^ hy) | (uz ^ hz);
+    uint32_t lvl = diff ? static_cast<uint32_t>(31 - __clz(static_cast<int>(diff))) >> 1 : 0u;
+    if (lvl >= L) return false;            // (an anchor outside the tree: never, but then from the root)
+    NodeRec node = anchor.brick;
+    if (lvl != 0u) { const uint4 c = stk[(lvl - 1) * kBlock]; node.lo = c.x; node.hi = c.y; node.base = c.z; }
+    // step 3: climb while nothing of the node lies ahead
+    bool climbed = false;
+#ifndef BLOK_RESUME_LAUNCH_PAD
+#define BLOK_RESUME_LAUNCH_PAD 1
+#endif
+    for (; BLOK_RESUME_LAUNCH_PAD;) {
+        const uint32_t shift = 2 * lvl;
+        const uint32_t bit = (digit2(qx, shift) | (digit2(qy, shift) << 2) | (digit2(qz, shift) << 4)) ^ R.mirror;
+        unsigned long long ahead = ((static_cast<unsigned long long>(node.hi) << 32) | node.lo) & ahead_box(bit, R.mirror);
+        if (climbed) ahead &= ~(1ull << bit);          // the child it came out of holds nothing ahead: established one level down
+        if (ahead != 0ull) break;
+        BLOK_STAT(6, lvl);                 // a level left on the launch pad
+        if (lvl + 1u >= L) { s.walking = false; return true; }      // nothing ahead in the whole tree
+        lvl += 1u; climbed = true;
+        const uint4 c = stk[(lvl - 1) * kBlock];
+        node.lo = c.x; node.hi = c.y; node.base = c.z;
+    }
+    if (lvl != 0u) {
+        const uint32_t keep = ~((1u << (2 * lvl)) - 1u);
+        s.size = cell_size(lvl);
+        s.fx = __uint_as_float(__float_as_uint(fx) & keep); s.fy = __uint_as_float(__float_as_uint(fy) & keep); s.fz = __uint_as_float(__float_as_uint(fz) & keep);
+        s.tFx = plane_t(R.ax, s.fx + s.size); s.tFy = plane_t(R.ay, s.fy + s.size); s.tFz = plane_t(R.az, s.fz + s.size);
+    }
+    if (climbed) {
+        // the cell the walk stands in (the child it climbed out of) holds nothing ahead: left through its nearest far plane exactly as the
+        // loop leaves an empty cell (the step of walk_loop, once, here — a flag inside the loop would cost every iteration of every walk)
+        BLOK_STAT(2, lvl);
+        const float tExit = fminf(fminf(s.tFx, s.tFy), s.tFz);
+        s.tCur = tExit;
+        if (!(tExit < r.tmax)) { s.walking = false; return true; }
+        const bool sx = s.tFx == tExit;
+        const bool sy = !sx && s.tFy == tExit;
+        const bool sz = !sx && !sy;
+        s.fx += sx ? s.size : 0.0f; s.fy += sy ? s.size : 0.0f; s.fz += sz ? s.size : 0.0f;
+        const uint32_t up = static_cast<uint32_t>(__ffs(static_cast<int>(__float_as_uint(sx ? s.fx : (sy ? s.fy : s.fz)))) - 1) >> 1;
+        if (up != lvl) {
+            BLOK_STAT(3, lvl);
+            if (up >= L) { s.walking = false; return true; }      // left the world box
+            lvl = up;
+            s.size = cell_size(lvl);
+            const uint32_t keep = ~((1u << (2 * up)) - 1u);
+            s.fx = __uint_as_float(__float_as_uint(s.fx) & keep); s.fy = __uint_as_float(__float_as_uint(s.fy) & keep); s.fz = __uint_as_float(__float_as_uint(s.fz) & keep);
+            const uint4 c = stk[(lvl - 1) * kBlock];
+            node.lo = c.x; node.hi = c.y; node.base = c.z;
+        }
+        s.tFx = plane_t(R.ax, s.fx + s.size); s.tFy = plane_t(R.ay, s.fy + s.size); s.tFz = plane_t(R.az, s.fz + s.size);
+    }
+    s.lvl = lvl; s.node = node;
+    return true;
 }
 
 // Walks one ray.  `stk` points at this lane's slot of the LDS node stack (stride kBlock entries between
@@ -330,6 +431,7 @@ BLOK_DEV HitInfo walk(const TraceArgs& A, const RayIn& r, uint4* stk) {
     BLOK_STAT(4, 0);                       // a walk begins
     HitInfo out;
     out.found = false; out.t = -1.0f; out.material = 0u; out.face = 0xFFu; out.vx = out.vy = out.vz = 0;
+    out.brick.lo = out.brick.hi = out.brick.base = 0u;
     const WalkRay R = walk_ray(A, r.ox, r.oy, r.oz, safe_inv(r.dx), safe_inv(r.dy), safe_inv(r.dz));
     WalkState s;
     walk_enter(A, R, r.tmin, r.tmax, s);

@@ -457,6 +457,10 @@ __device__ __forceinline__ void list_task(const TraceArgs& A, const TileFrames& 
 template <RayMode MODE, bool kFrames>
 __device__ __forceinline__ void list_walk(const TraceArgs& A, const TileFrames& F, const uint32_t walker, const uint32_t seg, uint4* lds_stack) {
     const LiveList& Q = A.list;
+    // a launch of fewer searches than segments (a rectangle of < 8 beam tiles, a rank with few tiles): segment `seg` has no search, nobody
+    // will ever write its final word for this serial, and its lists are empty — nothing to wait for (such waves spun their whole
+    // poll budget, ~1 ms, and tripped the stall counter)
+    if (seg >= Q.n_searches) return;
     // the segment's walk workgroups are dealt to the classes heaviest first
     uint32_t k = walker / kListSegments, cls = kListClasses - 1u;
     while (cls != 0u && k >= Q.walkers[cls]) { k -= Q.walkers[cls]; cls -= 1u; }
@@ -510,6 +514,7 @@ __global__ __launch_bounds__(kBlock) void list_cleanup_kernel(const TraceArgs A,
     const LiveList& Q = A.list;
     const uint32_t seg = blockIdx.x & (kListSegments - 1u), part = blockIdx.x / kListSegments, parts = gridDim.x / kListSegments;
     unsigned long long* const ctl = Q.ctl + seg * kListCtlWords;
+    if (seg >= Q.n_searches) return;                                                                               // a segment without searches (list_walk)
     if (__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(list_ld(ctl + kListGaveUp))) != Q.serial) return;      // nobody gave up in this launch
     for (uint32_t cls = 0; cls < kListClasses; ++cls) {
         const unsigned long long f = list_ld(ctl + kListFinal + cls);
@@ -747,7 +752,11 @@ __global__ __launch_bounds__(64) void sun_map_kernel(const SunMapArgs a) {
 #ifndef BLOK_PATH_WAVES
 #define BLOK_PATH_WAVES 6        // waves per SIMD the path kernel is compiled for (register budget 512 / waves): 4 (109 VGPRs) 74.2 ms, 5 70.7, 6 69.9, 8 71.1 at 4K 64 spp
 #endif
+// kResume: PathArgs::resume_secondary honoured (two kernels, so that the default — off, it measures slower — carries none of its state).
+template <bool kResume>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(BLOK_PATH_WAVES, BLOK_PATH_WAVES))) void path_kernel(const PathArgs P) {
+    // [levels - 1][kBlock] uint4: the walk's stack; then, with PathArgs::resume_secondary, the side area of the pixels' anchors (path_core.h):
+    // [levels - 2][kBlock] uint2 and [levels - 2][kBlock] words
     extern __shared__ uint4 lds_stack[];
     const TraceArgs& A = P.trace;
     const uint32_t tid = threadIdx.x;
@@ -758,10 +767,29 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(BLOK_PAT
     uint32_t bx, by;
     if (!block_to_tile(blockIdx.x, gridDim.x, bx_count, by_count, bx, by)) return;
     const uint32_t rx = bx * kTileW + lx, ry = by * kTileH + ly;
-    if (rx >= A.w || ry >= A.h) return;
     float t0 = 0.0f;
-    if (A.beam) t0 = A.beam[__builtin_amdgcn_readfirstlane(((ry - lane / kWaveW) / A.beam_tile) * A.beam_bx + (rx - lane % kWaveW) / A.beam_tile)];
-    shade_pixel(P, A.x0 + rx, A.y0 + ry, static_cast<size_t>(ry) * A.w + rx, lds_stack + tid, t0);
+    if (A.beam) {
+        const uint32_t wx = rx - lane % kWaveW, wy = ry - lane / kWaveW;          // the wave's 8x8 pixels start here (wave-uniform, inside the rectangle)
+        t0 = A.beam[__builtin_amdgcn_readfirstlane((wy / A.beam_tile) * A.beam_bx + wx / A.beam_tile)];
+        // The wave tile's OWN start parameter: the same cooperative search over its 8x8 pixels (all 64 lanes, before any leaves), looking
+        // only beyond what the beam tile found.  For one primary ray per pixel it costs what it saves (fine bounds);
+        // here every pixel sends spp primary rays through it.  Exact for the same reason as the beam tile's (beam.h): the frustum is
+        // the tile grown by a pixel, the sub-pixel jitter stays inside.
+        if (P.fine_beam != 0u && t0 < kBeamNone && P.spp > 1u) {
+            const uint32_t fx0 = A.x0 + wx, fy0 = A.y0 + wy;
+            const float fine = beam_start(A, static_cast<float>(fx0), static_cast<float>(fy0), static_cast<float>(min(fx0 + kWaveW, A.x0 + A.w)),
+                                          static_cast<float>(min(fy0 + kWaveH, A.y0 + A.h)), lane);
+            t0 = fmaxf(t0, fine);                                                   // (kBeamNone: no ray of this wave tile can hit anything)
+        }
+    }
+    if (rx >= A.w || ry >= A.h) return;
+    uint2* keep_lohi = nullptr; uint32_t* keep_base = nullptr;
+    if (kResume && P.resume_secondary != 0u && A.levels >= 2u) {
+        const uint32_t slots = A.levels - 1u, kept = A.levels - 2u;
+        keep_lohi = reinterpret_cast<uint2*>(lds_stack + slots * kBlock) + tid;
+        keep_base = reinterpret_cast<uint32_t*>(reinterpret_cast<uint2*>(lds_stack + slots * kBlock) + kept * kBlock) + tid;
+    }
+    shade_pixel<kResume>(P, A.x0 + rx, A.y0 + ry, static_cast<size_t>(ry) * A.w + rx, lds_stack + tid, t0, keep_lohi, keep_base);
 }
 
 __global__ __launch_bounds__(256) void tonemap_kernel(const TonemapArgs T) {
@@ -990,8 +1018,11 @@ void launch_sun_map(const SunMapArgs& args, hipStream_t stream) {
 void launch_paths(const PathArgs& args, uint32_t n_blocks, hipStream_t stream) {
     if (n_blocks == 0) return;
     const uint32_t levels = args.trace.levels;
-    const size_t lds = static_cast<size_t>(levels > 1 ? levels - 1 : 1) * kBlock * sizeof(uint4);
-    hipLaunchKernelGGL(path_kernel, dim3(n_blocks), dim3(kBlock), lds, stream, args);
+    size_t lds = static_cast<size_t>(levels > 1 ? levels - 1 : 1) * kBlock * sizeof(uint4);
+    if (args.resume_secondary && levels >= 2) {
+        lds += static_cast<size_t>(levels - 2) * kBlock * (sizeof(uint2) + sizeof(uint32_t));      // the anchors' side area
+        hipLaunchKernelGGL(path_kernel<true>, dim3(n_blocks), dim3(kBlock), lds, stream, args);
+    } else hipLaunchKernelGGL(path_kernel<false>, dim3(n_blocks), dim3(kBlock), lds, stream, args);
 }
 
 void launch_tonemap(const TonemapArgs& args, hipStream_t stream) {

@@ -148,6 +148,11 @@ class HipTracer:
     def post_reset(self):
         self._check(self._lib.blok_hip_post_reset(self._ctx))
 
+    def set_path_start(self, resume_from_anchor=False, wave_tile_beam=True):
+        """Where the path kernel's walks start (blok_hip_set_path_start): from the pixel's latest hit's ancestors, behind the wave tile's own
+        beam; frames are identical in every combination."""
+        self._check(self._lib.blok_hip_set_path_start(self._ctx, int(bool(resume_from_anchor)), int(bool(wave_tile_beam))))
+
     def set_ray_batching(self, mode):
         """Path kernel scheduling (never changes a result): 0 / False = off, 1 = one kind of ray at a time, 2 / True (default) = one
         kind at a time and the oldest sample first."""
@@ -479,6 +484,10 @@ class HipTracer:
         return out.reshape(h, w)
 
     # -- timing ----------------------------------------------------------------------------
+    def release_stream(self, stream: int):
+        """Before destroying a HIP stream that was passed to *_device entries: the context drops its per-stream scratch and markers."""
+        self._check(self._lib.blok_hip_release_stream(self._ctx, C.c_void_p(stream)))
+
     def set_timing(self, enabled: bool):
         self._check(self._lib.blok_hip_set_timing(self._ctx, int(enabled)))
 

@@ -1,4 +1,5 @@
-"""Would "leave the node at once when nothing else of it lies ahead" pay?  The walk's body compiled for the CPU with and without
+"""[round 4: the BLOK_WALK_SKIP block was deleted from trace_core.h (it lost, profiles/r03_skip_ahead_estimate.txt); this script needs the tree at feeb08d to run]
+Would "leave the node at once when nothing else of it lies ahead" pay?  The walk's body compiled for the CPU with and without
 -DBLOK_WALK_SKIP (trace_core.h), bands of the 4K benchmark frame behind a beam-like start parameter: same records required, then
 iterations per ray and per wave (the longest ray of each 8x8 tile), and the event totals by level.
     python3 scripts/r03/skip_ahead_estimate.py [pose=0]"""

@@ -3,13 +3,15 @@
 #define BLOK_TRACE_HOST_HARNESS 1
 #include <cstdint>
 // statistics build: events 0 iteration, 1 descend, 2 step, 3 ascend, per level
-static thread_local uint64_t g_stat[5][8];
+static thread_local uint64_t g_stat[8][8];      // [event][level]: 0 iteration, 1 descend, 2 step, 3 ascent, 4 walk begins, 5 walk resumed, 6 launch-pad level
 static thread_local unsigned char* g_seq = nullptr;      // optional per-ray event log: 1 descend, 2 step (+level*4)
 static thread_local uint32_t g_seq_len = 0, g_seq_cap = 0;
 static thread_local uint32_t g_kind = 0;                 // kind of the ray being walked (path loop): 0 primary, 1 shadow, 2 bounce
+static thread_local uint32_t g_resume = 0;                // PathArgs::resume_secondary of the path entries below (hh_set_path_resume)
 #define BLOK_PATH_KIND(kind) do { g_kind = (kind); } while (0)
-#define BLOK_STAT(event, level) do { ++g_stat[event][level]; \
-    if (g_seq && (event == 1 || event == 2 || event == 4) && g_seq_len < g_seq_cap) g_seq[g_seq_len++] = (unsigned char)(event | ((level) << 2) | (event == 4 ? g_kind << 3 : 0u)); } while (0)
+static thread_local uint64_t g_kstat[3][8];     // [kind of ray][event], path entries
+#define BLOK_STAT(event, level) do { ++g_stat[event][level]; ++g_kstat[g_kind < 3 ? g_kind : 0][event]; \
+    if (g_seq && (event == 1 || event == 2 || event == 4 || event == 6) && g_seq_len < g_seq_cap) g_seq[g_seq_len++] = (unsigned char)((event == 6 ? 3 : event) | ((level) << 2) | (event == 4 ? g_kind << 3 : 0u)); } while (0)
 #include "trace_core.h"
 #include "path_core.h"
 #include "post_core.h"
@@ -84,11 +86,13 @@ void hh_render_paths(const void* h, const blok_camera* cam, const blok_material*
     p.trace = make_args(H);
     p.trace.cam = *cam; p.trace.frame_w = width; p.trace.frame_h = height;
     p.trace.mat_table = materials; p.trace.n_materials = n_materials;
+    p.resume_secondary = g_resume;
     p.spp = spp; p.max_bounces = max_bounces; p.frame_count = frame_index;
     p.color = color; p.world_pos = world_pos; p.normal_roughness = normal_roughness; p.albedo_metallic = albedo_metallic;
     std::vector<uint4> stack(size_t(kMaxLevels) * 2 * kBlock);
+    std::vector<uint2> keep_lohi(size_t(kMaxLevels) * kBlock); std::vector<uint32_t> keep_base(size_t(kMaxLevels) * kBlock);
     for (uint32_t y = 0; y < height; ++y)
-        for (uint32_t x = 0; x < width; ++x) shade_pixel(p, x, y, size_t(y) * width + x, stack.data());
+        for (uint32_t x = 0; x < width; ++x) shade_pixel(p, x, y, size_t(y) * width + x, stack.data(), 0.0f, keep_lohi.data(), keep_base.data());
 }
 
 // Event log per ray (cap bytes each, zero padded) for an 8x8-tile wave simulation.
@@ -140,12 +144,14 @@ void hh_render_paths_events(const void* h, const blok_camera* cam, const blok_ma
     p.trace = make_args(H);
     p.trace.cam = *cam; p.trace.frame_w = width; p.trace.frame_h = height;
     p.trace.mat_table = materials; p.trace.n_materials = n_materials;
+    p.resume_secondary = g_resume;
     p.spp = spp; p.max_bounces = max_bounces; p.frame_count = 1;
     std::vector<uint4> stack(size_t(kMaxLevels) * 2 * kBlock);
+    std::vector<uint2> keep_lohi(size_t(kMaxLevels) * kBlock); std::vector<uint32_t> keep_base(size_t(kMaxLevels) * kBlock);
     for (uint32_t y = 0; y < hgt; ++y)
         for (uint32_t x = 0; x < w; ++x) {
             g_seq = events + (size_t(y) * w + x) * cap; g_seq_len = 0; g_seq_cap = cap;
-            shade_pixel(p, x0 + x, y0 + y, 0, stack.data());
+            shade_pixel(p, x0 + x, y0 + y, 0, stack.data(), 0.0f, keep_lohi.data(), keep_base.data());
         }
     g_seq = nullptr;
 }
@@ -160,12 +166,14 @@ void hh_render_paths_events2(const void* h, const blok_camera* cam, const blok_m
     p.trace = make_args(H);
     p.trace.cam = *cam; p.trace.frame_w = width; p.trace.frame_h = height;
     p.trace.mat_table = materials; p.trace.n_materials = n_materials;
+    p.resume_secondary = g_resume;
     p.spp = spp; p.max_bounces = max_bounces; p.frame_count = 1;
     std::vector<uint4> stack(size_t(kMaxLevels) * 2 * kBlock);
+    std::vector<uint2> keep_lohi(size_t(kMaxLevels) * kBlock); std::vector<uint32_t> keep_base(size_t(kMaxLevels) * kBlock);
     for (uint32_t y = 0; y < hgt; ++y)
         for (uint32_t x = 0; x < w; ++x) {
             g_seq = events + (size_t(y) * w + x) * cap; g_seq_len = 0; g_seq_cap = cap;
-            shade_pixel(p, x0 + x, y0 + y, 0, stack.data(), tstart ? tstart[size_t(y) * w + x] : 0.0f);
+            shade_pixel(p, x0 + x, y0 + y, 0, stack.data(), tstart ? tstart[size_t(y) * w + x] : 0.0f, keep_lohi.data(), keep_base.data());
         }
     g_seq = nullptr; g_kind = 0;
 }
@@ -213,7 +221,11 @@ void hh_trace_rect_stats2(const void* h, const blok_camera* cam, uint32_t width,
         }
 }
 
-void hh_stat_totals(uint64_t* totals) { std::memcpy(totals, g_stat, sizeof(g_stat)); }
+void hh_stat_totals(uint64_t* totals) { std::memcpy(totals, g_stat, 5 * 8 * sizeof(uint64_t)); }      // events 0-4 (older scripts size their array for five)
+void hh_stat_totals8(uint64_t* totals) { std::memcpy(totals, g_stat, sizeof(g_stat)); }
+void hh_set_path_resume(uint32_t enabled) { g_resume = enabled; }
+void hh_stat_reset() { std::memset(g_stat, 0, sizeof(g_stat)); std::memset(g_kstat, 0, sizeof(g_kstat)); }
+void hh_stat_by_kind(uint64_t* totals) { std::memcpy(totals, g_kstat, sizeof(g_kstat)); }
 
 // Per-ray iteration counts for a frame (row-major), plus the event totals [4][8].
 void hh_trace_primary_stats(const void* h, const blok_camera* cam, uint32_t width, uint32_t height, blok_hit* out,
@@ -233,7 +245,7 @@ void hh_trace_primary_stats(const void* h, const blok_camera* cam, uint32_t widt
             for (int l = 0; l < 8; ++l) after += g_stat[0][l];
             iters_per_ray[size_t(y) * width + x] = uint32_t(after - before);
         }
-    std::memcpy(totals, g_stat, sizeof(g_stat));
+    std::memcpy(totals, g_stat, 5 * 8 * sizeof(uint64_t));
 }
 
 void hh_trace_primary(const void* h, const blok_camera* cam, uint32_t width, uint32_t height, blok_hit* out) {

@@ -8,6 +8,8 @@
 
 struct uint4 { uint32_t x, y, z, w; };
 inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
+struct uint2 { uint32_t x, y; };
+inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
 typedef void* hipStream_t;
 
 inline int __mul24(int a, int b) { return a * b; }

@@ -18,12 +18,29 @@ def declared_functions(header: Path):
 
 
 def test_hip_library_exports_every_declared_symbol():
+    """Both headers: blok_hip.h is the drop-in surface (what a reference-side binding includes), blok_hip_debug.h the diagnostics,
+    test hooks and tuning knobs beside it.  Every declared name is exported, every binding is declared, nothing is declared twice."""
     names = declared_functions(ROOT / "include" / "blok_hip.h")
-    assert len(names) >= 18
+    debug = declared_functions(ROOT / "include" / "blok_hip_debug.h")
+    assert len(names) >= 18 and len(debug) >= 6
+    assert not set(names) & set(debug), "declared in both headers"
     lib = C.CDLL(str(_ffi.HIP_LIB))
-    for n in names:
+    for n in names + debug:
         assert hasattr(lib, n), f"libblok_hip.so does not export {n}"
-    assert set(names) == set(_ffi.HIP_SYMBOLS), "python bindings out of sync with include/blok_hip.h"
+    assert set(names) | set(debug) == set(_ffi.HIP_SYMBOLS), "python bindings out of sync with include/blok_hip.h + blok_hip_debug.h"
+
+
+def test_drop_in_header_carries_no_hooks_or_launch_knobs():
+    """the surface a maintainer links against holds lifecycle, world, trace, paths, post, volume, multi — no test hook, no
+    experiment switch.  (reference surface: blok/include/cuda_tracer.hpp:23-58, blok/include/renderer.hpp:29-77)"""
+    names = declared_functions(ROOT / "include" / "blok_hip.h")
+    for n in names:
+        assert "debug" not in n, n
+    for knob in ("blok_hip_set_fused", "blok_hip_set_beam_budget", "blok_hip_set_miss_writer", "blok_hip_set_list_classes", "blok_hip_set_joint_prefix_limit",
+                 "blok_hip_beam_prepass", "blok_hip_trace_wave_tiles_device", "blok_hip_set_tile_ordering", "blok_hip_set_moving_order"):
+        assert knob not in names, knob
+    mirror = (ROOT / "include" / "blok" / "hip_tracer.hpp").read_text()
+    assert "blok_hip_debug.h" not in mirror, "the C++ mirror must build against the drop-in header alone"
 
 
 def test_host_library_exports_every_declared_symbol():
@@ -81,7 +98,7 @@ def test_headers_compile_as_c11_and_the_mirror_as_cxx20(tmp_path):
     """The boundary is a C ABI: both headers must be consumable from plain C (the reference-side binding could be C, cgo, JNI ...)."""
     import subprocess
     src = tmp_path / "abi.c"
-    src.write_text('#include "blok_hip.h"\n#include "blok_world.h"\nint main(void) { return (int)sizeof(blok_hit) - 16; }\n')
+    src.write_text('#include "blok_hip.h"\n#include "blok_hip_debug.h"\n#include "blok_world.h"\nint main(void) { return (int)sizeof(blok_hit) - 16; }\n')
     r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-pedantic", "-Werror", f"-I{ROOT / 'include'}", "-fsyntax-only", str(src)],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr

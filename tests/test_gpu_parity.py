@@ -705,6 +705,84 @@ def test_list_launches_equal_the_two_launch_form(tracer_cls, scene1024):
     tr.shutdown(); ref.shutdown(); other.shutdown()
 
 
+def test_alternating_rectangles_with_three_streams_in_flight(tracer_cls, scene1024):
+    """a change of launch geometry used to leave the held markers of the LAST ADOPTION in place, which cover the readers of the
+    other order buffer — the first sort of the new rectangle could rewrite the buffer frames in flight on other streams were still
+    walking in.  Now the markers are held at the change too.  Two rectangles alternate every few frames, three streams in flight, the
+    sort due after every frame (interval 1): every frame equals the frame of a context with ordering off; then a stream is released
+    (blok_hip_release_stream) and the context goes on."""
+    import torch
+    cm, pw = scene1024
+    Wd, Ht = 3840, 2160
+    a, b = tracer_cls(Wd, Ht).init(), tracer_cls(Wd, Ht).init()
+    a.add_world(pw); b.add_world(pw)
+    a.set_tile_ordering(1); b.set_tile_ordering(False)
+    cam = W.scene_camera(1024, 0, Wd, Ht, SEED)
+    rects = [(0, 0, 3840, 2160), (256, 128, 3072, 1728)]
+    want = []
+    for r in rects:
+        h = torch.zeros((r[2] * r[3], 4), dtype=torch.int32, device="cuda")
+        b.draw_frame_device(cam, h.data_ptr(), 0, rect=r); torch.cuda.synchronize()
+        want.append(h)
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    outs = [[torch.zeros_like(w) for w in want] for _ in streams]
+    issued = []
+    for k in range(36):
+        which = (k // 4) % 2                             # four frames of one rectangle, then four of the other, no synchronisation in between
+        j = k % 3
+        if k >= 3 and k % 3 == 0:                        # the three frames issued a round ago have to be checked before their buffers are reused
+            for s_ in streams: s_.synchronize()
+            for jj, ww in issued[-3:]:
+                assert torch.equal(outs[jj][ww], want[ww]), (k, jj, ww)
+        with torch.cuda.stream(streams[j]):                # (torch's side streams do not wait for its default stream: the fill goes where the frame goes)
+            outs[j][which].fill_(7)
+        a.draw_frame_device(cam, outs[j][which].data_ptr(), 0, rect=rects[which], stream=streams[j].cuda_stream)
+        issued.append((j, which))
+    torch.cuda.synchronize()
+    for jj, ww in issued[-3:]:
+        assert torch.equal(outs[jj][ww], want[ww])
+    # a caller that destroys a stream tells the context first; the others go on, and so does a new stream
+    a.release_stream(streams[2].cuda_stream)
+    streams[2] = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for k in range(6):
+        a.draw_frame_device(cam, outs[k % 3][0].data_ptr(), 0, rect=rects[0], stream=streams[k % 3].cuda_stream)
+    torch.cuda.synchronize()
+    for o in outs:
+        assert torch.equal(o[0], want[0])
+    a.shutdown(); b.shutdown()
+
+
+def test_list_launches_on_rectangles_smaller_than_their_segments(tracer_cls, scene1024):
+    """ADVICE r3: list forms 4 and 5 over fewer than 8 beam tiles — the segments beyond the last search have no search to finalise them;
+    their walk workgroups used to spin out the whole poll budget (~1 ms) and trip the stall counter.  Rectangles of 1, 2, 3 and 7 beam
+    tiles (and a cut one), forms 4 and 5: frames equal the two-launch form's, no wave ever gave up, and a launch is not a millisecond."""
+    import torch, time
+    cm, pw = scene1024
+    Wd, Ht = 3840, 2160
+    ref = tracer_cls(Wd, Ht).init(); ref.add_world(pw); ref.set_fused(0)
+    tr = tracer_cls(Wd, Ht).init(); tr.add_world(pw)
+    cam = W.scene_camera(1024, 0, Wd, Ht, SEED)
+    for form in (4, 5):
+        tr.set_fused(form)
+        for rect in ((1800, 1100, 32, 32), (1800, 1100, 64, 32), (1800, 1100, 96, 32), (1700, 1100, 224, 32), (1811, 1103, 50, 40)):
+            for k in range(3):
+                got = tr.draw_frame(cam, rect).reshape(-1)
+                assert records_equal(got, ref.draw_frame(cam, rect).reshape(-1)).all(), (form, rect, k)
+            assert got["hit"].any(), rect
+        assert tr.frame_queue_stalls() == 0, form
+    # and it does not take a poll budget: 20 launches of the smallest rectangle
+    hits = torch.zeros((32 * 32, 4), dtype=torch.int32, device="cuda")
+    tr.set_fused(4)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(20):
+        tr.draw_frame_device(cam, hits.data_ptr(), 0, rect=(1800, 1100, 32, 32))
+    torch.cuda.synchronize()
+    per_launch = (time.perf_counter() - t0) / 20
+    assert per_launch < 0.5e-3, per_launch
+    tr.shutdown(); ref.shutdown()
+
+
 
 def test_degenerate_cameras_are_refused(tracer_cls, scene64):
     """A camera with a non-finite component or a zero field of view is an argument error (every ray would be NaN and the

@@ -62,6 +62,34 @@ def test_kernel_body_matches_oracle_on_cpu(world64, pose, spp, bounces):
     assert np.isfinite(ref["color"]).all() and (ref["color"][..., 3] == 1).all()
 
 
+@pytest.mark.parametrize("pose,spp,bounces", [(0, 6, 2), (1, 5, 4), (2, 3, 3)])
+def test_walks_entered_from_the_anchor_equal_walks_from_the_root_on_cpu(world64, pose, spp, bounces):
+    """walk_resume (trace_core.h): every ray of a pixel that has an anchor — shadow and bounce rays next to it, later samples' primary rays,
+    later bounces from their own hits — enters the walk from the anchor's ancestors: verified start voxel, lowest common ancestor from
+    the (restored) stack, launch pad.  The kernel body on the CPU must give the SAME planes bit for bit with it on and off (and the
+    libm-pow build still equals the oracle, test above, which runs with it off), and must actually take the path (event counts)."""
+    import ctypes as C
+    pw, mats, lat = world64
+    hk = H.HostKernel(pw.nodes, pw.sub_chunks)
+    L = H.lib()
+    L.hh_set_path_resume.argtypes = [C.c_uint32]; L.hh_stat_totals8.argtypes = [C.c_void_p]
+    cams = [W.scene_camera(64, pose, 80, 60, SEED)]
+    inside = cams[0].copy(); inside["pos"][0] = (30.5, 40.2, 33.1); cams.append(inside)           # primary rays start inside the box: they resume too
+    try:
+        for cam in cams:
+            L.hh_set_path_resume(0)
+            plain = hk.render_paths(cam, mats, 80, 60, spp=spp, max_bounces=bounces, frame_index=7)
+            L.hh_set_path_resume(1); L.hh_stat_reset()
+            got = hk.render_paths(cam, mats, 80, 60, spp=spp, max_bounces=bounces, frame_index=7)
+            tot = np.zeros((8, 8), dtype=np.uint64); L.hh_stat_totals8(C.c_void_p(tot.ctypes.data))
+            for k in plain:
+                assert plain[k].tobytes() == got[k].tobytes(), k
+            walks, resumed, pad = int(tot[4].sum()), int(tot[5].sum()), int(tot[6].sum())
+            assert resumed > 0.2 * walks and pad > 0, (walks, resumed, pad)
+    finally:
+        L.hh_set_path_resume(0)
+
+
 def test_gbuffer_agrees_with_first_hit_records(world64):
     """The G-buffer of sample 0 / bounce 0 is the first-hit record seen through hit.rchit."""
     pw, mats, lat = world64
@@ -293,3 +321,69 @@ def test_prepasses_random_cameras_path_frames():
             for name in plain:
                 assert got[name].tobytes() == plain[name].tobytes(), (k, mode, name)
     tr.shutdown()
+
+
+@pytest.mark.gpu
+def test_path_start_options_do_not_change_path_traced_frames(world64):
+    """blok_hip_set_path_start: rays entered from the pixel's anchor or from the root, wave-tile beam on or off — all four combinations give
+    the same planes bit for bit: the small world (odd frame, poses outside / inside / under overhangs, 1-5 bounces, 1-9 spp), random
+    cameras over the adversarial world of the pre-pass test (thin wall, isolated far voxels, negative coordinates), a voxel size of 1/2,
+    and 4K rectangles of the 1024^3 and 2048^3 worlds (5 and 6 tree levels: the side area has 3 and 4 entries)."""
+    from blok_amd.tracer import HipTracer
+    from tests.conftest import make_scene_world
+    pw, mats, _ = world64
+    combos = ((0, 0), (1, 0), (0, 1), (1, 1))
+
+    def same_in_all(tr, cam, tag, **kw):
+        ref = None
+        for resume, fine in combos:
+            tr.set_path_start(resume, fine)
+            got = tr.trace_paths(cam, **kw)
+            if ref is None: ref = got
+            for k in ref:
+                assert got[k].tobytes() == ref[k].tobytes(), (tag, resume, fine, k)
+        tr.set_path_start(False, True)                   # the defaults
+
+    tr = HipTracer(203, 117).init()
+    tr.add_world(pw)
+    cams = [W.scene_camera(64, pose, 203, 117, SEED) for pose in (0, 1, 2)]
+    inside = cams[0].copy(); inside["pos"][0] = (30.5, 40.2, 33.1); cams.append(inside)
+    cams.append(W.camera_look_at((5.0, 8.0, 5.0), (40.0, 12.0, 40.0), 70.0, 203, 117))
+    for i, cam in enumerate(cams):
+        same_in_all(tr, cam, ("small", i), spp=(1, 9, 4, 6, 5)[i], max_bounces=(2, 2, 5, 3, 1)[i], frame_index=2 + i)
+    tr.shutdown()
+    # adversarial world, random cameras
+    rng = np.random.default_rng(78)
+    cm = W.ChunkManager(128, 1.0)
+    pts = rng.integers(-40, 40, size=(5000, 3)).astype(np.int32)
+    wall = np.array([(x, y, 17) for x in range(-60, 60) for y in range(-30, 30)], dtype=np.int32)
+    roof = np.array([(x, 45, z) for x in range(-50, 50) for z in range(-50, 50) if (x + z) % 7], dtype=np.int32)
+    far = np.array([(-200, 90, -170), (211, -3, 140)], dtype=np.int32)
+    xyz = np.concatenate([pts, wall, roof, far])
+    cm.set_voxels(xyz, (rng.integers(1, 200, size=len(xyz))).astype(np.uint32))
+    cm.rebuild_dirty_chunks()
+    adv = cm.pack_chunks_to_gpu_svo(W.scene_materials(SEED))
+    w, h = 117, 71
+    tr = HipTracer(w, h).init()
+    tr.add_world(adv)
+    for k in range(12):
+        eye = rng.normal(0.0, (25.0, 70.0, 300.0)[k % 3], 3)
+        target = rng.normal(0.0, 20.0, 3)
+        cam = W.camera_look_at(tuple(float(v) for v in eye), tuple(float(v) for v in target), float(rng.uniform(10.0, 140.0)), w, h)
+        same_in_all(tr, cam, ("adversarial", k), spp=3, max_bounces=3, frame_index=k)
+    tr.shutdown()
+    # a power-of-two voxel size other than 1 (the start voxel's guess divides by it; the planes scale)
+    cmh = W.ChunkManager(128, 0.5)
+    cmh.generate_scene(64, SEED); cmh.rebuild_dirty_chunks()
+    half = cmh.pack_chunks_to_gpu_svo(mats)
+    tr = HipTracer(160, 100).init(); tr.set_voxel_size(0.5); tr.add_world(half)
+    cam = W.camera_look_at((-11.0, 27.0, -11.0), (16.0, 8.0, 16.0), 60.0, 160, 100)
+    same_in_all(tr, cam, "voxel size 1/2", spp=4, max_bounces=3, frame_index=1)
+    tr.shutdown()
+    for n, rect in ((1024, (1400, 800, 640, 320)), (2048, (1500, 900, 384, 192))):
+        cm, big = make_scene_world(n)
+        tr = HipTracer(3840, 2160).init()
+        tr.add_world(big)
+        for pose in (0, 1):
+            same_in_all(tr, W.scene_camera(n, pose, 3840, 2160, SEED), (n, pose), spp=4, max_bounces=2 + pose, frame_index=1, rect=rect)
+        tr.shutdown()
