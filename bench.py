@@ -326,6 +326,22 @@ def main():
     if world_size == 1 and args.orbit == 0.0 and not args.dense_dda:
         moving = HipBackend(tracer, cam)
         kernel_ms_moving = solitary_ms(moving, 16, orbit_arc(1.0))
+    # ... for a caller that alternates between two fixed views (stereo eyes, a cut back and forth): each view has its own cached order from its
+    # second appearance on (round 4) — and for the first frame of a view never seen before (no scheduling state at all: row-major order)
+    kernel_ms_alternating = kernel_ms_cold = None
+    if world_size == 1 and args.orbit == 0.0 and not args.dense_dda:
+        two = [cam, orbit_arc(6.0)[1]]
+        alt = HipBackend(tracer, cam)
+        solitary_ms(alt, 10, two)                                  # each view a few times, its sort, its adoption: untimed, like --settle for the one view
+        kernel_ms_alternating = solitary_ms(alt, 16, two)
+        tracer.set_timing(True)
+        cold = []
+        for k in range(4):
+            alt.cam = orbit_arc(50.0 + 17.0 * k)[1]
+            alt.trace_full(pipe.hits, pipe._frame[0], stream.cuda_stream); torch.cuda.synchronize()
+            cold.append(tracer.last_kernel_ms())
+        tracer.set_timing(False)
+        kernel_ms_cold = float(np.mean(cold))
     local_hits = (pipe.hits[:, 3] >> 24).sum()
     if dist is not None:
         dist.all_reduce(local_hits)
@@ -467,6 +483,13 @@ def main():
                                           + ("walked in the previous frame's dilated order carried over by a whole-tile shift; the three 4-5 us launches that keep that order follow each frame on its stream and are "
                                              "NOT in kernel_ms_moving (wall-clock period of synchronised frames with them: 257 us against 274 us in row-major order, profiles/r03_moving_order_solitary_frames.txt)"
                                              if args.moving_order else "row-major order")) if kernel_ms_moving else None,
+                               "frac_alternating": (alg["bytes_per_ray"] * rays_per_launch / (kernel_ms_alternating * 1e-3) / 1e9 / HBM_PEAK_GBS) if kernel_ms_alternating else None,
+                               "kernel_ms_alternating": kernel_ms_alternating,
+                               "frac_cold": (alg["bytes_per_ray"] * rays_per_launch / (kernel_ms_cold * 1e-3) / 1e9 / HBM_PEAK_GBS) if kernel_ms_cold else None,
+                               "kernel_ms_cold": kernel_ms_cold,
+                               "alternating_and_cold": ("the same launch alone (pose-A bytes per ray) for a caller alternating between two fixed views 6 degrees apart, each walking in its own cached "
+                                                        "order (12 untimed frames first); and for the FIRST frame of four views never seen before, 17 degrees apart: no order, no live prefix, "
+                                                        "row-major joint launch — the figure that uses no scheduling state at all") if kernel_ms_alternating else None,
                                "physical": physical,
                                "kernel": launch, "kernel_ms": kernel_ms_avg,
                                "timing": f"HIP events around single launches, one at a time on an otherwise idle chip; {args.settle} settle + {args.warmup} warmup frames before the timed region, 2 unmeasured launches before the single ones",

@@ -328,10 +328,14 @@ static bool camera_near(const blok_hip_ctx* ctx, const blok_camera& a, const blo
 
 static void free_order(blok_hip_ctx* ctx) {
     auto& O = ctx->order;
-    for (void* p : {static_cast<void*>(O.d_cost), static_cast<void*>(O.d_iota), static_cast<void*>(O.d_order[0]), static_cast<void*>(O.d_order[1]), static_cast<void*>(O.d_rank_of[0]),
-                    static_cast<void*>(O.d_rank_of[1]), static_cast<void*>(O.d_keys_in), static_cast<void*>(O.d_keys), O.d_class_scratch, O.d_temp})
+    for (void* p : {static_cast<void*>(O.d_cost), static_cast<void*>(O.d_iota), static_cast<void*>(O.d_keys_in), static_cast<void*>(O.d_keys), O.d_class_scratch, O.d_temp})
         if (p) (void)hipFree(p);
-    O.d_cost = O.d_iota = O.d_order[0] = O.d_order[1] = O.d_rank_of[0] = O.d_rank_of[1] = O.d_keys_in = O.d_keys = nullptr; O.d_class_scratch = nullptr;
+    for (auto& sl : O.slots) {
+        if (sl.d_order) (void)hipFree(sl.d_order);
+        if (sl.d_rank_of) (void)hipFree(sl.d_rank_of);
+        sl = blok_hip_ctx::TileOrder::Slot{};
+    }
+    O.d_cost = O.d_iota = O.d_keys_in = O.d_keys = nullptr; O.d_class_scratch = nullptr;
     O.d_temp = nullptr; O.capacity = 0;
 }
 
@@ -340,15 +344,20 @@ static void free_order(blok_hip_ctx* ctx) {
 // resizes between launches: a device-wide wait, because frames in flight and a pending sort may use the old buffers).
 int order_buffers(blok_hip_ctx* ctx, uint32_t blocks, hipStream_t stream) {
     auto& O = ctx->order;
+    constexpr int kSlots = blok_hip_ctx::TileOrder::kSlots;
     const uint32_t want = std::max<uint32_t>(blocks, blok::rect_grid_blocks(ctx->width, ctx->height));
     if (O.capacity >= want) return BLOK_OK;
     BLOK_HIP_TRY(ctx, hipDeviceSynchronize());
     free_order(ctx);
     const size_t bytes = static_cast<size_t>(want) * sizeof(uint32_t);
-    for (uint32_t** p : {&O.d_cost, &O.d_iota, &O.d_order[0], &O.d_order[1], &O.d_rank_of[0], &O.d_rank_of[1], &O.d_keys_in, &O.d_keys})
+    for (uint32_t** p : {&O.d_cost, &O.d_iota, &O.d_keys_in, &O.d_keys})
         BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(p), bytes));
-    if (!O.h_live) BLOK_HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&O.h_live), 2 * sizeof(uint32_t), hipHostMallocDefault));
-    if (!O.h_depth) BLOK_HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&O.h_depth), 2 * blok::kOrderDepthPartials * 3 * sizeof(float), hipHostMallocDefault));
+    for (auto& sl : O.slots) {
+        BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&sl.d_order), bytes));
+        BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&sl.d_rank_of), bytes));
+    }
+    if (!O.h_live) BLOK_HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&O.h_live), kSlots * sizeof(uint32_t), hipHostMallocDefault));
+    if (!O.h_depth) BLOK_HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&O.h_depth), kSlots * blok::kOrderDepthPartials * 3 * sizeof(float), hipHostMallocDefault));
     if (!O.h_fallback) { BLOK_HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&O.h_fallback), sizeof(uint32_t), hipHostMallocDefault)); *O.h_fallback = 0u; }
     if (!O.d_fallback) BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&O.d_fallback), sizeof(uint32_t)));
     O.temp_bytes = blok::tile_order_temp_bytes(want);
@@ -359,63 +368,84 @@ int order_buffers(blok_hip_ctx* ctx, uint32_t blocks, hipStream_t stream) {
     BLOK_HIP_TRY(ctx, hipMemsetAsync(O.d_cost, 0, bytes, stream));
     O.capacity = want;
     std::memset(O.key, 0xFF, sizeof(O.key));
-    O.current = -1; O.pending = false; O.orphan = false;
+    O.current = -1; O.chosen = -1; O.pending = false; O.orphan = false; O.n_recent = 0;
     return BLOK_OK;
 }
 
 // Before an orderable launch: adoption of a finished sort, the plan; fills args.order / rank_of / launched / cost_out.
 static int order_before_launch(blok_hip_ctx* ctx, blok::TraceArgs& args, uint32_t blocks, hipStream_t stream, bool alone, blok::OrderPlan* plan) {
     auto& O = ctx->order;
+    constexpr int kSlots = blok_hip_ctx::TileOrder::kSlots;
     const uint32_t key[7] = {args.x0, args.y0, args.w, args.h, ctx->width, ctx->height, ctx->world_version};
     if (O.capacity < blocks) { const int rc = order_buffers(ctx, blocks, stream); if (rc != BLOK_OK) return rc; }      // (never after create / resize: a rectangle has no more tiles than the frame)
+    O.launch_serial += 1;
     if (std::memcmp(key, O.key, sizeof(key)) != 0) {
-        // another launch geometry starts in natural order with no costs; in stream order, nothing waits (a sort still pending for the old
-        // geometry finishes into a buffer nobody will adopt: its event is simply never asked again)
+        // another launch geometry starts in natural order with no costs and no views; in stream order, nothing waits (a sort still pending
+        // for the old geometry finishes into a slot nobody will adopt: its event is simply never asked again)
         BLOK_HIP_TRY(ctx, hipMemsetAsync(O.d_cost, 0, static_cast<size_t>(blocks) * sizeof(uint32_t), stream));
         std::memcpy(O.key, key, sizeof(key));
         O.orphan = O.orphan || O.pending;                                    // (a sort of the old geometry may still be writing an order buffer)
-        // ... and frames in flight on other streams may still be READING the buffer that was current: the first sort of the new geometry,
-        // whichever buffer it targets, waits for the markers held from here (without this it waited for the markers of the last
+        // ... and frames in flight on other streams may still be READING the slots that were in use: the first sort of the new geometry,
+        // whichever slot it targets, waits for the markers held from here (without this it waited for the markers of the last
         // adoption only, which cover the readers of the other buffer)
-        hold_markers(ctx);
-        O.current = -1; O.pending = false; O.frames_since_sort = 0; O.still_frames = 0; O.interval_now = O.interval; O.have_residual = false;
+        hold_markers(ctx); O.hold_serial = O.launch_serial;
+        for (auto& sl : O.slots) { sl.valid = false; sl.last_use = 0; }
+        O.current = -1; O.pending = false; O.still_frames = 0; O.interval_now = O.interval; O.have_residual = false; O.n_recent = 0; O.revisit_streak = 0;
     }
     if (O.pending && hipEventQuery(O.done) == hipSuccess) {              // the sort launched some frames ago has finished
-        O.current = O.target;
-        O.live[O.current] = O.h_live[O.current];                         // written by the device before the event
-        if (O.dilated[O.current]) {
+        auto& sl = O.slots[O.target];
+        sl.valid = true; sl.dilated = O.pending_dilated; sl.radius = O.pending_radius; sl.cam = O.pending_cam;
+        sl.live = O.h_live[O.target];                                    // written by the device before the event
+        sl.frames_since_sort = 0; sl.interval_now = O.pending_interval; sl.last_use = 0;
+        if (sl.dilated) {
             // the frame's depths: mean and standard deviation of its live beam tiles' inverse start parameters, from the sort's partial sums
             double cnt = 0.0, s1 = 0.0, s2 = 0.0;
-            const float* part = O.h_depth + O.current * blok::kOrderDepthPartials * 3;
+            const float* part = O.h_depth + O.target * blok::kOrderDepthPartials * 3;
             for (uint32_t k = 0; k < blok::kOrderDepthPartials; ++k) { cnt += part[k * 3]; s1 += part[k * 3 + 1]; s2 += part[k * 3 + 2]; }
             const double mean = cnt > 0.0 ? s1 / cnt : 0.0, var = cnt > 0.0 ? s2 / cnt - mean * mean : 0.0;
-            O.inv_depth[O.current][0] = static_cast<float>(mean); O.inv_depth[O.current][1] = static_cast<float>(var > 0.0 ? std::sqrt(var) : 0.0);
+            sl.inv_depth[0] = static_cast<float>(mean); sl.inv_depth[1] = static_cast<float>(var > 0.0 ? std::sqrt(var) : 0.0);
         }
-        O.pending = false; O.frames_since_sort = 0;
-        // From here on no launch reads the OTHER buffer any more; the launches that may still be reading it are those already issued, on
-        // any stream of this context.  The marker each stream left behind its latest launch is held from now: what the next sort — which
-        // overwrites that buffer, many launches from now — has to wait for: long past by then, so the sort never holds up the frames in
+        // an older order of the same view, and older orders made to be carried (only the latest is of use), make room
+        for (int k = 0; k < kSlots; ++k)
+            if (k != O.target && O.slots[k].valid && (O.slots[k].dilated || (!sl.dilated && camera_near(ctx, sl.cam, O.slots[k].cam)))) O.slots[k].valid = false;
+        O.current = O.target; O.pending = false;
+        // From here on the slots just retired are read by no new launch; the launches that may still be reading them are those already
+        // issued, on any stream of this context.  The marker each stream left behind its latest launch is held from now: what a later sort —
+        // which overwrites such a slot, many launches from now — has to wait for: long past by then, so the sort never holds up the frames in
         // flight (waiting for the streams' LATEST launches instead did: a bubble in the three-deep pipeline per sort, 5 % of a 20-frame run).
-        hold_markers(ctx);
+        hold_markers(ctx); O.hold_serial = O.launch_serial;
     }
     (void)hipGetLastError();                                             // hipErrorNotReady is an answer, not a failure
+    // the order this launch may walk in: its own view's if the cache has one, else the one adopted last (a carried order, if it is dilated)
+    int own = -1;
+    for (int k = 0; k < kSlots; ++k)
+        if (O.slots[k].valid && !O.slots[k].dilated && camera_near(ctx, args.cam, O.slots[k].cam) && (own < 0 || O.slots[k].last_use > O.slots[own].last_use)) own = k;
+    const int chosen = own >= 0 ? own : O.current;
+    // At rest: the previous launch's view — or, for a caller that alternates between fixed views, one of the few before it, once that has
+    // happened three launches running (a camera that swings back and forth passes through a view of two launches ago at every turn: that is
+    // motion, and keeps the moving camera's carried order)
+    const bool rest = camera_near(ctx, args.cam, O.last_cam);
+    bool revisit = false;
+    for (uint32_t k = 0; k < O.n_recent && !rest && !revisit; ++k) revisit = camera_near(ctx, args.cam, O.recent[k]);
+    O.revisit_streak = revisit ? O.revisit_streak + 1u : (rest ? O.revisit_streak : 0u);
+    const bool seen = rest || (revisit && O.revisit_streak >= 3u);
     blok::OrderFacts f{};
-    f.enabled = true; f.have_order = O.current >= 0;
-    f.near_order_view = f.have_order && camera_near(ctx, args.cam, O.cam[O.current]);
-    f.near_last_view = camera_near(ctx, args.cam, O.last_cam);
+    f.enabled = true; f.have_order = chosen >= 0 && O.slots[chosen].valid;
+    f.near_order_view = f.have_order && own >= 0;
+    f.near_last_view = seen;
     f.sort_pending = O.pending; f.still_frames = O.still_frames;
-    f.frames_since_sort = O.frames_since_sort; f.interval = O.interval; f.interval_now = O.interval_now;
+    f.frames_since_sort = own >= 0 ? O.slots[own].frames_since_sort : 0u; f.interval = O.interval; f.interval_now = own >= 0 ? O.slots[own].interval_now : O.interval_now;
     f.moving_enabled = O.moving; f.alone = alone; f.alone_before = O.alone_before; O.alone_before = alone;
-    f.order_dilated = f.have_order && O.dilated[O.current];
+    f.order_dilated = f.have_order && O.slots[chosen].dilated;
     blok::ShiftPlan shift{};
     if (f.order_dilated && f.moving_enabled && f.alone) {
         blok::ShiftFacts sf{};
         static_assert(sizeof(blok::PolicyCamera) == sizeof(blok_camera), "launch_policy.h: PolicyCamera is blok_camera");
-        std::memcpy(&sf.then, &O.cam[O.current], sizeof(blok_camera)); std::memcpy(&sf.now, &args.cam, sizeof(blok_camera));
-        sf.inv_depth_mean = O.inv_depth[O.current][0]; sf.inv_depth_sigma = O.inv_depth[O.current][1];
+        std::memcpy(&sf.then, &O.slots[chosen].cam, sizeof(blok_camera)); std::memcpy(&sf.now, &args.cam, sizeof(blok_camera));
+        sf.inv_depth_mean = O.slots[chosen].inv_depth[0]; sf.inv_depth_sigma = O.slots[chosen].inv_depth[1];
         sf.frame_w = ctx->width; sf.frame_h = ctx->height;
         sf.tiles_x = (args.w + blok::kTileW - 1u) / blok::kTileW; sf.tiles_y = (args.h + blok::kTileH - 1u) / blok::kTileH; sf.tile_w = blok::kTileW; sf.tile_h = blok::kTileH;
-        sf.radius = O.radius[O.current];
+        sf.radius = O.slots[chosen].radius;
         shift = blok::plan_shift(sf);
         f.shift_ok = shift.ok;
         // what the shift leaves over sizes the next dilation and the strips — also when it is too large to use, the next dilation grows with it —
@@ -425,12 +455,15 @@ static int order_before_launch(blok_hip_ctx* ctx, blok::TraceArgs& args, uint32_
     }
     *plan = blok::plan_order(f);
     O.still_frames = plan->still_frames; O.last_cam = args.cam;
-    args.order = plan->use_order ? O.d_order[O.current] : nullptr;
+    { for (uint32_t k = std::min<uint32_t>(O.n_recent, 3u); k > 0; --k) O.recent[k] = O.recent[k - 1]; O.recent[0] = args.cam; O.n_recent = std::min<uint32_t>(O.n_recent + 1u, 4u); }
+    O.chosen = plan->use_order ? chosen : -1;
+    args.order = plan->use_order ? O.slots[chosen].d_order : nullptr;
     args.cost_out = plan->measure ? O.d_cost : nullptr;
     args.order_sx = args.order_sy = 0u;
     O.last_use = plan->use_order ? (plan->shifted ? 2 : 1) : 0; O.last_sx = O.last_sy = 0u;
     if (args.order) {
-        args.rank_of = O.d_rank_of[O.current]; args.launched = O.live[O.current];
+        O.slots[chosen].last_use = O.launch_serial;
+        args.rank_of = O.slots[chosen].d_rank_of; args.launched = O.slots[chosen].live;
         if (plan->shifted) { args.order_sx = O.last_sx = shift.sx; args.order_sy = O.last_sy = shift.sy; }
         if (O.debug_shift) {                                             // any shift of any order is a permutation: the frame must not change
             const uint32_t tiles_x = (args.w + blok::kTileW - 1u) / blok::kTileW, tiles_y = (args.h + blok::kTileH - 1u) / blok::kTileH;
@@ -444,32 +477,48 @@ static int order_before_launch(blok_hip_ctx* ctx, blok::TraceArgs& args, uint32_
 // the hardware queues the frame streams and the null stream occupy: measured, that alone costs 18 % of the pipelined rate).
 static int order_after_launch(blok_hip_ctx* ctx, const blok::TraceArgs& args, uint32_t blocks, uint32_t n_beams, hipStream_t stream, const blok::OrderPlan& plan) {
     auto& O = ctx->order;
-    O.frames_since_sort += 1;
-    O.interval_now = plan.next_interval_now;
+    constexpr int kSlots = blok_hip_ctx::TileOrder::kSlots;
+    if (O.chosen >= 0) { auto& sl = O.slots[O.chosen]; sl.frames_since_sort += 1; if (!sl.dilated) sl.interval_now = plan.next_interval_now; }
+    else O.interval_now = plan.next_interval_now;
     if (!plan.start_sort) return BLOK_OK;
-    const int target = O.current == 0 ? 1 : 0;
-    // Nothing still running may read the target buffer: it was last current before the previous adoption (or change of geometry), and
-    // everything issued before that is in front of the markers held then (order_before_launch).
+    // The slot to sort into: not the one this launch walks in; an empty one if there is one, else a retired-in-all-but-name dilated order, else
+    // the view walked in longest ago.
+    int target = -1;
+    for (int pass = 0; pass < 3 && target < 0; ++pass)
+        for (int k = 0; k < kSlots; ++k) {
+            if (k == O.chosen) continue;
+            const auto& sl = O.slots[k];
+            const bool fits = pass == 0 ? !sl.valid : (pass == 1 ? (sl.dilated && k != O.current) : true);
+            if (fits && (target < 0 || (pass == 2 && sl.last_use < O.slots[target].last_use))) { target = k; if (pass != 2) break; }
+        }
+    if (target < 0) return BLOK_OK;
+    // Nothing still running may read the target: whatever walked in it was issued before the latest holding of the markers (an adoption, a
+    // change of geometry) — or else they are held again now, behind the streams' latest launches (a cache with more views cycling than slots).
+    // (>=: the launch during which the markers were held was itself issued behind them)
+    if (O.slots[target].last_use >= O.hold_serial) { hold_markers(ctx); O.hold_serial = O.launch_serial; }
+    O.slots[target].valid = false;
+    if (O.current == target) O.current = -1;
     { const int rc = wait_for_held_markers(ctx, stream); if (rc != BLOK_OK) return rc; }
     // ... and nothing may still be WRITING it: a sort left behind by a change of launch geometry, possibly on another stream
     if (O.orphan) { BLOK_HIP_TRY(ctx, hipStreamWaitEvent(stream, O.done, 0)); O.orphan = false; }
     uint32_t radius = 0;
+    auto& T = O.slots[target];
     if (plan.dilate) {
         // a camera in motion: a counting sort of the dilated clocks (three small launches; it reads the live cost buffer — any mixture of old
         // and new costs is as good a key, and what it sorts is its own copy), and the frame's depths go along for the next launch's shift
         radius = blok::plan_dilation(O.have_residual, O.last_residual);
         const uint32_t tiles_x = (args.w + blok::kTileW - 1u) / blok::kTileW, tiles_y = (args.h + blok::kTileH - 1u) / blok::kTileH;
-        BLOK_HIP_TRY(ctx, blok::launch_tile_order_class_sort(O.d_cost, tiles_x, tiles_y, radius, O.d_class_scratch, O.d_order[target], O.d_rank_of[target], O.h_live + target,
+        BLOK_HIP_TRY(ctx, blok::launch_tile_order_class_sort(O.d_cost, tiles_x, tiles_y, radius, O.d_class_scratch, T.d_order, T.d_rank_of, O.h_live + target,
                                                              args.beam, args.beam_slots, args.beam_serial, n_beams, O.h_depth + target * blok::kOrderDepthPartials * 3, stream));
     } else {
         // the sort reads a SNAPSHOT of the costs: frames in flight on other streams keep writing the live buffer, and a radix sort that saw a
         // key change between its histogram and its scatter would not produce a permutation
         BLOK_HIP_TRY(ctx, hipMemcpyAsync(O.d_keys_in, O.d_cost, static_cast<size_t>(blocks) * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
-        BLOK_HIP_TRY(ctx, blok::launch_tile_order_sort(O.d_keys_in, O.d_keys, O.d_iota, O.d_order[target], O.d_temp, O.temp_bytes, blocks, stream));
-        BLOK_HIP_TRY(ctx, blok::launch_tile_order_finish(O.d_order[target], O.d_keys, blocks, O.d_rank_of[target], O.h_live + target, stream));
+        BLOK_HIP_TRY(ctx, blok::launch_tile_order_sort(O.d_keys_in, O.d_keys, O.d_iota, T.d_order, O.d_temp, O.temp_bytes, blocks, stream));
+        BLOK_HIP_TRY(ctx, blok::launch_tile_order_finish(T.d_order, O.d_keys, blocks, T.d_rank_of, O.h_live + target, stream));
     }
     BLOK_HIP_TRY(ctx, hipEventRecord(O.done, stream));
-    O.target = target; O.cam[target] = args.cam; O.dilated[target] = plan.dilate; O.radius[target] = radius; O.pending = true;
+    O.target = target; O.pending_cam = args.cam; O.pending_dilated = plan.dilate; O.pending_radius = radius; O.pending_interval = plan.next_interval_now; O.pending = true;
     return BLOK_OK;
 }
 

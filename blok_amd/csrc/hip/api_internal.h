@@ -118,27 +118,40 @@ struct blok_hip_ctx {
     // launch adopts it once hipEventQuery says it is complete — no launch ever waits.  Decisions: launch_policy.h plan_order.
     struct TileOrder {
         bool enabled = true;
-        uint32_t interval = 8, interval_now = 8;          // interval_now grows while the view rests
-        uint32_t *d_cost = nullptr, *d_iota = nullptr, *d_order[2] = {nullptr, nullptr}, *d_rank_of[2] = {nullptr, nullptr};
+        uint32_t interval = 8, interval_now = 8;          // interval_now: of a view that has no order of its own yet (a slot carries its own)
+        uint32_t *d_cost = nullptr, *d_iota = nullptr;
         uint32_t *d_keys_in = nullptr, *d_keys = nullptr;   // the sort's snapshot of the costs, and its sorted keys
         void* d_temp = nullptr;
         size_t temp_bytes = 0, capacity = 0;
-        uint32_t* h_live = nullptr;                         // pinned, two words: how many leading entries of d_order[k] walked (written by the device)
-        uint32_t live[2] = {0, 0};                          // ... as read when the order was adopted
+        // Round 4: a small CACHE of orders per launch geometry, one slot per view (round 3 kept two buffers — the order in use and the one
+        // being sorted — so a caller alternating between two fixed views, stereo eyes or a camera cycle, walked in row-major order for ever).
+        // A slot holds an order sorted from the clocks of the view `cam` (own-view: used by launches from that view only) or from dilated
+        // clocks (made to be carried to the next view by a shift: only the latest such order is of any use).
+        static constexpr int kSlots = 4;
+        struct Slot {
+            uint32_t *d_order = nullptr, *d_rank_of = nullptr;
+            bool valid = false, dilated = false;
+            uint32_t live = 0, radius = 0;                 // leading entries that walked (as read at adoption); dilation it was sorted with
+            blok_camera cam{};                             // the view its clocks were measured under
+            float inv_depth[2] = {};                       // mean and sigma of that frame's live beam tiles' inverse start parameters (dilated orders)
+            uint32_t frames_since_sort = 0, interval_now = 8;      // launches that walked in it; re-sort interval of its view (doubles while the view rests)
+            uint64_t last_use = 0;                         // serial of the latest launch that walked in it
+        } slots[kSlots];
+        uint32_t* h_live = nullptr;                         // pinned, kSlots words: how many leading entries of the slot's order walked (written by the device)
+        float* h_depth = nullptr;                           // pinned, kSlots x 64 x 3 floats: partial count, sum, sum of squares of the live beam tiles' inverse start parameters
         uint32_t key[7] = {};                               // launch rectangle, frame size, world version
-        int current = -1, target = 0;                       // -1: no order yet (natural)
+        int current = -1, target = 0;                       // the slot adopted last (-1: none yet); the slot a pending sort writes
         bool pending = false;
         bool orphan = false;                                // a sort of a previous launch geometry may still be running (the next sort waits for it)
-        uint32_t frames_since_sort = 0, still_frames = 0, prefix_limit = 0;
-        blok_camera cam[2] = {}, last_cam{};                // camera each order buffer was measured under; camera of the last launch
+        uint32_t still_frames = 0, prefix_limit = 0;
+        uint64_t launch_serial = 0, hold_serial = 0;        // orderable launches so far; ... at the latest hold_markers (what the held markers are behind)
+        blok_camera last_cam{};                             // camera of the last launch
+        blok_camera recent[4] = {}; uint32_t n_recent = 0, revisit_streak = 0;  // cameras of the latest launches; consecutive launches from a view seen among them (alternating views are views at rest)
+        blok_camera pending_cam{}; bool pending_dilated = false; uint32_t pending_radius = 0, pending_interval = 8;      // of the sort in flight
         hipEvent_t done = nullptr;
         // a camera in motion (launch_policy.h): orders sorted from dilated clocks, carried to the next view by a whole-tile shift
         bool moving = true;                                 // blok_hip_set_moving_order
         void* d_class_scratch = nullptr;                    // tile_order.h: count table and class bytes of the counting sort
-        bool dilated[2] = {false, false};
-        uint32_t radius[2] = {0, 0};
-        float* h_depth = nullptr;                           // pinned, 2 x 64 x 3 floats: partial count, sum, sum of squares of the live beam tiles' inverse start parameters (written by the device)
-        float inv_depth[2][2] = {};                         // ... mean and sigma as read when the order was adopted
         bool have_residual = false; float last_residual = 0.0f;     // what the latest shift left over (sizes the next dilation)
         bool debug_shift = false; uint32_t debug_sx = 0, debug_sy = 0;      // blok_hip_debug_force_order_shift: every ordered launch uses this shift (tests)
         uint32_t* d_fallback = nullptr;                     // wave tiles the search waves of the latest prefix launch walked themselves (cleared in stream order before it)
@@ -146,6 +159,7 @@ struct blok_hip_ctx {
         uint32_t last_fallback = 0;                         // ... as read before the next launch (blok_hip_last_fallback_tiles)
         bool alone_before = false;                          // the previous orderable launch had the device to itself
         int last_use = 0; uint32_t last_sx = 0, last_sy = 0;        // the latest launch: 0 natural order, 1 an order of its own view, 2 a carried one (blok_hip_last_order_use)
+        int chosen = -1;                                    // the slot the latest launch walked in (-1: none)
     } order;
     // list launches, rectangle frames: clocks per wave tile of the last frame of this launch geometry, and the camera they were measured under (trace_kernels.h: cost classes)
     uint32_t* d_list_cost = nullptr; size_t list_cost_capacity = 0; uint32_t list_cost_key[6] = {};

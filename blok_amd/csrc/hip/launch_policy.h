@@ -111,7 +111,7 @@ inline OrderPlan plan_order(const OrderFacts& f) {
 // the central point at the mean inverse depth, in tiles; `residual` the largest displacement any sample keeps after the shift
 // (Chebyshev, tiles) — parallax and the stretch of a rotation towards the screen's edge.  The order was sorted from costs dilated by
 // `radius` tiles; it is used while the residual stays within twice that (a residual of three radii still beats row-major order, it
-// no longer pays for its sort), the shift within a quarter of the screen and the lens unchanged.
+// no longer pays for its sort) and the shift within a quarter of the screen.
 struct PolicyCamera { float pos[3], fwd[3], right[3], up[3], tan_half_fov, aspect; };      // = blok_camera (include/blok_hip.h)
 struct ShiftFacts {
     PolicyCamera then, now;
@@ -134,8 +134,11 @@ inline bool policy_project(const PolicyCamera& c, const float p[3], float& u, fl
 inline ShiftPlan plan_shift(const ShiftFacts& f) {
     ShiftPlan p{false, 0u, 0u, 0.0f, false};
     if (!f.tiles_x || !f.tiles_y || !f.tile_w || !f.tile_h) return p;
-    const float lens = f.then.tan_half_fov - f.now.tan_half_fov, asp = f.then.aspect - f.now.aspect;
-    if (!(lens < 1e-6f && lens > -1e-6f && asp < 1e-6f && asp > -1e-6f)) return p;
+    // A change of lens (a zoom) is a scale of the screen about its centre: the samples below are projected through each camera's own lens, so
+    // the stretch it puts on the tiles towards the edges is part of `residual` like a rotation's — a slow zoom (0.4 % per frame moves an
+    // edge tile of a 4K frame by one tile) stays within the dilation, a fast one is refused by the residual test like any other jump.
+    // (Round 3 refused every lens change here: a zooming camera walked in row-major order, profiles/r04_views_probe.txt.)
+    if (!(f.now.tan_half_fov > 0.0f && f.then.tan_half_fov > 0.0f && f.now.aspect > 0.0f && f.then.aspect > 0.0f)) return p;
     const float near_inv = f.inv_depth_mean + 2.0f * f.inv_depth_sigma;
     const float far_inv = f.inv_depth_mean > 2.0f * f.inv_depth_sigma ? f.inv_depth_mean - 2.0f * f.inv_depth_sigma : 0.0f;
     const float depths[3] = {f.inv_depth_mean > 0.0f ? 1.0f / f.inv_depth_mean : 1.0e7f, near_inv > 0.0f ? 1.0f / near_inv : 1.0e7f, far_inv > 0.0f ? 1.0f / far_inv : 1.0e7f};

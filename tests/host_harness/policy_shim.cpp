@@ -35,7 +35,7 @@ int policy_plan_shift(const float* then14, const float* now14, float inv_depth_m
     f.tiles_x = tiles_x; f.tiles_y = tiles_y; f.tile_w = 8; f.tile_h = 8; f.radius = radius;
     const blok::ShiftPlan p = blok::plan_shift(f);
     *sx = p.sx; *sy = p.sy; *residual = p.residual;
-    return p.ok ? 1 : 0;
+    return (p.ok ? 1 : 0) | (p.measured ? 2 : 0);      // bit 1: the residual was computed (false on the early exits)
 }
 unsigned policy_plan_dilation(int have_residual, float residual) { return blok::plan_dilation(have_residual != 0, residual); }
 }

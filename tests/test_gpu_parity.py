@@ -705,6 +705,72 @@ def test_list_launches_equal_the_two_launch_form(tracer_cls, scene1024):
     tr.shutdown(); ref.shutdown(); other.shutdown()
 
 
+def test_alternating_views_each_get_their_own_order(tracer_cls, scene1024):
+    """Round 4: orders are cached per VIEW (four slots per launch geometry).  A caller that alternates between fixed views in one rectangle —
+    stereo eyes, a camera cycle — used to find the order of the other view in the one buffer and walk in row-major order for ever; now each
+    view's clocks are sorted into its own slot after its second appearance and every later frame of that view walks in it.  Two views, then
+    a cycle of three, then of five (more views than slots: the least recently walked one is evicted), on one stream and on three: every
+    frame equals the frame of a context with all ordering off."""
+    import torch
+    cm, pw = scene1024
+    Wd, Ht = 3840, 2160
+    ref = tracer_cls(Wd, Ht).init(); ref.add_world(pw); ref.set_fused(0); ref.set_tile_ordering(False)
+    tr = tracer_cls(Wd, Ht).init(); tr.add_world(pw)
+    hits = torch.zeros((Wd * Ht, 4), dtype=torch.int32, device="cuda"); rgba = torch.zeros(Wd * Ht, dtype=torch.int32, device="cuda")
+    centre = np.array([512.0, 256.0, 512.0]); start = np.array([-358.0, 870.0, -358.0]) - centre
+
+    def orbit(deg):
+        r = np.radians(deg)
+        p = centre + np.array([start[0] * np.cos(r) - start[2] * np.sin(r), start[1], start[0] * np.sin(r) + start[2] * np.cos(r)])
+        return W.camera_look_at(tuple(float(v) for v in p), tuple(float(v) for v in centre), 60.0, Wd, Ht)
+
+    views = [W.scene_camera(1024, 0, Wd, Ht, SEED), orbit(3.0), W.scene_camera(1024, 2, Wd, Ht, SEED), orbit(40.0), W.scene_camera(1024, 1, Wd, Ht, SEED)]
+    want = []
+    for cam in views:
+        h = torch.zeros_like(hits); c = torch.zeros_like(rgba)
+        ref.draw_frame_device(cam, h.data_ptr(), c.data_ptr()); torch.cuda.synchronize()
+        want.append((h, c))
+    for n_views in (2, 3, 5):
+        uses = []
+        for k in range(8 * n_views):
+            v = k % n_views
+            hits.fill_(5); rgba.fill_(5)
+            tr.draw_frame_device(views[v], hits.data_ptr(), rgba.data_ptr()); torch.cuda.synchronize()
+            uses.append(tr.last_order_use()[0])
+            assert torch.equal(hits, want[v][0]) and torch.equal(rgba, want[v][1]), (n_views, k)
+        if n_views <= 3:                                 # every view found its own order: the last two rounds walked in them
+            assert all(u == 1 for u in uses[-2 * n_views:]), (n_views, uses)
+    # a zoom: the lens changes from frame to frame (0.25 degrees of field of view, then 3): the previous frame's order is carried across it
+    # (the stretch about the screen's centre is residual to the shift, launch_policy.h) while the zoom is slow, dropped when it is not
+    want_h = torch.zeros_like(hits); want_c = torch.zeros_like(rgba)
+    uses = []
+    fov = 60.0
+    for k, step in enumerate([0.25] * 10 + [3.0] * 3 + [-0.25] * 6):
+        fov -= step
+        cam = W.camera_look_at((-358.0, 870.0, -358.0), (512.0, 256.0, 512.0), fov, Wd, Ht)
+        hits.fill_(5); rgba.fill_(5)
+        tr.draw_frame_device(cam, hits.data_ptr(), rgba.data_ptr())
+        ref.draw_frame_device(cam, want_h.data_ptr(), want_c.data_ptr()); torch.cuda.synchronize()
+        uses.append(tr.last_order_use()[0])
+        assert torch.equal(hits, want_h) and torch.equal(rgba, want_c), ("zoom", k, fov)
+    # (the first 3-degree step leaves more over than twice the dilation the slow zoom was sorted with; the sorts that follow dilate by more)
+    assert sum(1 for u in uses[2:10] if u == 2) >= 5 and uses[10] == 0, uses
+    # three streams in flight, two views alternating
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    outs = [(torch.zeros_like(hits), torch.zeros_like(rgba)) for _ in streams]
+    for k in range(24):
+        j, v = k % 3, (k // 2) % 2
+        if k >= 3 and j == 0:
+            torch.cuda.synchronize()
+            for jj in range(3):
+                vv = ((k - 3 + jj) // 2) % 2
+                assert torch.equal(outs[jj][0], want[vv][0]) and torch.equal(outs[jj][1], want[vv][1]), (k, jj)
+        tr.draw_frame_device(views[v], outs[j][0].data_ptr(), outs[j][1].data_ptr(), stream=streams[j].cuda_stream)
+    torch.cuda.synchronize()
+    assert tr.frame_queue_stalls() == 0
+    tr.shutdown(); ref.shutdown()
+
+
 def test_alternating_rectangles_with_three_streams_in_flight(tracer_cls, scene1024):
     """a change of launch geometry used to leave the held markers of the LAST ADOPTION in place, which cover the readers of the
     other order buffer — the first sort of the new rectangle could rewrite the buffer frames in flight on other streams were still

@@ -161,7 +161,8 @@ def shift(L, then, now, inv_mean=1 / 1400.0, inv_sigma=0.0, radius=4, w=3840, h=
     sx, sy, res = C.c_uint(0), C.c_uint(0), C.c_float(0)
     ok = L.policy_plan_shift(then, now, inv_mean, inv_sigma, w, h, w // 8, h // 8, radius, C.byref(sx), C.byref(sy), C.byref(res))
     tx, ty = w // 8, h // 8
-    return bool(ok), (sx.value + tx // 2) % tx - tx // 2, (sy.value + ty // 2) % ty - ty // 2, res.value
+    shift.measured = bool(ok & 2)
+    return bool(ok & 1), (sx.value + tx // 2) % tx - tx // 2, (sy.value + ty // 2) % ty - ty // 2, res.value
 
 
 def test_shift_between_two_views(policy):
@@ -193,11 +194,16 @@ def test_shift_between_two_views(policy):
     yaw = np.radians(20.0)
     t = pos + np.array([np.cos(yaw) * a[3] - np.sin(yaw) * a[5], a[4], np.sin(yaw) * a[3] + np.cos(yaw) * a[5]]) * 100.0
     assert not shift(policy, a, camera(pos, t))[0]
-    # about-face, another lens, a non-finite camera: never
-    assert not shift(policy, a, camera(pos, pos - (np.array(centre) - pos)))[0]
-    assert not shift(policy, a, camera((-358.0, 870.0, -358.0), centre, fov_deg=50.0))[0]
+    # about-face, a non-finite camera: never — and the residual then says nothing (it read 0, the smallest dilation for the next sort)
+    assert not shift(policy, a, camera(pos, pos - (np.array(centre) - pos)))[0] and not shift.measured
     n = (C.c_float * 14)(*a); n[0] = float("nan")
-    assert not shift(policy, a, n)[0]
+    assert not shift(policy, a, n)[0] and not shift.measured
+    # another lens (round 4): a zoom is a scale about the screen's centre, and what it does to the tiles is residual like any other stretch — a
+    # slow zoom (60 -> 59.75 degrees: 0.5 % = 1.2 tiles at the 0.8-corner samples of 480 x 270 tiles) is carried, a cut to another lens is not
+    ok, sx, sy, res = shift(policy, a, camera((-358.0, 870.0, -358.0), centre, fov_deg=59.75))
+    assert ok and shift.measured and (sx, sy) == (0, 0) and 0.5 < res < 2.0, (ok, sx, sy, res)
+    ok, sx, sy, res = shift(policy, a, camera((-358.0, 870.0, -358.0), centre, fov_deg=50.0))
+    assert not ok and shift.measured and res > 20.0
     # what the shift leaves over sizes the next dilation: rounded up, 2 to 8 tiles, 4 when nothing has been seen yet
     assert [policy.policy_plan_dilation(1, r) for r in (0.0, 1.2, 2.0, 3.1, 7.9, 30.0)] == [2, 2, 2, 4, 8, 8]
     assert policy.policy_plan_dilation(0, 0.0) == 4 and policy.policy_plan_dilation(1, float("nan")) == 4
