@@ -343,7 +343,25 @@ def main():
         tracer.set_timing(False)
         kernel_ms_cold = float(np.mean(cold))
     local_hits = (pipe.hits[:, 3] >> 24).sum()
+    # N > 1: what the process group actually was — every rank reports itself through the collective backend (so that the line cannot claim N
+    # ranks unless N ranks answered): its device, its share of the tiles, its tile launch alone on its device
+    ranks_info = backend_info = None
     if dist is not None:
+        props = torch.cuda.get_device_properties(torch.cuda.current_device())
+        mine = {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "device": torch.cuda.current_device(), "device_name": props.name,
+                "device_uuid": str(getattr(props, "uuid", "")), "pci_bus_id": getattr(props, "pci_bus_id", None),
+                "tiles": int(tracer.tiles_for_rank(args.tile, rank, world_size)), "kernel_ms_alone": kernel_ms_avg, "order_in_use": int(tracer.last_order_use()[0]),
+                "pid": os.getpid()}
+        gathered = [None] * world_size
+        dist.all_gather_object(gathered, mine)
+        ranks_info = gathered
+        nccl = None
+        try:
+            nccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            pass
+        backend_info = {"backend": dist.get_backend(), "world_size_reported": dist.get_world_size(), "collective_library": (f"RCCL (torch.cuda.nccl.version) {nccl}" if dist.get_backend() == "nccl" else dist.get_backend()),
+                        "hip": torch.version.hip, "distinct_devices": len({(r["device_uuid"], r["pci_bus_id"], r["device"]) for r in gathered})}
         dist.all_reduce(local_hits)
     hits = int(local_hits.item())
     sky = 0xFF000000 | (230 << 16) | (200 << 8) | 160
@@ -441,6 +459,7 @@ def main():
                        "outputs": "16-B first-hit records (kept on the tracing GPU) + RGBA8 framebuffer on rank 0",
                        "tile_records_gathered_per_frame_and_rank": (pipe.records_gathered / max(1, pipe.frames_done)) if world_size > 1 and args.sparse_gather else None,
                        "tiles_per_rank": pipe.per_rank if world_size > 1 else None,
+                       "ranks": ranks_info, "process_group": backend_info,
                        "camera_orbit_deg_per_frame": args.orbit,
                        "frames_in_flight": args.frames_in_flight, "settle_frames": args.settle, "walk_waves_that_gave_up_waiting": gave_up, "device_ms_per_step": device_ms / args.steps, "kernel_ms_alone": kernel_ms_avg, "kernel_ms_alone_moving": kernel_ms_moving, "beam_tile": args.beam,
                        "poses": poses, "also_measured_paths": paths},

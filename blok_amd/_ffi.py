@@ -197,6 +197,7 @@ HIP_SYMBOLS = {
     "blok_hip_set_list_classes": (C.c_int, [C.c_void_p, C.c_int]),
     "blok_hip_set_joint_prefix_limit": (C.c_int, [C.c_void_p, C.c_uint32]),
     "blok_hip_set_tile_ordering": (C.c_int, [C.c_void_p, C.c_int]),
+    "blok_hip_set_rank_tile_ordering": (C.c_int, [C.c_void_p, C.c_int]),
     "blok_hip_set_moving_order": (C.c_int, [C.c_void_p, C.c_int]),
     "blok_hip_last_fallback_tiles": (C.c_int64, [C.c_void_p]),
     "blok_hip_debug_force_order_shift": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32]),

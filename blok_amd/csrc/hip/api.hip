@@ -373,10 +373,12 @@ int order_buffers(blok_hip_ctx* ctx, uint32_t blocks, hipStream_t stream) {
 }
 
 // Before an orderable launch: adoption of a finished sort, the plan; fills args.order / rank_of / launched / cost_out.
-static int order_before_launch(blok_hip_ctx* ctx, blok::TraceArgs& args, uint32_t blocks, hipStream_t stream, bool alone, blok::OrderPlan* plan) {
+// rect: a rectangle launch (else a rank's tiles: orders of a view's own clocks only — a whole-tile shift of the screen does not map a rank's
+// round-robin share of the tiles onto itself); uniform_view: every camera of the launch is the same view (several frames per launch).
+static int order_before_launch(blok_hip_ctx* ctx, blok::TraceArgs& args, uint32_t blocks, hipStream_t stream, bool alone, bool rect, bool uniform_view, blok::OrderPlan* plan) {
     auto& O = ctx->order;
     constexpr int kSlots = blok_hip_ctx::TileOrder::kSlots;
-    const uint32_t key[7] = {args.x0, args.y0, args.w, args.h, ctx->width, ctx->height, ctx->world_version};
+    const uint32_t key[7] = {rect ? args.x0 : (0x80000000u | args.tile), rect ? args.y0 : args.rank, rect ? args.w : args.n_ranks, rect ? args.h : 0u, ctx->width, ctx->height, ctx->world_version};
     if (O.capacity < blocks) { const int rc = order_buffers(ctx, blocks, stream); if (rc != BLOK_OK) return rc; }      // (never after create / resize: a rectangle has no more tiles than the frame)
     O.launch_serial += 1;
     if (std::memcmp(key, O.key, sizeof(key)) != 0) {
@@ -418,15 +420,15 @@ static int order_before_launch(blok_hip_ctx* ctx, blok::TraceArgs& args, uint32_
     (void)hipGetLastError();                                             // hipErrorNotReady is an answer, not a failure
     // the order this launch may walk in: its own view's if the cache has one, else the one adopted last (a carried order, if it is dilated)
     int own = -1;
-    for (int k = 0; k < kSlots; ++k)
+    for (int k = 0; k < kSlots && uniform_view; ++k)
         if (O.slots[k].valid && !O.slots[k].dilated && camera_near(ctx, args.cam, O.slots[k].cam) && (own < 0 || O.slots[k].last_use > O.slots[own].last_use)) own = k;
     const int chosen = own >= 0 ? own : O.current;
     // At rest: the previous launch's view — or, for a caller that alternates between fixed views, one of the few before it, once that has
     // happened three launches running (a camera that swings back and forth passes through a view of two launches ago at every turn: that is
     // motion, and keeps the moving camera's carried order)
-    const bool rest = camera_near(ctx, args.cam, O.last_cam);
+    const bool rest = uniform_view && camera_near(ctx, args.cam, O.last_cam);
     bool revisit = false;
-    for (uint32_t k = 0; k < O.n_recent && !rest && !revisit; ++k) revisit = camera_near(ctx, args.cam, O.recent[k]);
+    for (uint32_t k = 0; k < O.n_recent && uniform_view && !rest && !revisit; ++k) revisit = camera_near(ctx, args.cam, O.recent[k]);
     O.revisit_streak = revisit ? O.revisit_streak + 1u : (rest ? O.revisit_streak : 0u);
     const bool seen = rest || (revisit && O.revisit_streak >= 3u);
     blok::OrderFacts f{};
@@ -435,7 +437,7 @@ static int order_before_launch(blok_hip_ctx* ctx, blok::TraceArgs& args, uint32_
     f.near_last_view = seen;
     f.sort_pending = O.pending; f.still_frames = O.still_frames;
     f.frames_since_sort = own >= 0 ? O.slots[own].frames_since_sort : 0u; f.interval = O.interval; f.interval_now = own >= 0 ? O.slots[own].interval_now : O.interval_now;
-    f.moving_enabled = O.moving; f.alone = alone; f.alone_before = O.alone_before; O.alone_before = alone;
+    f.moving_enabled = O.moving && rect; f.alone = alone; f.alone_before = O.alone_before; O.alone_before = alone;
     f.order_dilated = f.have_order && O.slots[chosen].dilated;
     blok::ShiftPlan shift{};
     if (f.order_dilated && f.moving_enabled && f.alone) {
@@ -658,9 +660,14 @@ int launch_timed(blok_hip_ctx* ctx, blok::RayMode mode, blok::TraceArgs args, ui
     }
     // static forms over a rectangle: longest-first order of a camera at rest, and walk waves for its live prefix only
     const bool static_form = plan.kind == blok::LaunchKind::TwoLaunches || plan.kind == blok::LaunchKind::Joint;
-    const bool orderable = !capturing && ctx->order.enabled && static_form && mode == blok::RayMode::Rect && !frames && n_beams && blocks >= blok::kOrderMinTiles && BLOK_XCD_MAP == 0;
+    // (round 4: a rank's tile launches too — one frame or several per launch — for a view at rest: ctx->order.rank_tiles)
+    const bool rect = mode == blok::RayMode::Rect;
+    const bool orderable = !capturing && ctx->order.enabled && static_form && ((rect && !frames) || (mode == blok::RayMode::Tiles && ctx->order.rank_tiles)) && n_beams &&
+                           blocks >= blok::kOrderMinTiles && BLOK_XCD_MAP == 0 && blok::kBlock == 64;
+    bool uniform_view = true;
+    if (frames) for (uint32_t f = 1; f < frames->n_frames; ++f) uniform_view = uniform_view && camera_near(ctx, frames->cam[0], frames->cam[f]);
     blok::OrderPlan order_plan{};
-    if (orderable) { const int rc = order_before_launch(ctx, args, blocks, stream, !busy, &order_plan); if (rc != BLOK_OK) return rc; }
+    if (orderable) { const int rc = order_before_launch(ctx, args, blocks, stream, !busy, rect, uniform_view, &order_plan); if (rc != BLOK_OK) return rc; }
     else ctx->order.last_use = 0;
     uint32_t walk_blocks = blocks;
     if (args.order && args.rank_of && plan.may_use_prefix && args.launched <= blocks) {
@@ -699,7 +706,7 @@ int launch_timed(blok_hip_ctx* ctx, blok::RayMode mode, blok::TraceArgs args, ui
             if (frames) blok::launch_tile_frames(args, fr, stream); else blok::launch_trace(mode, args, blocks, stream);
             break;
         case blok::LaunchKind::TwoLaunches:
-            if (frames) blok::launch_tile_frames(args, fr, stream);
+            if (frames) blok::launch_tile_frames(args, fr, stream, walk_blocks);
             else { blok::launch_beam(mode, args, n_beams, stream); blok::launch_trace(mode, args, walk_blocks, stream); }
             break;
         case blok::LaunchKind::Queues: blok::launch_frame(mode, args, queue, frame_blocks, stream); break;
@@ -1635,6 +1642,12 @@ int blok_hip_set_tile_ordering(blok_hip_ctx* ctx, int resort_every_n_frames) {
     if (resort_every_n_frames < 0) return set_error(ctx, BLOK_ERR_INVALID_ARG, "tile ordering: interval must be >= 0");
     ctx->order.enabled = resort_every_n_frames != 0;
     if (resort_every_n_frames) ctx->order.interval = ctx->order.interval_now = static_cast<uint32_t>(resort_every_n_frames);
+    return BLOK_OK;
+}
+
+int blok_hip_set_rank_tile_ordering(blok_hip_ctx* ctx, int enabled) {
+    if (!ctx) return BLOK_ERR_INVALID_ARG;
+    ctx->order.rank_tiles = enabled != 0;
     return BLOK_OK;
 }
 

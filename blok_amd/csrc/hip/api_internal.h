@@ -118,6 +118,7 @@ struct blok_hip_ctx {
     // launch adopts it once hipEventQuery says it is complete — no launch ever waits.  Decisions: launch_policy.h plan_order.
     struct TileOrder {
         bool enabled = true;
+        bool rank_tiles = true;                            // ... also for a rank's tile launches (blok_hip_set_rank_tile_ordering)
         uint32_t interval = 8, interval_now = 8;          // interval_now: of a view that has no order of its own yet (a slot carries its own)
         uint32_t *d_cost = nullptr, *d_iota = nullptr;
         uint32_t *d_keys_in = nullptr, *d_keys = nullptr;   // the sort's snapshot of the costs, and its sorted keys

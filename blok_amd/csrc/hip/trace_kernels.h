@@ -139,8 +139,8 @@ struct TraceArgs {
     // beam_kernel and read by the Rect / Tiles trace kernels of the same stream; null = no pre-pass
     float* beam;
     uint32_t beam_tile, beam_bx;           // beam_bx: beam tiles per row of the rectangle (Rect)
-    const uint32_t* order;                 // Rect: workgroup b walks tile order[b] (null = b): longest-first scheduling
-    uint32_t* cost_out;                    // Rect: per tile, the clocks its wave spent (null = not recorded)
+    const uint32_t* order;                 // Rect / Tiles: workgroup b (of a frame) walks wave tile order[b] (null = b): longest-first scheduling
+    uint32_t* cost_out;                    // Rect / Tiles: per wave tile, the clocks its wave spent (null = not recorded)
     // joint launch (joint_kernel): the pre-pass waves and the walk waves are ONE grid; a beam tile's result is published as
     // (serial << 32 | start parameter bits) and a walk wave waits for its tile's word to carry this launch's serial
     unsigned long long* beam_slots;        // null = the two-launch form (TraceArgs::beam holds plain floats)
@@ -279,7 +279,7 @@ uint32_t beam_tiles(RayMode mode, const TraceArgs& args, uint32_t tiles_of_rank)
 void launch_beam(RayMode mode, const TraceArgs& args, uint32_t n_beam_tiles, hipStream_t stream);
 void launch_untile(const UntileArgs& args, uint32_t n_frames, hipStream_t stream);
 // Beam pre-pass (if args.beam) and walk of frames.n_frames frames of the rank's tiles, one launch each (Tiles mode).
-void launch_tile_frames(const TraceArgs& args, const TileFrames& frames, hipStream_t stream);
+void launch_tile_frames(const TraceArgs& args, const TileFrames& frames, hipStream_t stream, uint32_t walk_blocks_per_frame = 0);
 void launch_beam_frames(const TraceArgs& args, const TileFrames& frames, hipStream_t stream);      // the pre-pass alone (list launches: it fills the list)
 // One-launch frame: pre-pass and walk in one persistent grid of n_blocks waves (Rect and Tiles).
 void launch_frame(RayMode mode, const TraceArgs& args, const FrameQueue& queue, uint32_t n_blocks, hipStream_t stream);

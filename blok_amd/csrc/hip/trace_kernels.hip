@@ -208,7 +208,7 @@ __device__ __forceinline__ void trace_block(const TraceArgs& A, const uint32_t b
         // where this wave's 8x8 pixels start inside the block (wave-uniform)
         const uint32_t wave_x = __builtin_amdgcn_readfirstlane((wave & 1u) * kWaveW), wave_y = __builtin_amdgcn_readfirstlane((wave >> 1) * kWaveH);
         uint32_t x, y;
-        [[maybe_unused]] uint64_t clock0 = 0;      // Rect: the wave's cost (clocks from here to its last record) goes to cost_slot
+        [[maybe_unused]] uint64_t clock0 = 0;      // the wave's cost (clocks from here to its last record) goes to cost_slot
         [[maybe_unused]] uint32_t* cost_slot = nullptr;
         float t0 = 0.0f;                           // start parameter of this wave's beam tile (beam.h); kBeamNone: the pre-pass
         size_t out_index;                          // has already written the tile's pixels as misses, nothing left to do
@@ -259,7 +259,10 @@ __device__ __forceinline__ void trace_block(const TraceArgs& A, const uint32_t b
         } else {
             const uint32_t per_side = A.tile / kTileW;                  // blocks per tile row
             const uint32_t per_tile = per_side * (A.tile / kTileH);
-            const uint32_t local_tile = block / per_tile, sub = block % per_tile;
+            // longest first, as for rectangles: workgroup i of a frame walks the rank's wave tile order[i] (a listed block names its wave tile itself)
+            const uint32_t wave_tile = (!kListed && A.order) ? A.order[block] : block;
+            if constexpr (!kListed) cost_slot = A.cost_out ? A.cost_out + wave_tile : nullptr;
+            const uint32_t local_tile = wave_tile / per_tile, sub = wave_tile % per_tile;
             const uint32_t global_tile = A.rank + local_tile * A.n_ranks;
             const uint32_t tx = global_tile % A.tiles_x, ty = global_tile / A.tiles_x;
             const uint32_t ix = (sub % per_side) * kTileW + lx, iy = (sub / per_side) * kTileH + ly;
@@ -268,6 +271,7 @@ __device__ __forceinline__ void trace_block(const TraceArgs& A, const uint32_t b
             inside = x < A.frame_w && y < A.frame_h;
             if (global_tile >= A.tiles_total) {                        // whole workgroup: padding tile of the last round
                 write_miss(Sink{A.out ? A.out + out_index : nullptr, A.out_rgba ? A.out_rgba + out_index : nullptr});
+                if (cost_slot && tid == 0) *cost_slot = 0u;            // (a prefix launch leaves these to the tile's search wave, which writes them as misses)
                 return;
             }
             if constexpr (kListed) t0 = listed_t0;
@@ -277,6 +281,7 @@ __device__ __forceinline__ void trace_block(const TraceArgs& A, const uint32_t b
                                             ((sub % per_side) * kTileW + wave_x) / A.beam_tile;
                 t0 = A.beam_slots ? await_beam(A.beam_slots + beam_index, A.beam_serial, A.joint_gave_up) : A.beam[beam_index];
                 if (t0 >= kBeamNone) {
+                    if (cost_slot && tid == 0) *cost_slot = 0u;
                     if (A.miss_in_walk) write_miss(Sink{A.out ? A.out + out_index : nullptr, A.out_rgba ? A.out_rgba + out_index : nullptr});   // the tile buffer is dense
                     return;
                 }
@@ -284,19 +289,21 @@ __device__ __forceinline__ void trace_block(const TraceArgs& A, const uint32_t b
         }
         const Sink sink{A.out ? A.out + out_index : nullptr, A.out_rgba ? A.out_rgba + out_index : nullptr};
         if (!inside) {
-            if constexpr (MODE == RayMode::Tiles) write_miss(sink);     // the tile buffer is dense
+            if constexpr (MODE == RayMode::Tiles) {
+                write_miss(sink);                                       // the tile buffer is dense
+                // a wave tile that straddles or lies beyond the frame's edge always keeps its walk workgroup in a prefix launch (someone has to write these)
+                if (cost_slot && tid == 0) *cost_slot = 256u;
+            }
             return;
         }
         if constexpr (MODE == RayMode::Rect) {
             if constexpr (kListed) cost_slot = A.debug_clocks ? A.debug_clocks + block : nullptr;
-            if (cost_slot && tid == 0) clock0 = __builtin_amdgcn_s_memtime();      // the walk's cost: any wait for the tile's search is not part of it
         }
+        if (cost_slot && tid == 0) clock0 = __builtin_amdgcn_s_memtime();      // the walk's cost: any wait for the tile's search is not part of it
         RayIn r = primary_ray(A, x, y);
         r.tmin = fmaxf(r.tmin, t0);
         trace_one(A, r, stk, sink);
-        if constexpr (MODE == RayMode::Rect) {
-            if (cost_slot && tid == 0) *cost_slot = max(static_cast<uint32_t>(__builtin_amdgcn_s_memtime() - clock0), 256u);     // it walked: any key >= 256 clocks counts as live in the next order
-        }
+        if (cost_slot && tid == 0) *cost_slot = max(static_cast<uint32_t>(__builtin_amdgcn_s_memtime() - clock0), 256u);     // it walked: any key >= 256 clocks counts as live in the next order
     }
 }
 
@@ -346,7 +353,8 @@ __device__ __forceinline__ void beam_block(const TraceArgs& A, const uint32_t b,
         const uint32_t local_tile = b / per_tile, sub = b % per_tile;
         const uint32_t global_tile = A.rank + local_tile * A.n_ranks;
         padding = global_tile >= A.tiles_total;                        // a tile slot beyond the frame's last tile: all misses
-        if (padding && !A.list.entries) { if (lane == 0) { if (A.beam_slots) publish_beam(A.beam_slots + b, A.beam_serial, kBeamNone); else A.beam[b] = kBeamNone; } return; }
+        // (a padding tile's miss records are written by its walk workgroups — unless this launch has none for it: a prefix launch, miss_in_walk 0)
+        if (padding && !A.list.entries && A.miss_in_walk) { if (lane == 0) { if (A.beam_slots) publish_beam(A.beam_slots + b, A.beam_serial, kBeamNone); else A.beam[b] = kBeamNone; } return; }
         tile_x0 = (global_tile % A.tiles_x) * A.tile; tile_y0 = (global_tile / A.tiles_x) * A.tile;
         tile_base = static_cast<size_t>(local_tile) * A.tile * A.tile;
         px = tile_x0 + (sub % per_side) * B; py = tile_y0 + (sub / per_side) * B;
@@ -400,6 +408,25 @@ __device__ __forceinline__ void beam_block(const TraceArgs& A, const uint32_t b,
             if (walked && A.fallback_tiles && lane == 0) (void)__hip_atomic_fetch_add(A.fallback_tiles, walked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    if constexpr (MODE == RayMode::Tiles && kBlock == 64) {
+        // the same for a rank's tiles (round 4): the wave tiles of this live beam tile that the order's prefix has no walk workgroup for
+        if (A.rank_of && lds_stack && t0 < kBeamNone) {
+            const uint32_t per_side = A.tile / kTileW, per_tile_blocks = per_side * (A.tile / kTileH), bps = A.tile / B;
+            const uint32_t local_tile = b / (bps * bps), rem = b % (bps * bps);
+            const uint32_t subs_x = B / kWaveW, subs_y = B / kWaveH;
+            uint32_t walked = 0u;
+            for (uint32_t sy = 0; sy < subs_y; ++sy)
+                for (uint32_t sx = 0; sx < subs_x; ++sx) {
+                    const uint32_t wave_tile = local_tile * per_tile_blocks + ((rem / bps) * subs_y + sy) * per_side + (rem % bps) * subs_x + sx;
+                    if (__builtin_amdgcn_readfirstlane(A.rank_of[wave_tile]) < A.launched) continue;
+                    const uint64_t clock0 = __builtin_amdgcn_s_memtime();
+                    trace_block<RayMode::Tiles, true>(A, wave_tile, 0u, lds_stack, t0);
+                    if (A.cost_out && lane == 0) A.cost_out[wave_tile] = max(static_cast<uint32_t>(__builtin_amdgcn_s_memtime() - clock0), 256u);
+                    ++walked;
+                }
+            if (walked && A.fallback_tiles && lane == 0) (void)__hip_atomic_fetch_add(A.fallback_tiles, walked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 template <RayMode MODE>
@@ -426,10 +453,11 @@ __global__ __launch_bounds__(kBlock) void joint_kernel(const TraceArgs A, const 
 }
 
 __global__ __launch_bounds__(64) void beam_frames_kernel(const TraceArgs A, const TileFrames F) {
+    extern __shared__ uint4 lds_stack[];       // sized by the launch whenever the searches may walk (TraceArgs::rank_of), else 0 bytes and unused
     const uint32_t f = blockIdx.x / F.beams_per_frame;
     if (f >= F.n_frames) return;
     const TraceArgs L = frame_args(A, F, f);
-    beam_block<RayMode::Tiles>(L, blockIdx.x - f * F.beams_per_frame, F.beams_per_frame, nullptr, blockIdx.x, f * F.blocks_per_frame);
+    beam_block<RayMode::Tiles>(L, blockIdx.x - f * F.beams_per_frame, F.beams_per_frame, A.rank_of ? lds_stack : nullptr, blockIdx.x, f * F.blocks_per_frame);
 }
 
 // ---- list launches: the walk takes its wave tiles from the frame's live list (trace_kernels.h: LiveList) -------------------------
@@ -922,12 +950,15 @@ void launch_scatter_tiles(const ScatterArgs& args, bool codes, hipStream_t strea
     else hipLaunchKernelGGL(scatter_tiles_kernel<false>, dim3(args.tiles_total, args.n_frames), dim3(64), 0, stream, args);
 }
 
-void launch_tile_frames(const TraceArgs& args, const TileFrames& frames, hipStream_t stream) {
+// walk_blocks_per_frame: the walk's workgroups per frame when it runs over the prefix of an order (TraceArgs::rank_of), else blocks_per_frame
+void launch_tile_frames(const TraceArgs& args, const TileFrames& frames, hipStream_t stream, uint32_t walk_blocks_per_frame) {
     if (frames.n_frames == 0 || frames.blocks_per_frame == 0) return;
     const size_t lds = static_cast<size_t>(args.levels > 1 ? args.levels - 1 : 1) * kBlock * sizeof(uint4);
     if (args.beam && frames.beams_per_frame)
-        hipLaunchKernelGGL(beam_frames_kernel, dim3(frames.n_frames * frames.beams_per_frame), dim3(64), 0, stream, args, frames);
-    hipLaunchKernelGGL(trace_frames_kernel, dim3(frames.n_frames * frames.blocks_per_frame), dim3(kBlock), lds, stream, args, frames);
+        hipLaunchKernelGGL(beam_frames_kernel, dim3(frames.n_frames * frames.beams_per_frame), dim3(64), args.rank_of ? lds : 0, stream, args, frames);
+    TileFrames walk = frames;
+    if (args.rank_of) walk.blocks_per_frame = walk_blocks_per_frame;          // frame f = workgroups [f * prefix, (f + 1) * prefix)
+    if (walk.blocks_per_frame) hipLaunchKernelGGL(trace_frames_kernel, dim3(walk.n_frames * walk.blocks_per_frame), dim3(kBlock), lds, stream, args, walk);
 }
 
 void launch_beam_frames(const TraceArgs& args, const TileFrames& frames, hipStream_t stream) {

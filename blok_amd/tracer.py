@@ -211,6 +211,10 @@ class HipTracer:
         n = 8 if resort_every_n_frames is True else int(resort_every_n_frames or 0)
         self._check(self._lib.blok_hip_set_tile_ordering(self._ctx, n))
 
+    def set_rank_tile_ordering(self, enabled: bool):
+        """Longest-first order and live prefix for a rank's tile launches too (a view at rest); never changes a frame."""
+        self._check(self._lib.blok_hip_set_rank_tile_ordering(self._ctx, int(bool(enabled))))
+
     def set_moving_order(self, enabled: bool):
         """Longest-first scheduling for a camera in motion: the previous frame's clocks, dilated, carried to this view by a whole-tile
         shift (default on; launches alone on the device only); never changes a result."""

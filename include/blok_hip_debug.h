@@ -87,6 +87,12 @@ int blok_hip_set_tile_ordering(blok_hip_ctx* ctx, int resort_every_n_frames);
  * Measured (4K over 1024^3, walk alone, camera orbiting by 1-2 degrees per frame): 209-216 us row-major, 171-178 us carried order, 167-170
  * us in the order of the frame's own clocks (profiles/r03_moving_order_experiment.txt).  0 = off. */
 int blok_hip_set_moving_order(blok_hip_ctx* ctx, int enabled);
+/* The same scheduling for a RANK's tile launches (blok_hip_trace_tiles_device / _tile_frames_device, 4096 wave tiles per frame or more;
+ * round 4, default on): the rank's wave tiles are walked longest first and, in the automatic launch form, walk workgroups are dispatched for
+ * the live prefix only — for a view at rest (all cameras of a several-frame launch the same view): a whole-tile shift of the screen does
+ * not map a rank's round-robin share of the tiles onto itself, so a camera in motion keeps the natural order there.  Pure scheduling
+ * (tests/test_gpu_parity.py).  0 = off (round 3's launches). */
+int blok_hip_set_rank_tile_ordering(blok_hip_ctx* ctx, int enabled);
 /* Diagnostic / test hook: the counting sort that follows a moving camera's frames, run on the caller's host arrays — cost[tiles_x * tiles_y]
  * (row-major wave tiles), dilation radius <= 8, optionally n_beams start parameters (>= 1e38 = none) — and read back: out_order (tiles by
  * descending class of the largest cost within `radius` tiles: 64 classes, four to the octave from 256 up, 0 = nothing near; within a class by

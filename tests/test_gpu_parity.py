@@ -1084,6 +1084,67 @@ def test_sparse_tile_exchange_kernels(tracer_cls, scene1024):
     tr.shutdown()
 
 
+def test_rank_tile_launches_in_their_own_order_equal_the_plain_ones(tracer_cls, scene1024):
+    """Round 4 (extends the several-frames test to the ORDERED form): a rank's tile launches — one frame or several per launch — walk their
+    wave tiles longest first and, in the automatic form, over the order's live prefix, once the view rests.  4K over 1024^3, ranks 1 of 2, 3 of
+    4 and 0 and 7 of 8, 1 / 4 / 8 frames per launch: launch after launch of the same view (the order is measured, sorted for, adopted and in use
+    by the end), then a jump to another view and back, then launches whose frames differ (no order applies): every launch equals the launch of
+    a context with the ordering off, hit records and RGBA8, padding tiles and the half row of tiles below the frame included.  Then three
+    streams in flight."""
+    import torch
+    cm, pw = scene1024
+    Wd, Ht = 3840, 2160
+    ref = tracer_cls(Wd, Ht).init(); ref.add_world(pw); ref.set_tile_ordering(False)
+    tr = tracer_cls(Wd, Ht).init(); tr.add_world(pw)
+    camA, camB, camC = (W.scene_camera(1024, pose, Wd, Ht, SEED) for pose in (0, 2, 1))
+    tile = 32
+    for n_ranks, rank, n_frames in ((2, 1, 1), (4, 3, 4), (8, 0, 8), (8, 7, 1), (7, 6, 2)):
+        per = tr.tiles_for_rank(tile, 0, n_ranks)          # the most any rank has: ranks beyond the last tile hold a padding tile
+        px = tile * tile
+        hits = torch.zeros((n_frames, per * px, 4), dtype=torch.int32, device="cuda"); rgba = torch.zeros((n_frames, per * px), dtype=torch.int32, device="cuda")
+        want_h = torch.zeros_like(hits); want_c = torch.zeros_like(rgba)
+
+        def same(cams, tag):
+            hits.fill_(3); rgba.fill_(3); want_h.fill_(3); want_c.fill_(3)
+            batch = np.concatenate(cams)
+            if n_frames == 1:
+                tr.draw_tiles_device(cams[0], tile, rank, n_ranks, hits_ptr=hits.data_ptr(), rgba_ptr=rgba.data_ptr())
+                ref.draw_tiles_device(cams[0], tile, rank, n_ranks, hits_ptr=want_h.data_ptr(), rgba_ptr=want_c.data_ptr())
+            else:
+                tr.draw_tile_frames_device(batch, tile, rank, n_ranks, per, hits_ptr=hits.data_ptr(), rgba_ptr=rgba.data_ptr())
+                ref.draw_tile_frames_device(batch, tile, rank, n_ranks, per, hits_ptr=want_h.data_ptr(), rgba_ptr=want_c.data_ptr())
+            torch.cuda.synchronize()
+            use = tr.last_order_use()[0]
+            assert torch.equal(hits, want_h) and torch.equal(rgba, want_c), (n_ranks, rank, n_frames, tag, use)
+            return use
+
+        uses = [same([camA] * n_frames, ("rest", k)) for k in range(14)]
+        assert all(u == 1 for u in uses[-4:]), (n_ranks, rank, n_frames, uses)      # the view's own order is in use
+        assert same([camB] * n_frames, "jump") == 0
+        assert same([camA] * n_frames, "back") == 1                                # still cached
+        if n_frames > 1:
+            mixed = [camA, camB, camC, camA][:n_frames] + [camB] * max(0, n_frames - 4)
+            for k in range(3):
+                assert same(mixed, ("mixed", k)) == 0
+        for k in range(3):
+            same([camA] * n_frames, ("after", k))
+    # three launches in flight on three streams (4 frames per launch, rank 2 of 4)
+    n_ranks, rank, n_frames = 4, 2, 4
+    per = tr.tiles_for_rank(tile, 0, n_ranks); px = tile * tile
+    want_h = torch.zeros((n_frames, per * px, 4), dtype=torch.int32, device="cuda")
+    ref.draw_tile_frames_device(np.concatenate([camA] * n_frames), tile, rank, n_ranks, per, hits_ptr=want_h.data_ptr()); torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    outs = [torch.zeros_like(want_h) for _ in streams]
+    for k in range(18):
+        tr.draw_tile_frames_device(np.concatenate([camA] * n_frames), tile, rank, n_ranks, per, hits_ptr=outs[k % 3].data_ptr(), stream=streams[k % 3].cuda_stream)
+        if k % 3 == 2:
+            torch.cuda.synchronize()
+            for o in outs:
+                assert torch.equal(o, want_h), k
+    assert tr.frame_queue_stalls() == 0
+    tr.shutdown(); ref.shutdown()
+
+
 def test_several_frames_per_launch_equal_frame_by_frame(tracer_cls, scene1024):
     """blok_hip_trace_tile_frames_device and the *_frames_device forms of compact / scatter / un-permute (one launch for up to 8
     frames of a rank's tile share, each frame with its own camera): every frame bit-identical to what the one-frame entries
