@@ -118,27 +118,47 @@ int rebuild_sun_map(blok_hip_ctx* ctx) {
     return BLOK_OK;
 }
 
-// After an edit of the installed world that left its lattice alone (same origin, same levels): only the texels whose prism can meet the
-// edited box [lo, hi) (world voxels) are searched again, on the new tree.  Anything else: the whole map.
-int update_sun_map(blok_hip_ctx* ctx, const int32_t lo[3], const int32_t hi[3], bool same_lattice) {
-    if (!same_lattice || !ctx->has_sun_map || !ctx->d_sun_map || ctx->world_voxel_size != 1.0f || !ctx->has_world || ctx->stats.n_voxels == 0) return rebuild_sun_map(ctx);
+// After an edit of the installed world that left its lattice alone (same origin, same levels), [lo, hi) = the edited box in world voxels.
+// The map is an UPPER bound per texel (a shadow ray's tmax is capped there: a larger value caps later, never wrongly), so it is kept
+// valid cheaply — an edit that can only have emptied voxels (may_add false) changes nothing; one that may have filled some raises the texels
+// whose prism meets the box to the box's farthest corner along the sun (one tiny launch) — and made TIGHT again by the search (one wave
+// per texel through the new tree, 30-60 us: round 3 ran it behind every edit, a seventh of the brush -> tree latency) only every
+// kSunMapLooseEdits edits, over the union of their boxes.  Anything else: the whole map.
+constexpr uint32_t kSunMapLooseEdits = 32;
+int update_sun_map(blok_hip_ctx* ctx, const int32_t lo[3], const int32_t hi[3], bool same_lattice, bool may_add) {
+    if (!same_lattice || !ctx->has_sun_map || !ctx->d_sun_map || ctx->world_voxel_size != 1.0f || !ctx->has_world || ctx->stats.n_voxels == 0) {
+        ctx->sun_loose_edits = 0;
+        return rebuild_sun_map(ctx);
+    }
     blok::SunMapArgs& m = ctx->sun;
     m.trace.nodes = ctx->d_nodes; m.trace.materials = ctx->d_tree_materials;
     if (lo[0] >= hi[0] || lo[1] >= hi[1] || lo[2] >= hi[2]) return BLOK_OK;            // nothing was edited
-    double ulo = 1e30, uhi = -1e30, vlo = 1e30, vhi = -1e30;
+    if (ctx->sun_loose_edits == 0) for (int a = 0; a < 3; ++a) { ctx->sun_loose_lo[a] = lo[a]; ctx->sun_loose_hi[a] = hi[a]; }
+    else for (int a = 0; a < 3; ++a) { ctx->sun_loose_lo[a] = std::min(ctx->sun_loose_lo[a], lo[a]); ctx->sun_loose_hi[a] = std::max(ctx->sun_loose_hi[a], hi[a]); }
+    ctx->sun_loose_edits += 1;
+    const bool tighten = ctx->sun_loose_edits >= kSunMapLooseEdits;
+    if (!tighten && !may_add) return BLOK_OK;
+    const int32_t* blo = tighten ? ctx->sun_loose_lo : lo;
+    const int32_t* bhi = tighten ? ctx->sun_loose_hi : hi;
+    double ulo = 1e30, uhi = -1e30, vlo = 1e30, vhi = -1e30, far_depth = -1e30;
     for (int c = 0; c < 8; ++c) {
-        const double p[3] = {double((c & 1) ? hi[0] : lo[0]), double((c & 2) ? hi[1] : lo[1]), double((c & 4) ? hi[2] : lo[2])};
+        const double p[3] = {double((c & 1) ? bhi[0] : blo[0]), double((c & 2) ? bhi[1] : blo[1]), double((c & 4) ? bhi[2] : blo[2])};
         const double pu = m.u[0] * p[0] + m.u[1] * p[1] + m.u[2] * p[2], pv = m.v[0] * p[0] + m.v[1] * p[1] + m.v[2] * p[2];
         ulo = std::min(ulo, pu); uhi = std::max(uhi, pu); vlo = std::min(vlo, pv); vhi = std::max(vhi, pv);
+        far_depth = std::max(far_depth, m.s[0] * p[0] + m.s[1] * p[1] + m.s[2] * p[2]);
     }
     const auto texel_of = [&](double x, double x0, uint32_t n) { const double t = std::floor((x - x0) / m.texel); return static_cast<int64_t>(std::min<double>(std::max<double>(t, -1.0), double(n))); };
     const int64_t iu0 = std::max<int64_t>(texel_of(ulo, m.u0, m.nu) - 1, 0), iu1 = std::min<int64_t>(texel_of(uhi, m.u0, m.nu) + 1, int64_t(m.nu) - 1);
     const int64_t iv0 = std::max<int64_t>(texel_of(vlo, m.v0, m.nv) - 1, 0), iv1 = std::min<int64_t>(texel_of(vhi, m.v0, m.nv) + 1, int64_t(m.nv) - 1);
     if (iu1 < iu0 || iv1 < iv0) return BLOK_OK;
     m.iu0 = static_cast<uint32_t>(iu0); m.iv0 = static_cast<uint32_t>(iv0); m.sub_nu = static_cast<uint32_t>(iu1 - iu0 + 1); m.sub_nv = static_cast<uint32_t>(iv1 - iv0 + 1);
-    blok::launch_sun_map(m, nullptr);
+    if (tighten) { blok::launch_sun_map(m, nullptr); ctx->sun_loose_edits = 0; }
+    else blok::launch_sun_map_raise(m, static_cast<float>(far_depth + 1.0e-3 * std::fabs(far_depth) + 0.01), nullptr);      // (rounded up: the bound must not fall short in float)
     BLOK_HIP_TRY(ctx, hipGetLastError());
-    BLOK_HIP_TRY(ctx, hipDeviceSynchronize());
+    // launches on other (non-blocking) streams do not wait for the null stream: the path entries wait for this marker instead
+    if (!ctx->sun_event) BLOK_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->sun_event, hipEventDisableTiming));
+    BLOK_HIP_TRY(ctx, hipEventRecord(ctx->sun_event, nullptr));
+    ctx->sun_event_pending = true;
     return BLOK_OK;
 }
 
@@ -839,6 +859,7 @@ void blok_hip_destroy(blok_hip_ctx* ctx) {
     if (ctx->order.done) (void)hipEventDestroy(ctx->order.done);
     if (ctx->d_accum) (void)hipFree(ctx->d_accum);
     if (ctx->d_color) (void)hipFree(ctx->d_color);
+    if (ctx->sun_event) (void)hipEventDestroy(ctx->sun_event);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
     delete ctx;
@@ -1412,6 +1433,10 @@ static int launch_path_frame(blok_hip_ctx* ctx, const blok_camera* cam, uint32_t
         p.sun_u0 = m.u0; p.sun_v0 = m.v0; p.sun_inv_texel = 1.0f / m.texel; p.sun_nu = m.nu; p.sun_nv = m.nv;
     }
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    if (ctx->sun_event_pending && p.sun_map) {              // a patch of the map enqueued behind the latest rebuild (update_sun_map)
+        if (hipEventQuery(ctx->sun_event) == hipSuccess) ctx->sun_event_pending = false;
+        else { (void)hipGetLastError(); BLOK_HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->sun_event, 0)); }
+    }
     uint32_t n_beams = 0;                                   // the primary rays of every sample start behind the beam pre-pass
     rc = prepare_beam(ctx, blok::RayMode::Rect, p.trace, stream, 0, &n_beams);
     if (rc != BLOK_OK) return rc;

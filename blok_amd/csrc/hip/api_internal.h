@@ -91,6 +91,8 @@ struct blok_hip_ctx {
     // "last occluder" map of the shadow rays (beam.h: prism_far), rebuilt with every world
     float* d_sun_map = nullptr;
     bool sun_map_enabled = true, has_sun_map = false;
+    uint32_t sun_loose_edits = 0; int32_t sun_loose_lo[3] = {0, 0, 0}, sun_loose_hi[3] = {0, 0, 0};      // edits since the map was last made tight, and the union of their boxes (update_sun_map)
+    hipEvent_t sun_event = nullptr; bool sun_event_pending = false;                                      // behind the latest patch of the map
     uint32_t ray_batching = 2;          // PathArgs::batch_kinds (blok_hip_set_ray_batching)
     bool path_resume = false, path_fine_beam = true;      // PathArgs::resume_secondary / fine_beam (blok_hip_set_path_start)
     blok::SunMapArgs sun{};
@@ -198,7 +200,7 @@ void free_world(blok_hip_ctx* ctx);
 int install_materials(blok_hip_ctx* ctx, const blok_material* materials, size_t n_materials);
 int install_tree(blok_hip_ctx* ctx, const blok::HostTree& tree, const blok_material* materials, size_t n_materials);
 int rebuild_sun_map(blok_hip_ctx* ctx);
-int update_sun_map(blok_hip_ctx* ctx, const int32_t lo[3], const int32_t hi[3], bool same_lattice);
+int update_sun_map(blok_hip_ctx* ctx, const int32_t lo[3], const int32_t hi[3], bool same_lattice, bool may_add = true);
 int ensure_frame(blok_hip_ctx* ctx, size_t records);
 blok::TraceArgs base_args(const blok_hip_ctx* ctx, const blok_camera* cam);
 int prepare_beam(blok_hip_ctx* ctx, blok::RayMode mode, blok::TraceArgs& args, hipStream_t stream, uint32_t tiles_of_rank, uint32_t* n_beams);

@@ -1,5 +1,7 @@
 // C ABI, device-resident dense voxel store (include/blok_hip.h: blok_hip_volume_*; kernels in gpu_build.hip).
 #include "api_internal.h"
+#include <chrono>
+#include <cstdlib>
 
 using namespace blok_api;
 
@@ -86,7 +88,10 @@ int blok_hip_volume_rebuild(blok_hip_ctx* ctx, const blok_material* materials, s
     int rc = need_volume(ctx);
     if (rc != BLOK_OK) return rc;
     if (n_materials && !materials) return set_error(ctx, BLOK_ERR_INVALID_ARG, "null material table");
+    const bool timing = std::getenv("BLOK_VOLUME_TIMING") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
     BLOK_HIP_TRY(ctx, hipDeviceSynchronize());            // frames still reading a tree of an earlier build
+    const auto t_synced = std::chrono::steady_clock::now();
     blok::GpuVolume& v = ctx->volume;
     // the voxels edited since the last build, in world coordinates (for the shadow rays' last-occluder map)
     int32_t lo[3], hi[3];
@@ -95,8 +100,11 @@ int blok_hip_volume_rebuild(blok_hip_ctx* ctx, const blok_material* materials, s
     if (!edited) { lo[0] = lo[1] = lo[2] = 0; hi[0] = hi[1] = hi[2] = 0; }
     blok::GpuTree gpu;
     std::string why;
+    const bool may_add = v.edit_may_add;
     const blok::GpuBuildStatus st = blok::gpu_volume_build(&v, &gpu, &why);
+    const auto t_built = std::chrono::steady_clock::now();
     for (int a = 0; a < 3; ++a) { v.edit_lo[a] = 0xFFFFFFFFu; v.edit_hi[a] = 0u; }
+    v.edit_may_add = false;
     if (st == blok::GpuBuildStatus::UseHostBuilder) {      // nothing filled: an empty world
         blok::HostTree tree;
         std::vector<blok::VoxelRec> none;
@@ -137,7 +145,13 @@ int blok_hip_volume_rebuild(blok_hip_ctx* ctx, const blok_material* materials, s
     ctx->order.interval_now = ctx->order.interval;
     ctx->built_on_device = true;
     if (same_lattice) { ctx->d_sun_map = keep_sun; ctx->has_sun_map = keep_has_sun; }
-    return update_sun_map(ctx, lo, hi, same_lattice);
+    const auto t_installed = std::chrono::steady_clock::now();
+    rc = update_sun_map(ctx, lo, hi, same_lattice, may_add);
+    if (timing) {
+        const auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        std::fprintf(stderr, "[volume_rebuild us] wait-for-device %.1f build %.1f install %.1f sun-map %.1f\n", us(t_begin, t_synced), us(t_synced, t_built), us(t_built, t_installed), us(t_installed, std::chrono::steady_clock::now()));
+    }
+    return rc;
 }
 
 }  // extern "C"

@@ -76,6 +76,7 @@ struct GpuVolume {
     } scratch;
     // voxels edited since the last build (box-local, half-open); empty = lo > hi
     uint32_t edit_lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, edit_hi[3] = {0, 0, 0};
+    bool edit_may_add = false;                   // ... and one of those edits may have FILLED a voxel (an ADD brush with a positive value, setVoxel): what the shadow rays' map has to know
 };
 
 GpuBuildStatus gpu_volume_create(const int32_t origin[3], uint32_t nx, uint32_t ny, uint32_t nz, uint32_t chunk, float voxel_size,

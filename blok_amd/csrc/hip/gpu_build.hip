@@ -22,6 +22,9 @@
 #include <vector>
 
 #include "gpu_build.h"
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 namespace blok {
 
@@ -533,6 +536,40 @@ __global__ __launch_bounds__(256) void keyed_brick_kernel(const KeyedCtx v, cons
     v.dirty[g] = 1;                       // its material ids are read from the dense store at the next build (an id can change under an unchanged mask)
 }
 
+// The same for a SMALL range (an edit): one wave per brick, lane b = voxel b — the 64 density reads of a brick are 16 short rows instead of
+// one lane's 64 strided loads (radius-8 brush, 216 bricks: 13.8 -> ~3 us).
+__global__ __launch_bounds__(64) void keyed_brick_wave_kernel(const KeyedCtx v, const CellRange r) {
+    const uint32_t t = blockIdx.x, b = threadIdx.x;
+    const uint32_t b_x = r.x0 + t % r.nx, b_y = r.y0 + (t / r.nx) % r.ny, b_z = r.z0 + t / (r.nx * r.ny);
+    const uint32_t vx = b_x * 4u + (b & 3u), vy = b_y * 4u + ((b >> 2) & 3u), vz = b_z * 4u + (b >> 4);
+    const bool filled = vx < v.nx && vy < v.ny && vz < v.nz && v.density[(static_cast<size_t>(vz) * v.ny + vy) * v.nx + vx] > 0.0f;
+    const uint64_t mask = __ballot(filled);
+    if (b == 0) {
+        const uint64_t g = cell_key(b_x, b_y, b_z, v.levels - 1u);
+        v.masks[g] = mask;
+        v.dirty[g] = 1;
+    }
+}
+
+// The occupancy words above an edit, ALL levels in one workgroup (the ranges are a handful of cells per level; one launch instead of
+// levels - 1): level l reads what level l - 1 has just written, a workgroup barrier and a device-scope fence in between.
+struct OccLevels { const uint64_t* below[8]; uint64_t* occ[8]; uint32_t digits[8]; CellRange range[8]; uint32_t first, last; };
+__global__ __launch_bounds__(256) void occupancy_levels_kernel(const OccLevels o) {
+    for (uint32_t l = o.first; l <= o.last; ++l) {
+        const CellRange r = o.range[l];
+        const uint32_t total = r.nx * r.ny * r.nz;
+        for (uint32_t tid = threadIdx.x; tid < total; tid += 256u) {
+            const uint64_t c = cell_key(r.x0 + tid % r.nx, r.y0 + (tid / r.nx) % r.ny, r.z0 + tid / (r.nx * r.ny), o.digits[l]);
+            const uint64_t* child = o.below[l] + c * 64u;
+            uint64_t word = 0;
+            for (uint32_t b = 0; b < 64u; ++b) word |= static_cast<uint64_t>(__hip_atomic_load(child + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) << b;
+            o.occ[l][c] = word;
+        }
+        __threadfence();
+        __syncthreads();
+    }
+}
+
 // One lane per cell of level l in the range: its occupancy word from the 64 cells below it (the brick masks for l = 2).
 __global__ __launch_bounds__(256) void occupancy_kernel(const uint64_t* below, uint64_t* occ, const uint32_t digits, const CellRange r) {
     const uint64_t tid = static_cast<uint64_t>(blockIdx.x) * 256u + threadIdx.x;
@@ -609,25 +646,30 @@ __global__ __launch_bounds__(64) void gather_bricks_kernel(const uint64_t* occ2,
     masks_sorted[i] = m; src[i] = g; counts[i] = static_cast<uint32_t>(__popcll(m));
 }
 
-// One lane per (brick, voxel bit): the voxel's material id at its rank — from the previous build's array when the brick has not been
-// touched since (its mask, hence every rank, is the same), from the dense store otherwise.
+// Sixteen lanes per brick (a brick of the benchmark world holds 12 voxels on average; one lane per voxel BIT left four lanes in five
+// idle: 55 us per rebuild of 230 K bricks): the voxels' material ids at their ranks — copied from the previous build's array when the brick has
+// not been touched since (its mask, hence every rank, is the same: a short coalesced run), from the dense store otherwise.
 __global__ __launch_bounds__(256) void keyed_material_kernel(const KeyedCtx v, const uint64_t* masks_sorted, const uint32_t* src, const uint32_t* mat_base,
                                                              uint32_t n_bricks, const uint32_t* old_base, const uint32_t* previous, uint32_t* materials) {
     const uint64_t tid = static_cast<uint64_t>(blockIdx.x) * 256u + threadIdx.x;
-    const uint32_t i = static_cast<uint32_t>(tid >> 6), bit = static_cast<uint32_t>(tid & 63u);
+    const uint32_t i = static_cast<uint32_t>(tid >> 4), q = static_cast<uint32_t>(tid & 15u);
     if (i >= n_bricks) return;
     const uint64_t mask = masks_sorted[i];
-    if (!((mask >> bit) & 1ull)) return;
-    const uint32_t g = src[i];
-    const uint32_t rank = static_cast<uint32_t>(__popcll(mask & ((1ull << bit) - 1ull)));
-    uint32_t id;
-    if (previous && !v.dirty[g] && old_base[g] != 0xFFFFFFFFu) id = previous[old_base[g] + rank];
-    else {
-        uint32_t bx, by, bz;
-        key_cell(g, v.levels - 1u, bx, by, bz);
-        id = v.ids[(static_cast<size_t>(bz * 4u + (bit >> 4)) * v.ny + (by * 4u + ((bit >> 2) & 3u))) * v.nx + bx * 4u + (bit & 3u)];
+    const uint32_t count = static_cast<uint32_t>(__popcll(mask));
+    const uint32_t g = src[i], out = mat_base[i];
+    if (previous && !v.dirty[g] && old_base[g] != 0xFFFFFFFFu) {
+        const uint32_t from = old_base[g];
+        for (uint32_t r = q; r < count; r += 16u) materials[out + r] = previous[from + r];
+        return;
     }
-    materials[mat_base[i] + rank] = id;
+    uint32_t bx, by, bz;
+    key_cell(g, v.levels - 1u, bx, by, bz);
+    for (uint32_t k = 0; k < 4u; ++k) {                      // this lane's four voxel bits: q, q + 16, q + 32, q + 48 = row (y = q >> 2, x = q & 3) of the z-slices
+        const uint32_t bit = q + 16u * k;
+        if (!((mask >> bit) & 1ull)) continue;
+        const uint32_t rank = static_cast<uint32_t>(__popcll(mask & ((1ull << bit) - 1ull)));
+        materials[out + rank] = v.ids[(static_cast<size_t>(bz * 4u + (bit >> 4)) * v.ny + (by * 4u + ((bit >> 2) & 3u))) * v.nx + bx * 4u + (bit & 3u)];
+    }
 }
 
 // Brick nodes, and the bookkeeping for the next build: where each brick's ids now lie, nothing dirty.
@@ -651,14 +693,32 @@ KeyedCtx keyed_ctx(const GpuVolume& v) {
 GpuBuildStatus keyed_refresh(GpuVolume* v, const uint32_t lo[3], const uint32_t hi[3], std::string* why) {
     if (hi[0] <= lo[0] || hi[1] <= lo[1] || hi[2] <= lo[2]) return GpuBuildStatus::Ok;
     const KeyedCtx k = keyed_ctx(*v);
+    CellRange ranges[9] = {};
+    uint64_t totals[9] = {};
     for (uint32_t l = 1; l <= v->levels; ++l) {
-        CellRange r{};
+        CellRange& r = ranges[l];
         r.x0 = lo[0] >> (2u * l); r.y0 = lo[1] >> (2u * l); r.z0 = lo[2] >> (2u * l);
         r.nx = ((hi[0] - 1u) >> (2u * l)) - r.x0 + 1u; r.ny = ((hi[1] - 1u) >> (2u * l)) - r.y0 + 1u; r.nz = ((hi[2] - 1u) >> (2u * l)) - r.z0 + 1u;
-        const uint64_t total = static_cast<uint64_t>(r.nx) * r.ny * r.nz;
-        if (l == 1) hipLaunchKernelGGL(keyed_brick_kernel, dim3(blocks_for(total)), dim3(256), 0, nullptr, k, r);
-        else hipLaunchKernelGGL(occupancy_kernel, dim3(blocks_for(total)), dim3(256), 0, nullptr, l == 2 ? v->d_masks : v->d_occ[l - 1], v->d_occ[l], v->levels - l, r);
+        totals[l] = static_cast<uint64_t>(r.nx) * r.ny * r.nz;
+    }
+    // an edit (few bricks): a wave per brick, then every level above in one workgroup; an upload (the whole box): a lane per brick, a launch per level
+    const bool small = totals[1] <= 65536u && (v->levels < 2 || totals[2] <= 4096u);
+    if (small) {
+        hipLaunchKernelGGL(keyed_brick_wave_kernel, dim3(static_cast<uint32_t>(totals[1])), dim3(64), 0, nullptr, k, ranges[1]);
         GB_TRY(hipGetLastError());
+        if (v->levels >= 2) {
+            OccLevels o{};
+            o.first = 2; o.last = v->levels;
+            for (uint32_t l = 2; l <= v->levels; ++l) { o.below[l] = l == 2 ? v->d_masks : v->d_occ[l - 1]; o.occ[l] = v->d_occ[l]; o.digits[l] = v->levels - l; o.range[l] = ranges[l]; }
+            hipLaunchKernelGGL(occupancy_levels_kernel, dim3(1), dim3(256), 0, nullptr, o);
+            GB_TRY(hipGetLastError());
+        }
+    } else {
+        for (uint32_t l = 1; l <= v->levels; ++l) {
+            if (l == 1) hipLaunchKernelGGL(keyed_brick_kernel, dim3(blocks_for(totals[l])), dim3(256), 0, nullptr, k, ranges[l]);
+            else hipLaunchKernelGGL(occupancy_kernel, dim3(blocks_for(totals[l])), dim3(256), 0, nullptr, l == 2 ? v->d_masks : v->d_occ[l - 1], v->d_occ[l], v->levels - l, ranges[l]);
+            GB_TRY(hipGetLastError());
+        }
     }
     for (int a = 0; a < 3; ++a) { v->edit_lo[a] = std::min(v->edit_lo[a], lo[a]); v->edit_hi[a] = std::max(v->edit_hi[a], hi[a]); }
     return GpuBuildStatus::Ok;
@@ -674,7 +734,16 @@ template <class T> hipError_t grow(T** p, uint64_t* capacity, uint64_t need, uin
 }
 
 // The rebuild of a keyed volume: scans over the occupancy pyramid, the gather of the non-empty bricks, the node writes.
+// BLOK_VOLUME_TIMING=1: host wall clock between the phases of a rebuild, to stderr (diagnostic; scripts/r04/edit_latency.py)
+struct PhaseClock {
+    bool on; std::chrono::steady_clock::time_point t; std::string line;
+    PhaseClock() : on(std::getenv("BLOK_VOLUME_TIMING") != nullptr), t(std::chrono::steady_clock::now()) {}
+    void mark(const char* what) { if (!on) return; const auto n = std::chrono::steady_clock::now(); char b[64]; std::snprintf(b, sizeof b, " %s %.1f", what, std::chrono::duration<double, std::micro>(n - t).count()); line += b; t = n; }
+    ~PhaseClock() { if (on) std::fprintf(stderr, "[keyed_build us]%s\n", line.c_str()); }
+};
+
 GpuBuildStatus keyed_build(GpuVolume* v, GpuTree* out, std::string* why) {
+    PhaseClock clock;
     auto& S = v->scratch;
     const uint32_t L = v->levels;
     uint64_t cells[8] = {};                                                 // cells of level l = 64^(L - l)
@@ -698,8 +767,10 @@ GpuBuildStatus keyed_build(GpuVolume* v, GpuTree* out, std::string* why) {
     }
     hipLaunchKernelGGL(small_levels_kernel, dim3(1), dim3(1024), 0, nullptr, small, S.d_info);      // (small.first > small.last: just the big levels' totals)
     GB_TRY(hipGetLastError());
+    clock.mark("scans-enqueued");
     uint64_t totals[8] = {};
-    GB_TRY(hipMemcpy(totals, S.d_info, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));              // the one wait in the middle: the launch sizes below
+    GB_TRY(hipMemcpy(totals, S.d_info, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    clock.mark("totals-read");              // the one wait in the middle: the launch sizes below
     uint32_t n_nodes[9] = {};                                               // nodes per level; n_nodes[1] = bricks
     for (uint32_t l = 2; l <= L; ++l) { n_nodes[l] = static_cast<uint32_t>(totals[l] >> 32); if (l == 2) n_nodes[1] = static_cast<uint32_t>(totals[l]); }
     const uint32_t n_bricks = n_nodes[1];
@@ -709,7 +780,9 @@ GpuBuildStatus keyed_build(GpuVolume* v, GpuTree* out, std::string* why) {
     const uint64_t n_tree = static_cast<uint64_t>(start[1]) + n_bricks;
     const int next = S.current == 0 ? 1 : 0;
     GB_TRY(grow(&S.d_tree[next], &S.tree_capacity[next], n_tree));
-    GB_TRY(grow(&S.d_materials[next], &S.material_capacity[next], static_cast<uint64_t>(n_bricks) * 64u, 1, 1));      // by its bound: no wait for the count
+    // by its bound (no wait for the voxel count), with a sixteenth to spare: sized exactly, every edit that added a brick re-allocated 59 MB —
+    // a device-wide wait, a free and a malloc, 210 us of the 0.44 ms a radius-8 brush took to become a tree (BLOK_VOLUME_TIMING, round 4)
+    GB_TRY(grow(&S.d_materials[next], &S.material_capacity[next], static_cast<uint64_t>(n_bricks) * 64u, 17, 16));
     if (S.brick_capacity < n_bricks + 1ull) {
         GB_TRY(hipDeviceSynchronize());
         for (void* p : {static_cast<void*>(S.d_masks_sorted), static_cast<void*>(S.d_src), static_cast<void*>(S.d_counts), static_cast<void*>(S.d_mat_base)}) if (p) (void)hipFree(p);
@@ -719,12 +792,14 @@ GpuBuildStatus keyed_build(GpuVolume* v, GpuTree* out, std::string* why) {
         S.brick_capacity = want;
     }
     GB_TRY(grow(&S.d_cells2, &S.cells2_capacity, n_nodes[2]));
+    clock.mark("grown");
     // 2. nodes of levels L .. 2, the list of non-empty level-2 cells
     for (uint32_t l = L; l >= 2; --l) {
         hipLaunchKernelGGL(level_nodes_kernel, dim3(blocks_for(cells[l])), dim3(256), 0, nullptr, v->d_occ[l], S.d_scanned[l], cells[l], start[l], start[l - 1],
                            S.d_tree[next], l == 2 ? S.d_cells2 : nullptr);
         GB_TRY(hipGetLastError());
     }
+    clock.mark("level-nodes");
     // 3. the non-empty bricks in key order, their voxel counts, the material offsets
     hipLaunchKernelGGL(gather_bricks_kernel, dim3(n_nodes[2]), dim3(64), 0, nullptr, v->d_occ[2], S.d_scanned[2], S.d_cells2, v->d_masks, S.d_masks_sorted, S.d_src, S.d_counts, n_bricks);
     GB_TRY(hipGetLastError());
@@ -735,17 +810,20 @@ GpuBuildStatus keyed_build(GpuVolume* v, GpuTree* out, std::string* why) {
         size_t bytes = S.scan_temp_bytes;
         GB_TRY(hipcub::DeviceScan::ExclusiveSum(S.d_scan_temp, bytes, S.d_counts, S.d_mat_base, static_cast<int>(n_bricks + 1u)));
     }
+    clock.mark("gather+scan");
     // 4. material ids (untouched bricks from the previous build's array), brick nodes
     const KeyedCtx k = keyed_ctx(*v);
     const uint32_t* previous = S.have_previous_materials && S.current >= 0 ? S.d_materials[S.current] : nullptr;
-    hipLaunchKernelGGL(keyed_material_kernel, dim3(blocks_for(static_cast<uint64_t>(n_bricks) * 64u)), dim3(256), 0, nullptr, k, S.d_masks_sorted, S.d_src, S.d_mat_base,
+    hipLaunchKernelGGL(keyed_material_kernel, dim3(blocks_for(static_cast<uint64_t>(n_bricks) * 16u)), dim3(256), 0, nullptr, k, S.d_masks_sorted, S.d_src, S.d_mat_base,
                        n_bricks, S.d_old_base, previous, S.d_materials[next]);
     GB_TRY(hipGetLastError());
     hipLaunchKernelGGL(keyed_brick_nodes_kernel, dim3(blocks_for(n_bricks)), dim3(256), 0, nullptr, S.d_masks_sorted, S.d_src, S.d_mat_base, n_bricks, S.d_tree[next] + start[1],
                        S.d_old_base, v->d_dirty);
     GB_TRY(hipGetLastError());
+    clock.mark("nodes-enqueued");
     uint32_t n_voxels = 0;
-    GB_TRY(hipMemcpy(&n_voxels, S.d_mat_base + n_bricks, sizeof(uint32_t), hipMemcpyDeviceToHost));      // also: everything above has completed
+    GB_TRY(hipMemcpy(&n_voxels, S.d_mat_base + n_bricks, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    clock.mark("count-read");      // also: everything above has completed
     S.current = next; S.have_previous_materials = true;
     out->d_nodes = S.d_tree[next]; out->d_materials = S.d_materials[next]; out->owned_by_volume = true;
     out->n_nodes = n_tree; out->n_voxels = n_voxels; out->levels = L;
@@ -854,6 +932,7 @@ GpuBuildStatus gpu_volume_set_voxels(GpuVolume* v, const int32_t* xyz, const uin
     GB_TRY(hipMemcpy(d_edits, edits.data(), m * sizeof(VoxelEdit), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(volume_set_kernel, dim3(blocks_for(m)), dim3(256), 0, nullptr, v->d_density, v->d_ids, d_edits, static_cast<uint32_t>(m));
     GB_TRY(hipGetLastError());
+    v->edit_may_add = true;                               // (a written density may be positive)
     const GpuBuildStatus st = volume_refresh(v, lo, hi, why);
     GB_TRY(hipDeviceSynchronize());
     return st;
@@ -879,6 +958,7 @@ GpuBuildStatus gpu_volume_brush(GpuVolume* v, const float center[3], float radiu
     b.ex = hi[0] - lo[0]; b.ey = hi[1] - lo[1]; b.ez = hi[2] - lo[2];
     b.chunk = static_cast<int32_t>(v->chunk); b.voxel_size = v->voxel_size;
     b.cx = center[0]; b.cy = center[1]; b.cz = center[2]; b.radius = radius; b.value = value; b.mode = mode;
+    if (mode == 0 && value > 0.0f) v->edit_may_add = true;          // max(density, value) can fill; min(density, value) never does (brush.cpp:52-57)
     const uint64_t total = static_cast<uint64_t>(b.ex) * b.ey * b.ez;
     if (!total) return GpuBuildStatus::Ok;
     hipLaunchKernelGGL(volume_brush_kernel, dim3(blocks_for(total)), dim3(256), 0, nullptr, b);

@@ -252,6 +252,7 @@ struct SunMapArgs {                        // beam.h: prism_far, one wave per te
     uint32_t iu0, iv0, sub_nu, sub_nv;     // the texels this launch computes: [iu0, iu0 + sub_nu) x [iv0, iv0 + sub_nv) (the whole map, or what an edit can have changed)
 };
 void launch_sun_map(const SunMapArgs& args, hipStream_t stream);
+void launch_sun_map_raise(const SunMapArgs& args, float far_depth, hipStream_t stream);      // texels of the sub-rectangle: max(value, far_depth)
 
 struct PathArgs;
 struct TonemapArgs;

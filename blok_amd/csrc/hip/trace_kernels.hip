@@ -776,6 +776,18 @@ __global__ __launch_bounds__(64) void sun_map_kernel(const SunMapArgs a) {
     if (lane == 0) a.map[static_cast<size_t>(iv) * a.nu + iu] = last;
 }
 
+// After an edit that may have FILLED voxels inside a box: every texel whose prism can meet the box is raised to the box's farthest corner
+// along the sun — an upper bound of whatever the edit put there.  The map is conservative by construction (a larger "last occluder" only caps
+// a shadow ray's tmax later: path_core.h), so this keeps every answer; an edit that only EMPTIES voxels needs nothing at all.
+__global__ __launch_bounds__(64) void sun_map_raise_kernel(const SunMapArgs a, const float far_depth) {
+    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+    if (i >= a.sub_nu * a.sub_nv) return;
+    const uint32_t iu = a.iu0 + i % a.sub_nu, iv = a.iv0 + i / a.sub_nu;
+    if (iu >= a.nu || iv >= a.nv) return;
+    float* t = a.map + static_cast<size_t>(iv) * a.nu + iu;
+    *t = fmaxf(*t, far_depth);
+}
+
 // raygen.rgen main(): one lane per pixel of the rectangle, same 16x16 / 8x8 pixel mapping as the trace kernel.
 #ifndef BLOK_PATH_WAVES
 #define BLOK_PATH_WAVES 6        // waves per SIMD the path kernel is compiled for (register budget 512 / waves): 4 (109 VGPRs) 74.2 ms, 5 70.7, 6 69.9, 8 71.1 at 4K 64 spp
@@ -1044,6 +1056,11 @@ void launch_frame(RayMode mode, const TraceArgs& args, const FrameQueue& queue, 
 void launch_sun_map(const SunMapArgs& args, hipStream_t stream) {
     const uint32_t n = args.sub_nu * args.sub_nv;
     if (n) hipLaunchKernelGGL(sun_map_kernel, dim3(n), dim3(64), 0, stream, args);
+}
+
+void launch_sun_map_raise(const SunMapArgs& args, float far_depth, hipStream_t stream) {
+    const uint32_t n = args.sub_nu * args.sub_nv;
+    if (n) hipLaunchKernelGGL(sun_map_raise_kernel, dim3((n + 63u) / 64u), dim3(64), 0, stream, args, far_depth);
 }
 
 void launch_paths(const PathArgs& args, uint32_t n_blocks, hipStream_t stream) {
