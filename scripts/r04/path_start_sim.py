@@ -29,9 +29,23 @@ def beam_t0(tx, ty, B):
     t = np.where(out['hit'] == 1, out['t'], np.inf)
     return max(float(t.min()) - 2.0, 0.0) if np.isfinite(t.min()) else 3.0e38
 
+def fine_t0(tx, ty, B):
+    """per-lane start parameters of the 8x8 wave tile from B x B-pixel sub-tiles (B < 8), each grown by a pixel like a beam tile"""
+    x0, y0 = max(tx * 8 - 1, 0), max(ty * 8 - 1, 0); w, h = min(tx * 8 + 9, Wd) - x0, min(ty * 8 + 9, Ht) - y0
+    out = np.zeros(w * h, dtype=O.HIT); it = np.zeros(w * h, dtype=np.uint32)
+    L.hh_trace_rect_stats(hk.h, C.c_void_p(cam.ctypes.data), Wd, Ht, x0, y0, w, h, None, C.c_void_p(out.ctypes.data), C.c_void_p(it.ctypes.data))
+    t = np.where(out['hit'] == 1, out['t'], np.inf).reshape(h, w)
+    ts = np.zeros((8, 8), dtype=np.float32)
+    for sy in range(0, 8, B):
+        for sx in range(0, 8, B):
+            ax, ay = tx * 8 + sx - x0, ty * 8 + sy - y0
+            m = t[max(ay - 1, 0):ay + B + 1, max(ax - 1, 0):ax + B + 1].min()
+            ts[sy:sy + B, sx:sx + B] = max(float(m) - 2.0, 0.0) if np.isfinite(m) else 3.0e38
+    return ts.reshape(-1)
+
 def tile_events(tx, ty, B, resume):
     L.hh_set_path_resume(resume)
-    ts = np.full(64, beam_t0(tx, ty, B), dtype=np.float32)
+    ts = np.full(64, beam_t0(tx, ty, B), dtype=np.float32) if B >= 8 else np.maximum(fine_t0(tx, ty, B), np.float32(beam_t0(tx, ty, 8)))
     ev = np.zeros((64, cap), dtype=np.uint8)
     L.hh_render_paths_events2(hk.h, C.c_void_p(cam.ctypes.data), C.c_void_p(mats.ctypes.data), len(mats), Wd, Ht, tx * 8, ty * 8, 8, 8,
                               spp, 2, C.c_void_p(ts.ctypes.data), cap, C.c_void_p(ev.ctypes.data))
@@ -75,7 +89,8 @@ tiles = [(tx, ty) for ty in rows for tx in (25, 100, 175, 250, 325, 400, 470)]
 live = [t for t in tiles if beam_t0(t[0], t[1], 8) < 1e38]
 print(f"pose {'ABC'[pose]}, {spp} spp: {len(live)} live wave tiles of {len(tiles)} sampled")
 base = None
-for name, B, resume in (("beam 32, from the root (round 3)", 32, 0), ("beam 8, from the root", 8, 0), ("beam 32, resumed", 32, 1), ("beam 8, resumed", 8, 1)):
+for name, B, resume in (("beam 32, from the root (round 3)", 32, 0), ("beam 8, from the root", 8, 0), ("beam 32, resumed", 32, 1), ("beam 8, resumed", 8, 1),
+                        ("beam 4, from the root", 4, 0), ("beam 4, resumed", 4, 1), ("beam 2, from the root", 2, 0), ("beam 2, resumed", 2, 1), ("beam 1, from the root", 1, 0), ("beam 1, resumed", 1, 1)):
     tot = np.zeros(3); it = np.zeros(3); li = np.zeros(3); ry = np.zeros(3)
     for tx, ty in live:
         c, i, l, r = lockstep_cost(tile_events(tx, ty, B, resume)); tot += c; it += i; li += l; ry += r

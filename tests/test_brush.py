@@ -233,7 +233,7 @@ def test_sun_map_stays_valid_across_volume_edits():
 
     same("scene")
     for k in range(70):
-        c = tuple(float(v) for v in rng.uniform((6, 20, 6), (58, 88, 58)))
+        c = tuple(float(v) for v in rng.uniform((9, 22, 9), (54, 86, 54)))
         if k % 3 == 2:
             tr.volume_apply_brush(c, float(rng.integers(2, 7)), 0.0, 1)                       # dig
         elif k % 7 == 3:
