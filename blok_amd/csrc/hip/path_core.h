@@ -328,6 +328,8 @@ BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t in
                 }
                 resumed = walk_resume(A, r, R, anchor, stk, ws);
             }
+            // (the frame kernels' common start of a wave's primary rays, trace_core.h: walk_enter_wave, was tried here too: 44.7 -> 45.6 ms at 64 spp — 61 spilled
+            // registers instead of 28 cost more than a round's shared descents save; profiles/r04_paths_start_ab.txt)
             if (!resumed) walk_enter(A, R, r.tmin, r.tmax, ws);
             if (ws.walking) stack_is_anchor = false;
             walk_loop(A, R, r.tmax, ws, stk);

@@ -415,6 +415,67 @@ BLOK_DEV bool walk_resume(const TraceArgs& A, const RayIn& r, const WalkRay& R, 
     return true;
 }
 
+#ifndef BLOK_TRACE_HOST_HARNESS
+// ---- primary rays: the wave's COMMON prefix of descents, once per wave --------------------------------------------------------------------
+// The 64 rays of a wave tile start in nearly the same place (behind their beam tile's start parameter), so their walks begin with the same
+// descents from the root — each a dependent node load and ~90 vector instructions, executed by all 64 lanes for one answer.  Here every lane
+// finds its verified start voxel (walk_resume, step 1), the wave agrees on the lowest level m at which the 64 start voxels still share a cell
+// (ballots), and ONE scalar chain walks from the root through the shared cells of levels L-1 .. m — uniform node loads, mask test and rank on
+// the scalar unit — until a shared cell is empty or the cells part; the nodes passed go to every lane's stack slots, and each lane takes up the
+// walk at its own cell of the level reached, in the state the walk from the root would be in (same argument as walk_resume: that walk descends
+// through the cells that contain its start voxel for as long as they are occupied).  Measured on the benchmark frame's live wave tiles
+// (scripts/r04/common_prefix_estimate.py): 2.2 / 4.0 / 2.4 of the 5 descents are shared in poses A / B / C.  false: the wave starts at the
+// root as before (a lane without a verified start voxel, cells that part at the root).
+BLOK_DEV bool walk_enter_wave(const TraceArgs& A, const RayIn& r, const WalkRay& R, uint4* stk, WalkState& s) {
+    const uint32_t L = A.levels;
+    const int W = 1 << (2 * L);
+    const float tS = r.tmin;
+    const bool negx = !(R.ax.inv > 0.0f), negy = !(R.ay.inv > 0.0f), negz = !(R.az.inv > 0.0f);
+    float fx, fy, fz, tFx, tFy, tFz;
+    bool ok = resume_axis(R.ax, negx, __builtin_fmaf(r.dx, tS, r.ox), A.inv_voxel_size, A.origin[0], W, tS, fx, tFx);
+    ok = resume_axis(R.ay, negy, __builtin_fmaf(r.dy, tS, r.oy), A.inv_voxel_size, A.origin[1], W, tS, fy, tFy) && ok;
+    ok = resume_axis(R.az, negz, __builtin_fmaf(r.dz, tS, r.oz), A.inv_voxel_size, A.origin[2], W, tS, fz, tFz) && ok;
+    ok = ok && tS < r.tmax;
+    if (__ballot(!ok) != 0ull) return false;
+    const uint32_t qx = __float_as_uint(fx) & 0x7FFFFFu, qy = __float_as_uint(fy) & 0x7FFFFFu, qz = __float_as_uint(fz) & 0x7FFFFFu;
+    const uint32_t ux = negx ? static_cast<uint32_t>(W - 1) - qx : qx, uy = negy ? static_cast<uint32_t>(W - 1) - qy : qy, uz = negz ? static_cast<uint32_t>(W - 1) - qz : qz;
+    const uint32_t ux0 = __builtin_amdgcn_readfirstlane(ux), uy0 = __builtin_amdgcn_readfirstlane(uy), uz0 = __builtin_amdgcn_readfirstlane(uz);
+    const uint32_t diff = (ux ^ ux0) | (uy ^ uy0) | (uz ^ uz0);
+    const uint32_t mine = diff ? (static_cast<uint32_t>(31 - __clz(static_cast<int>(diff))) >> 1) + 1u : 0u;      // cells of 4^mine voxels hold this lane's start voxel and the first lane's
+    uint32_t m = 0u;                                                       // ... of 4^m: all of them
+    for (uint32_t k = 0; k < L; ++k) if (__ballot(mine > k) != 0ull) m = k + 1u;
+    if (m >= L) return false;                                              // they part at the root: nothing to share
+    // the scalar chain
+    uint4 n4 = A.nodes[0];
+    uint32_t n_lo = __builtin_amdgcn_readfirstlane(n4.x), n_hi = __builtin_amdgcn_readfirstlane(n4.y), n_base = __builtin_amdgcn_readfirstlane(n4.z);
+    uint32_t lvl = L - 1u;
+    for (;;) {
+        if (lvl < m) break;                                                // from here on every lane has its own cell
+        const uint32_t shift = 2u * lvl;
+        const uint32_t bit = ((ux0 >> shift) & 3u) | (((uy0 >> shift) & 3u) << 2) | (((uz0 >> shift) & 3u) << 4);      // un-mirrored digits: the node's own bit order
+        const uint32_t word = bit < 32u ? n_lo : n_hi;
+        if (!((word >> (bit & 31u)) & 1u) || lvl == 0u) break;             // an empty shared cell (the walk steps on from it), or the start voxel itself
+        BLOK_STAT(1, lvl);
+        stk[(lvl - 1u) * kBlock] = make_uint4(n_lo, n_hi, n_base, 0u);
+        const uint32_t below_lo = bit < 32u ? (n_lo & ((1u << bit) - 1u)) : n_lo;
+        const uint32_t below_hi = bit < 32u ? 0u : (n_hi & ((1u << (bit & 31u)) - 1u));
+        const uint32_t child = n_base + static_cast<uint32_t>(__builtin_popcount(below_lo)) + static_cast<uint32_t>(__builtin_popcount(below_hi));
+        n4 = A.nodes[child];
+        n_lo = __builtin_amdgcn_readfirstlane(n4.x); n_hi = __builtin_amdgcn_readfirstlane(n4.y); n_base = __builtin_amdgcn_readfirstlane(n4.z);
+        lvl -= 1u;
+    }
+    s.found = false; s.bit = 0u; s.tCur = tS; s.walking = true;
+    s.lvl = lvl; s.size = cell_size(lvl);
+    s.node.lo = n_lo; s.node.hi = n_hi; s.node.base = n_base;
+    if (lvl != 0u) {
+        const uint32_t keep = ~((1u << (2 * lvl)) - 1u);
+        s.fx = __uint_as_float(__float_as_uint(fx) & keep); s.fy = __uint_as_float(__float_as_uint(fy) & keep); s.fz = __uint_as_float(__float_as_uint(fz) & keep);
+        s.tFx = plane_t(R.ax, s.fx + s.size); s.tFy = plane_t(R.ay, s.fy + s.size); s.tFz = plane_t(R.az, s.fz + s.size);
+    } else { s.fx = fx; s.fy = fy; s.fz = fz; s.tFx = tFx; s.tFy = tFy; s.tFz = tFz; }
+    return true;
+}
+#endif
+
 // Walks one ray.  `stk` points at this lane's slot of the LDS node stack (stride kBlock entries between
 // levels; slot l-2 holds the node of level l on the current path).
 //
@@ -440,9 +501,27 @@ BLOK_DEV HitInfo walk(const TraceArgs& A, const RayIn& r, uint4* stk) {
     return out;
 }
 
-// Walks one ray and writes its 16-byte record and/or RGBA8 pixel.
+// As walk(), the wave's rays entered together (walk_enter_wave): for the primary rays of a wave tile.  Every active lane of the wave must call it.
+BLOK_DEV HitInfo walk_wave(const TraceArgs& A, const RayIn& r, uint4* stk) {
+#ifdef BLOK_TRACE_HOST_HARNESS
+    return walk(A, r, stk);
+#else
+    HitInfo out;
+    out.found = false; out.t = -1.0f; out.material = 0u; out.face = 0xFFu; out.vx = out.vy = out.vz = 0;
+    out.brick.lo = out.brick.hi = out.brick.base = 0u;
+    const WalkRay R = walk_ray(A, r.ox, r.oy, r.oz, safe_inv(r.dx), safe_inv(r.dy), safe_inv(r.dz));
+    WalkState s;
+    if (!walk_enter_wave(A, r, R, stk, s)) walk_enter(A, R, r.tmin, r.tmax, s);
+    walk_loop(A, R, r.tmax, s, stk);
+    if (s.found) out = walk_hit(A, r, R, s);
+    return out;
+#endif
+}
+
+// Walks one ray and writes its 16-byte record and/or RGBA8 pixel.  kWave: through walk_wave (the coherent primary rays of a wave tile).
+template <bool kWave = false>
 BLOK_DEV void trace_one(const TraceArgs& A, const RayIn& r, uint4* stk, const Sink& dst) {
-    const HitInfo h = walk(A, r, stk);
+    const HitInfo h = kWave ? walk_wave(A, r, stk) : walk(A, r, stk);
     if (!h.found) { write_miss(dst); return; }
     uint4 rec;
     rec.x = __float_as_uint(h.t);

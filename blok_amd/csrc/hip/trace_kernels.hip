@@ -302,7 +302,10 @@ __device__ __forceinline__ void trace_block(const TraceArgs& A, const uint32_t b
         if (cost_slot && tid == 0) clock0 = __builtin_amdgcn_s_memtime();      // the walk's cost: any wait for the tile's search is not part of it
         RayIn r = primary_ray(A, x, y);
         r.tmin = fmaxf(r.tmin, t0);
-        trace_one(A, r, stk, sink);
+#ifndef BLOK_WAVE_START
+#define BLOK_WAVE_START 1
+#endif
+        trace_one<BLOK_WAVE_START != 0>(A, r, stk, sink);
         if (cost_slot && tid == 0) *cost_slot = max(static_cast<uint32_t>(__builtin_amdgcn_s_memtime() - clock0), 256u);     // it walked: any key >= 256 clocks counts as live in the next order
     }
 }
