@@ -61,7 +61,7 @@ def parse():
     ap.add_argument("--beam", type=int, default=32, help="beam pre-pass tile in pixels (0 = off)")
     ap.add_argument("--fused", type=int, default=3, help="launch form of a frame (blok_hip_set_fused): 0 = beam kernel then trace kernel, 1 = one persistent launch with work queues (measured slower), "
                     "2 = joint launch (searches and one walk wave per wave tile in one grid), 4 = list-fed joint launch (walk waves take the live wave tiles from the list the frame's searches publish), "
-                    "5 = beam kernel, then list-fed walk, 3 = automatic: 4 when a launch has the device to itself, else 5")
+                    "5 = beam kernel, then list-fed walk, 3 = automatic: 2 when a launch has the device to itself, else 0 (either over the live prefix of the view's order when one is in force)")
     ap.add_argument("--beam-budget", type=int, default=0, help="node visits a beam search may spend (0 = the library's default, 256); running out is answered conservatively")
     ap.add_argument("--moving-order", type=int, default=1, help="camera in motion, launch alone on the device: walk in the previous frame's dilated order carried over by a whole-tile shift (0 = row-major)")
     ap.add_argument("--tile-ordering", type=int, default=8, help="camera at rest: longest-first scheduling of the walk from earlier frames' per-wave clocks, re-sorted every N launches (0 = off)")
@@ -422,7 +422,7 @@ def main():
             per_pixel = seg_bytes / px + 48.0
             achieved = per_pixel * W_ * H_ / (path_ms * 1e-3) / 1e9
             paths["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                                 "kernel": "path_kernel (behind its beam_kernel), one launch per frame, alone", "kernel_ms": path_ms,
+                                 "kernel": "path_kernel (behind its beam_kernel; every wave tile also behind its own 8x8 beam), one launch per frame, alone", "kernel_ms": path_ms,
                                  "algorithmic_bytes_per_pixel": per_pixel, "ray_segments_per_pixel": int(pc["rays"]) / px,
                                  "Gsegments_per_s": int(pc["rays"]) / px * W_ * H_ / (path_ms * 1e-3) / 1e9,
                                  "sample": f"oracle counters on every 8th pixel in x and y ({px} pixels, 64 spp)"}

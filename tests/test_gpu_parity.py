@@ -628,8 +628,9 @@ def test_carried_order_of_a_moving_camera_is_pure_scheduling(tracer_cls, scene10
 
 
 def test_list_launches_equal_the_two_launch_form(tracer_cls, scene1024):
-    """List launches (blok_hip_set_fused 4, 5 and the automatic default 3): the walk waves take their wave tiles from the list the
-    frame's own searches publish, and the walk grid is sized from the previous launch's list — a hint.  4K over 1024^3: a static
+    """List launches (blok_hip_set_fused 4 and 5; the automatic default 3 is NOT one of them — it picks the joint launch 2 for a launch that has the
+    device to itself and two launches otherwise — and runs here beside them, like the plain joint form): the walk waves take their wave tiles from
+    the list the frame's own searches publish, and the walk grid is sized from the previous launch's list — a hint.  4K over 1024^3: a static
     camera; a camera creeping by 0.05 degrees per frame; jumps between poses; a view of nothing but sky followed by the top-down pose
     (the hint says "empty", every walk wave strides over several entries); the plain joint form 2 — every frame equals the
     two-launch form's, records and RGBA8, and no wave ever gave up waiting.  Then a rectangle, and frames in flight on three streams
@@ -758,6 +759,7 @@ def test_alternating_views_each_get_their_own_order(tracer_cls, scene1024):
     # three streams in flight, two views alternating
     streams = [torch.cuda.Stream() for _ in range(3)]
     outs = [(torch.zeros_like(hits), torch.zeros_like(rgba)) for _ in streams]
+    torch.cuda.synchronize()                             # (torch fills on its own stream; the side streams do not wait for it)
     for k in range(24):
         j, v = k % 3, (k // 2) % 2
         if k >= 3 and j == 0:
@@ -792,6 +794,7 @@ def test_alternating_rectangles_with_three_streams_in_flight(tracer_cls, scene10
         want.append(h)
     streams = [torch.cuda.Stream() for _ in range(3)]
     outs = [[torch.zeros_like(w) for w in want] for _ in streams]
+    torch.cuda.synchronize()                             # (torch fills on its own stream; the side streams do not wait for it)
     issued = []
     for k in range(36):
         which = (k // 4) % 2                             # four frames of one rectangle, then four of the other, no synchronisation in between
@@ -1135,6 +1138,7 @@ def test_rank_tile_launches_in_their_own_order_equal_the_plain_ones(tracer_cls, 
     ref.draw_tile_frames_device(np.concatenate([camA] * n_frames), tile, rank, n_ranks, per, hits_ptr=want_h.data_ptr()); torch.cuda.synchronize()
     streams = [torch.cuda.Stream() for _ in range(3)]
     outs = [torch.zeros_like(want_h) for _ in streams]
+    torch.cuda.synchronize()                             # (torch fills on its own stream; the side streams do not wait for it)
     for k in range(18):
         tr.draw_tile_frames_device(np.concatenate([camA] * n_frames), tile, rank, n_ranks, per, hits_ptr=outs[k % 3].data_ptr(), stream=streams[k % 3].cuda_stream)
         if k % 3 == 2:
