@@ -444,13 +444,13 @@ static int order_before_launch(blok_hip_ctx* ctx, blok::TraceArgs& args, uint32_
         if (O.slots[k].valid && !O.slots[k].dilated && camera_near(ctx, args.cam, O.slots[k].cam) && (own < 0 || O.slots[k].last_use > O.slots[own].last_use)) own = k;
     const int chosen = own >= 0 ? own : O.current;
     // At rest: the previous launch's view — or, for a caller that alternates between fixed views, one of the few before it, once that has
-    // happened three launches running (a camera that swings back and forth passes through a view of two launches ago at every turn: that is
+    // happened four launches running (a camera that swings back and forth passes through a view of two launches ago at every turn: that is
     // motion, and keeps the moving camera's carried order)
     const bool rest = uniform_view && camera_near(ctx, args.cam, O.last_cam);
     bool revisit = false;
     for (uint32_t k = 0; k < O.n_recent && uniform_view && !rest && !revisit; ++k) revisit = camera_near(ctx, args.cam, O.recent[k]);
     O.revisit_streak = revisit ? O.revisit_streak + 1u : (rest ? O.revisit_streak : 0u);
-    const bool seen = rest || (revisit && O.revisit_streak >= 3u);
+    const bool seen = rest || (revisit && O.revisit_streak >= 4u);      // (a swing back through a view the camera rested in makes three in a row: four)
     blok::OrderFacts f{};
     f.enabled = true; f.have_order = chosen >= 0 && O.slots[chosen].valid;
     f.near_order_view = f.have_order && own >= 0;

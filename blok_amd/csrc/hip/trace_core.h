@@ -445,9 +445,17 @@ BLOK_DEV bool walk_enter_wave(const TraceArgs& A, const RayIn& r, const WalkRay&
     uint32_t m = 0u;                                                       // ... of 4^m: all of them
     for (uint32_t k = 0; k < L; ++k) if (__ballot(mine > k) != 0ull) m = k + 1u;
     if (m >= L) return false;                                              // they part at the root: nothing to share
-    // the scalar chain
-    uint4 n4 = A.nodes[0];
-    uint32_t n_lo = __builtin_amdgcn_readfirstlane(n4.x), n_hi = __builtin_amdgcn_readfirstlane(n4.y), n_base = __builtin_amdgcn_readfirstlane(n4.z);
+    // the scalar chain: the nodes through the scalar cache (they are read-only while frames run; the compiler, which cannot know that next to the
+    // kernel's stores, would make them vector loads of one address: 64 lanes' worth of latency for a wave-uniform record)
+    typedef uint32_t Words4 __attribute__((ext_vector_type(4)));
+    auto uniform_node = [&](uint32_t index, uint32_t& lo, uint32_t& hi, uint32_t& base) {
+        const uint4* p = A.nodes + __builtin_amdgcn_readfirstlane(index);
+        Words4 v;
+        asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p));
+        lo = v.x; hi = v.y; base = v.z;
+    };
+    uint32_t n_lo, n_hi, n_base;
+    uniform_node(0u, n_lo, n_hi, n_base);
     uint32_t lvl = L - 1u;
     for (;;) {
         if (lvl < m) break;                                                // from here on every lane has its own cell
@@ -460,8 +468,7 @@ BLOK_DEV bool walk_enter_wave(const TraceArgs& A, const RayIn& r, const WalkRay&
         const uint32_t below_lo = bit < 32u ? (n_lo & ((1u << bit) - 1u)) : n_lo;
         const uint32_t below_hi = bit < 32u ? 0u : (n_hi & ((1u << (bit & 31u)) - 1u));
         const uint32_t child = n_base + static_cast<uint32_t>(__builtin_popcount(below_lo)) + static_cast<uint32_t>(__builtin_popcount(below_hi));
-        n4 = A.nodes[child];
-        n_lo = __builtin_amdgcn_readfirstlane(n4.x); n_hi = __builtin_amdgcn_readfirstlane(n4.y); n_base = __builtin_amdgcn_readfirstlane(n4.z);
+        uniform_node(child, n_lo, n_hi, n_base);
         lvl -= 1u;
     }
     s.found = false; s.bit = 0u; s.tCur = tS; s.walking = true;
