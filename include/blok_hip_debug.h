@@ -40,7 +40,8 @@ int blok_hip_set_volume_layout(blok_hip_ctx* ctx, int keyed);
 int blok_hip_set_ray_batching(blok_hip_ctx* ctx, int enabled);
 /* Where the path kernel's walks start (round 4; no reference counterpart: raygen.rgen:217-229, 282-298 hand every ray to traceRayEXT).
  * wave_tile_beam (default 1): every 8x8-pixel wave tile searches a start parameter of its own once per launch, on top of its 32x32 beam
- * tile's: all spp primary rays of its pixels start behind it (4K, 64 spp over 1024^3: 46.7 -> 44.5 ms).
+ * tile's, from 8 samples per pixel on: all spp primary rays of its pixels start behind it (4K over 1024^3, 64 spp: 46.7 -> 44.5 ms; 8 spp: 6.06 -> 5.90;
+ * 2 spp would lose: 1.68 -> 1.82).
  * resume_from_anchor (default 0 — built, exact, and slower): a pixel's rays enter the walk from the ancestors of its latest reported
  * voxel — the shadow and bounce rays start a hair off it (raygen.rgen:284, :376), the next sample's primary ray ends near it — instead
  * of descending from the root: the start voxel is found with the walk's own plane rule and verified, the lowest common ancestor comes

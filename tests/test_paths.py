@@ -350,7 +350,7 @@ def test_path_start_options_do_not_change_path_traced_frames(world64):
     inside = cams[0].copy(); inside["pos"][0] = (30.5, 40.2, 33.1); cams.append(inside)
     cams.append(W.camera_look_at((5.0, 8.0, 5.0), (40.0, 12.0, 40.0), 70.0, 203, 117))
     for i, cam in enumerate(cams):
-        same_in_all(tr, cam, ("small", i), spp=(1, 9, 4, 6, 5)[i], max_bounces=(2, 2, 5, 3, 1)[i], frame_index=2 + i)
+        same_in_all(tr, cam, ("small", i), spp=(1, 9, 8, 12, 8)[i], max_bounces=(2, 2, 5, 3, 1)[i], frame_index=2 + i)      # (the wave-tile beam applies from 8 spp on)
     tr.shutdown()
     # adversarial world, random cameras
     rng = np.random.default_rng(78)
@@ -370,7 +370,7 @@ def test_path_start_options_do_not_change_path_traced_frames(world64):
         eye = rng.normal(0.0, (25.0, 70.0, 300.0)[k % 3], 3)
         target = rng.normal(0.0, 20.0, 3)
         cam = W.camera_look_at(tuple(float(v) for v in eye), tuple(float(v) for v in target), float(rng.uniform(10.0, 140.0)), w, h)
-        same_in_all(tr, cam, ("adversarial", k), spp=3, max_bounces=3, frame_index=k)
+        same_in_all(tr, cam, ("adversarial", k), spp=8 if k % 2 else 3, max_bounces=3, frame_index=k)
     tr.shutdown()
     # a power-of-two voxel size other than 1 (the start voxel's guess divides by it; the planes scale)
     cmh = W.ChunkManager(128, 0.5)
@@ -378,12 +378,12 @@ def test_path_start_options_do_not_change_path_traced_frames(world64):
     half = cmh.pack_chunks_to_gpu_svo(mats)
     tr = HipTracer(160, 100).init(); tr.set_voxel_size(0.5); tr.add_world(half)
     cam = W.camera_look_at((-11.0, 27.0, -11.0), (16.0, 8.0, 16.0), 60.0, 160, 100)
-    same_in_all(tr, cam, "voxel size 1/2", spp=4, max_bounces=3, frame_index=1)
+    same_in_all(tr, cam, "voxel size 1/2", spp=8, max_bounces=3, frame_index=1)
     tr.shutdown()
     for n, rect in ((1024, (1400, 800, 640, 320)), (2048, (1500, 900, 384, 192))):
         cm, big = make_scene_world(n)
         tr = HipTracer(3840, 2160).init()
         tr.add_world(big)
         for pose in (0, 1):
-            same_in_all(tr, W.scene_camera(n, pose, 3840, 2160, SEED), (n, pose), spp=4, max_bounces=2 + pose, frame_index=1, rect=rect)
+            same_in_all(tr, W.scene_camera(n, pose, 3840, 2160, SEED), (n, pose), spp=8, max_bounces=2 + pose, frame_index=1, rect=rect)
         tr.shutdown()
