@@ -793,7 +793,10 @@ __global__ __launch_bounds__(64) void sun_map_raise_kernel(const SunMapArgs a, c
 
 // raygen.rgen main(): one lane per pixel of the rectangle, same 16x16 / 8x8 pixel mapping as the trace kernel.
 #ifndef BLOK_PATH_WAVES
-#define BLOK_PATH_WAVES 6        // waves per SIMD the path kernel is compiled for (register budget 512 / waves): 4 (109 VGPRs) 74.2 ms, 5 70.7, 6 69.9, 8 71.1 at 4K 64 spp
+// waves per SIMD the path kernel is compiled for (register budget 512 / waves).  Round 4 sweep, 4K 64 spp, poses A / B (profiles/r04_paths_start_ab.txt): 4 waves (115 VGPRs,
+// no spill) 50.9 ms, 5 (96, 12 spilled) 48.7, 6 (80, 28) 44.2-44.6 / 96.5, 7 (72, 64) 43.8-44.5 / 95.8, 8 (64, 104) 44.3-44.8 / 94.7: occupancy beats spill-freedom — the
+// spills sit in the state machine around the walk, none in the walk loop
+#define BLOK_PATH_WAVES 7
 #endif
 // kResume: PathArgs::resume_secondary honoured (two kernels, so that the default — off, it measures slower — carries none of its state).
 template <bool kResume>
