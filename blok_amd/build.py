@@ -52,7 +52,11 @@ def build_hip(force: bool = False) -> Path:
         return out
     obj_dir = ROOT / "build" / "obj"
     obj_dir.mkdir(parents=True, exist_ok=True)
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-ffp-contract=off", "-fPIC", f"-I{INCLUDE}", f"-I{PKG / 'csrc/hip'}"]
+    # -fno-slp-vectorize: left to itself the SLP pass pairs the walk's float adds / multiplies / fmas into v_pk_*_f32; on gfx950 a packed
+    # instruction issues at 1.64x the cost of a plain one for its two results (scripts/microbench/valu_rate2.hip), and gathering operands into
+    # register pairs costs moves and registers (joint_kernel 67 -> 61 VGPRs: eight waves per SIMD instead of seven).  Measured: frame alone
+    # 0.198 -> 0.191 ms, three in flight 0.177 -> 0.167 ms, configs[4] 45.0 -> 40.3 ms (profiles/r04_no_slp_ab.txt).  Results are bit-identical.
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", f"-I{INCLUDE}", f"-I{PKG / 'csrc/hip'}"]
     jobs = []
     for src in HIP_SRC:
         obj = obj_dir / (src.stem + ".o")
