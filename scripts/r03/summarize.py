@@ -54,9 +54,12 @@ def derive(kernel, c, dur_ns):
         if dur_ns:
             cycles = dur_ns * CLOCK_GHZ
             out["valu_issue_interval_cycles_per_simd"] = N_SIMD * cycles / c["SQ_INSTS_VALU"]
-            # against the interval the loop's instruction mix would need alone on a SIMD (54 full-rate at 2.2 cycles + 66 half-rate at 4.2:
-            # scripts/microbench/valu_rate.hip): 1 = the VALU never waits
-            out["valu_issue_frac"] = ((54 * 2.2 + 66 * 4.2) / 120.0) / out["valu_issue_interval_cycles_per_simd"]
+            # against the interval the loop's instruction mix would need alone on a SIMD (static mix of the walk loop's ISA: 62 full-rate
+            # at 2.2 cycles + 61 half-rate at 4.2 since the build without the SLP pass, 54 + 66 before it: scripts/microbench/valu_rate*.hip,
+            # DESIGN.md §9): 1 = the VALU never waits.  A static mix — the frames in flight run below this interval — so a figure near 1 says
+            # "the vector pipe is what the launch waits for", not more
+            fr, hr = (62, 61) if tag >= "r04d" else (54, 66)
+            out["valu_issue_frac"] = ((fr * 2.2 + hr * 4.2) / float(fr + hr)) / out["valu_issue_interval_cycles_per_simd"]
     if "SQ_THREAD_CYCLES_VALU" in c and c.get("SQ_ACTIVE_INST_VALU"):
         out["lane_utilisation"] = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
     if c.get("TCC_REQ_sum"):
