@@ -74,10 +74,11 @@ int install_tree(blok_hip_ctx* ctx, const blok::HostTree& tree, const blok_mater
 }
 
 // Rebuilds the shadow rays' last-occluder map for the installed world (one wave per texel of the plane perpendicular to the
-// sun; texel = 4 voxels, coarser for worlds wider than 2048 voxels so that the map stays <= 512 x 512).
+// sun; texel = 1 voxel, coarser for worlds wider than 1024 voxels so that the map stays <= 2048 x 2048).
 int rebuild_sun_map(blok_hip_ctx* ctx) {
     if (ctx->d_sun_map) { (void)hipDeviceSynchronize(); (void)hipFree(ctx->d_sun_map); ctx->d_sun_map = nullptr; }
     ctx->has_sun_map = false;
+    ctx->sun_loose_edits = 0; ctx->sun_tighten_pending = false;      // a whole new map owes nothing
     if (!ctx->has_world || ctx->stats.levels == 0 || ctx->stats.n_voxels == 0) return BLOK_OK;
     if (ctx->world_voxel_size != 1.0f) return BLOK_OK;      // the map is laid out in world units = voxel units; other voxel sizes go without it
     blok::SunMapArgs& m = ctx->sun;
@@ -105,7 +106,9 @@ int rebuild_sun_map(blok_hip_ctx* ctx) {
         lo[0] = std::min(lo[0], pu); hi[0] = std::max(hi[0], pu); lo[1] = std::min(lo[1], pv); hi[1] = std::max(hi[1], pv);
     }
     const double extent = std::max(hi[0] - lo[0], hi[1] - lo[1]);
-    m.texel = static_cast<float>(std::max(4.0, std::ceil(extent / 512.0)));
+    // (round 4: texels of one voxel instead of four — a texel's bound is the farthest occluder of its whole column, so finer texels cap more
+    // shadow rays at once: configs[4] 39.3 -> 38.4 ms, B 84.2 -> 83.2, C 62.5 -> 61.1, profiles/r04_sun_texel_ab.txt; 13 MB at 1024^3, 6 ms to build)
+    m.texel = static_cast<float>(std::max(1.0, std::ceil(extent / 2048.0)));
     m.u0 = static_cast<float>(std::floor(lo[0]) - m.texel); m.v0 = static_cast<float>(std::floor(lo[1]) - m.texel);
     m.nu = static_cast<uint32_t>(std::ceil((hi[0] - m.u0) / m.texel)) + 1u; m.nv = static_cast<uint32_t>(std::ceil((hi[1] - m.v0) / m.texel)) + 1u;
     BLOK_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_sun_map), static_cast<size_t>(m.nu) * m.nv * sizeof(float)));
@@ -123,11 +126,14 @@ int rebuild_sun_map(blok_hip_ctx* ctx) {
 // valid cheaply — an edit that can only have emptied voxels (may_add false) changes nothing; one that may have filled some raises the texels
 // whose prism meets the box to the box's farthest corner along the sun (one tiny launch) — and made TIGHT again by the search (one wave
 // per texel through the new tree, 30-60 us: round 3 ran it behind every edit, a seventh of the brush -> tree latency) only every
-// kSunMapLooseEdits edits, over the union of their boxes.  Anything else: the whole map.
+// kSunMapLooseEdits edits, over the union of their boxes, a band of rows per edit.  Anything else: the whole map.
 constexpr uint32_t kSunMapLooseEdits = 32;
+// (round 4, texels of one voxel: the union of 32 scattered boxes can be the whole map — 3 M searches, 5 ms behind one edit.  The texels to be
+// made tight are kept as a rectangle and searched a band of rows at a time, at most kSunMapBandTexels per edit: about 50 us.)
+constexpr uint32_t kSunMapBandTexels = 32768;
 int update_sun_map(blok_hip_ctx* ctx, const int32_t lo[3], const int32_t hi[3], bool same_lattice, bool may_add) {
     if (!same_lattice || !ctx->has_sun_map || !ctx->d_sun_map || ctx->world_voxel_size != 1.0f || !ctx->has_world || ctx->stats.n_voxels == 0) {
-        ctx->sun_loose_edits = 0;
+        ctx->sun_loose_edits = 0; ctx->sun_tighten_pending = false;
         return rebuild_sun_map(ctx);
     }
     blok::SunMapArgs& m = ctx->sun;
@@ -136,24 +142,50 @@ int update_sun_map(blok_hip_ctx* ctx, const int32_t lo[3], const int32_t hi[3], 
     if (ctx->sun_loose_edits == 0) for (int a = 0; a < 3; ++a) { ctx->sun_loose_lo[a] = lo[a]; ctx->sun_loose_hi[a] = hi[a]; }
     else for (int a = 0; a < 3; ++a) { ctx->sun_loose_lo[a] = std::min(ctx->sun_loose_lo[a], lo[a]); ctx->sun_loose_hi[a] = std::max(ctx->sun_loose_hi[a], hi[a]); }
     ctx->sun_loose_edits += 1;
-    const bool tighten = ctx->sun_loose_edits >= kSunMapLooseEdits;
-    if (!tighten && !may_add) return BLOK_OK;
-    const int32_t* blo = tighten ? ctx->sun_loose_lo : lo;
-    const int32_t* bhi = tighten ? ctx->sun_loose_hi : hi;
-    double ulo = 1e30, uhi = -1e30, vlo = 1e30, vhi = -1e30, far_depth = -1e30;
-    for (int c = 0; c < 8; ++c) {
-        const double p[3] = {double((c & 1) ? bhi[0] : blo[0]), double((c & 2) ? bhi[1] : blo[1]), double((c & 4) ? bhi[2] : blo[2])};
-        const double pu = m.u[0] * p[0] + m.u[1] * p[1] + m.u[2] * p[2], pv = m.v[0] * p[0] + m.v[1] * p[1] + m.v[2] * p[2];
-        ulo = std::min(ulo, pu); uhi = std::max(uhi, pu); vlo = std::min(vlo, pv); vhi = std::max(vhi, pv);
-        far_depth = std::max(far_depth, m.s[0] * p[0] + m.s[1] * p[1] + m.s[2] * p[2]);
+    // the texels whose prism meets a box of world voxels (one more on every side), and the box's farthest corner along the sun
+    const auto texels_of = [&](const int32_t* blo, const int32_t* bhi, uint32_t& u0, uint32_t& u1, uint32_t& v0, uint32_t& v1, double& far_depth) {
+        double ulo = 1e30, uhi = -1e30, vlo = 1e30, vhi = -1e30; far_depth = -1e30;
+        for (int c = 0; c < 8; ++c) {
+            const double p[3] = {double((c & 1) ? bhi[0] : blo[0]), double((c & 2) ? bhi[1] : blo[1]), double((c & 4) ? bhi[2] : blo[2])};
+            const double pu = m.u[0] * p[0] + m.u[1] * p[1] + m.u[2] * p[2], pv = m.v[0] * p[0] + m.v[1] * p[1] + m.v[2] * p[2];
+            ulo = std::min(ulo, pu); uhi = std::max(uhi, pu); vlo = std::min(vlo, pv); vhi = std::max(vhi, pv);
+            far_depth = std::max(far_depth, m.s[0] * p[0] + m.s[1] * p[1] + m.s[2] * p[2]);
+        }
+        const auto texel_of = [&](double x, double x0, uint32_t n) { const double t = std::floor((x - x0) / m.texel); return static_cast<int64_t>(std::min<double>(std::max<double>(t, -1.0), double(n))); };
+        const int64_t iu0 = std::max<int64_t>(texel_of(ulo, m.u0, m.nu) - 1, 0), iu1 = std::min<int64_t>(texel_of(uhi, m.u0, m.nu) + 1, int64_t(m.nu) - 1);
+        const int64_t iv0 = std::max<int64_t>(texel_of(vlo, m.v0, m.nv) - 1, 0), iv1 = std::min<int64_t>(texel_of(vhi, m.v0, m.nv) + 1, int64_t(m.nv) - 1);
+        if (iu1 < iu0 || iv1 < iv0) return false;
+        u0 = static_cast<uint32_t>(iu0); u1 = static_cast<uint32_t>(iu1); v0 = static_cast<uint32_t>(iv0); v1 = static_cast<uint32_t>(iv1);
+        return true;
+    };
+    if (ctx->sun_loose_edits >= kSunMapLooseEdits) {
+        // the union of the loose edits' boxes joins the texels still to be made tight
+        uint32_t u0, u1, v0, v1; double unused;
+        if (texels_of(ctx->sun_loose_lo, ctx->sun_loose_hi, u0, u1, v0, v1, unused)) {
+            if (ctx->sun_tighten_pending) { u0 = std::min(u0, ctx->sun_tighten_u0); u1 = std::max(u1, ctx->sun_tighten_u1); v0 = std::min(v0, ctx->sun_tighten_v0); v1 = std::max(v1, ctx->sun_tighten_v1); }
+            ctx->sun_tighten_u0 = u0; ctx->sun_tighten_u1 = u1; ctx->sun_tighten_v0 = v0; ctx->sun_tighten_v1 = v1; ctx->sun_tighten_pending = true;
+        }
+        ctx->sun_loose_edits = 0;
     }
-    const auto texel_of = [&](double x, double x0, uint32_t n) { const double t = std::floor((x - x0) / m.texel); return static_cast<int64_t>(std::min<double>(std::max<double>(t, -1.0), double(n))); };
-    const int64_t iu0 = std::max<int64_t>(texel_of(ulo, m.u0, m.nu) - 1, 0), iu1 = std::min<int64_t>(texel_of(uhi, m.u0, m.nu) + 1, int64_t(m.nu) - 1);
-    const int64_t iv0 = std::max<int64_t>(texel_of(vlo, m.v0, m.nv) - 1, 0), iv1 = std::min<int64_t>(texel_of(vhi, m.v0, m.nv) + 1, int64_t(m.nv) - 1);
-    if (iu1 < iu0 || iv1 < iv0) return BLOK_OK;
-    m.iu0 = static_cast<uint32_t>(iu0); m.iv0 = static_cast<uint32_t>(iv0); m.sub_nu = static_cast<uint32_t>(iu1 - iu0 + 1); m.sub_nv = static_cast<uint32_t>(iv1 - iv0 + 1);
-    if (tighten) { blok::launch_sun_map(m, nullptr); ctx->sun_loose_edits = 0; }
-    else blok::launch_sun_map_raise(m, static_cast<float>(far_depth + 1.0e-3 * std::fabs(far_depth) + 0.01), nullptr);      // (rounded up: the bound must not fall short in float)
+    bool launched = false;
+    if (ctx->sun_tighten_pending) {
+        // a band of rows through the tree as it is NOW (this edit included): exact for it; later edits raise it again
+        const uint32_t width = ctx->sun_tighten_u1 - ctx->sun_tighten_u0 + 1u, rows_left = ctx->sun_tighten_v1 - ctx->sun_tighten_v0 + 1u;
+        const uint32_t rows = std::min(rows_left, std::max(1u, kSunMapBandTexels / width));
+        m.iu0 = ctx->sun_tighten_u0; m.iv0 = ctx->sun_tighten_v0; m.sub_nu = width; m.sub_nv = rows;
+        blok::launch_sun_map(m, nullptr);
+        launched = true;
+        if (rows == rows_left) ctx->sun_tighten_pending = false; else ctx->sun_tighten_v0 += rows;
+    }
+    if (may_add) {
+        uint32_t u0, u1, v0, v1; double far_depth;
+        if (texels_of(lo, hi, u0, u1, v0, v1, far_depth)) {
+            m.iu0 = u0; m.iv0 = v0; m.sub_nu = u1 - u0 + 1u; m.sub_nv = v1 - v0 + 1u;
+            blok::launch_sun_map_raise(m, static_cast<float>(far_depth + 1.0e-3 * std::fabs(far_depth) + 0.01), nullptr);      // (rounded up: the bound must not fall short in float)
+            launched = true;
+        }
+    }
+    if (!launched) return BLOK_OK;
     BLOK_HIP_TRY(ctx, hipGetLastError());
     // launches on other (non-blocking) streams do not wait for the null stream: the path entries wait for this marker instead
     if (!ctx->sun_event) BLOK_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->sun_event, hipEventDisableTiming));
