@@ -109,8 +109,16 @@ __device__ __forceinline__ float beam_search(const TraceArgs& A, BeamVec ref, Be
     // with the brick visits (most of a search) gone.  Only kClampAtZero searches (the others want an exact answer).
     const uint32_t coarse1 = kClampAtZero ? budget0 - budget0 * kBeamCoarsen1 / 8u : 0u, coarse2 = kClampAtZero ? budget0 - budget0 * kBeamCoarsen2 / 8u : 0u;
     for (; budget != 0u; --budget) {
-        const uint4 rec = A.nodes[node];
-        const uint32_t mlo = beam_uniform(rec.x), mhi = beam_uniform(rec.y), base = beam_uniform(rec.z);
+        // the node record through the scalar cache: `node` is wave-uniform and the tree is read-only while frames run, which the compiler
+        // cannot know next to the kernels' stores — left alone it issues a vector load of one address and three v_readfirstlane
+#ifdef BLOK_BEAM_VECTOR_LOADS
+        const uint4 rec0 = A.nodes[node];
+        const uint4 rec = make_uint4(beam_uniform(rec0.x), beam_uniform(rec0.y), beam_uniform(rec0.z), 0u);
+#else
+        typedef uint32_t BeamWords4 __attribute__((ext_vector_type(4)));
+        const BeamWords4 rec = reinterpret_cast<const __attribute__((address_space(4))) BeamWords4*>(reinterpret_cast<uintptr_t>(A.nodes))[beam_uniform(node)];
+#endif
+        const uint32_t mlo = rec.x, mhi = rec.y, base = rec.z;
         const uint32_t shift = 2u * (level - 1u);
         const float s = static_cast<float>(1u << shift);
         const float g4 = __builtin_fmaf(s, a4, p4);
