@@ -446,12 +446,11 @@ BLOK_DEV bool walk_enter_wave(const TraceArgs& A, const RayIn& r, const WalkRay&
     for (uint32_t k = 0; k < L; ++k) if (__ballot(mine > k) != 0ull) m = k + 1u;
     if (m >= L) return false;                                              // they part at the root: nothing to share
     // the scalar chain: the nodes through the scalar cache (they are read-only while frames run; the compiler, which cannot know that next to the
-    // kernel's stores, would make them vector loads of one address: 64 lanes' worth of latency for a wave-uniform record)
+    // kernel's stores, would make them vector loads of one address: 64 lanes' worth of latency for a wave-uniform record) — a load from the
+    // constant address space at a wave-uniform index is an s_load_dwordx4
     typedef uint32_t Words4 __attribute__((ext_vector_type(4)));
     auto uniform_node = [&](uint32_t index, uint32_t& lo, uint32_t& hi, uint32_t& base) {
-        const uint4* p = A.nodes + __builtin_amdgcn_readfirstlane(index);
-        Words4 v;
-        asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p));
+        const Words4 v = reinterpret_cast<const __attribute__((address_space(4))) Words4*>(reinterpret_cast<uintptr_t>(A.nodes))[__builtin_amdgcn_readfirstlane(index)];
         lo = v.x; hi = v.y; base = v.z;
     };
     uint32_t n_lo, n_hi, n_base;
