@@ -11,7 +11,7 @@ ROOT = PKG.parent
 INCLUDE = ROOT / "include"
 
 HOST_SRC = [PKG / "csrc/host/world.cpp", PKG / "csrc/host/scene.cpp", PKG / "csrc/host/vox.cpp"]
-HIP_SRC = [PKG / "csrc/hip/api.hip", PKG / "csrc/hip/api_post.hip", PKG / "csrc/hip/api_volume.hip", PKG / "csrc/hip/api_multi.hip", PKG / "csrc/hip/trace_kernels.hip", PKG / "csrc/hip/dense_kernels.hip", PKG / "csrc/hip/tile_order.hip", PKG / "csrc/hip/gpu_build.hip",
+HIP_SRC = [PKG / "csrc/hip/api.hip", PKG / "csrc/hip/api_launch.hip", PKG / "csrc/hip/api_debug.hip", PKG / "csrc/hip/api_post.hip", PKG / "csrc/hip/api_volume.hip", PKG / "csrc/hip/api_multi.hip", PKG / "csrc/hip/trace_kernels.hip", PKG / "csrc/hip/dense_kernels.hip", PKG / "csrc/hip/tile_order.hip", PKG / "csrc/hip/gpu_build.hip",
            PKG / "csrc/hip/post_kernels.hip", PKG / "csrc/hip/tree_build.cpp"]
 HIP_HDR = sorted((PKG / "csrc/hip").glob("*.h")) + sorted((PKG / "csrc/common").glob("*.h")) + [INCLUDE / "blok_hip.h", INCLUDE / "blok_hip_debug.h", INCLUDE / "blok_world.h"]
 

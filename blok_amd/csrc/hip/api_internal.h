@@ -207,6 +207,11 @@ blok::TraceArgs base_args(const blok_hip_ctx* ctx, const blok_camera* cam);
 int prepare_beam(blok_hip_ctx* ctx, blok::RayMode mode, blok::TraceArgs& args, hipStream_t stream, uint32_t tiles_of_rank, uint32_t* n_beams);
 int prepare_queue(blok_hip_ctx* ctx, blok::RayMode mode, const blok::TraceArgs& args, hipStream_t stream, uint32_t n_beams, blok::FrameQueue* queue, uint32_t* n_blocks);
 int check_trace(blok_hip_ctx* ctx, const blok_camera* cam);
+// api_launch.hip
+int beam_buffer(blok_hip_ctx* ctx, hipStream_t stream, size_t n, float** out);
+void free_order(blok_hip_ctx* ctx);
+int order_buffers(blok_hip_ctx* ctx, uint32_t blocks, hipStream_t stream);
+int live_list(blok_hip_ctx* ctx, blok::TraceArgs& args, hipStream_t stream, uint32_t n_searches, uint32_t per_search);
 int launch_timed(blok_hip_ctx* ctx, blok::RayMode mode, blok::TraceArgs args, uint32_t blocks, hipStream_t stream, uint32_t tiles_of_rank = 0,
                  const blok::TileFrames* frames = nullptr);
 void forget_device_activity(const blok_hip_ctx* ctx, bool one_stream = false, hipStream_t stream = nullptr);

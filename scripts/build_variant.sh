@@ -6,7 +6,7 @@ set -e
 NAME=$1; shift
 cd "$(dirname "$0")/.."
 SRC_DIR=blok_amd/csrc/hip
-ALL="api.hip api_post.hip api_volume.hip api_multi.hip trace_kernels.hip dense_kernels.hip tile_order.hip gpu_build.hip post_kernels.hip tree_build.cpp"
+ALL="api.hip api_launch.hip api_debug.hip api_post.hip api_volume.hip api_multi.hip trace_kernels.hip dense_kernels.hip tile_order.hip gpu_build.hip post_kernels.hip tree_build.cpp"
 VARIANT_SRC=${VARIANT_SRC:-trace_kernels.hip}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++20 -ffp-contract=off ${BASE_EXTRA--fno-slp-vectorize} -fPIC -Iinclude -Iblok_amd/csrc/hip"
 OBJ=build/variant_obj; mkdir -p $OBJ blok_amd/variants
