@@ -245,7 +245,19 @@ BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t in
 
 #ifdef BLOK_PATH_CLOCKS
     uint32_t kind_clocks[3] = {0u, 0u, 0u}, kind_rounds[3] = {0u, 0u, 0u}, kind_lanes[3] = {0u, 0u, 0u};
+    const uint64_t wave_clock0 = __builtin_amdgcn_s_memtime();
 #endif
+    // A tile whose frustum meets no voxel (beam.h: the start parameter says "none"; sub-pixel jitter stays inside the grown frustum): every
+    // primary ray of every sample misses, so a sample is its camera ray's sky colour — the same sums in the same order as below, without the
+    // ray set-up (three divisions), the empty walk and the round's bookkeeping.  Three quarters of the benchmark frame's wave tiles.
+    if (t0 >= kBeamNone && P.max_bounces != 0u) {
+        while (s < P.spp) {
+            radiance = vadd(radiance, vmul(throughput, sky_color(ray_dir)));                  // :232-235, miss.rmiss
+            accumulated = vadd(accumulated, radiance);                                        // :379
+            s += 1u;
+            if (s < P.spp) begin_sample();
+        }
+    }
     while (s < P.spp && P.max_bounces != 0u) {
 #if !defined(BLOK_TRACE_HOST_HARNESS) && !defined(BLOK_PATH_NO_PHASES)
         {
@@ -374,29 +386,35 @@ BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t in
             radiance = vadd(radiance, vmul(throughput, sky_color(ray_dir)));
             end_sample = true;
         } else {
-            hit_pos = vadd(ray_org, vscale(ray_dir, hit.t));                                  // :238
             // hit.rchit:58-75
             const uint32_t id = hit.material < 65535u ? hit.material : 65535u;
             const blok_material mat = A.mat_table[id < A.n_materials ? id : 0u];
-            n = v3(hit.face == 0u ? 1.0f : (hit.face == 1u ? -1.0f : 0.0f),
-                   hit.face == 2u ? 1.0f : (hit.face == 3u ? -1.0f : 0.0f),
-                   hit.face == 4u ? 1.0f : (hit.face == 5u ? -1.0f : 0.0f));
-            albedo = v3(mat.albedo[0], mat.albedo[1], mat.albedo[2]);
             const V3 emission = v3(mat.emission[0], mat.emission[1], mat.emission[2]);
-            metallic = static_cast<float>((mat.flags >> 24) & 0xFFu) / 255.0f;
-            roughness = fmaxf(static_cast<float>((mat.flags >> 16) & 0xFFu) / 255.0f, 0.04f);
-            if (vdot(n, ray_dir) > 0.0f) n = vneg(n);                                         // :248-250
-            if (bounce == 0u && s == 0u) {                                                    // :253-263, :403-407 (reached once)
-                const V3 final_albedo = is_emissive(emission) ? emission : albedo;
-                store4(P.world_pos, index, hit_pos.x, hit_pos.y, hit_pos.z, hit.t);
-                store4(P.normal_roughness, index, n.x, n.y, n.z, roughness);
-                store4(P.albedo_metallic, index, final_albedo.x, final_albedo.y, final_albedo.z, metallic);
-                store_narrow(P, index, px, py, hit_pos, hit.t, true, n, roughness, final_albedo, metallic);
+            // the voxel a path's LAST segment reports (bounce + 1 = the loop bound, :212) can give the pixel its emission and nothing else: no
+            // shadow ray leaves it (:282, bounce 0 only), no further segment — its position, normal and surface parameters are not formed
+            const bool last_segment = bounce != 0u && bounce + 1u >= P.max_bounces;
+            if (!last_segment) {
+                hit_pos = vadd(ray_org, vscale(ray_dir, hit.t));                              // :238
+                n = v3(hit.face == 0u ? 1.0f : (hit.face == 1u ? -1.0f : 0.0f),
+                       hit.face == 2u ? 1.0f : (hit.face == 3u ? -1.0f : 0.0f),
+                       hit.face == 4u ? 1.0f : (hit.face == 5u ? -1.0f : 0.0f));
+                albedo = v3(mat.albedo[0], mat.albedo[1], mat.albedo[2]);
+                metallic = static_cast<float>((mat.flags >> 24) & 0xFFu) / 255.0f;
+                roughness = fmaxf(static_cast<float>((mat.flags >> 16) & 0xFFu) / 255.0f, 0.04f);
+                if (vdot(n, ray_dir) > 0.0f) n = vneg(n);                                     // :248-250
+                if (bounce == 0u && s == 0u) {                                                // :253-263, :403-407 (reached once)
+                    const V3 final_albedo = is_emissive(emission) ? emission : albedo;
+                    store4(P.world_pos, index, hit_pos.x, hit_pos.y, hit_pos.z, hit.t);
+                    store4(P.normal_roughness, index, n.x, n.y, n.z, roughness);
+                    store4(P.albedo_metallic, index, final_albedo.x, final_albedo.y, final_albedo.z, metallic);
+                    store_narrow(P, index, px, py, hit_pos, hit.t, true, n, roughness, final_albedo, metallic);
+                }
             }
             if (is_emissive(emission)) {                                                      // :265-277
                 radiance = vadd(radiance, vmul(throughput, emission));
                 if (luminance(emission) > 5.0f || bounce > 0u) end_sample = true;
             }
+            if (last_segment) end_sample = true;
             if (!end_sample) {
                 n_dot_l = fmaxf(vdot(n, sun_dir), 0.0f);                                      // :280
                 if (n_dot_l > 0.0f && bounce == 0u) shadow_phase = true;                      // next trace: the shadow ray
@@ -404,6 +422,10 @@ BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t in
             }
         }
 
+        // The path's last segment has been traced: what the shader still does with it — Russian roulette, the next direction, the throughput
+        // (:329-376) — feeds a ray its loop bound (:212) never lets it trace, so none of it can reach `radiance`: the sample ends here.
+        // (Round 4: with two bounces that is every bounce ray that reports a voxel, and two sincos + a handful of divisions each.)
+        if (continue_path && bounce + 1u >= P.max_bounces) { continue_path = false; end_sample = true; }
         if (continue_path) {
             if (bounce > 0u) {                                                                // :329-335
                 const float p = fminf(max3f(throughput), 0.95f);
@@ -454,6 +476,9 @@ BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t in
 
 #ifdef BLOK_PATH_CLOCKS
     if (A.debug_clocks) {                                   // [kind] clocks / 16, rounds, active lanes: summed over the wave, added once
+        if ((threadIdx.x & 63u) == 0u)                      // [9]: the wave's clocks / 16 from its first sample to here; [10]: waves
+            { (void)__hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(A.debug_clocks) + 9, static_cast<unsigned long long>((__builtin_amdgcn_s_memtime() - wave_clock0) >> 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              (void)__hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(A.debug_clocks) + 10, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         for (int k = 0; k < 3; ++k) {
             uint32_t c = kind_clocks[k], n = kind_rounds[k], l = kind_lanes[k];
             for (int off = 32; off > 0; off >>= 1) { c += __shfl_down(c, off); n += __shfl_down(n, off); l += __shfl_down(l, off); }
