@@ -87,32 +87,16 @@ BLOK_DEV uint32_t init_rng(uint32_t px, uint32_t py, uint32_t width, uint32_t fr
     pcg(seed);
     return seed;
 }
-BLOK_DEV void tangent_frame(V3 n, V3& tangent, V3& bitangent) {       // :108-110, :125-127
+// The shader's tangent frame (:108-110, :125-127: up = |n.z| < 0.999 ? z : x; tangent = normalize(cross(up, n)); bitangent = cross(n, tangent))
+// for the normal of a voxel face, n = +-e_k exactly (hit.rchit:69-75): every product in cross(up, n) is 0 or +-1, the vector is a
+// signed unit axis, its squared length is exactly 1, sqrt(1) = 1 and x / 1 = x bit for bit (signed zeros included) — the shader's
+// normalize() is the identity here, and its square root and three divisions are not spent.
+BLOK_DEV void tangent_frame_of_face(V3 n, V3& tangent, V3& bitangent) {
     const V3 up = fabsf(n.z) < 0.999f ? v3(0.0f, 0.0f, 1.0f) : v3(1.0f, 0.0f, 0.0f);
-    tangent = vnormalize(vcross(up, n));
+    tangent = vcross(up, n);
     bitangent = vcross(n, tangent);
 }
-BLOK_DEV V3 sample_cosine_hemisphere(float ux, float uy, V3 n) {       // :101-113
-    const float r = rn_sqrt(ux);
-    const float phi = 2.0f * kPi * uy;
-    const float x = r * cosf(phi);
-    const float y = r * sinf(phi);
-    const float z = rn_sqrt(fmaxf(0.0f, 1.0f - ux));
-    V3 t, b;
-    tangent_frame(n, t, b);
-    return vnormalize(vadd(vadd(vscale(t, x), vscale(b, y)), vscale(n, z)));
-}
-BLOK_DEV V3 sample_ggx(float ux, float uy, V3 n, float roughness) {    // :115-130
-    const float a = roughness * roughness;
-    const float a2 = a * a;
-    const float phi = 2.0f * kPi * ux;
-    const float cos_theta = rn_sqrt((1.0f - uy) / (1.0f + (a2 - 1.0f) * uy));
-    const float sin_theta = rn_sqrt(fmaxf(0.0f, 1.0f - cos_theta * cos_theta));
-    const V3 h = v3(sin_theta * cosf(phi), sin_theta * sinf(phi), cos_theta);
-    V3 t, b;
-    tangent_frame(n, t, b);
-    return vnormalize(vadd(vadd(vscale(t, h.x), vscale(b, h.y)), vscale(n, h.z)));
-}
+// (sample_cosine_hemisphere :101-113 and sample_ggx :115-130 are written out in shade_pixel, where their common tail runs once per wave.)
 // pow(x, k) for the shader's integer exponents 5, 8, 128 by multiplication (<= 4 ulp from a correctly rounded
 // pow; GLSL's own pow is exp2(y*log2(x)) at driver precision).  Far inside the stated colour tolerance, and
 // ~10x fewer instructions than the library powf on a path where every miss sample evaluates two of them.
@@ -441,8 +425,28 @@ BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t in
                 const V3 f = fresnel_schlick(n_dot_v, f0);
                 float spec_w = (f.x + f.y + f.z) / 3.0f;
                 spec_w = spec_w * (1.0f - metallic) + 1.0f * metallic;
-                if (random_float(rng) < spec_w) {                                             // :349-360
-                    const V3 h = sample_ggx(ux, uy, n, fmaxf(roughness, 0.04f));
+                // One of the shader's two samplers per lane (sample_ggx :115-130, sample_cosine_hemisphere :101-113).  Both are "a point in the
+                // normal's tangent frame, normalised": what differs is the point's polar part and which random number turns it.  The polar part is
+                // formed per branch; the sine and cosine, the frame, the combination and the normalisation — the expensive, identical rest — once
+                // for all lanes instead of once per branch (a wave nearly always holds lanes of both kinds).  Per lane the same operations as
+                // the shader's, in the same order.
+                const bool specular = random_float(rng) < spec_w;                             // :349
+                float turn, k_plane, k_normal;
+                if (specular) {                                                               // :116-123
+                    const float a = fmaxf(roughness, 0.04f) * fmaxf(roughness, 0.04f);
+                    const float a2 = a * a;
+                    const float cos_theta = rn_sqrt((1.0f - uy) / (1.0f + (a2 - 1.0f) * uy));
+                    turn = ux; k_plane = rn_sqrt(fmaxf(0.0f, 1.0f - cos_theta * cos_theta)); k_normal = cos_theta;
+                } else {                                                                      // :102-106
+                    turn = uy; k_plane = rn_sqrt(ux); k_normal = rn_sqrt(fmaxf(0.0f, 1.0f - ux));
+                }
+                const float phi = 2.0f * kPi * turn;
+                const float lx = k_plane * cosf(phi), ly = k_plane * sinf(phi);
+                V3 tangent, bitangent;
+                tangent_frame_of_face(n, tangent, bitangent);
+                const V3 sampled = vnormalize(vadd(vadd(vscale(tangent, lx), vscale(bitangent, ly)), vscale(n, k_normal)));
+                if (specular) {                                                               // :349-360
+                    const V3 h = sampled;
                     const V3 new_dir = vsub(ray_dir, vscale(h, 2.0f * vdot(h, ray_dir)));
                     if (vdot(new_dir, n) <= 0.0f) end_sample = true;
                     else {
@@ -452,10 +456,9 @@ BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t in
                         ray_dir = new_dir;
                     }
                 } else {                                                                      // :361-367
-                    const V3 new_dir = sample_cosine_hemisphere(ux, uy, n);
                     const V3 diffuse = vscale(albedo, 1.0f - metallic);
                     throughput = vmul(throughput, vdivs(diffuse, fmaxf(1.0f - spec_w, 0.001f)));
-                    ray_dir = new_dir;
+                    ray_dir = sampled;
                 }
                 if (!end_sample) {
                     const float max_t = max3f(throughput);                                    // :370-373
