@@ -108,27 +108,35 @@ __device__ __forceinline__ float beam_search(const TraceArgs& A, BeamVec ref, Be
     // corners stand for their voxels), past kBeamCoarsen2/8 at the 16^3 cells — still a front-to-back search with a valid bound,
     // with the brick visits (most of a search) gone.  Only kClampAtZero searches (the others want an exact answer).
     const uint32_t coarse1 = kClampAtZero ? budget0 - budget0 * kBeamCoarsen1 / 8u : 0u, coarse2 = kClampAtZero ? budget0 - budget0 * kBeamCoarsen2 / 8u : 0u;
-    for (; budget != 0u; --budget) {
+    // The loop, as two: a node entered for the first time is evaluated and its nearest candidate descended into (the outer loop); a node
+    // without candidates sends the search back up, where what is left of the parent's candidates is looked at again (the inner loop).  One
+    // unit of the budget per evaluation, first or repeated, as when this was a single loop with a `fresh` flag — written apart because in
+    // the single loop the eight stack registers and the five plane values lived in two register sets copied into each other on every trip.
+    typedef uint32_t BeamWords4 __attribute__((ext_vector_type(4)));
+    const auto* const tree = reinterpret_cast<const __attribute__((address_space(4))) BeamWords4*>(reinterpret_cast<uintptr_t>(A.nodes));
+    bool exhausted = false;
+    for (;;) {
+        // ---- a node entered for the first time
+        if (budget == 0u) { exhausted = true; fresh = true; break; }
+        const uint32_t spent_before = budget0 - budget;                                // evaluations before this one
+        --budget;
         // the node record through the scalar cache: `node` is wave-uniform and the tree is read-only while frames run, which the compiler
         // cannot know next to the kernels' stores — left alone it issues a vector load of one address and three v_readfirstlane
         // (profiles/r04_search_scalar_loads_ab.txt: the frame alone 0.191 -> 0.182 ms)
-        typedef uint32_t BeamWords4 __attribute__((ext_vector_type(4)));
-        const BeamWords4 rec = reinterpret_cast<const __attribute__((address_space(4))) BeamWords4*>(reinterpret_cast<uintptr_t>(A.nodes))[beam_uniform(node)];
-        const uint32_t mlo = rec.x, mhi = rec.y, base = rec.z;
-        const uint32_t shift = 2u * (level - 1u);
-        const float s = static_cast<float>(1u << shift);
-        const float g4 = __builtin_fmaf(s, a4, p4);
-        const float depth = __builtin_fmaf(s, near4, g4);                              // lower bound of the child's depth
-        const bool nearer = !(depth >= best);
-        float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f, g3 = 0.0f;
-        if (fresh) {
-            g0 = __builtin_fmaf(s, a0, p0); g1 = __builtin_fmaf(s, a1, p1); g2 = __builtin_fmaf(s, a2, p2); g3 = __builtin_fmaf(s, a3, p3);
+        BeamWords4 rec = tree[beam_uniform(node)];
+        uint32_t shift = 2u * (level - 1u);
+        float s = static_cast<float>(1u << shift);
+        float g4 = __builtin_fmaf(s, a4, p4);
+        float depth = __builtin_fmaf(s, near4, g4);                                    // lower bound of the child's depth
+        float g0 = __builtin_fmaf(s, a0, p0), g1 = __builtin_fmaf(s, a1, p1), g2 = __builtin_fmaf(s, a2, p2), g3 = __builtin_fmaf(s, a3, p3);
+        {
             // behind any side plane?  fminf drops NaNs, so a NaN never culls (as with four separate comparisons)
             const bool outside = fminf(fminf(__builtin_fmaf(s, far0, g0), __builtin_fmaf(s, far1, g1)),
                                        fminf(__builtin_fmaf(s, far2, g2), __builtin_fmaf(s, far3, g3))) < -kBeamSlack;
-            const bool filled = ((child_hi ? mhi : mlo) & child_bit) != 0u;
-            cand = __ballot(filled && !outside && nearer);
-            const uint32_t stop_level = budget < coarse2 ? BLOK_BEAM_STOP_LEVEL + 2u : (budget < coarse1 ? BLOK_BEAM_STOP_LEVEL + 1u : BLOK_BEAM_STOP_LEVEL);
+            const bool filled = ((child_hi ? rec.y : rec.x) & child_bit) != 0u;
+            cand = __ballot(filled && !outside && !(depth >= best));
+            const uint32_t left = budget0 - spent_before;                              // the budget as the single loop saw it during this evaluation
+            const uint32_t stop_level = left < coarse2 ? BLOK_BEAM_STOP_LEVEL + 2u : (left < coarse1 ? BLOK_BEAM_STOP_LEVEL + 1u : BLOK_BEAM_STOP_LEVEL);
             if (level <= stop_level) {
                 while (cand) {
                     const uint32_t j = static_cast<uint32_t>(__builtin_ctzll(cand));
@@ -139,39 +147,48 @@ __device__ __forceinline__ float beam_search(const TraceArgs& A, BeamVec ref, Be
                     cand &= __ballot(!(depth >= best));
                 }
             }
-        } else {
-            cand &= __ballot(nearer);
         }
-        if (cand == 0u) {
-            if (level == root_level) break;
+        // ---- nothing (left) to descend into: up, and the parent's remaining candidates against the bound as it is now
+        bool finished = false, revisited = false;
+        while (cand == 0u) {
+            if (level == root_level) { finished = true; break; }
             ++level;
             node = __builtin_amdgcn_readlane(stk_node, level);
             cand = static_cast<uint64_t>(__builtin_amdgcn_readlane(stk_lo, level)) |
                    (static_cast<uint64_t>(__builtin_amdgcn_readlane(stk_hi, level)) << 32);
             p0 = beam_lane(stk_p0, level); p1 = beam_lane(stk_p1, level); p2 = beam_lane(stk_p2, level); p3 = beam_lane(stk_p3, level);
             p4 = beam_lane(stk_p4, level);
-            fresh = false;
-            continue;
+            if (budget == 0u) { exhausted = true; fresh = false; break; }
+            --budget;
+            rec = tree[beam_uniform(node)];
+            shift = 2u * (level - 1u);
+            s = static_cast<float>(1u << shift);
+            g4 = __builtin_fmaf(s, a4, p4);
+            depth = __builtin_fmaf(s, near4, g4);
+            cand &= __ballot(!(depth >= best));
+            revisited = true;
         }
+        if (finished || exhausted) break;
+        // ---- into the nearest candidate
         const uint32_t j = static_cast<uint32_t>(__builtin_ctzll(cand));
         cand &= cand - 1u;
         if (lane == level) {
             stk_node = node; stk_lo = static_cast<uint32_t>(cand); stk_hi = static_cast<uint32_t>(cand >> 32);
             stk_p0 = p0; stk_p1 = p1; stk_p2 = p2; stk_p3 = p3; stk_p4 = p4;
         }
+        const uint32_t mlo = rec.x, mhi = rec.y, base = rec.z;
         const uint32_t cj = j ^ mirror;
         const uint32_t below_lo = cj < 32u ? (mlo & ((1u << cj) - 1u)) : mlo;
         const uint32_t below_hi = cj < 32u ? 0u : (mhi & ((1u << (cj & 31u)) - 1u));
         node = base + __builtin_popcount(below_lo) + __builtin_popcount(below_hi);
-        if (!fresh) {                                                                  // revisited node: the side values were not formed
+        if (revisited) {                                                               // the side values of a revisited node were not formed
             g0 = __builtin_fmaf(s, a0, p0); g1 = __builtin_fmaf(s, a1, p1); g2 = __builtin_fmaf(s, a2, p2); g3 = __builtin_fmaf(s, a3, p3);
         }
         p0 = beam_lane(g0, j); p1 = beam_lane(g1, j); p2 = beam_lane(g2, j); p3 = beam_lane(g3, j); p4 = beam_lane(g4, j);
         --level;
-        fresh = true;
     }
-    if (visits_out) *visits_out = budget0 - budget;                                    // diagnostics: node visits this search spent
-    if (budget == 0u) {
+    if (visits_out) *visits_out = budget0 - budget - (exhausted ? 0u : 1u);            // diagnostics: node visits this search spent (the last evaluation of a finished search not counted, as before)
+    if (exhausted) {
         if constexpr (!kClampAtZero) return -kBeamNone;
         // Out of visits.  Every filled voxel the search has not seen lies in a cell that is still pending: the node just entered
         // (fresh), or the candidates left at this level and at every level on the stack.  A cell's `depth` is a lower bound for
