@@ -23,5 +23,5 @@ for pose in (0, 1, 2):
             torch.cuda.synchronize(); ms.append(tr.last_kernel_ms())
         digest = color.view(torch.int32).sum().item()
         if ref is None: ref = digest
-        print(f"pose {'ABC'[pose]} {spp} spp, batching mode {mode}: {np.mean(ms[1:]):8.3f} ms   same frame as first mode: {digest == ref}", flush=True)
+        print(f"pose {'ABC'[pose]} {spp} spp, batching mode {mode}: {np.mean(ms[1:]):8.3f} ms   same frame as first mode: {digest == ref}" + (f"   digest {digest & 0xFFFFFFFF:08x}" if len(sys.argv) > 3 else ""), flush=True)
 tr.shutdown()
