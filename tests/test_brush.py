@@ -245,3 +245,43 @@ def test_sun_map_stays_valid_across_volume_edits():
         if k % 6 == 0 or k in (30, 31, 32, 33, 63, 64, 65):
             same(k)
     tr.shutdown()
+
+
+@pytest.mark.gpu
+def test_sun_map_tightens_in_bands_on_a_wide_world():
+    """Round 4: with texels of one voxel the union of 32 scattered edits' boxes can span the map, so it is made tight a band of rows per edit (api.hip:
+    update_sun_map, at most 32 768 texels each).  A world wide enough for several bands (256 x 128 x 256: a map of ~450 x 450 texels), edits scattered
+    over all of it: planes bit-identical with the map on and off before the tightening starts, while bands are pending, after a second union has joined
+    the pending rectangle, and at the end."""
+    from blok_amd.tracer import HipTracer
+    w, h = 160, 120
+    mats = W.scene_materials(SEED)
+    rng = np.random.default_rng(23)
+    tr = HipTracer(w, h).init()
+    tr.volume_create((0, 0, 0), (256, 128, 256), 128, 1.0)
+    ids = W.scene_dense(256, SEED)[:, :128, :]
+    z, y, x = np.nonzero(ids)
+    tr.volume_set_voxels(np.stack([x, y, z], 1).astype(np.int32), ids[z, y, x], np.ones(len(x), dtype=np.float32))
+    tr.volume_rebuild(mats)
+    cams = [W.camera_look_at((-60.0, 150.0, -60.0), (128.0, 30.0, 128.0), 60.0, w, h), W.camera_look_at((20.0, 70.0, 20.0), (200.0, 20.0, 180.0), 70.0, w, h)]
+
+    def same(tag):
+        for cam in cams:
+            tr.set_sun_map(False)
+            plain = tr.trace_paths(cam, spp=2, max_bounces=2, frame_index=4)
+            tr.set_sun_map(True)
+            got = tr.trace_paths(cam, spp=2, max_bounces=2, frame_index=4)
+            for k in plain:
+                assert got[k].tobytes() == plain[k].tobytes(), (tag, k)
+
+    same("scene")
+    for k in range(72):
+        c = tuple(float(v) for v in rng.uniform((12, 20, 12), (244, 110, 244)))
+        if k % 3 == 2:
+            tr.volume_apply_brush(c, float(rng.integers(2, 7)), 0.0, 1)                       # dig
+        else:
+            tr.volume_apply_brush(c, float(rng.integers(2, 6)), 1.0, 0)                       # a ball: a new shadow
+        tr.volume_rebuild(mats)
+        if k in (5, 30, 31, 32, 33, 36, 50, 63, 64, 65, 71):
+            same(k)
+    tr.shutdown()
