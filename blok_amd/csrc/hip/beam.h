@@ -115,15 +115,18 @@ __device__ __forceinline__ float beam_search(const TraceArgs& A, BeamVec ref, Be
     typedef uint32_t BeamWords4 __attribute__((ext_vector_type(4)));
     const auto* const tree = reinterpret_cast<const __attribute__((address_space(4))) BeamWords4*>(reinterpret_cast<uintptr_t>(A.nodes));
     bool exhausted = false;
+    // the node record through the scalar cache: `node` is wave-uniform and the tree is read-only while frames run, which the compiler
+    // cannot know next to the kernels' stores — left alone it issues a vector load of one address and three v_readfirstlane
+    // (profiles/r04_search_scalar_loads_ab.txt: the frame alone 0.191 -> 0.182 ms).  A child's record is asked for as soon as its index
+    // is known, before the stack and the plane values are dealt with: the load's way through the scalar cache runs beside that work
+    // (worth 0.4 % of the frame alone, profiles/r04_search_two_loops_ab.txt)
+    BeamWords4 entered = tree[beam_uniform(node)];
     for (;;) {
         // ---- a node entered for the first time
         if (budget == 0u) { exhausted = true; fresh = true; break; }
         const uint32_t spent_before = budget0 - budget;                                // evaluations before this one
         --budget;
-        // the node record through the scalar cache: `node` is wave-uniform and the tree is read-only while frames run, which the compiler
-        // cannot know next to the kernels' stores — left alone it issues a vector load of one address and three v_readfirstlane
-        // (profiles/r04_search_scalar_loads_ab.txt: the frame alone 0.191 -> 0.182 ms)
-        BeamWords4 rec = tree[beam_uniform(node)];
+        BeamWords4 rec = entered;
         uint32_t shift = 2u * (level - 1u);
         float s = static_cast<float>(1u << shift);
         float g4 = __builtin_fmaf(s, a4, p4);
@@ -172,15 +175,19 @@ __device__ __forceinline__ float beam_search(const TraceArgs& A, BeamVec ref, Be
         // ---- into the nearest candidate
         const uint32_t j = static_cast<uint32_t>(__builtin_ctzll(cand));
         cand &= cand - 1u;
+        const uint32_t parent = node;
+        {
+            const uint32_t mlo = rec.x, mhi = rec.y, base = rec.z;
+            const uint32_t cj = j ^ mirror;
+            const uint32_t below_lo = cj < 32u ? (mlo & ((1u << cj) - 1u)) : mlo;
+            const uint32_t below_hi = cj < 32u ? 0u : (mhi & ((1u << (cj & 31u)) - 1u));
+            node = base + __builtin_popcount(below_lo) + __builtin_popcount(below_hi);
+            entered = tree[beam_uniform(node)];
+        }
         if (lane == level) {
-            stk_node = node; stk_lo = static_cast<uint32_t>(cand); stk_hi = static_cast<uint32_t>(cand >> 32);
+            stk_node = parent; stk_lo = static_cast<uint32_t>(cand); stk_hi = static_cast<uint32_t>(cand >> 32);
             stk_p0 = p0; stk_p1 = p1; stk_p2 = p2; stk_p3 = p3; stk_p4 = p4;
         }
-        const uint32_t mlo = rec.x, mhi = rec.y, base = rec.z;
-        const uint32_t cj = j ^ mirror;
-        const uint32_t below_lo = cj < 32u ? (mlo & ((1u << cj) - 1u)) : mlo;
-        const uint32_t below_hi = cj < 32u ? 0u : (mhi & ((1u << (cj & 31u)) - 1u));
-        node = base + __builtin_popcount(below_lo) + __builtin_popcount(below_hi);
         if (revisited) {                                                               // the side values of a revisited node were not formed
             g0 = __builtin_fmaf(s, a0, p0); g1 = __builtin_fmaf(s, a1, p1); g2 = __builtin_fmaf(s, a2, p2); g3 = __builtin_fmaf(s, a3, p3);
         }
