@@ -383,6 +383,7 @@ void blok_hip_destroy(blok_hip_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     free_world(ctx);
     if (ctx->d_frame) (void)hipFree(ctx->d_frame);
+    if (ctx->d_tail_pool) (void)hipFree(ctx->d_tail_pool);
     free_post(ctx);
     if (ctx->has_volume) blok::gpu_volume_destroy(&ctx->volume);
     forget_device_activity(ctx);
@@ -834,9 +835,22 @@ static int launch_path_frame(blok_hip_ctx* ctx, const blok_camera* cam, uint32_t
     uint32_t n_beams = 0;                                   // the primary rays of every sample start behind the beam pre-pass
     rc = prepare_beam(ctx, blok::RayMode::Rect, p.trace, stream, 0, &n_beams);
     if (rc != BLOK_OK) return rc;
+    const uint32_t path_blocks = blok::rect_grid_blocks(w, h);
+    // the bounce rounds' tail pool (path_core.h: shade_pixel): with the rounds taken sample by sample, two bounces or more, rays from the root
+    p.tail_pool = nullptr;
+    if (ctx->ray_batching >= 3u && max_bounces >= 2u && !ctx->path_resume && blok::kBlock == 64) {
+        const size_t bytes = static_cast<size_t>(path_blocks) * blok::kTailCapacity * sizeof(blok::TailRecord);
+        if (bytes > ctx->tail_pool_bytes) {
+            if (ctx->d_tail_pool) { BLOK_HIP_TRY(ctx, hipDeviceSynchronize()); (void)hipFree(ctx->d_tail_pool); ctx->d_tail_pool = nullptr; ctx->tail_pool_bytes = 0; }
+            BLOK_HIP_TRY(ctx, hipMalloc(&ctx->d_tail_pool, bytes));
+            ctx->tail_pool_bytes = bytes;
+        }
+        p.tail_pool = static_cast<blok::TailRecord*>(ctx->d_tail_pool);
+        p.tail_cap = ctx->tail_cap; p.tail_cap_parked = ctx->tail_cap_parked;
+    }
     if (ctx->timing) BLOK_HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, stream));
     if (n_beams) blok::launch_beam(blok::RayMode::Rect, p.trace, n_beams, stream);
-    blok::launch_paths(p, blok::rect_grid_blocks(w, h), stream);
+    blok::launch_paths(p, path_blocks, stream);
     BLOK_HIP_TRY(ctx, hipGetLastError());
     if (ctx->timing) { BLOK_HIP_TRY(ctx, hipEventRecord(ctx->ev_end, stream)); ctx->timed = true; }
     return BLOK_OK;

@@ -2,6 +2,7 @@
 // experiment scripts.  Nothing a drop-in user of include/blok_hip.h needs; split from api.hip in round 4.
 #include "api_internal.h"
 #include <cstdlib>
+#include <cstdio>
 
 using namespace blok_api;
 
@@ -158,8 +159,12 @@ int blok_hip_set_path_start(blok_hip_ctx* ctx, int resume_from_anchor, int wave_
 
 int blok_hip_set_ray_batching(blok_hip_ctx* ctx, int enabled) {
     if (!ctx) return BLOK_ERR_INVALID_ARG;
-    if (enabled < 0 || enabled > 2) return set_error(ctx, BLOK_ERR_INVALID_ARG, "ray batching: 0 off, 1 by kind, 2 by sample and kind");
+    if (enabled < 0 || enabled > 3) return set_error(ctx, BLOK_ERR_INVALID_ARG, "ray batching: 0 off, 1 by kind, 2 by sample and kind, 3 and the bounce rounds' tail pool");
     ctx->ray_batching = static_cast<uint32_t>(enabled);
+    if (const char* caps = std::getenv("BLOK_TAIL_CAPS")) {      // "24,32": experiments
+        unsigned a = 0, b = 0;
+        if (std::sscanf(caps, "%u,%u", &a, &b) == 2 && a && b) { ctx->tail_cap = a; ctx->tail_cap_parked = b; }
+    }
     return BLOK_OK;
 }
 

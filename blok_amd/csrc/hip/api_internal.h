@@ -94,7 +94,9 @@ struct blok_hip_ctx {
     uint32_t sun_loose_edits = 0; int32_t sun_loose_lo[3] = {0, 0, 0}, sun_loose_hi[3] = {0, 0, 0};      // edits since the map was last made tight, and the union of their boxes (update_sun_map)
     bool sun_tighten_pending = false; uint32_t sun_tighten_u0 = 0, sun_tighten_u1 = 0, sun_tighten_v0 = 0, sun_tighten_v1 = 0;      // texels still to be made tight, a band of rows per edit (update_sun_map)
     hipEvent_t sun_event = nullptr; bool sun_event_pending = false;                                      // behind the latest patch of the map
-    uint32_t ray_batching = 2;          // PathArgs::batch_kinds (blok_hip_set_ray_batching)
+    uint32_t ray_batching = 3;          // PathArgs::batch_kinds (blok_hip_set_ray_batching); 3 = 2 + the bounce rounds' tail pool
+    void* d_tail_pool = nullptr; size_t tail_pool_bytes = 0;      // path_core.h: TailRecord[blocks][kTailCapacity], grown on demand
+    uint32_t tail_cap = 24, tail_cap_parked = 32;                 // trips after which a bounce round / a round over parked rays stops (BLOK_TAIL_CAPS overrides, experiments)
     bool path_resume = false, path_fine_beam = true;      // PathArgs::resume_secondary / fine_beam (blok_hip_set_path_start)
     blok::SunMapArgs sun{};
     // beam pre-pass (beam.h): start parameters per beam tile, one buffer per stream (launches on one stream are

@@ -53,7 +53,21 @@ struct PathArgs {
     uint32_t* albedo_metallic_u8;
     uint16_t* motion_h;
     float prev_view_proj[16];
+    // The bounce rounds' tail pool (shade_pixel): kTailCapacity records per wave of the launch, in global memory; null = off.  A bounce round
+    // stops after tail_cap trips of the walk's loop, a round over parked rays after tail_cap_parked.
+    struct TailRecord* tail_pool;
+    uint32_t tail_cap, tail_cap_parked;
 };
+
+// A last-segment ray cut off in its round: the ray, the parameter to go on from, what its answer is worth to its pixel, and the lane that owns the pixel.
+struct TailRecord { float ox, oy, oz, tcur, dx, dy, dz, wx, wy, wz; uint32_t owner, pad; };
+struct TailAnswer { float x, y, z; uint32_t owner; };          // a parked ray's term of its pixel's sum, and the lane whose pixel it is (~0: none)
+constexpr uint32_t kTailBatch = 64u, kTailCapacity = 128u;
+#ifndef BLOK_TRACE_HOST_HARNESS
+// a record is written by one lane and read by another later on: read past the vector L1, which may still hold the slot's previous record
+__device__ __forceinline__ float tail_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t tail_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#endif
 
 struct V3 { float x, y, z; };
 BLOK_DEV V3 v3(float x, float y, float z) { V3 v; v.x = x; v.y = y; v.z = z; return v; }
@@ -174,7 +188,8 @@ BLOK_DEV void store_narrow(const PathArgs& P, size_t index, uint32_t px, uint32_
 // walks of other rays overwrite the stack.
 // kResume: compiled with the anchor machinery (walk_resume); the build without it is the one without its register pressure.
 template <bool kResume = true>
-BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t index, uint4* stk, float t0 = 0.0f, uint2* keep_lohi = nullptr, uint32_t* keep_base = nullptr) {
+BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t index, uint4* stk, float t0 = 0.0f, uint2* keep_lohi = nullptr, uint32_t* keep_base = nullptr,
+                          [[maybe_unused]] TailRecord* pool = nullptr, [[maybe_unused]] TailAnswer* tail_results = nullptr) {
     const TraceArgs& A = P.trace;
     const blok_camera& cam = A.cam;
     const V3 cam_pos = v3(cam.pos[0], cam.pos[1], cam.pos[2]);
@@ -242,9 +257,54 @@ BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t in
             if (s < P.spp) begin_sample();
         }
     }
-    while (s < P.spp && P.max_bounces != 0u) {
+    // ---- the bounce rounds' tail pool (round 4) ----
+    // Nearly half of a bounce round's trips run with eight lanes or fewer still walking (profiles/r04_paths_kind_clocks.txt): a few grazing rays.
+    // With two bounces a bounce ray is its path's LAST segment — nothing follows from it but a term of the pixel's sum: throughput x sky colour if
+    // it leaves the world, throughput x emission if the voxel it reports glows.  So such a round stops after tail_cap trips; a ray still walking is
+    // PARKED — ray, the parameter to go on from, throughput, owner lane: a record in the wave's pool — and its lane ends the sample without that term.
+    // When 64 rays are parked (or the wave has nothing else left) they get a round of their own, one per lane whoever owns them, each
+    // walked again from the root with tmin = where it stood (exact: walk_loop), again cut off after tail_cap_parked trips and parked
+    // again if need be: rays of a kind, long with long.  An answer goes to the owner's sum through LDS, the owners taking them in record
+    // order (deterministic).  What changes for the pixel is the ORDER of its float sum (the parked term is added later), inside
+    // tests/test_paths.py's tolerance by five orders of magnitude; the G-buffer is untouched.  The CPU harness runs without it.
+    // The pool's two counters — parked records, answers waiting for their owners — live in LDS behind the answers and are read by every
+    // lane at the top of every trip: lanes sit rounds out, and a count kept in a register would be stale in those.
+    [[maybe_unused]] uint32_t pool_n = 0u, pickup_n = 0u;
+#if !defined(BLOK_TRACE_HOST_HARNESS)
+    const auto lane_id = []() { return static_cast<uint32_t>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))); };      // (two instructions: not kept in a register across the walks)
+    uint32_t* const tail_ctl = pool != nullptr ? reinterpret_cast<uint32_t*>(tail_results + kTailBatch) : nullptr;
+    if (pool != nullptr) { tail_ctl[0] = 0u; tail_ctl[1] = 0u; }
+#endif
+    for (;;) {
+        [[maybe_unused]] bool tail_round = false;
+        [[maybe_unused]] uint32_t tail_rank = 0u, tail_count = 0u;
+#if !defined(BLOK_TRACE_HOST_HARNESS)
+        if (pool != nullptr) { pool_n = __builtin_amdgcn_readfirstlane(tail_ctl[0]); pickup_n = __builtin_amdgcn_readfirstlane(tail_ctl[1]); }      // (every lane reads the same words: scalar registers)
+#endif
+        if (!((s < P.spp || pool_n != 0u || pickup_n != 0u) && P.max_bounces != 0u)) break;
+#if !defined(BLOK_TRACE_HOST_HARNESS)
+        if (pool != nullptr) {
+            if (pickup_n != 0u) {                                   // answers of the last parked round: every lane takes its own, in record order
+                for (uint32_t k = 0; k < pickup_n; ++k) {
+                    const TailAnswer e = tail_results[k];
+                    if (e.owner == lane_id()) accumulated = vadd(accumulated, v3(e.x, e.y, e.z));
+                }
+                if (lane_id() == static_cast<uint32_t>(__builtin_ctzll(__ballot(true)))) tail_ctl[1] = 0u;
+                pickup_n = 0u;
+            }
+            const uint64_t here = __ballot(true);
+            const uint32_t workers = static_cast<uint32_t>(__builtin_popcountll(here));
+            const bool busy_any = __ballot(s < P.spp) != 0ull;
+            if (pool_n >= kTailBatch || (!busy_any && pool_n != 0u)) {
+                tail_round = true;
+                tail_count = pool_n < workers ? pool_n : workers;
+                tail_rank = static_cast<uint32_t>(__builtin_popcountll(here & ((1ull << lane_id()) - 1ull)));
+            }
+        }
+#endif
+        if (!tail_round && s >= P.spp) continue;                    // nothing of its own left: this lane only helps with parked rays
 #if !defined(BLOK_TRACE_HOST_HARNESS) && !defined(BLOK_PATH_NO_PHASES)
-        {
+        if (!tail_round) {
             // The wave walks one kind of ray at a time — primary rays (coherent, short behind the beam pre-pass), then shadow
             // rays (parallel, short behind the last-occluder map), then bounce rays (long, incoherent): a lane whose pending ray
             // is of another kind sits the iteration out, instead of a few bounce rays stretching every iteration and the kinds
@@ -274,6 +334,20 @@ BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t in
         }
 #endif
         RayIn r;
+        [[maybe_unused]] TailRecord* my_record = nullptr;
+#if !defined(BLOK_TRACE_HOST_HARNESS)
+        if (tail_round) {
+            // a parked ray for each of the first tail_count lanes (the pool's top records); the others walk nothing (an empty interval) but stay
+            // in the round: its counts are formed by ballots
+            r.ox = r.oy = r.oz = 0.0f; r.dx = r.dy = r.dz = 1.0f; r.tmin = 0.0f; r.tmax = 0.0f;
+            if (tail_rank < tail_count) {
+                my_record = pool + (pool_n - tail_count + tail_rank);
+                r.ox = tail_load(&my_record->ox); r.oy = tail_load(&my_record->oy); r.oz = tail_load(&my_record->oz);
+                r.dx = tail_load(&my_record->dx); r.dy = tail_load(&my_record->dy); r.dz = tail_load(&my_record->dz);
+                r.tmin = tail_load(&my_record->tcur); r.tmax = 10000.0f;
+            }
+        } else
+#endif
         if (shadow_phase) {
             const V3 so = vadd(hit_pos, vscale(n, 0.001f));                                   // :284
             r.ox = so.x; r.oy = so.y; r.oz = so.z;
@@ -296,7 +370,7 @@ BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t in
             r.dx = ray_dir.x; r.dy = ray_dir.y; r.dz = ray_dir.z;
             r.tmin = 0.001f; r.tmax = 10000.0f;                                               // :225,:227
         }
-        if (!shadow_phase && bounce == 0u && t0 > 0.0f) {         // primary ray behind the beam pre-pass (one walk call site)
+        if (!tail_round && !shadow_phase && bounce == 0u && t0 > 0.0f) {         // primary ray behind the beam pre-pass (one walk call site)
             r.tmin = fmaxf(r.tmin, t0);
             if (t0 >= kBeamNone) r.tmax = 0.0f;                   // the tile's frustum meets no voxel: empty interval, immediate miss
         }
@@ -308,6 +382,8 @@ BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t in
 #endif
         HitInfo hit;
         hit.found = false; hit.t = -1.0f; hit.material = 0u; hit.face = 0xFFu; hit.vx = hit.vy = hit.vz = 0; hit.brick.lo = hit.brick.hi = hit.brick.base = 0u;
+        [[maybe_unused]] bool cut_off = false;                    // the walk was stopped by its round's cap: the ray is parked (or parked again)
+        [[maybe_unused]] float tcur_at_cut = 0.0f;
         {
             BLOK_STAT(4, 0);                       // a walk begins
             const WalkRay R = walk_ray(A, r.ox, r.oy, r.oz, safe_inv(r.dx), safe_inv(r.dy), safe_inv(r.dz));
@@ -328,8 +404,20 @@ BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t in
             // registers instead of 28 cost more than a round's shared descents save; profiles/r04_paths_start_ab.txt)
             if (!resumed) walk_enter(A, R, r.tmin, r.tmax, ws);
             if (ws.walking) stack_is_anchor = false;
+#if !defined(BLOK_TRACE_HOST_HARNESS)
+            // the round's cap: a round over parked rays; a bounce round all of whose rays are their paths' last segments (with room in the pool)
+            uint32_t cap = 0xFFFFFFFFu;
+            if (pool != nullptr) {
+                if (tail_round) cap = P.tail_cap_parked;
+                else if (__ballot(!(bounce != 0u && !shadow_phase && bounce + 1u >= P.max_bounces)) == 0ull && pool_n + kTailBatch <= kTailCapacity) cap = P.tail_cap;
+            }
+            walk_loop<true>(A, R, r.tmax, ws, stk, cap);
+            cut_off = ws.walking;
+#else
             walk_loop(A, R, r.tmax, ws, stk);
+#endif
             if (ws.found) hit = walk_hit(A, r, R, ws);
+            tcur_at_cut = ws.tCur;
             // a report becomes the anchor when it is a first hit or another ray of this path will start from it; its ancestors go to the side
             if (kResume && ws.found && !shadow_phase && keep_lohi != nullptr && (bounce == 0u || bounce + 1u < P.max_bounces)) {
                 anchor.vx = hit.vx; anchor.vy = hit.vy; anchor.vz = hit.vz; anchor.brick = hit.brick;
@@ -346,6 +434,47 @@ BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t in
         }
 #endif
 
+#if !defined(BLOK_TRACE_HOST_HARNESS)
+        if (pool != nullptr) {
+            const uint32_t first = static_cast<uint32_t>(__builtin_ctzll(__ballot(true)));
+            const uint32_t my_lane = lane_id();
+            if (tail_round) {
+                // answers to LDS (owner in .w; none for a lane without a record or with a ray parked again), rays still walking back onto the pool
+                const bool worker = my_record != nullptr;
+                float wx = 0.0f, wy = 0.0f, wz = 0.0f; uint32_t owner = 0xFFFFFFFFu;
+                if (worker) { wx = tail_load(&my_record->wx); wy = tail_load(&my_record->wy); wz = tail_load(&my_record->wz); owner = tail_load(&my_record->owner); }
+                const bool again = worker && cut_off;
+                const uint64_t again_lanes = __ballot(again);
+                V3 term = v3(0.0f, 0.0f, 0.0f);
+                if (worker && !again) {
+                    if (!hit.found) term = vmul(v3(wx, wy, wz), sky_color(v3(r.dx, r.dy, r.dz)));                   // :232-235
+                    else {
+                        const uint32_t id = hit.material < 65535u ? hit.material : 65535u;
+                        const blok_material mat = A.mat_table[id < A.n_materials ? id : 0u];
+                        const V3 emission = v3(mat.emission[0], mat.emission[1], mat.emission[2]);
+                        if (is_emissive(emission)) term = vmul(v3(wx, wy, wz), emission);                              // :265-277
+                    }
+                }
+                tail_results[tail_rank < kTailBatch ? tail_rank : 0u] = TailAnswer{term.x, term.y, term.z, worker && !again ? owner : 0xFFFFFFFFu};
+                const uint32_t base = pool_n - tail_count;
+                if (again) {
+                    // (every worker has read its record: the loads above are complete before these stores in program order)
+                    TailRecord* to = pool + base + static_cast<uint32_t>(__builtin_popcountll(again_lanes & ((1ull << my_lane) - 1ull)));
+                    to->ox = r.ox; to->oy = r.oy; to->oz = r.oz; to->tcur = tcur_at_cut; to->dx = r.dx; to->dy = r.dy; to->dz = r.dz;
+                    to->wx = wx; to->wy = wy; to->wz = wz; to->owner = owner;
+                }
+                if (my_lane == first) { tail_ctl[0] = base + static_cast<uint32_t>(__builtin_popcountll(again_lanes)); tail_ctl[1] = tail_count; }
+                continue;
+            }
+            const uint64_t parked_lanes = __ballot(cut_off);
+            if (cut_off) {
+                TailRecord* to = pool + pool_n + static_cast<uint32_t>(__builtin_popcountll(parked_lanes & ((1ull << my_lane) - 1ull)));
+                to->ox = r.ox; to->oy = r.oy; to->oz = r.oz; to->tcur = tcur_at_cut; to->dx = r.dx; to->dy = r.dy; to->dz = r.dz;
+                to->wx = throughput.x; to->wy = throughput.y; to->wz = throughput.z; to->owner = my_lane;
+            }
+            if (parked_lanes != 0ull && my_lane == first) tail_ctl[0] = pool_n + static_cast<uint32_t>(__builtin_popcountll(parked_lanes));
+        }
+#endif
         bool end_sample = false, continue_path = false;
         if (shadow_phase) {
             shadow_phase = false;
@@ -367,7 +496,7 @@ BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t in
             }
             continue_path = true;
         } else if (!hit.found) {                                                              // :232-235, miss.rmiss
-            radiance = vadd(radiance, vmul(throughput, sky_color(ray_dir)));
+            if (!cut_off) radiance = vadd(radiance, vmul(throughput, sky_color(ray_dir)));    // (a parked ray's term comes later, through the pool)
             end_sample = true;
         } else {
             // hit.rchit:58-75

@@ -196,7 +196,11 @@ BLOK_DEV void walk_enter(const TraceArgs& A, const WalkRay& R, float tmin, float
 }
 
 // The loop: from the state walk_enter left to the first reported voxel, the end of the interval or the world's far side.
-BLOK_DEV void walk_loop(const TraceArgs& A, const WalkRay& R, const float tmax, WalkState& s, uint4* stk) {
+// kCapped: at most `cap` trips; a lane cut off leaves with `walking` still set and tCur = the parameter at which it entered the cell it stands in —
+// a walk of the same ray from the root with tmin = that tCur reports what this one would have (every voxel before it has an empty clipped
+// interval, every one after it is entered at or after tCur: the argument of the beam pre-pass).  path_core.h: the bounce rounds' tail pool.
+template <bool kCapped = false>
+BLOK_DEV void walk_loop(const TraceArgs& A, const WalkRay& R, const float tmax, WalkState& s, uint4* stk, [[maybe_unused]] const uint32_t cap = 0u) {
     const uint32_t L = A.levels;
     // Invariant: tCur starts at max(world entry, tmin) and never decreases — a cell's far planes are never
     // before the plane through which it was entered (T is monotone along each axis and the start cell of a
@@ -207,7 +211,10 @@ BLOK_DEV void walk_loop(const TraceArgs& A, const WalkRay& R, const float tmax, 
     NodeRec node = s.node;
     bool found = false;
     const bool walking = s.walking;
+    [[maybe_unused]] uint32_t trips = 0u;
+    [[maybe_unused]] bool cut = false;
     while (walking) {
+        if constexpr (kCapped) { if (trips >= cap) { cut = true; break; } ++trips; }
         BLOK_STAT(0, lvl);
         const uint32_t shift = 2 * lvl;
         bit = (digit2(__float_as_uint(fx), shift) | (digit2(__float_as_uint(fy), shift) << 2) | (digit2(__float_as_uint(fz), shift) << 4)) ^ R.mirror;
@@ -255,7 +262,7 @@ BLOK_DEV void walk_loop(const TraceArgs& A, const WalkRay& R, const float tmax, 
         tFx = plane_t(R.ax, fx + size); tFy = plane_t(R.ay, fy + size); tFz = plane_t(R.az, fz + size);
     }
     s.fx = fx; s.fy = fy; s.fz = fz; s.tCur = tCur; s.bit = bit; s.node = node; s.found = found;
-    s.walking = false;
+    if constexpr (kCapped) s.walking = cut; else s.walking = false;
 }
 
 // The reported voxel of a finished walk: intersect.rint:136-141, hit.rchit:58-74.  r: the ray itself (origin, direction).

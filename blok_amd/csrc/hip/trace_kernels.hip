@@ -795,8 +795,9 @@ __global__ __launch_bounds__(64) void sun_map_raise_kernel(const SunMapArgs a, c
 #ifndef BLOK_PATH_WAVES
 // waves per SIMD the path kernel is compiled for (register budget 512 / waves).  Round 4 sweep, 4K 64 spp, poses A / B (profiles/r04_paths_start_ab.txt): 4 waves (115 VGPRs,
 // no spill) 50.9 ms, 5 (96, 12 spilled) 48.7, 6 (80, 28) 44.2-44.6 / 96.5, 7 (72, 64) 43.8-44.5 / 95.8, 8 (64, 104) 44.3-44.8 / 94.7: occupancy beats spill-freedom — the
-// spills sit in the state machine around the walk, none in the walk loop
-#define BLOK_PATH_WAVES 7
+// spills sit in the state machine around the walk, none in the walk loop.  With the bounce rounds' tail pool (path_core.h) the state machine is larger: at 7 waves two
+// scratch loads land INSIDE the walk loop (37.2 / 82.6 ms), at 6 (80 VGPRs, 49 spilled) the loop is clean: 29.6 / 67.6; 5: 30.8 / 70.6 (profiles/r04_tail_pool_ab.txt)
+#define BLOK_PATH_WAVES 6
 #endif
 // kResume: PathArgs::resume_secondary honoured (two kernels, so that the default — off, it measures slower — carries none of its state).
 template <bool kResume>
@@ -836,7 +837,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(BLOK_PAT
         keep_lohi = reinterpret_cast<uint2*>(lds_stack + slots * kBlock) + tid;
         keep_base = reinterpret_cast<uint32_t*>(reinterpret_cast<uint2*>(lds_stack + slots * kBlock) + kept * kBlock) + tid;
     }
-    shade_pixel<kResume>(P, A.x0 + rx, A.y0 + ry, static_cast<size_t>(ry) * A.w + rx, lds_stack + tid, t0, keep_lohi, keep_base);
+    // the bounce rounds' tail pool (path_core.h): this wave's records in global memory, its answers and two counters in LDS behind the stack
+    // (and the side area); one wave per workgroup
+    TailRecord* pool = nullptr; TailAnswer* tail_results = nullptr;
+    if (kBlock == 64u && P.tail_pool != nullptr) {
+        pool = P.tail_pool + static_cast<size_t>(blockIdx.x) * kTailCapacity;
+        const uint32_t slots = A.levels > 1u ? A.levels - 1u : 1u;
+        size_t words4 = static_cast<size_t>(slots) * kBlock;                                       // uint4 units
+        if (kResume && P.resume_secondary != 0u && A.levels >= 2u) words4 += (static_cast<size_t>(A.levels - 2u) * kBlock * 12u + 15u) / 16u;
+        tail_results = reinterpret_cast<TailAnswer*>(lds_stack + words4);
+    }
+    shade_pixel<kResume>(P, A.x0 + rx, A.y0 + ry, static_cast<size_t>(ry) * A.w + rx, lds_stack + tid, t0, keep_lohi, keep_base, pool, tail_results);
 }
 
 __global__ __launch_bounds__(256) void tonemap_kernel(const TonemapArgs T) {
@@ -1074,10 +1085,11 @@ void launch_paths(const PathArgs& args, uint32_t n_blocks, hipStream_t stream) {
     if (n_blocks == 0) return;
     const uint32_t levels = args.trace.levels;
     size_t lds = static_cast<size_t>(levels > 1 ? levels - 1 : 1) * kBlock * sizeof(uint4);
+    const size_t tail_lds = args.tail_pool ? (kTailBatch + 1u) * sizeof(TailAnswer) : 0u;               // the tail pool's answers and counters
     if (args.resume_secondary && levels >= 2) {
-        lds += static_cast<size_t>(levels - 2) * kBlock * (sizeof(uint2) + sizeof(uint32_t));      // the anchors' side area
-        hipLaunchKernelGGL(path_kernel<true>, dim3(n_blocks), dim3(kBlock), lds, stream, args);
-    } else hipLaunchKernelGGL(path_kernel<false>, dim3(n_blocks), dim3(kBlock), lds, stream, args);
+        lds += (static_cast<size_t>(levels - 2) * kBlock * (sizeof(uint2) + sizeof(uint32_t)) + 15u) / 16u * 16u;      // the anchors' side area
+        hipLaunchKernelGGL(path_kernel<true>, dim3(n_blocks), dim3(kBlock), lds + tail_lds, stream, args);
+    } else hipLaunchKernelGGL(path_kernel<false>, dim3(n_blocks), dim3(kBlock), lds + tail_lds, stream, args);
 }
 
 void launch_tonemap(const TonemapArgs& args, hipStream_t stream) {

@@ -336,13 +336,15 @@ def test_path_start_options_do_not_change_path_traced_frames(world64):
 
     def same_in_all(tr, cam, tag, **kw):
         ref = None
-        for resume, fine in combos:
+        tr.set_ray_batching(2)                           # the plain rounds: the tail pool (the default, mode 3) is not used with rays entered from the anchor,
+        for resume, fine in combos:                      # and with it a pixel's float sum is taken in another order (test_tail_pool_*)
             tr.set_path_start(resume, fine)
             got = tr.trace_paths(cam, **kw)
             if ref is None: ref = got
             for k in ref:
                 assert got[k].tobytes() == ref[k].tobytes(), (tag, resume, fine, k)
         tr.set_path_start(False, True)                   # the defaults
+        tr.set_ray_batching(3)
 
     tr = HipTracer(203, 117).init()
     tr.add_world(pw)
@@ -387,3 +389,40 @@ def test_path_start_options_do_not_change_path_traced_frames(world64):
         for pose in (0, 1):
             same_in_all(tr, W.scene_camera(n, pose, 3840, 2160, SEED), (n, pose), spp=8, max_bounces=2 + pose, frame_index=1, rect=rect)
         tr.shutdown()
+
+
+@pytest.mark.gpu
+def test_tail_pool_changes_only_the_order_of_a_pixels_sum(world64):
+    """Round 4: the bounce rounds' tail pool (blok_hip_set_ray_batching 3, the default; path_core.h) parks a path's last segment when its round is cut off and
+    adds its term to the pixel later.  Against the plain rounds (mode 2): the G-buffer planes bit-identical, the colour plane inside a thousandth of
+    test_paths' tolerance (the same terms in another order); the same launch twice: identical bits (the owners take their answers in record order); a
+    1024^3 rectangle at 64 spp (pools fill and drain many times, rays parked more than once) and the small world with 1, 2, 3 and 5 bounces
+    (more than two: only last segments are parked; one: no bounce rounds at all)."""
+    from blok_amd.tracer import HipTracer
+    from tests.conftest import make_scene_world
+    pw, mats, _ = world64
+
+    def check(tr, cam, **kw):
+        tr.set_ray_batching(2); plain = tr.trace_paths(cam, **kw)
+        tr.set_ray_batching(3); pooled = tr.trace_paths(cam, **kw); again = tr.trace_paths(cam, **kw)
+        for k in plain:
+            assert pooled[k].tobytes() == again[k].tobytes(), ("not deterministic", k)
+            if k == "color":
+                a, b = plain[k][..., :3].astype(np.float64), pooled[k][..., :3].astype(np.float64)
+                assert np.isfinite(b).all()
+                assert (np.abs(a - b) <= 1e-3 * (1e-4 + 1e-3 * np.abs(a))).all(), float((np.abs(a - b) / (1e-4 + 1e-3 * np.abs(a))).max())
+            else:
+                assert pooled[k].tobytes() == plain[k].tobytes(), k
+
+    tr = HipTracer(203, 117).init()
+    tr.add_world(pw)
+    cams = [W.scene_camera(64, pose, 203, 117, SEED) for pose in (0, 1, 2)]
+    for i, (spp, bounces) in enumerate(((16, 2), (9, 3), (8, 5), (12, 1), (64, 2))):
+        check(tr, cams[i % 3], spp=spp, max_bounces=bounces, frame_index=3 + i)
+    tr.shutdown()
+    cm, big = make_scene_world(1024)
+    tr = HipTracer(3840, 2160).init()
+    tr.add_world(big)
+    for pose, rect in ((0, (1500, 1300, 256, 128)), (1, (800, 900, 200, 120))):
+        check(tr, W.scene_camera(1024, pose, 3840, 2160, SEED), rect=rect, spp=64, max_bounces=2, frame_index=7)
+    tr.shutdown()
