@@ -334,14 +334,13 @@ BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t in
         }
 #endif
         RayIn r;
-        [[maybe_unused]] TailRecord* my_record = nullptr;
 #if !defined(BLOK_TRACE_HOST_HARNESS)
         if (tail_round) {
             // a parked ray for each of the first tail_count lanes (the pool's top records); the others walk nothing (an empty interval) but stay
             // in the round: its counts are formed by ballots
             r.ox = r.oy = r.oz = 0.0f; r.dx = r.dy = r.dz = 1.0f; r.tmin = 0.0f; r.tmax = 0.0f;
             if (tail_rank < tail_count) {
-                my_record = pool + (pool_n - tail_count + tail_rank);
+                const TailRecord* my_record = pool + (pool_n - tail_count + tail_rank);
                 r.ox = tail_load(&my_record->ox); r.oy = tail_load(&my_record->oy); r.oz = tail_load(&my_record->oz);
                 r.dx = tail_load(&my_record->dx); r.dy = tail_load(&my_record->dy); r.dz = tail_load(&my_record->dz);
                 r.tmin = tail_load(&my_record->tcur); r.tmax = 10000.0f;
@@ -440,7 +439,8 @@ BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t in
             const uint32_t my_lane = lane_id();
             if (tail_round) {
                 // answers to LDS (owner in .w; none for a lane without a record or with a ray parked again), rays still walking back onto the pool
-                const bool worker = my_record != nullptr;
+                const bool worker = tail_rank < tail_count;
+                const TailRecord* my_record = pool + (pool_n - tail_count + (worker ? tail_rank : 0u));      // (formed again: not kept across the walk)
                 float wx = 0.0f, wy = 0.0f, wz = 0.0f; uint32_t owner = 0xFFFFFFFFu;
                 if (worker) { wx = tail_load(&my_record->wx); wy = tail_load(&my_record->wy); wz = tail_load(&my_record->wz); owner = tail_load(&my_record->owner); }
                 const bool again = worker && cut_off;
