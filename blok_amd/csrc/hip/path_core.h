@@ -187,7 +187,9 @@ BLOK_DEV void store_narrow(const PathArgs& P, size_t index, uint32_t px, uint32_
 // compact LDS area of levels - 2 entries (12 bytes each; the root needs none) that holds the ancestors of the pixel's anchor while the
 // walks of other rays overwrite the stack.
 // kResume: compiled with the anchor machinery (walk_resume); the build without it is the one without its register pressure.
-template <bool kResume = true>
+// kSkyOnly: for a pixel of a tile whose frustum meets no voxel (the caller has checked t0 >= kBeamNone): only the sky path below is compiled, a
+// function of a few registers — in the full one, values spilled at its head were written out by three quarters of a frame's waves for nothing.
+template <bool kResume = true, bool kSkyOnly = false>
 BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t index, uint4* stk, float t0 = 0.0f, uint2* keep_lohi = nullptr, uint32_t* keep_base = nullptr,
                           [[maybe_unused]] TailRecord* pool = nullptr, [[maybe_unused]] TailAnswer* tail_results = nullptr) {
     const TraceArgs& A = P.trace;
@@ -257,6 +259,7 @@ BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t in
             if (s < P.spp) begin_sample();
         }
     }
+    if constexpr (!kSkyOnly) {
     // ---- the bounce rounds' tail pool (round 4) ----
     // Nearly half of a bounce round's trips run with eight lanes or fewer still walking (profiles/r04_paths_kind_clocks.txt): a few grazing rays.
     // With two bounces a bounce ray is its path's LAST segment — nothing follows from it but a term of the pixel's sum: throughput x sky colour if
@@ -605,6 +608,8 @@ BLOK_DEV void shade_pixel(const PathArgs& P, uint32_t px, uint32_t py, size_t in
             if (s < P.spp) begin_sample();
         }
     }
+
+    }      // !kSkyOnly
 
 #ifdef BLOK_PATH_CLOCKS
     if (A.debug_clocks) {                                   // [kind] clocks / 16, rounds, active lanes: summed over the wave, added once

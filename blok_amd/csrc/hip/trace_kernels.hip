@@ -847,7 +847,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(BLOK_PAT
         if (kResume && P.resume_secondary != 0u && A.levels >= 2u) words4 += (static_cast<size_t>(A.levels - 2u) * kBlock * 12u + 15u) / 16u;
         tail_results = reinterpret_cast<TailAnswer*>(lds_stack + words4);
     }
-    shade_pixel<kResume>(P, A.x0 + rx, A.y0 + ry, static_cast<size_t>(ry) * A.w + rx, lds_stack + tid, t0, keep_lohi, keep_base, pool, tail_results);
+    if (t0 >= kBeamNone && P.max_bounces != 0u) shade_pixel<kResume, true>(P, A.x0 + rx, A.y0 + ry, static_cast<size_t>(ry) * A.w + rx, lds_stack + tid, t0);      // (wave-uniform)
+    else shade_pixel<kResume>(P, A.x0 + rx, A.y0 + ry, static_cast<size_t>(ry) * A.w + rx, lds_stack + tid, t0, keep_lohi, keep_base, pool, tail_results);
 }
 
 __global__ __launch_bounds__(256) void tonemap_kernel(const TonemapArgs T) {
