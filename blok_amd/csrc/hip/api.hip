@@ -360,7 +360,7 @@ int blok_hip_resize(blok_hip_ctx* ctx, uint32_t width, uint32_t height) {
 
 static void free_stream_scratch(blok_hip_ctx::StreamScratch& sc) {
     for (void* p : {static_cast<void*>(sc.beam), static_cast<void*>(sc.ctl), static_cast<void*>(sc.entries), static_cast<void*>(sc.tile_map),
-                    static_cast<void*>(sc.slots), static_cast<void*>(sc.gave_up), static_cast<void*>(sc.list_entries), static_cast<void*>(sc.list_ctl)})
+                    static_cast<void*>(sc.slots), static_cast<void*>(sc.gave_up), static_cast<void*>(sc.list_entries), static_cast<void*>(sc.list_ctl), sc.tail_pool})
         if (p) (void)hipFree(p);
     if (sc.list_hint) (void)hipHostFree(sc.list_hint);
     sc = blok_hip_ctx::StreamScratch{};
@@ -383,7 +383,6 @@ void blok_hip_destroy(blok_hip_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     free_world(ctx);
     if (ctx->d_frame) (void)hipFree(ctx->d_frame);
-    if (ctx->d_tail_pool) (void)hipFree(ctx->d_tail_pool);
     free_post(ctx);
     if (ctx->has_volume) blok::gpu_volume_destroy(&ctx->volume);
     forget_device_activity(ctx);
@@ -841,12 +840,13 @@ static int launch_path_frame(blok_hip_ctx* ctx, const blok_camera* cam, uint32_t
     // (from four samples per pixel on: with fewer a wave's pool never fills, and the rays parked wait for the end: 1 spp 0.82 -> 0.93 ms, 4 spp 2.78 -> 2.54)
     if (ctx->ray_batching >= 3u && max_bounces >= 2u && spp >= 4u && !ctx->path_resume && blok::kBlock == 64) {
         const size_t bytes = static_cast<size_t>(path_blocks) * blok::kTailCapacity * sizeof(blok::TailRecord);
-        if (bytes > ctx->tail_pool_bytes) {
-            if (ctx->d_tail_pool) { BLOK_HIP_TRY(ctx, hipDeviceSynchronize()); (void)hipFree(ctx->d_tail_pool); ctx->d_tail_pool = nullptr; ctx->tail_pool_bytes = 0; }
-            BLOK_HIP_TRY(ctx, hipMalloc(&ctx->d_tail_pool, bytes));
-            ctx->tail_pool_bytes = bytes;
+        auto& scratch = ctx->beam_buffers[stream];             // per launch stream: launches on two streams may be in flight together
+        if (bytes > scratch.tail_pool_bytes) {
+            if (scratch.tail_pool) { BLOK_HIP_TRY(ctx, hipStreamSynchronize(stream)); (void)hipFree(scratch.tail_pool); scratch.tail_pool = nullptr; scratch.tail_pool_bytes = 0; }
+            BLOK_HIP_TRY(ctx, hipMalloc(&scratch.tail_pool, bytes));
+            scratch.tail_pool_bytes = bytes;
         }
-        p.tail_pool = static_cast<blok::TailRecord*>(ctx->d_tail_pool);
+        p.tail_pool = static_cast<blok::TailRecord*>(scratch.tail_pool);
         p.tail_cap = ctx->tail_cap; p.tail_cap_parked = ctx->tail_cap_parked;
     }
     if (ctx->timing) BLOK_HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, stream));

@@ -95,7 +95,6 @@ struct blok_hip_ctx {
     bool sun_tighten_pending = false; uint32_t sun_tighten_u0 = 0, sun_tighten_u1 = 0, sun_tighten_v0 = 0, sun_tighten_v1 = 0;      // texels still to be made tight, a band of rows per edit (update_sun_map)
     hipEvent_t sun_event = nullptr; bool sun_event_pending = false;                                      // behind the latest patch of the map
     uint32_t ray_batching = 3;          // PathArgs::batch_kinds (blok_hip_set_ray_batching); 3 = 2 + the bounce rounds' tail pool
-    void* d_tail_pool = nullptr; size_t tail_pool_bytes = 0;      // path_core.h: TailRecord[blocks][kTailCapacity], grown on demand
     uint32_t tail_cap = 24, tail_cap_parked = 32;                 // trips after which a bounce round / a round over parked rays stops (BLOK_TAIL_CAPS overrides, experiments)
     bool path_resume = false, path_fine_beam = true;      // PathArgs::resume_secondary / fine_beam (blok_hip_set_path_start)
     blok::SunMapArgs sun{};
@@ -115,6 +114,7 @@ struct blok_hip_ctx {
         uint32_t list_serial = 0;
         uint32_t* list_hint = nullptr; bool list_hint_valid = false; uint32_t list_hint_key = 0;
         uint32_t* tile_map = nullptr; size_t n_tile_map = 0;            // sparse exchange, root: frame tile -> record (zero between launches)
+        void* tail_pool = nullptr; size_t tail_pool_bytes = 0;           // path launches: the bounce rounds' tail pool (path_core.h: TailRecord[blocks][kTailCapacity]), grown on demand
     };
     std::unordered_map<hipStream_t, StreamScratch> beam_buffers;
     // Longest-first scheduling of the walk for a camera at rest (tile_order.h; rectangle launches of the static forms): every walk wave

@@ -426,3 +426,31 @@ def test_tail_pool_changes_only_the_order_of_a_pixels_sum(world64):
     for pose, rect in ((0, (1500, 1300, 256, 128)), (1, (800, 900, 200, 120))):
         check(tr, W.scene_camera(1024, pose, 3840, 2160, SEED), rect=rect, spp=64, max_bounces=2, frame_index=7)
     tr.shutdown()
+
+
+@pytest.mark.gpu
+def test_path_launches_on_two_streams_do_not_share_a_tail_pool(world64):
+    """The tail pool is scratch of the launch STREAM (as the start parameters are): two path launches in flight on two streams, different cameras, give the
+    frames they give one after the other."""
+    import torch
+    from blok_amd.tracer import HipTracer
+    pw, mats, _ = world64
+    w, h = 640, 360
+    tr = HipTracer(w, h).init()
+    tr.add_world(pw)
+    cams = [W.scene_camera(64, 0, w, h, SEED), W.scene_camera(64, 1, w, h, SEED)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    serial = []
+    for cam in cams:
+        c = torch.zeros((w * h, 4), dtype=torch.float32, device="cuda"); torch.cuda.synchronize()
+        tr.trace_paths_device(cam, c.data_ptr(), spp=32, max_bounces=2, frame_index=5); torch.cuda.synchronize()
+        serial.append(c.cpu().numpy())
+    for rep in range(3):
+        outs = [torch.zeros((w * h, 4), dtype=torch.float32, device="cuda") for _ in cams]
+        torch.cuda.synchronize()
+        for cam, c, st in zip(cams, outs, streams):
+            tr.trace_paths_device(cam, c.data_ptr(), spp=32, max_bounces=2, frame_index=5, stream=st.cuda_stream)
+        torch.cuda.synchronize()
+        for c, ref in zip(outs, serial):
+            assert c.cpu().numpy().tobytes() == ref.tobytes(), rep
+    tr.shutdown()
