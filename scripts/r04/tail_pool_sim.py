@@ -64,3 +64,33 @@ for K in (16, 24, 32):
                 drain(False)
             drain(True)
         print(f"  cap {K}, tail cap {K2}: {total / base:.3f}x, {tails} tail rounds")
+print("cut by lanes still walking (<= N, after at least M trips) instead of by trips; rounds over parked rays the same way:")
+for N in (8, 16, 24, 32):
+    for M in (8, 16):
+        T, R = 64, 6
+        total = 0; tails = 0
+        def cut_round(lens):
+            lens = np.sort(np.array(lens))[::-1]
+            # trips until at most N lanes are left (the (N+1)-th longest ray's length), at least M, at most the longest
+            k = lens[N] if len(lens) > N else 0
+            trips = min(max(k, M), lens[0])
+            return trips, [int(x - trips + R) for x in lens if x > trips]
+        for per in per_tile:
+            pool = []
+            def drain(final):
+                global total, tails, pool
+                while len(pool) >= T or (final and pool):
+                    batch, pool = pool[:64], pool[64:]
+                    if final and len(batch) <= N: total += max(batch); tails += 1; continue
+                    trips, left = cut_round(batch)
+                    total += trips; tails += 1
+                    pool += left
+            for (s, k) in sorted(per):
+                lens = per[(s, k)]
+                if k != 2:
+                    total += max(lens); continue
+                trips, left = cut_round(lens)
+                total += trips; pool += left
+                drain(False)
+            drain(True)
+        print(f"  N {N}, M {M}: {total / base:.3f}x, {tails} rounds over parked rays")
