@@ -39,7 +39,7 @@ int blok_hip_set_volume_layout(blok_hip_ctx* ctx, int keyed);
  * pixels of a wave stay in step sample by sample.  Per-lane work and results are identical in these three (tests/test_paths.py).
  * 3 (default, round 4) = 2 and the bounce rounds' tail pool (from 4 samples per pixel on, two bounces or more, rays from the root): a round
  * of last-segment rays is cut off after 24 trips of the walk, the rays still walking are parked and walked 64 at a time in rounds of
- * their own, and their terms reach the pixels' sums later — the same terms in another order (colour inside a thousandth of the test
+ * their own, and their terms reach the pixels' sums later — the same terms in another order (colour inside a hundredth of the test
  * tolerance of mode 2's, G-buffer bit-identical, launches deterministic; 64 spp at 4K 35 -> 30 ms). */
 int blok_hip_set_ray_batching(blok_hip_ctx* ctx, int enabled);
 /* Where the path kernel's walks start (round 4; no reference counterpart: raygen.rgen:217-229, 282-298 hand every ray to traceRayEXT).
